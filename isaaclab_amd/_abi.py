@@ -1,0 +1,81 @@
+"""ctypes binding of ``libisaaclab_amd.so`` (the C ABI declared in ``include/isaaclab_amd.h``).
+
+There is no fallback: if the shared library is missing, importing this module raises, and every wrapper
+refuses tensors that do not live on a GPU.  ``torch`` is imported first so that the HIP runtime the
+library binds to is the one PyTorch already loaded (same process-wide streams and allocations).
+"""
+
+from __future__ import annotations
+
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libisaaclab_amd.so")
+
+
+class IlxError(RuntimeError):
+    """Raised when a C-ABI call returns a negative status."""
+
+
+def _load() -> ctypes.CDLL:
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: the HIP kernels have not been built. Run `make -C isaaclab_amd/csrc` "
+            "(or `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback."
+        )
+    return ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+
+
+lib = _load()
+lib.ilx_last_error.restype = ctypes.c_char_p
+lib.ilx_version.restype = ctypes.c_int
+
+c_void_p = ctypes.c_void_p
+c_int = ctypes.c_int
+c_int64 = ctypes.c_int64
+c_float = ctypes.c_float
+
+
+def _sig(name, *argtypes):
+    fn = getattr(lib, name)
+    fn.argtypes = list(argtypes)
+    fn.restype = ctypes.c_int
+    return fn
+
+
+def check(status: int, what: str = ""):
+    if status != 0:
+        msg = lib.ilx_last_error()
+        raise IlxError(f"{what} failed ({status}): {msg.decode() if msg else ''}")
+
+
+def ptr(t: torch.Tensor | None) -> int | None:
+    """Device pointer of a dense GPU tensor (None passes NULL)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise IlxError("isaaclab_amd kernels need GPU tensors (got a CPU tensor); there is no CPU fallback")
+    if not t.is_contiguous():
+        raise IlxError("isaaclab_amd kernels need contiguous tensors")
+    return t.data_ptr()
+
+
+def stream() -> int:
+    """The current torch stream as a raw hipStream_t."""
+    return torch.cuda.current_stream().cuda_stream
+
+
+def f32c(t: torch.Tensor) -> torch.Tensor:
+    """Dense float32 view/copy of ``t``."""
+    if t.dtype != torch.float32:
+        t = t.to(torch.float32)
+    return t if t.is_contiguous() else t.contiguous()
+
+
+# ---- signatures --------------------------------------------------------------------------------
+P = c_void_p
+math_op = _sig("ilx_math_op", c_int, P, P, P, P, P, P, c_int64, P)
+math_range_op = _sig("ilx_math_range_op", c_int, P, P, P, c_int, P, c_int64, c_int, P)
