@@ -24,7 +24,8 @@ struct f4 {
 #define ILX_DEV __device__ __forceinline__
 
 ILX_DEV float fmaf_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
-ILX_DEV float sqrt_(float x) { return __fsqrt_rn(x); }
+// __fsqrt_rn lowers to a bare v_sqrt_f32 (1 ulp); __builtin_sqrtf gets the correctly rounded fix-up sequence.
+ILX_DEV float sqrt_(float x) { return __builtin_sqrtf(x); }
 ILX_DEV float div_(float a, float b) { return __fdiv_rn(a, b); }
 
 constexpr float kPi = 3.14159265358979323846f;      // fp32(pi)
