@@ -1,0 +1,90 @@
+"""Oracle for the actuator models (test infrastructure, CPU only).
+
+Follows ``source/isaaclab/isaaclab/actuators/actuator_pd.py`` and ``actuator_net.py`` of the reference.
+State that the reference keeps on the actuator object (histories) is passed in and returned.
+"""
+
+from __future__ import annotations
+
+import torch
+
+ACTIVATIONS = {
+    "softsign": torch.nn.functional.softsign,
+    "elu": torch.nn.functional.elu,
+    "tanh": torch.tanh,
+    "relu": torch.relu,
+    "identity": lambda x: x,
+}
+
+
+def pd_torque(q_des, qd_des, tau_ff, q, qd, stiffness, damping):
+    """actuator_pd.py:135-138: kp*(q_des-q) + kd*(qd_des-qd) + tau_ff, evaluated left to right."""
+    error_pos = q_des - q
+    error_vel = qd_des - qd
+    return stiffness * error_pos + damping * error_vel + tau_ff
+
+
+def clip_effort(effort, effort_limit):
+    """actuator_base.py:252-261."""
+    return torch.clip(effort, min=-effort_limit, max=effort_limit)
+
+
+def dc_motor_clip(effort, joint_vel, saturation_effort: float, velocity_limit, effort_limit):
+    """actuator_pd.py:223-233: velocity dependent torque envelope, then clip."""
+    zeros = torch.zeros_like(effort)
+    max_effort = saturation_effort * (1.0 - joint_vel / velocity_limit)
+    max_effort = torch.clip(max_effort, min=zeros, max=effort_limit)
+    min_effort = saturation_effort * (-1.0 - joint_vel / velocity_limit)
+    min_effort = torch.clip(min_effort, min=-effort_limit, max=zeros)
+    return torch.clip(effort, min=min_effort, max=max_effort)
+
+
+def ideal_pd(q_des, qd_des, tau_ff, q, qd, stiffness, damping, effort_limit):
+    """IdealPDActuator.compute / ImplicitActuator.compute (actuator_pd.py:62-87, 131-145)."""
+    computed = pd_torque(q_des, qd_des, tau_ff, q, qd, stiffness, damping)
+    return computed, clip_effort(computed, effort_limit)
+
+
+def dc_motor(q_des, qd_des, tau_ff, q, qd, stiffness, damping, effort_limit, velocity_limit, saturation_effort):
+    """DCMotor.compute (actuator_pd.py:211-233)."""
+    computed = pd_torque(q_des, qd_des, tau_ff, q, qd, stiffness, damping)
+    return computed, dc_motor_clip(computed, qd, saturation_effort, velocity_limit, effort_limit)
+
+
+def mlp_forward(x, weights, biases, activation: str):
+    """Linear -> act -> ... -> Linear, the layout of the actuator nets (activation on all but the last layer)."""
+    act = ACTIVATIONS[activation]
+    h = x
+    for i, (w, b) in enumerate(zip(weights, biases)):
+        h = torch.nn.functional.linear(h, w, b)
+        if i + 1 < len(weights):
+            h = act(h)
+    return h
+
+
+def actuator_net_mlp(
+    q_des, q, qd, pos_err_hist, vel_hist, weights, biases, activation, input_idx, input_order, pos_scale, vel_scale,
+    torque_scale, effort_limit, velocity_limit, saturation_effort,
+):
+    """ActuatorNetMLP.compute (actuator_net.py:147-188).
+
+    ``pos_err_hist`` / ``vel_hist`` are (N, K, J) with slot 0 the newest; returns
+    (computed, applied, new_pos_err_hist, new_vel_hist).
+    """
+    n, _, j = pos_err_hist.shape
+    pe = pos_err_hist.roll(1, 1)
+    pe[:, 0] = q_des - q
+    vh = vel_hist.roll(1, 1)
+    vh[:, 0] = qd
+    pos_in = torch.cat([pe[:, i].unsqueeze(2) for i in input_idx], dim=2).reshape(n * j, -1)
+    vel_in = torch.cat([vh[:, i].unsqueeze(2) for i in input_idx], dim=2).reshape(n * j, -1)
+    if input_order == "pos_vel":
+        net_in = torch.cat([pos_in * pos_scale, vel_in * vel_scale], dim=1)
+    elif input_order == "vel_pos":
+        net_in = torch.cat([vel_in * vel_scale, pos_in * pos_scale], dim=1)
+    else:
+        raise ValueError(f"Invalid input order for MLP actuator net: {input_order}. Must be 'pos_vel' or 'vel_pos'.")
+    torques = mlp_forward(net_in, weights, biases, activation).reshape(n, j)
+    computed = torques * torque_scale
+    applied = dc_motor_clip(computed, qd, saturation_effort, velocity_limit, effort_limit)
+    return computed, applied, pe, vh

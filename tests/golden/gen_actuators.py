@@ -1,0 +1,211 @@
+"""Golden fixtures for the actuator models and the derived ArticulationData quantities, produced by the
+reference's own classes (actuator_pd.py, actuator_net.py, articulation_data.py)."""
+
+from __future__ import annotations
+
+import io
+import sys
+import types
+
+import torch
+
+import _refload as R
+from gen_golden import gen, save
+
+SECTIONS = {}
+
+
+def section(fn):
+    SECTIONS[fn.__name__] = fn
+    return fn
+
+
+class Cfg(types.SimpleNamespace):
+    pass
+
+
+def _names(j):
+    return [f"joint_{i}" for i in range(j)]
+
+
+def _run_pd_like(cls, cfg, n, j, steps, g, reset_at=None):
+    act = cls(cfg, joint_names=_names(j), joint_ids=slice(None), num_envs=n, device="cpu")
+    Types = R.bootstrap()["types"]
+    rec = dict(q_des=[], qd_des=[], tau_ff=[], q=[], qd=[], computed=[], applied=[])
+    for s in range(steps):
+        q_des = torch.randn(n, j, generator=g)
+        qd_des = torch.randn(n, j, generator=g) * 0.5
+        tau_ff = torch.randn(n, j, generator=g) * 2.0
+        q = q_des + torch.randn(n, j, generator=g) * 0.6
+        qd = torch.randn(n, j, generator=g) * 6.0
+        if reset_at is not None and s == reset_at:
+            act.reset([0, 2, 5])
+        ca = Types.ArticulationActions(joint_positions=q_des.clone(), joint_velocities=qd_des.clone(),
+                                       joint_efforts=tau_ff.clone(), joint_indices=slice(None))
+        act.compute(ca, q.clone(), qd.clone())
+        for k, v in zip(("q_des", "qd_des", "tau_ff", "q", "qd", "computed", "applied"),
+                        (q_des, qd_des, tau_ff, q, qd, act.computed_effort.clone(), act.applied_effort.clone())):
+            rec[k].append(v)
+    out = {k: torch.stack(v) for k, v in rec.items()}
+    out.update(stiffness=act.stiffness, damping=act.damping, effort_limit=act.effort_limit,
+               velocity_limit=act.velocity_limit)
+    return out
+
+
+@section
+def actuators_pd():
+    m = R.bootstrap()
+    pd = m["actuator_pd"]
+    g = gen(2001)
+    n, j = 96, 12
+    base = dict(joint_names_expr=[".*"], armature=None, friction=None)
+    # ANYmal-C simple DC motor constants (isaaclab_assets/robots/anymal.py:34-41)
+    cfg_dc = Cfg(stiffness={".*": 40.0}, damping={".*": 5.0}, effort_limit=80.0, velocity_limit=7.5,
+                 saturation_effort=120.0, **base)
+    cfg_pd = Cfg(stiffness=25.0, damping=0.5, effort_limit=23.5, velocity_limit=30.0, **base)
+    out = {}
+    for tag, cls, cfg in (("ideal", pd.IdealPDActuator, cfg_pd), ("implicit", pd.ImplicitActuator, cfg_pd),
+                          ("dcmotor", pd.DCMotor, cfg_dc)):
+        r = _run_pd_like(cls, cfg, n, j, 6, g)
+        out.update({f"{tag}_{k}": v for k, v in r.items()})
+    # per-joint dict parameters (Unitree H1 legs style, unitree.py:216-260), DCMotor
+    names = ["left_hip_yaw", "left_knee", "torso", "left_ankle", "right_knee"]
+    cfg_h1 = Cfg(joint_names_expr=[".*"], armature=None, friction=None,
+                 stiffness={".*_hip_yaw": 150.0, ".*_knee": 200.0, "torso": 200.0, ".*_ankle": 20.0},
+                 damping={".*_hip_yaw": 5.0, ".*_knee": 5.0, "torso": 5.0, ".*_ankle": 4.0},
+                 effort_limit={".*_hip_yaw": 300.0, ".*_knee": 300.0, "torso": 300.0, ".*_ankle": 100.0},
+                 velocity_limit=100.0, saturation_effort=300.0)
+    act = pd.DCMotor(cfg_h1, joint_names=names, joint_ids=slice(None), num_envs=4, device="cpu")
+    out["h1_names_stiffness"] = act.stiffness
+    out["h1_names_damping"] = act.damping
+    out["h1_names_effort_limit"] = act.effort_limit
+    save("actuators_pd", **out)
+
+
+def make_mlp(g, in_dim=6, hidden=32, layers=3, act="softsign"):
+    acts = {"softsign": torch.nn.Softsign, "elu": torch.nn.ELU, "tanh": torch.nn.Tanh, "relu": torch.nn.ReLU}
+    mods, d = [], in_dim
+    for _ in range(layers):
+        mods += [torch.nn.Linear(d, hidden), acts[act]()]
+        d = hidden
+    mods.append(torch.nn.Linear(d, 1))
+    net = torch.nn.Sequential(*mods)
+    with torch.no_grad():
+        for mod in net:
+            if isinstance(mod, torch.nn.Linear):
+                mod.weight.copy_(torch.randn(mod.weight.shape, generator=g) / (mod.in_features ** 0.5))
+                mod.bias.copy_(torch.randn(mod.bias.shape, generator=g) * 0.1)
+    return net
+
+
+@section
+def actuators_mlp():
+    m = R.bootstrap()
+    Types = m["types"]
+    netmod = m["actuator_net"]
+    g = gen(7)
+    n, j, steps = 40, 12, 8
+    out = {}
+    for tag, act_name, order, idx, hidden, layers in (
+        ("go1", "softsign", "pos_vel", [0, 1, 2], 32, 3),  # Unitree Go1 parameters (unitree.py:30-41)
+        ("alt", "elu", "vel_pos", [0, 2, 4], 32, 2),
+    ):
+        net = make_mlp(g, in_dim=2 * len(idx), hidden=hidden, layers=layers, act=act_name)
+        buf = io.BytesIO()
+        torch.jit.save(torch.jit.script(net), buf)
+        buf.seek(0)
+        sys.modules["isaaclab.utils.assets"].read_file = lambda p, b=buf: b
+        netmod.read_file = lambda p, b=buf: b
+        cfg = Cfg(joint_names_expr=[".*"], armature=None, friction=None, stiffness=None, damping=None,
+                  network_file="synthetic", pos_scale=-1.0, vel_scale=1.0, torque_scale=1.0, input_order=order,
+                  input_idx=idx, effort_limit=23.7 if tag == "go1" else 80.0,
+                  velocity_limit=30.0 if tag == "go1" else 7.5, saturation_effort=23.7 if tag == "go1" else 120.0)
+        act = netmod.ActuatorNetMLP(cfg, joint_names=_names(j), joint_ids=slice(None), num_envs=n, device="cpu",
+                                    stiffness=0.0, damping=0.0)
+        rec = dict(q_des=[], q=[], qd=[], computed=[], applied=[], pe_hist=[], v_hist=[])
+        for s in range(steps):
+            q_des = torch.randn(n, j, generator=g)
+            q = q_des + torch.randn(n, j, generator=g) * 0.3
+            qd = torch.randn(n, j, generator=g) * (12.0 if tag == "go1" else 4.0)
+            if s == 5:
+                act.reset([1, 3])
+            ca = Types.ArticulationActions(joint_positions=q_des.clone(), joint_velocities=torch.zeros(n, j),
+                                           joint_efforts=torch.zeros(n, j), joint_indices=slice(None))
+            with torch.no_grad():
+                act.compute(ca, q.clone(), qd.clone())
+            for k, v in zip(rec, (q_des, q, qd, act.computed_effort.detach().clone(), act.applied_effort.detach().clone(),
+                                  act._joint_pos_error_history.clone(), act._joint_vel_history.clone())):
+                rec[k].append(v)
+        out.update({f"{tag}_{k}": torch.stack(v) for k, v in rec.items()})
+        lin = [mod for mod in net if isinstance(mod, torch.nn.Linear)]
+        for li, mod in enumerate(lin):
+            out[f"{tag}_w{li}"] = mod.weight.detach()
+            out[f"{tag}_b{li}"] = mod.bias.detach()
+        out[f"{tag}_nlayers"] = torch.tensor(len(lin))
+    save("actuators_mlp", **out)
+
+
+@section
+def articulation_data():
+    """Real ArticulationData on a fake physics view: derived root quantities and joint_acc."""
+    m = R.bootstrap()
+    physx = sys.modules["omni.physics.tensors.impl.api"]
+
+    class SimView:
+        def set_subspace_roots(self, p):
+            pass
+
+        def get_gravity(self):
+            return (0.0, 0.0, -9.81)
+
+    physx.create_simulation_view = lambda backend: SimView()
+    ad = R.load("isaaclab.assets.articulation.articulation_data", f"{R.L}/assets/articulation/articulation_data.py")
+    g = gen(3001)
+    n, j = 128, 12
+    q = torch.randn(n, 4, generator=g)
+    q = q / q.norm(dim=-1, keepdim=True)
+    root_tf = torch.cat([torch.randn(n, 3, generator=g), q[:, [1, 2, 3, 0]]], dim=-1)  # xyzw like PhysX
+    root_vel = torch.randn(n, 6, generator=g)
+    vels = [torch.randn(n, j, generator=g) * 2.0 for _ in range(4)]
+
+    class View:
+        count = n
+
+        def __init__(self):
+            self.k = 0
+
+        def get_root_transforms(self):
+            return root_tf.clone()
+
+        def get_root_velocities(self):
+            return root_vel.clone()
+
+        def get_dof_positions(self):
+            return torch.zeros(n, j)
+
+        def get_dof_velocities(self):
+            return vels[self.k].clone()
+
+    view = View()
+    data = ad.ArticulationData(view, "cpu")
+    dts = [0.005, 0.005, 0.005]
+    accs = []
+    for i, dt in enumerate(dts):
+        view.k = i + 1
+        data.update(dt)
+        accs.append(data.joint_acc.clone())
+    out = dict(root_transforms_xyzw=root_tf, root_velocities=root_vel, joint_vels=torch.stack(vels),
+               dts=torch.tensor(dts, dtype=torch.float64), joint_acc=torch.stack(accs),
+               root_state_w=data.root_state_w, root_lin_vel_b=data.root_lin_vel_b, root_ang_vel_b=data.root_ang_vel_b,
+               projected_gravity_b=data.projected_gravity_b, heading_w=data.heading_w,
+               gravity_vec=data.GRAVITY_VEC_W[0])
+    # the elapsed times the reference divided by (sim timestamp differences in double)
+    # (TimestampedBuffer.timestamp starts at -1.0, so the first difference is 1 + dt: timestamped_buffer.py)
+    ts, el = 0.0, []
+    last = -1.0
+    for dt in dts:
+        ts += dt
+        el.append(ts - last)
+        last = ts
+    out["time_elapsed"] = torch.tensor(el, dtype=torch.float64)
+    save("articulation_data", **out)
