@@ -76,6 +76,84 @@ int ilx_math_op(int op, const float* a, const float* b, const float* c, const fl
 int ilx_math_range_op(int mode, const float* x, const float* lower, const float* upper, int bounds_per_row,
                       float* out, int64_t n, int w, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * ArticulationData derived quantities — source/isaaclab/isaaclab/assets/articulation/articulation_data.py
+ * ------------------------------------------------------------------------------------------------ */
+
+/* articulation_data.py:263-279  root_state_w (n,13) = [pos, quat wxyz, lin vel, ang vel] from the physics
+ * view's root transforms (n,7; quaternion xyzw) and root velocities (n,6). */
+int ilx_root_state_pack(const float* root_transforms_xyzw, const float* root_velocities, float* root_state,
+                        int64_t n, void* stream);
+
+/* articulation_data.py:502-518 (root_lin_vel_b, root_ang_vel_b), :411-414 (projected_gravity_b, gravity
+ * direction (gx,gy,gz) already normalised), :416-425 (heading_w).  Any output may be NULL. */
+int ilx_root_frame_derive(const float* root_state, float gx, float gy, float gz, float* lin_vel_b,
+                          float* ang_vel_b, float* projected_gravity_b, float* heading_w, int64_t n,
+                          void* stream);
+
+/* articulation_data.py:445-455  joint_acc = (joint_vel - previous_joint_vel) / time_elapsed, then
+ * previous_joint_vel <- joint_vel; `count` = n * num_joints elements. */
+int ilx_joint_acc(const float* joint_vel, float* previous_joint_vel, float* joint_acc, float time_elapsed,
+                  int64_t count, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Actuators — source/isaaclab/isaaclab/actuators/
+ * Per-joint parameters are (j,) when params_per_env == 0, else (n, j) like the reference's buffers.
+ * ------------------------------------------------------------------------------------------------ */
+#define ILX_ACTUATOR_IDEAL_PD 0 /* IdealPDActuator.compute / ImplicitActuator torque estimate: actuator_pd.py:62-87,131-145 */
+#define ILX_ACTUATOR_DC_MOTOR 1 /* DCMotor.compute + _clip_effort: actuator_pd.py:211-233 */
+
+/* computed = kp*(q_des-q) + kd*(qd_des-qd) + tau_ff ; applied = clip (symmetric, or the DC-motor envelope).
+ * qd_des / tau_ff may be NULL (treated as zeros).  All state tensors are (n, j). */
+int ilx_actuator_pd(int model, const float* q_des, const float* qd_des, const float* tau_ff, const float* q,
+                    const float* qd, const float* stiffness, const float* damping, const float* effort_limit,
+                    const float* velocity_limit, int params_per_env, float saturation_effort, float* computed,
+                    float* applied, int64_t n, int j, void* stream);
+
+#define ILX_ACT_SOFTSIGN 0
+#define ILX_ACT_ELU 1
+#define ILX_ACT_TANH 2
+#define ILX_ACT_RELU 3
+#define ILX_ACT_IDENTITY 4
+
+/* Actuator network: Linear(dims[0],dims[1]) act ... Linear(dims[L-1],dims[L]=1); stands in for the
+ * TorchScript module the reference loads at actuator_net.py:128-129.  weights_host[l] is (dims[l+1], dims[l])
+ * row-major (torch.nn.Linear layout), biases_host[l] is (dims[l+1],); HOST pointers, copied to the current
+ * device.  Widths <= 64, input width <= 16. */
+typedef struct ilx_mlp_s* ilx_mlp_t;
+int ilx_mlp_create(int num_layers, const int32_t* dims, int activation, const float* const* weights_host,
+                   const float* const* biases_host, ilx_mlp_t* out);
+void ilx_mlp_destroy(ilx_mlp_t net);
+
+#define ILX_MLP_FORCE_GENERIC 1 /* flags: skip the MFMA path (testing) */
+
+/* ActuatorNetMLP.compute — actuator_net.py:147-188.  In one launch: roll pos_error_history / velocity_history
+ * (n, history_length, j; slot 0 newest) and write q_des - q / qd into slot 0, gather input_idx, scale,
+ * concatenate (input_order 0 = "pos_vel", 1 = "vel_pos"), run the network per (env, joint) row,
+ * computed = out * torque_scale, applied = DC-motor clip. */
+int ilx_actuator_net_mlp(ilx_mlp_t net, const float* q_des, const float* q, const float* qd,
+                         float* pos_error_history, float* velocity_history, int history_length,
+                         const int32_t* input_idx_host, int num_input_idx, int input_order, float pos_scale,
+                         float vel_scale, float torque_scale, const float* effort_limit,
+                         const float* velocity_limit, int params_per_env, float saturation_effort,
+                         float* computed, float* applied, int64_t n, int j, int flags, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Contact sensor bookkeeping — source/isaaclab/isaaclab/sensors/contact_sensor/contact_sensor.py:314-373
+ * plus the update timing of sensors/sensor_base.py:197-205,284-293.
+ * ------------------------------------------------------------------------------------------------ */
+
+/* advance_clock = 1: one SensorBase.update(dt) (timestamp += dt; flag sensors whose period elapsed) followed by
+ * the refresh of the flagged sensors; advance_clock = 0: only SensorBase._update_outdated_buffers (refresh the
+ * sensors already flagged; dt is ignored).  A refresh copies net_forces_in (n,b,3) into net_forces_w, shifts
+ * the history ring (n,h,b,3; slot 0 newest; NULL when h == 0) and advances the air / contact timers (n,b; all
+ * four NULL when air time is not tracked).  timestamp, timestamp_last_update (n,) float and is_outdated (n,)
+ * uint8 are the SensorBase clocks. */
+int ilx_contact_update(const float* net_forces_in, float* net_forces_w, float* history, float* current_air_time,
+                       float* last_air_time, float* current_contact_time, float* last_contact_time,
+                       float* timestamp, float* timestamp_last_update, uint8_t* is_outdated, int advance_clock,
+                       float dt, float update_period, float force_threshold, int64_t n, int b, int h, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

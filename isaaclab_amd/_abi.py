@@ -79,3 +79,14 @@ def f32c(t: torch.Tensor) -> torch.Tensor:
 P = c_void_p
 math_op = _sig("ilx_math_op", c_int, P, P, P, P, P, P, c_int64, P)
 math_range_op = _sig("ilx_math_range_op", c_int, P, P, P, c_int, P, c_int64, c_int, P)
+root_state_pack = _sig("ilx_root_state_pack", P, P, P, c_int64, P)
+root_frame_derive = _sig("ilx_root_frame_derive", P, c_float, c_float, c_float, P, P, P, P, c_int64, P)
+joint_acc = _sig("ilx_joint_acc", P, P, P, c_float, c_int64, P)
+actuator_pd = _sig("ilx_actuator_pd", c_int, P, P, P, P, P, P, P, P, P, c_int, c_float, P, P, c_int64, c_int, P)
+mlp_create = _sig("ilx_mlp_create", c_int, P, c_int, P, P, P)
+lib.ilx_mlp_destroy.argtypes = [P]
+lib.ilx_mlp_destroy.restype = None
+actuator_net_mlp = _sig("ilx_actuator_net_mlp", P, P, P, P, P, P, c_int, P, c_int, c_int, c_float, c_float, c_float,
+                        P, P, c_int, c_float, P, P, c_int64, c_int, c_int, P)
+contact_update = _sig("ilx_contact_update", P, P, P, P, P, P, P, P, P, P, c_int, c_float, c_float, c_float, c_int64, c_int,
+                      c_int, P)

@@ -1,0 +1,95 @@
+"""Actuator-network model on the fused HIP kernel ``ilx_actuator_net_mlp``
+(interface of ``isaaclab/actuators/actuator_net.py:102-188``).
+
+The reference loads an arbitrary TorchScript module; here the network is a stack of Linear layers with one
+activation (softsign / elu / tanh / relu), given as tensors.  History roll, input gather, the network and the
+DC-motor clip run in a single launch; hidden width 32 uses fp32 MFMA.
+"""
+
+from __future__ import annotations
+
+import ctypes
+from collections.abc import Sequence
+
+import torch
+
+from .. import _abi
+from .actuator_pd import DCMotor
+
+_ACT = {"softsign": 0, "elu": 1, "tanh": 2, "relu": 3, "identity": 4}
+
+
+class MlpHandle:
+    """Owns an ``ilx_mlp_t`` (device copy of the weights in kernel order)."""
+
+    def __init__(self, weights: list[torch.Tensor], biases: list[torch.Tensor], activation: str):
+        if activation not in _ACT:
+            raise ValueError(f"unsupported activation '{activation}', expected one of {sorted(_ACT)}")
+        ws = [w.detach().to("cpu", torch.float32).contiguous() for w in weights]
+        bs = [b.detach().to("cpu", torch.float32).contiguous() for b in biases]
+        dims = [ws[0].shape[1]] + [w.shape[0] for w in ws]
+        for i, (w, b) in enumerate(zip(ws, bs)):
+            if w.shape != (dims[i + 1], dims[i]) or b.shape != (dims[i + 1],):
+                raise ValueError(f"layer {i}: weight {tuple(w.shape)} / bias {tuple(b.shape)} do not chain")
+        n = len(ws)
+        c_dims = (ctypes.c_int32 * (n + 1))(*dims)
+        c_w = (ctypes.c_void_p * n)(*[w.data_ptr() for w in ws])
+        c_b = (ctypes.c_void_p * n)(*[b.data_ptr() for b in bs])
+        self.handle = ctypes.c_void_p()
+        _abi.check(_abi.mlp_create(n, c_dims, _ACT[activation], c_w, c_b, ctypes.byref(self.handle)), "ilx_mlp_create")
+        self.dims = dims
+        self.activation = activation
+
+    def __del__(self):
+        h = getattr(self, "handle", None)
+        if h:
+            _abi.lib.ilx_mlp_destroy(h)
+            self.handle = None
+
+
+def load_network(cfg, device) -> tuple[list[torch.Tensor], list[torch.Tensor], str]:
+    """Weights from ``cfg.network`` or from a state-dict file holding ``<k>.weight`` / ``<k>.bias`` pairs."""
+    if getattr(cfg, "network", None) is not None:
+        net = cfg.network
+        return list(net["weights"]), list(net["biases"]), net.get("activation", "softsign")
+    if not cfg.network_file:
+        raise ValueError("ActuatorNetMLPCfg needs `network` or `network_file`")
+    sd = torch.load(cfg.network_file, map_location="cpu", weights_only=True)
+    keys = sorted({k.rsplit(".", 1)[0] for k in sd if k.endswith(".weight")}, key=lambda s: [int(t) if t.isdigit() else t for t in s.split(".")])
+    return [sd[k + ".weight"] for k in keys], [sd[k + ".bias"] for k in keys], sd.get("activation", "softsign")
+
+
+class ActuatorNetMLP(DCMotor):
+    """actuator_net.py:102-188."""
+
+    def __init__(self, cfg, *args, **kwargs):
+        super().__init__(cfg, *args, **kwargs)
+        weights, biases, activation = load_network(cfg, self._device)
+        self.network = MlpHandle(weights, biases, activation)
+        history_length = max(self.cfg.input_idx) + 1
+        self._joint_pos_error_history = torch.zeros(self._num_envs, history_length, self.num_joints, device=self._device)
+        self._joint_vel_history = torch.zeros(self._num_envs, history_length, self.num_joints, device=self._device)
+        self._idx = (ctypes.c_int32 * len(self.cfg.input_idx))(*self.cfg.input_idx)
+        if self.cfg.input_order not in ("pos_vel", "vel_pos"):
+            raise ValueError(f"Invalid input order for MLP actuator net: {self.cfg.input_order}. Must be 'pos_vel' or 'vel_pos'.")
+        self._flags = 0
+
+    def reset(self, env_ids: Sequence[int]):
+        self._joint_pos_error_history[env_ids] = 0.0
+        self._joint_vel_history[env_ids] = 0.0
+
+    def compute(self, control_action, joint_pos, joint_vel):
+        q_des, q, qd = _abi.f32c(control_action.joint_positions), _abi.f32c(joint_pos), _abi.f32c(joint_vel)
+        n, j = q.shape
+        self._joint_vel = joint_vel
+        _abi.check(_abi.actuator_net_mlp(
+            self.network.handle, _abi.ptr(q_des), _abi.ptr(q), _abi.ptr(qd), _abi.ptr(self._joint_pos_error_history),
+            _abi.ptr(self._joint_vel_history), self._joint_pos_error_history.shape[1], self._idx, len(self.cfg.input_idx),
+            0 if self.cfg.input_order == "pos_vel" else 1, float(self.cfg.pos_scale), float(self.cfg.vel_scale),
+            float(self.cfg.torque_scale), _abi.ptr(self.effort_limit), _abi.ptr(self.velocity_limit), 1,
+            float(self._saturation_effort), _abi.ptr(self.computed_effort), _abi.ptr(self.applied_effort), n, j,
+            self._flags, _abi.stream()), "ilx_actuator_net_mlp")
+        control_action.joint_efforts = self.applied_effort
+        control_action.joint_positions = None
+        control_action.joint_velocities = None
+        return control_action

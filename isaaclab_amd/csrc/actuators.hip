@@ -1,0 +1,469 @@
+// Actuator models (reference: isaaclab/actuators/actuator_pd.py, actuator_net.py).
+//
+//  * ilx_actuator_pd       IdealPD / Implicit torque estimate / DCMotor: one thread per (env, joint), streaming.
+//  * ilx_actuator_net_mlp  ActuatorNetMLP: history roll + per-(env,joint) MLP + DC-motor clip in ONE launch.
+//      - fast path: hidden width 32, output width 1 -> chained v_mfma_f32_32x32x2_f32 (exact fp32 MFMA).
+//        One wave owns 32 rows (= (env, joint) pairs).  The network is evaluated transposed,
+//        H_out^T[unit][row] = W[unit][k] * H_in^T[k][row], so a layer's 32x32 accumulator (row on the lane,
+//        units in the 16 registers) is directly the B operand of the next layer's MFMAs: no LDS, no shuffles.
+//        Weights are re-packed once at ilx_mlp_create into the per-lane operand order, so every weight load
+//        is a coalesced 256-byte read.
+//      - generic path: any widths <= 64, one thread per row, activations staged through LDS.
+#include "common.h"
+#include "math_dev.h"
+
+#include <vector>
+
+namespace ilx {
+
+// ------------------------------------------------------------------------------------------------
+// PD family
+// ------------------------------------------------------------------------------------------------
+// actuator_pd.py:223-233
+ILX_DEV float dc_motor_clip(float effort, float qd, float sat, float vel_limit, float effort_limit) {
+    const float ratio = div_(qd, vel_limit);
+    float mx = sat * (1.0f - ratio);
+    mx = fminf(fmaxf(mx, 0.0f), effort_limit);
+    float mn = sat * (-1.0f - ratio);
+    mn = fminf(fmaxf(mn, -effort_limit), 0.0f);
+    return fminf(fmaxf(effort, mn), mx);
+}
+
+template <int MODEL>
+__global__ void __launch_bounds__(256)
+actuator_pd_kernel(const float* __restrict__ q_des, const float* __restrict__ qd_des, const float* __restrict__ tau_ff,
+                   const float* __restrict__ q, const float* __restrict__ qd, const float* __restrict__ kp,
+                   const float* __restrict__ kd, const float* __restrict__ effort_limit,
+                   const float* __restrict__ vel_limit, int per_env, float sat, float* __restrict__ computed,
+                   float* __restrict__ applied, int64_t total, int j) {
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int64_t pi = per_env ? i : (i % j);
+    const float vel = qd[i];
+    // actuator_pd.py:135-138, evaluated left to right
+    const float e_pos = q_des[i] - q[i];
+    const float e_vel = (qd_des ? qd_des[i] : 0.0f) - vel;
+    const float tau = kp[pi] * e_pos + kd[pi] * e_vel + (tau_ff ? tau_ff[i] : 0.0f);
+    const float lim = effort_limit[pi];
+    float out;
+    if (MODEL == 1) {
+        out = dc_motor_clip(tau, vel, sat, vel_limit[pi], lim);
+    } else {
+        out = fminf(fmaxf(tau, -lim), lim);  // actuator_base.py:252-261
+    }
+    computed[i] = tau;
+    applied[i] = out;
+}
+
+// ------------------------------------------------------------------------------------------------
+// MLP
+// ------------------------------------------------------------------------------------------------
+constexpr int kMaxLayers = 8;
+constexpr int kMaxWidth = 64;
+constexpr int kMaxHist = 8;
+
+template <int ACT>
+ILX_DEV float activate(float x) {
+    if (ACT == ILX_ACT_SOFTSIGN) return div_(x, 1.0f + fabsf(x));
+    if (ACT == ILX_ACT_ELU) return x > 0.0f ? x : (expf(x) - 1.0f);
+    if (ACT == ILX_ACT_TANH) return tanhf(x);
+    if (ACT == ILX_ACT_RELU) return fmaxf(x, 0.0f);
+    return x;
+}
+
+struct MlpDev {
+    int num_layers;               // linear layers
+    int dims[kMaxLayers + 1];     // in, h1, ..., out
+    int act;
+    const float* raw;             // per layer: W (out x in, row-major) then b (out)
+    const float* packed;          // MFMA operand order, or nullptr
+    int ks0;                      // k-steps of the first layer (ceil(in/2))
+};
+
+struct NetArgs {
+    MlpDev net;
+    const float* q_des;
+    const float* q;
+    const float* qd;
+    float* pe_hist;
+    float* v_hist;
+    int hist_len;  // K
+    int n_idx;
+    int idx[kMaxHist];
+    int order;  // 0 pos_vel, 1 vel_pos
+    float pos_scale, vel_scale, torque_scale;
+    const float* effort_limit;
+    const float* vel_limit;
+    int per_env;
+    float sat;
+    float* computed;
+    float* applied;
+    int64_t rows;  // N * J
+    int j;
+};
+
+// Reads the row's inputs, forms the network input features, and hands back the old history values.
+// feat[f] follows actuator_net.py:160-171 (input_idx gather, scaling, pos_vel / vel_pos concatenation).
+struct RowIn {
+    float pe_new0, vel;           // q_des - q, qd
+    float pe_old[kMaxHist - 1];   // previous slots 0..K-2
+    float v_old[kMaxHist - 1];
+    float feat[2 * kMaxHist];
+};
+
+ILX_DEV void load_row(const NetArgs& a, int64_t row, bool valid, RowIn& r) {
+    const int64_t env = row / a.j;
+    const int joint = static_cast<int>(row - env * a.j);
+    const int64_t hbase = (env * a.hist_len) * a.j + joint;
+    r.pe_new0 = valid ? (a.q_des[row] - a.q[row]) : 0.0f;
+    r.vel = valid ? a.qd[row] : 0.0f;
+#pragma unroll
+    for (int k = 0; k < kMaxHist - 1; ++k) {
+        const bool on = valid && (k < a.hist_len - 1);
+        r.pe_old[k] = on ? a.pe_hist[hbase + static_cast<int64_t>(k) * a.j] : 0.0f;
+        r.v_old[k] = on ? a.v_hist[hbase + static_cast<int64_t>(k) * a.j] : 0.0f;
+    }
+    float xp[kMaxHist], xv[kMaxHist];
+#pragma unroll
+    for (int m = 0; m < kMaxHist; ++m) {
+        const int id = a.idx[m];
+        float p = r.pe_new0, v = r.vel;
+#pragma unroll
+        for (int k = 0; k < kMaxHist - 1; ++k) {
+            p = (id == k + 1) ? r.pe_old[k] : p;
+            v = (id == k + 1) ? r.v_old[k] : v;
+        }
+        xp[m] = p * a.pos_scale;
+        xv[m] = v * a.vel_scale;
+    }
+#pragma unroll
+    for (int f = 0; f < 2 * kMaxHist; ++f) {
+        float val = 0.0f;
+#pragma unroll
+        for (int m = 0; m < kMaxHist; ++m) {
+            const float first = a.order == 0 ? xp[m] : xv[m];
+            const float second = a.order == 0 ? xv[m] : xp[m];
+            val = (f == m && m < a.n_idx) ? first : val;
+            val = (f == m + a.n_idx && m < a.n_idx) ? second : val;
+        }
+        r.feat[f] = val;
+    }
+}
+
+// actuator_net.py:150-156: roll both histories by one slot and write the newest sample into slot 0.
+ILX_DEV void store_history(const NetArgs& a, int64_t row, const RowIn& r, bool do_pos, bool do_vel) {
+    const int64_t env = row / a.j;
+    const int joint = static_cast<int>(row - env * a.j);
+    const int64_t hbase = (env * a.hist_len) * a.j + joint;
+    if (do_pos) a.pe_hist[hbase] = r.pe_new0;
+    if (do_vel) a.v_hist[hbase] = r.vel;
+#pragma unroll
+    for (int k = 0; k < kMaxHist - 1; ++k) {
+        if (k < a.hist_len - 1) {
+            const int64_t o = hbase + static_cast<int64_t>(k + 1) * a.j;
+            if (do_pos) a.pe_hist[o] = r.pe_old[k];
+            if (do_vel) a.v_hist[o] = r.v_old[k];
+        }
+    }
+}
+
+ILX_DEV void store_torque(const NetArgs& a, int64_t row, float net_out, float vel) {
+    const int64_t pi = a.per_env ? row : (row % a.j);
+    const float tau = net_out * a.torque_scale;  // actuator_net.py:179
+    a.computed[row] = tau;
+    a.applied[row] = dc_motor_clip(tau, vel, a.sat, a.vel_limit[pi], a.effort_limit[pi]);
+}
+
+// ---- generic path ------------------------------------------------------------------------------
+template <int ACT>
+__global__ void __launch_bounds__(128) mlp_generic_kernel(NetArgs a) {
+    // activations of the two most recent layers: [buffer][unit][thread] -> conflict-free LDS columns
+    __shared__ float act[2][kMaxWidth][128];
+    const int t = threadIdx.x;
+    const int64_t row = static_cast<int64_t>(blockIdx.x) * blockDim.x + t;
+    const bool valid = row < a.rows;
+    RowIn r;
+    load_row(a, valid ? row : 0, valid, r);
+#pragma unroll
+    for (int f = 0; f < 2 * kMaxHist; ++f) act[0][f][t] = r.feat[f];
+    const float* p = a.net.raw;
+    int cur = 0;
+    float out = 0.0f;
+    for (int l = 0; l < a.net.num_layers; ++l) {
+        const int din = a.net.dims[l], dout = a.net.dims[l + 1];
+        const float* w = p;
+        const float* b = p + static_cast<int64_t>(din) * dout;
+        const bool last = (l + 1 == a.net.num_layers);
+        for (int o = 0; o < dout; ++o) {
+            float acc = b[o];
+            for (int i = 0; i < din; ++i) acc = fmaf_(w[o * din + i], act[cur][i][t], acc);
+            if (!last) acc = activate<ACT>(acc);
+            act[cur ^ 1][o][t] = acc;
+            out = acc;
+        }
+        p = b + dout;
+        cur ^= 1;
+    }
+    if (valid) {
+        store_torque(a, row, out, r.vel);
+        store_history(a, row, r, true, true);
+    }
+}
+
+// ---- MFMA path -----------------------------------------------------------------------------------
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+// Packed layout (floats), L = number of hidden layers (all 32 wide), lane = 0..63, r = 0..15:
+//   [ks0][64]        first-layer A operands: W0[lane&31][2s + (lane>>5)] (0 beyond in_dim)
+//   L x [16][64]     hidden biases in accumulator order: b_l[unit(r, lane>>5)]
+//   (L-1) x [16][64] hidden A operands: W_l[lane&31][unit(r, lane>>5)]
+//   [16][64]         output weights in accumulator order: w_out[unit(r, lane>>5)]
+//   [1]              output bias
+// where unit(r, h) = (r & 3) + 8 * (r >> 2) + 4 * h is the MFMA 32x32 accumulator row of register r.
+__host__ __device__ inline int acc_unit(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+template <int ACT>
+ILX_DEV f32x16 activate16(f32x16 v) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        if (ACT == ILX_ACT_SOFTSIGN) {
+            v[r] = v[r] * __builtin_amdgcn_rcpf(1.0f + fabsf(v[r]));  // 1 ulp reciprocal; value path only
+        } else {
+            v[r] = activate<ACT>(v[r]);
+        }
+    }
+    return v;
+}
+
+template <int ACT>
+__global__ void __launch_bounds__(256) mlp_mfma_kernel(NetArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int64_t tile = static_cast<int64_t>(blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t row = tile * 32 + (lane & 31);
+    const int half = lane >> 5;
+    if (tile * 32 >= a.rows) return;  // wave-uniform
+    const bool valid = row < a.rows;
+    const int nhid = a.net.num_layers - 1;
+    const float* pk = a.net.packed;
+
+    RowIn r;
+    load_row(a, valid ? row : 0, valid, r);
+
+    // ---- layer 0: K = in_dim, two features per MFMA (half 0 feeds the even one, half 1 the odd one)
+    const float* bias = pk + a.net.ks0 * 64;
+    f32x16 acc;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) acc[k] = bias[k * 64 + lane];
+#pragma unroll
+    for (int s = 0; s < kMaxHist; ++s) {
+        if (s < a.net.ks0) {
+            const float bop = half ? r.feat[2 * s + 1] : r.feat[2 * s];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pk[s * 64 + lane], bop, acc, 0, 0, 0);
+        }
+    }
+    acc = activate16<ACT>(acc);
+
+    // ---- hidden layers 1..L-1: the accumulator registers are the B operands
+    const float* wts = pk + a.net.ks0 * 64 + nhid * 1024;
+    for (int l = 1; l < nhid; ++l) {
+        const float* b = bias + l * 1024;
+        const float* w = wts + (l - 1) * 1024;
+        f32x16 nxt;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) nxt[k] = b[k * 64 + lane];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) nxt = __builtin_amdgcn_mfma_f32_32x32x2f32(w[k * 64 + lane], acc[k], nxt, 0, 0, 0);
+        acc = activate16<ACT>(nxt);
+    }
+
+    // ---- output layer (width 1): per-lane partial dot over its 16 units, then add the other half
+    const float* wo = wts + (nhid - 1) * 1024;
+    float part = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) part = fmaf_(wo[k * 64 + lane], acc[k], part);
+    const float other = __shfl_xor(part, 32, 64);
+    const float out = (half ? other + part : part + other) + wo[1024];
+
+    if (valid) {
+        if (half == 0) store_torque(a, row, out, r.vel);
+        store_history(a, row, r, half == 0, half == 1);
+    }
+}
+
+struct MlpHost {
+    MlpDev dev;
+    float* d_raw = nullptr;
+    float* d_packed = nullptr;
+    int device = 0;
+};
+
+}  // namespace ilx
+
+using namespace ilx;
+
+struct ilx_mlp_s {
+    MlpHost h;
+};
+
+extern "C" int ilx_mlp_create(int num_layers, const int32_t* dims, int activation, const float* const* weights_host,
+                              const float* const* biases_host, ilx_mlp_t* out) {
+    ILX_REQUIRE(out, ILX_EINVAL, "ilx_mlp_create: out is NULL");
+    *out = nullptr;
+    ILX_REQUIRE(num_layers >= 1 && num_layers <= kMaxLayers, ILX_ESHAPE, "ilx_mlp_create: %d layers (1..%d supported)",
+                num_layers, kMaxLayers);
+    ILX_REQUIRE(dims && weights_host && biases_host, ILX_EINVAL, "ilx_mlp_create: NULL argument");
+    ILX_REQUIRE(activation >= 0 && activation <= ILX_ACT_IDENTITY, ILX_EINVAL, "ilx_mlp_create: unknown activation %d",
+                activation);
+    for (int l = 0; l <= num_layers; ++l)
+        ILX_REQUIRE(dims[l] >= 1 && dims[l] <= kMaxWidth, ILX_ESHAPE, "ilx_mlp_create: layer width %d (1..%d supported)",
+                    dims[l], kMaxWidth);
+    ILX_REQUIRE(dims[0] <= 2 * kMaxHist, ILX_ESHAPE, "ilx_mlp_create: input width %d (max %d)", dims[0], 2 * kMaxHist);
+    ILX_REQUIRE(dims[num_layers] == 1, ILX_ESHAPE, "ilx_mlp_create: output width must be 1 (one torque per joint)");
+
+    auto* obj = new ilx_mlp_s();
+    MlpHost& h = obj->h;
+    h.dev.num_layers = num_layers;
+    for (int l = 0; l <= num_layers; ++l) h.dev.dims[l] = dims[l];
+    h.dev.act = activation;
+    h.dev.ks0 = (dims[0] + 1) / 2;
+    (void)hipGetDevice(&h.device);
+
+    std::vector<float> raw;
+    for (int l = 0; l < num_layers; ++l) {
+        raw.insert(raw.end(), weights_host[l], weights_host[l] + static_cast<size_t>(dims[l]) * dims[l + 1]);
+        raw.insert(raw.end(), biases_host[l], biases_host[l] + dims[l + 1]);
+    }
+    int rc = check_hip(hipMalloc(&h.d_raw, raw.size() * sizeof(float)), "ilx_mlp_create: hipMalloc");
+    if (rc == ILX_OK) rc = check_hip(hipMemcpy(h.d_raw, raw.data(), raw.size() * sizeof(float), hipMemcpyHostToDevice),
+                                     "ilx_mlp_create: hipMemcpy");
+    h.dev.raw = h.d_raw;
+    h.dev.packed = nullptr;
+
+    bool mfma = num_layers >= 2;
+    for (int l = 1; l < num_layers; ++l) mfma = mfma && dims[l] == 32;
+    if (rc == ILX_OK && mfma) {
+        const int nhid = num_layers - 1, ks0 = h.dev.ks0;
+        std::vector<float> pk(static_cast<size_t>(ks0) * 64 + static_cast<size_t>(2 * nhid) * 1024 + 1, 0.0f);
+        float* p = pk.data();
+        for (int s = 0; s < ks0; ++s)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int f = 2 * s + (lane >> 5);
+                p[s * 64 + lane] = f < dims[0] ? weights_host[0][(lane & 31) * dims[0] + f] : 0.0f;
+            }
+        p += ks0 * 64;
+        for (int l = 0; l < nhid; ++l)
+            for (int r = 0; r < 16; ++r)
+                for (int lane = 0; lane < 64; ++lane) p[l * 1024 + r * 64 + lane] = biases_host[l][acc_unit(r, lane >> 5)];
+        p += nhid * 1024;
+        for (int l = 1; l < nhid; ++l)
+            for (int r = 0; r < 16; ++r)
+                for (int lane = 0; lane < 64; ++lane)
+                    p[(l - 1) * 1024 + r * 64 + lane] = weights_host[l][(lane & 31) * 32 + acc_unit(r, lane >> 5)];
+        p += (nhid - 1) * 1024;
+        for (int r = 0; r < 16; ++r)
+            for (int lane = 0; lane < 64; ++lane) p[r * 64 + lane] = weights_host[nhid][acc_unit(r, lane >> 5)];
+        p[1024] = biases_host[nhid][0];
+        rc = check_hip(hipMalloc(&h.d_packed, pk.size() * sizeof(float)), "ilx_mlp_create: hipMalloc");
+        if (rc == ILX_OK) rc = check_hip(hipMemcpy(h.d_packed, pk.data(), pk.size() * sizeof(float), hipMemcpyHostToDevice),
+                                         "ilx_mlp_create: hipMemcpy");
+        h.dev.packed = h.d_packed;
+    }
+    if (rc != ILX_OK) {
+        if (h.d_raw) (void)hipFree(h.d_raw);
+        if (h.d_packed) (void)hipFree(h.d_packed);
+        delete obj;
+        return rc;
+    }
+    *out = obj;
+    return ILX_OK;
+}
+
+extern "C" void ilx_mlp_destroy(ilx_mlp_t net) {
+    if (!net) return;
+    if (net->h.d_raw) (void)hipFree(net->h.d_raw);
+    if (net->h.d_packed) (void)hipFree(net->h.d_packed);
+    delete net;
+}
+
+extern "C" int ilx_actuator_pd(int model, const float* q_des, const float* qd_des, const float* tau_ff, const float* q,
+                               const float* qd, const float* stiffness, const float* damping, const float* effort_limit,
+                               const float* velocity_limit, int params_per_env, float saturation_effort, float* computed,
+                               float* applied, int64_t n, int j, void* stream) {
+    ILX_REQUIRE(model == ILX_ACTUATOR_IDEAL_PD || model == ILX_ACTUATOR_DC_MOTOR, ILX_EINVAL,
+                "ilx_actuator_pd: unknown model %d", model);
+    ILX_REQUIRE(n >= 0 && j > 0, ILX_EINVAL, "ilx_actuator_pd: bad shape (%lld, %d)", (long long)n, j);
+    ILX_REQUIRE(q_des && q && qd && stiffness && damping && effort_limit && computed && applied, ILX_EINVAL,
+                "ilx_actuator_pd: NULL operand");
+    ILX_REQUIRE(model != ILX_ACTUATOR_DC_MOTOR || velocity_limit, ILX_EINVAL,
+                "ilx_actuator_pd: the DC motor model needs velocity_limit");
+    const int64_t total = n * j;
+    if (total == 0) return ILX_OK;
+    dim3 g(blocks_for(total)), b(256);
+    hipStream_t s = as_stream(stream);
+    if (model == ILX_ACTUATOR_DC_MOTOR)
+        hipLaunchKernelGGL(actuator_pd_kernel<1>, g, b, 0, s, q_des, qd_des, tau_ff, q, qd, stiffness, damping,
+                           effort_limit, velocity_limit, params_per_env, saturation_effort, computed, applied, total, j);
+    else
+        hipLaunchKernelGGL(actuator_pd_kernel<0>, g, b, 0, s, q_des, qd_des, tau_ff, q, qd, stiffness, damping,
+                           effort_limit, velocity_limit, params_per_env, saturation_effort, computed, applied, total, j);
+    ILX_LAUNCH_CHECK("ilx_actuator_pd");
+    return ILX_OK;
+}
+
+template <int ACT>
+static void launch_mlp(const NetArgs& a, bool force_generic, hipStream_t s) {
+    if (a.net.packed && !force_generic) {
+        const int64_t tiles = (a.rows + 31) / 32;
+        hipLaunchKernelGGL(mlp_mfma_kernel<ACT>, dim3(static_cast<unsigned>((tiles + 3) / 4)), dim3(256), 0, s, a);
+    } else {
+        hipLaunchKernelGGL(mlp_generic_kernel<ACT>, dim3(blocks_for(a.rows, 128)), dim3(128), 0, s, a);
+    }
+}
+
+extern "C" int ilx_actuator_net_mlp(ilx_mlp_t net, const float* q_des, const float* q, const float* qd,
+                                    float* pos_error_history, float* velocity_history, int history_length,
+                                    const int32_t* input_idx_host, int num_input_idx, int input_order, float pos_scale,
+                                    float vel_scale, float torque_scale, const float* effort_limit,
+                                    const float* velocity_limit, int params_per_env, float saturation_effort,
+                                    float* computed, float* applied, int64_t n, int j, int flags, void* stream) {
+    ILX_REQUIRE(net, ILX_EINVAL, "ilx_actuator_net_mlp: net is NULL");
+    ILX_REQUIRE(n >= 0 && j > 0, ILX_EINVAL, "ilx_actuator_net_mlp: bad shape (%lld, %d)", (long long)n, j);
+    ILX_REQUIRE(q_des && q && qd && pos_error_history && velocity_history && effort_limit && velocity_limit && computed &&
+                    applied && input_idx_host,
+                ILX_EINVAL, "ilx_actuator_net_mlp: NULL operand");
+    ILX_REQUIRE(history_length >= 1 && history_length <= kMaxHist, ILX_ESHAPE,
+                "ilx_actuator_net_mlp: history length %d (1..%d supported)", history_length, kMaxHist);
+    ILX_REQUIRE(num_input_idx >= 1 && num_input_idx <= kMaxHist, ILX_ESHAPE, "ilx_actuator_net_mlp: %d input indices",
+                num_input_idx);
+    ILX_REQUIRE(2 * num_input_idx == net->h.dev.dims[0], ILX_ESHAPE,
+                "ilx_actuator_net_mlp: network input width %d != 2 * %d input indices", net->h.dev.dims[0], num_input_idx);
+    ILX_REQUIRE(input_order == 0 || input_order == 1, ILX_EINVAL, "ilx_actuator_net_mlp: input_order must be 0 or 1");
+    NetArgs a;
+    a.net = net->h.dev;
+    a.q_des = q_des, a.q = q, a.qd = qd;
+    a.pe_hist = pos_error_history, a.v_hist = velocity_history;
+    a.hist_len = history_length;
+    a.n_idx = num_input_idx;
+    for (int m = 0; m < kMaxHist; ++m) {
+        a.idx[m] = m < num_input_idx ? input_idx_host[m] : 0;
+        ILX_REQUIRE(a.idx[m] >= 0 && a.idx[m] < history_length, ILX_EINVAL,
+                    "ilx_actuator_net_mlp: input index %d outside the history (length %d)", a.idx[m], history_length);
+    }
+    a.order = input_order;
+    a.pos_scale = pos_scale, a.vel_scale = vel_scale, a.torque_scale = torque_scale;
+    a.effort_limit = effort_limit, a.vel_limit = velocity_limit, a.per_env = params_per_env, a.sat = saturation_effort;
+    a.computed = computed, a.applied = applied;
+    a.rows = n * j, a.j = j;
+    if (a.rows == 0) return ILX_OK;
+    hipStream_t s = as_stream(stream);
+    const bool generic = (flags & ILX_MLP_FORCE_GENERIC) != 0;
+    switch (a.net.act) {
+        case ILX_ACT_SOFTSIGN: launch_mlp<ILX_ACT_SOFTSIGN>(a, generic, s); break;
+        case ILX_ACT_ELU: launch_mlp<ILX_ACT_ELU>(a, generic, s); break;
+        case ILX_ACT_TANH: launch_mlp<ILX_ACT_TANH>(a, generic, s); break;
+        case ILX_ACT_RELU: launch_mlp<ILX_ACT_RELU>(a, generic, s); break;
+        default: launch_mlp<ILX_ACT_IDENTITY>(a, generic, s); break;
+    }
+    ILX_LAUNCH_CHECK("ilx_actuator_net_mlp");
+    return ILX_OK;
+}

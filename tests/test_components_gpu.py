@@ -1,0 +1,196 @@
+"""GPU: actuator / articulation-data / contact-sensor classes (HIP through the C ABI) against the oracle and
+the reference-generated fixtures."""
+
+import types
+
+import pytest
+import torch
+
+from conftest import assert_close, assert_exact, load_golden
+from oracle import actuators as OA
+
+pytestmark = pytest.mark.gpu
+
+
+def _names(j):
+    return [f"joint_{i}" for i in range(j)]
+
+
+def test_pd_actuators(dev):
+    from isaaclab_amd.actuators import DCMotor, DCMotorCfg, IdealPDActuator, IdealPDActuatorCfg, ImplicitActuator
+    from isaaclab_amd.utils.types import ArticulationActions
+
+    g = load_golden("actuators_pd")
+    n, j = g["ideal_q"].shape[1:]
+    cfg_pd = IdealPDActuatorCfg(stiffness=25.0, damping=0.5, effort_limit=23.5, velocity_limit=30.0)
+    cfg_dc = DCMotorCfg(stiffness={".*": 40.0}, damping={".*": 5.0}, effort_limit=80.0, velocity_limit=7.5,
+                        saturation_effort=120.0)
+    for tag, cls, cfg in (("ideal", IdealPDActuator, cfg_pd), ("implicit", ImplicitActuator, cfg_pd),
+                          ("dcmotor", DCMotor, cfg_dc)):
+        act = cls(cfg, joint_names=_names(j), joint_ids=slice(None), num_envs=n, device=dev)
+        assert_exact(act.stiffness, g[f"{tag}_stiffness"], f"{tag} stiffness buffer")
+        for s in range(g[f"{tag}_q"].shape[0]):
+            ca = ArticulationActions(joint_positions=g[f"{tag}_q_des"][s].to(dev), joint_velocities=g[f"{tag}_qd_des"][s].to(dev),
+                                     joint_efforts=g[f"{tag}_tau_ff"][s].to(dev), joint_indices=slice(None))
+            out = act.compute(ca, g[f"{tag}_q"][s].to(dev), g[f"{tag}_qd"][s].to(dev))
+            assert_exact(act.computed_effort, g[f"{tag}_computed"][s], f"{tag} computed step {s}")
+            assert_exact(act.applied_effort, g[f"{tag}_applied"][s], f"{tag} applied step {s}")
+            if tag == "implicit":
+                assert out.joint_positions is not None
+            else:
+                assert out.joint_positions is None and out.joint_efforts is act.applied_effort
+
+
+def test_pd_regex_parameters(dev):
+    from isaaclab_amd.actuators import DCMotor, DCMotorCfg
+
+    g = load_golden("actuators_pd")
+    names = ["left_hip_yaw", "left_knee", "torso", "left_ankle", "right_knee"]
+    cfg = DCMotorCfg(stiffness={".*_hip_yaw": 150.0, ".*_knee": 200.0, "torso": 200.0, ".*_ankle": 20.0},
+                     damping={".*_hip_yaw": 5.0, ".*_knee": 5.0, "torso": 5.0, ".*_ankle": 4.0},
+                     effort_limit={".*_hip_yaw": 300.0, ".*_knee": 300.0, "torso": 300.0, ".*_ankle": 100.0},
+                     velocity_limit=100.0, saturation_effort=300.0)
+    act = DCMotor(cfg, joint_names=names, joint_ids=slice(None), num_envs=4, device=dev)
+    assert_exact(act.stiffness, g["h1_names_stiffness"], "stiffness")
+    assert_exact(act.damping, g["h1_names_damping"], "damping")
+    assert_exact(act.effort_limit, g["h1_names_effort_limit"], "effort_limit")
+    with pytest.raises(ValueError):
+        DCMotor(DCMotorCfg(stiffness={"nope": 1.0}, damping=0.0, velocity_limit=1.0), joint_names=names,
+                joint_ids=slice(None), num_envs=4, device=dev)
+
+
+@pytest.mark.parametrize("generic", [False, True])
+def test_actuator_net_mlp(dev, generic):
+    from isaaclab_amd.actuators import ActuatorNetMLP, ActuatorNetMLPCfg
+    from isaaclab_amd.utils.types import ArticulationActions
+
+    g = load_golden("actuators_mlp")
+    for tag, actname, order, idx, lim, vl, sat in (("go1", "softsign", "pos_vel", [0, 1, 2], 23.7, 30.0, 23.7),
+                                                   ("alt", "elu", "vel_pos", [0, 2, 4], 80.0, 7.5, 120.0)):
+        nl = int(g[f"{tag}_nlayers"])
+        net = dict(weights=[g[f"{tag}_w{i}"] for i in range(nl)], biases=[g[f"{tag}_b{i}"] for i in range(nl)],
+                   activation=actname)
+        n, j = g[f"{tag}_q"].shape[1:]
+        cfg = ActuatorNetMLPCfg(network=net, pos_scale=-1.0, vel_scale=1.0, torque_scale=1.0, input_order=order,
+                                input_idx=idx, effort_limit=lim, velocity_limit=vl, saturation_effort=sat)
+        act = ActuatorNetMLP(cfg, joint_names=_names(j), joint_ids=slice(None), num_envs=n, device=dev)
+        act._flags = 1 if generic else 0
+        for s in range(g[f"{tag}_q"].shape[0]):
+            if s == 5:
+                act.reset([1, 3])
+            ca = ArticulationActions(joint_positions=g[f"{tag}_q_des"][s].to(dev))
+            act.compute(ca, g[f"{tag}_q"][s].to(dev), g[f"{tag}_qd"][s].to(dev))
+            assert_exact(act._joint_pos_error_history, g[f"{tag}_pe_hist"][s], f"{tag} pos-error history step {s}")
+            assert_exact(act._joint_vel_history, g[f"{tag}_v_hist"][s], f"{tag} velocity history step {s}")
+            # torques are O(1..20): 1e-5 relative with an absolute floor of 2e-5 for near-zero outputs
+            assert_close(act.computed_effort, g[f"{tag}_computed"][s], atol=2e-5, what=f"{tag} computed step {s}")
+            assert_close(act.applied_effort, g[f"{tag}_applied"][s], atol=2e-5, what=f"{tag} applied step {s}")
+
+
+def test_actuator_net_mlp_anymal_shape_vs_oracle(dev):
+    """16k-env shape (196,608 rows), MFMA path vs the oracle; also a row count that is not a multiple of 32."""
+    from isaaclab_amd.actuators import ActuatorNetMLP, ActuatorNetMLPCfg
+    from isaaclab_amd.utils.types import ArticulationActions
+
+    gen = torch.Generator().manual_seed(7)
+    dims = [6, 32, 32, 32, 1]
+    ws = [torch.randn(dims[i + 1], dims[i], generator=gen) / dims[i] ** 0.5 for i in range(4)]
+    bs = [torch.randn(dims[i + 1], generator=gen) * 0.1 for i in range(4)]
+    for n in (16384, 37):
+        j = 12
+        cfg = ActuatorNetMLPCfg(network=dict(weights=ws, biases=bs, activation="softsign"), pos_scale=-1.0, vel_scale=1.0,
+                                torque_scale=1.0, input_order="pos_vel", input_idx=[0, 1, 2], effort_limit=80.0,
+                                velocity_limit=7.5, saturation_effort=120.0)
+        act = ActuatorNetMLP(cfg, joint_names=_names(j), joint_ids=slice(None), num_envs=n, device=dev)
+        pe, vh = torch.zeros(n, 3, j), torch.zeros(n, 3, j)
+        lim, vl = torch.full((n, j), 80.0), torch.full((n, j), 7.5)
+        for s in range(3):
+            q_des = torch.randn(n, j, generator=gen)
+            q = q_des + torch.randn(n, j, generator=gen) * 0.3
+            qd = torch.randn(n, j, generator=gen) * 3.0
+            comp, app, pe, vh = OA.actuator_net_mlp(q_des, q, qd, pe, vh, ws, bs, "softsign", [0, 1, 2], "pos_vel", -1.0,
+                                                    1.0, 1.0, lim, vl, 120.0)
+            act.compute(ArticulationActions(joint_positions=q_des.to(dev)), q.to(dev), qd.to(dev))
+            assert_exact(act._joint_pos_error_history, pe, f"n={n} history step {s}")
+            assert_close(act.computed_effort, comp, atol=2e-5, what=f"n={n} computed step {s}")
+            assert_close(act.applied_effort, app, atol=2e-5, what=f"n={n} applied step {s}")
+
+
+def test_articulation_data(dev):
+    from isaaclab_amd.assets.articulation_data import ArticulationData
+
+    g = load_golden("articulation_data")
+    n, j = g["joint_vels"].shape[1:]
+    data = ArticulationData(n, j, 1, dev)
+    data._previous_joint_vel = g["joint_vels"][0].to(dev).clone()
+    data.set_sim_state(root_transforms_xyzw=g["root_transforms_xyzw"].to(dev), root_velocities=g["root_velocities"].to(dev))
+    assert_exact(data.root_state_w, g["root_state_w"], "root_state_w")
+    assert_exact(data.GRAVITY_VEC_W[0], g["gravity_vec"], "gravity direction")
+    for i in range(g["joint_acc"].shape[0]):
+        data.set_sim_state(joint_vel=g["joint_vels"][i + 1].to(dev))
+        data.update(float(g["dts"][i]))
+        assert_exact(data.joint_acc, g["joint_acc"][i], f"joint_acc step {i}")
+    assert_exact(data.root_lin_vel_b, g["root_lin_vel_b"], "root_lin_vel_b")
+    assert_exact(data.root_ang_vel_b, g["root_ang_vel_b"], "root_ang_vel_b")
+    assert_exact(data.projected_gravity_b, g["projected_gravity_b"], "projected_gravity_b")
+    assert_close(data.heading_w, g["heading_w"], what="heading_w")
+
+
+def _drive_contact(dev, g, period, reset_step=None, reset_ids=None):
+    from isaaclab_amd.sensors.contact_sensor import ContactSensor, ContactSensorCfg
+
+    f = g["forces"]
+    steps, n, b, _ = f.shape
+    h = g["hist"].shape[2]
+    s = ContactSensor(ContactSensorCfg(update_period=period, history_length=h, track_air_time=True, force_threshold=1.0),
+                      n, [f"body_{i}" for i in range(b)], dev)
+    for k in range(steps):
+        if reset_step is not None and k == reset_step:
+            s.reset(reset_ids)
+        s.set_net_contact_forces(f[k].to(dev))
+        s.update(0.005)
+        yield k, s
+
+
+def test_contact_sensor(dev):
+    g = load_golden("contact_sensor")
+    for k, s in _drive_contact(dev, g, 0.005, int(g["reset_step"]), g["reset_ids"].tolist()):
+        d = s.data
+        for key, val in (("net", d.net_forces_w), ("hist", d.net_forces_w_history), ("cur_air", d.current_air_time),
+                         ("last_air", d.last_air_time), ("cur_contact", d.current_contact_time),
+                         ("last_contact", d.last_contact_time), ("ts", s._timestamp), ("ts_last", s._timestamp_last_update)):
+            assert_exact(val, g[key][k], f"{key} step {k}")
+        assert_exact(s.compute_first_contact(0.02), g["first_contact"][k], f"first_contact step {k}")
+        assert_exact(s.compute_first_air(0.02), g["first_air"][k], f"first_air step {k}")
+
+
+def test_contact_sensor_slow_period(dev):
+    g = load_golden("contact_sensor")
+    for k, s in _drive_contact(dev, g, 0.02):
+        assert_exact(s._data.net_forces_w_history, g["slow_hist"][k], f"slow hist step {k}")
+        assert_exact(s._data.current_air_time, g["slow_cur_air"][k], f"slow cur_air step {k}")
+        assert_exact(s._data.current_contact_time, g["slow_cur_contact"][k], f"slow cur_contact step {k}")
+        assert_exact(s._is_outdated, g["slow_outdated"][k], f"slow outdated step {k}")
+
+
+def test_contact_sensor_many_bodies(dev):
+    """More bodies than threads in a block (the strided path), vs the oracle."""
+    from isaaclab_amd.sensors.contact_sensor import ContactSensor, ContactSensorCfg
+    from oracle import contact as OC
+
+    gen = torch.Generator().manual_seed(5)
+    n, b, h = 5, 300, 2
+    s = ContactSensor(ContactSensorCfg(update_period=0.0, history_length=h, track_air_time=True), n,
+                      [f"b{i}" for i in range(b)], dev)
+    st = dict(net=torch.zeros(n, b, 3), hist=torch.zeros(n, h, b, 3), ca=torch.zeros(n, b), la=torch.zeros(n, b),
+              cc=torch.zeros(n, b), lc=torch.zeros(n, b), ts=torch.zeros(n), tl=torch.zeros(n),
+              od=torch.ones(n, dtype=torch.bool))
+    for k in range(4):
+        f = torch.randn(n, b, 3, generator=gen) * (torch.rand(n, b, 1, generator=gen) < 0.5)
+        OC.contact_update(f, st["net"], st["hist"], st["ca"], st["la"], st["cc"], st["lc"], st["ts"], st["tl"], st["od"],
+                          0.01, 0.0, 1.0)
+        s.set_net_contact_forces(f.to(dev))
+        s.update(0.01)
+        assert_exact(s.data.net_forces_w_history, st["hist"], f"hist step {k}")
+        assert_exact(s.data.current_air_time, st["ca"], f"cur_air step {k}")
+        assert_exact(s.data.last_contact_time, st["lc"], f"last_contact step {k}")
