@@ -154,6 +154,38 @@ int ilx_contact_update(const float* net_forces_in, float* net_forces_w, float* h
                        float* timestamp, float* timestamp_last_update, uint8_t* is_outdated, int advance_clock,
                        float dt, float update_period, float force_threshold, int64_t n, int b, int h, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Mesh ray casting — source/isaaclab/isaaclab/utils/warp/ops.py, utils/warp/kernels.py,
+ * sensors/ray_caster/ray_caster.py
+ * ------------------------------------------------------------------------------------------------ */
+
+/* convert_to_warp_mesh (ops.py:130-145): builds the acceleration structure (4-wide BVH) for a triangle mesh
+ * given as HOST arrays: vertices (num_verts, 3) float32 and triangles (num_tris, 3) int32.  The handle owns
+ * device memory on the current device and is immutable. */
+typedef struct ilx_mesh_s* ilx_mesh_t;
+int ilx_mesh_create(const float* verts_host, int64_t num_verts, const int32_t* tris_host, int64_t num_tris,
+                    ilx_mesh_t* out);
+void ilx_mesh_destroy(ilx_mesh_t mesh);
+int ilx_mesh_info(ilx_mesh_t mesh, int64_t* num_tris, int64_t* num_nodes, int32_t* depth);
+
+/* raycast_mesh (ops.py:24-127) + raycast_mesh_kernel (kernels.py:13-75): closest hit per ray with
+ * 0 <= t < max_dist; ray_hits (n,3) = start + t*dir, +inf on a miss; optional outputs (NULL to skip):
+ * ray_distance (n) [+inf], ray_normal (n,3) unit face normal [+inf], ray_face_id (n) int32 [-1].
+ * Ties in t go to the lowest face index. */
+int ilx_raycast_mesh(ilx_mesh_t mesh, const float* ray_starts, const float* ray_directions, int64_t num_rays,
+                     float max_dist, float* ray_hits, float* ray_distance, float* ray_normal, int32_t* ray_face_id,
+                     void* stream);
+
+/* RayCaster._update_buffers_impl (ray_caster.py:242-260) in one launch: for every env flagged in env_mask
+ * (n) uint8 (NULL = all), rotate the local ray starts (num_rays,3) by the sensor orientation quat_w (n,4)
+ * (yaw only when attach_yaw_only, directions then stay unrotated), add pos_w (n,3), cast, and write
+ * ray_hits_w (n,num_rays,3).  If height_scan (n,num_rays) is not NULL it receives
+ * pos_w.z - hit.z - height_offset (observations.py:165-173). */
+int ilx_raycaster_update(ilx_mesh_t mesh, const float* pos_w, const float* quat_w, const float* ray_starts_local,
+                         const float* ray_directions_local, const uint8_t* env_mask, int attach_yaw_only,
+                         float max_dist, float* ray_hits_w, float* height_scan, float height_offset, int64_t n,
+                         int num_rays, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -90,3 +90,9 @@ actuator_net_mlp = _sig("ilx_actuator_net_mlp", P, P, P, P, P, P, c_int, P, c_in
                         P, P, c_int, c_float, P, P, c_int64, c_int, c_int, P)
 contact_update = _sig("ilx_contact_update", P, P, P, P, P, P, P, P, P, P, c_int, c_float, c_float, c_float, c_int64, c_int,
                       c_int, P)
+mesh_create = _sig("ilx_mesh_create", P, c_int64, P, c_int64, P)
+lib.ilx_mesh_destroy.argtypes = [P]
+lib.ilx_mesh_destroy.restype = None
+mesh_info = _sig("ilx_mesh_info", P, P, P, P)
+raycast_mesh = _sig("ilx_raycast_mesh", P, P, P, c_int64, c_float, P, P, P, P, P)
+raycaster_update = _sig("ilx_raycaster_update", P, P, P, P, P, P, c_int, c_float, P, P, c_float, c_int64, c_int, P)

@@ -1,0 +1,509 @@
+// Mesh ray casting for the RayCaster sensor (reference: isaaclab/utils/warp/ops.py:24-127,
+// isaaclab/utils/warp/kernels.py:13-75, isaaclab/sensors/ray_caster/ray_caster.py:220-260).
+//
+// Acceleration structure: a 4-wide BVH built on the host at ilx_mesh_create.
+//   * triangles are sorted along a 63-bit Morton curve of their centroids; a node splits its range of the
+//     sorted order into four equal-count children; ranges of <= 4 triangles become leaves;
+//   * nodes are numbered breadth first, so the top of the tree is one contiguous prefix that every block
+//     stages into LDS once; each node is one 128-byte line: child boxes as SoA float4s + 4 child references;
+//   * leaf triangles are stored in leaf order as (v0, e1, e2, original face id) in three float4s.
+// Traversal: one lane per ray, per-lane stack of child references in LDS ([slot][thread] -> conflict free),
+// children pushed far-to-near.  Box culling is conservative (boxes are inflated at build time and the slab test
+// carries slack), so the result equals testing every triangle: closest t, ties to the lowest face index.
+#include "common.h"
+#include "raytri.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <numeric>
+#include <vector>
+
+namespace ilx {
+
+constexpr int kLeafSize = 4;
+constexpr int kStackSlots = 40;       // 3 pushes net per level, depth <= 12, plus slack
+constexpr int kMaxDepth = 12;
+constexpr int kCachedNodes = 85;      // levels 0..3 of the 4-wide tree
+constexpr int kRayBlock = 256;
+constexpr int kEmptyRef = INT32_MIN;
+
+struct alignas(16) Node {
+    float minx[4], miny[4], minz[4], maxx[4], maxy[4], maxz[4];
+    int32_t ref[4];   // >= 0: node index;  < 0 (and != kEmptyRef): leaf -(1 + (first << 2 | (count - 1)))
+    int32_t pad[4];
+};
+static_assert(sizeof(Node) == 128, "one node per 128-byte line");
+
+struct MeshDev {
+    const Node* nodes;
+    const float4* tris;  // 3 float4 per triangle, leaf order
+    int32_t num_nodes;
+    int32_t num_tris;
+};
+
+struct Hit {
+    float t;
+    int32_t face;
+    f3 normal_raw;  // e1 x e2 of the hit face (not normalised)
+};
+
+// Closed-interval slab test with explicit handling of zero direction components (a ray that runs inside a
+// slab's boundary plane counts as overlapping).  Returns the entry distance, or +inf when the box is missed.
+ILX_DEV float ray_box(f3 o, f3 inv, bool zx, bool zy, bool zz, float bminx, float bminy, float bminz, float bmaxx,
+                      float bmaxy, float bmaxz, float t_limit) {
+    const float inf = __builtin_inff();
+    float t0 = 0.0f, t1 = t_limit;
+    bool ok = true;
+    if (zx) {
+        ok = ok && (o.x >= bminx && o.x <= bmaxx);
+    } else {
+        const float a = (bminx - o.x) * inv.x, b = (bmaxx - o.x) * inv.x;
+        t0 = fmaxf(t0, fminf(a, b));
+        t1 = fminf(t1, fmaxf(a, b));
+    }
+    if (zy) {
+        ok = ok && (o.y >= bminy && o.y <= bmaxy);
+    } else {
+        const float a = (bminy - o.y) * inv.y, b = (bmaxy - o.y) * inv.y;
+        t0 = fmaxf(t0, fminf(a, b));
+        t1 = fminf(t1, fmaxf(a, b));
+    }
+    if (zz) {
+        ok = ok && (o.z >= bminz && o.z <= bmaxz);
+    } else {
+        const float a = (bminz - o.z) * inv.z, b = (bmaxz - o.z) * inv.z;
+        t0 = fmaxf(t0, fminf(a, b));
+        t1 = fminf(t1, fmaxf(a, b));
+    }
+    // slack: rounding in the slab arithmetic must never cull a box whose triangle the exact formula hits
+    ok = ok && (t0 <= t1 * (1.0f + 4.0e-6f) + 1.0e-6f);
+    return ok ? t0 : inf;
+}
+
+// `stack` points at this thread's column of an LDS array laid out [slot][blockDim.x].
+// `cache` holds the first `ncache` nodes (LDS).
+template <bool WANT_NORMAL>
+ILX_DEV Hit trace(const MeshDev& m, const Node* cache, int ncache, int32_t* stack, int stride, f3 o, f3 d,
+                  float max_dist) {
+    const float inf = __builtin_inff();
+    Hit best{inf, -1, {0.0f, 0.0f, 0.0f}};
+    float limit = max_dist;  // candidates must satisfy t < max_dist; afterwards t <= best.t
+    const bool zx = d.x == 0.0f, zy = d.y == 0.0f, zz = d.z == 0.0f;
+    const f3 inv = {zx ? 0.0f : div_(1.0f, d.x), zy ? 0.0f : div_(1.0f, d.y), zz ? 0.0f : div_(1.0f, d.z)};
+    int sp = 0;
+    stack[0] = 0;
+    sp = 1;
+    while (sp > 0) {
+        const int32_t ref = stack[(--sp) * stride];
+        if (ref >= 0) {
+            const Node* n = (ref < ncache) ? (cache + ref) : (m.nodes + ref);
+            const float4 mnx = *reinterpret_cast<const float4*>(n->minx), mny = *reinterpret_cast<const float4*>(n->miny),
+                         mnz = *reinterpret_cast<const float4*>(n->minz), mxx = *reinterpret_cast<const float4*>(n->maxx),
+                         mxy = *reinterpret_cast<const float4*>(n->maxy), mxz = *reinterpret_cast<const float4*>(n->maxz);
+            const int4 refs = *reinterpret_cast<const int4*>(n->ref);
+            const float cut = limit * (1.0f + 1.0e-5f) + 1.0e-6f;
+            float tn[4];
+            int32_t rf[4] = {refs.x, refs.y, refs.z, refs.w};
+            tn[0] = ray_box(o, inv, zx, zy, zz, mnx.x, mny.x, mnz.x, mxx.x, mxy.x, mxz.x, cut);
+            tn[1] = ray_box(o, inv, zx, zy, zz, mnx.y, mny.y, mnz.y, mxx.y, mxy.y, mxz.y, cut);
+            tn[2] = ray_box(o, inv, zx, zy, zz, mnx.z, mny.z, mnz.z, mxx.z, mxy.z, mxz.z, cut);
+            tn[3] = ray_box(o, inv, zx, zy, zz, mnx.w, mny.w, mnz.w, mxx.w, mxy.w, mxz.w, cut);
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (rf[c] == kEmptyRef) tn[c] = inf;
+            // sort descending by entry distance (5-comparator network), so the nearest child is popped first
+#define ILX_CSWAP(i, j)                    \
+    if (tn[i] < tn[j]) {                   \
+        const float tf = tn[i];            \
+        tn[i] = tn[j];                     \
+        tn[j] = tf;                        \
+        const int32_t ti = rf[i];          \
+        rf[i] = rf[j];                     \
+        rf[j] = ti;                        \
+    }
+            ILX_CSWAP(0, 1) ILX_CSWAP(2, 3) ILX_CSWAP(0, 2) ILX_CSWAP(1, 3) ILX_CSWAP(1, 2)
+#undef ILX_CSWAP
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                if (tn[c] < inf && sp < kStackSlots) {
+                    stack[sp * stride] = rf[c];
+                    ++sp;
+                }
+            }
+        } else {
+            const int32_t code = -(ref + 1);
+            const int32_t first = code >> 2, count = (code & 3) + 1;
+            for (int k = 0; k < count; ++k) {
+                const float4* tp = m.tris + 3 * static_cast<int64_t>(first + k);
+                const float4 a = tp[0], b = tp[1], c = tp[2];
+                const f3 v0 = {a.x, a.y, a.z}, e1 = {a.w, b.x, b.y}, e2 = {b.z, b.w, c.x};
+                const int32_t face = __float_as_int(c.y);
+                float t;
+                if (ray_triangle(o, d, v0, e1, e2, max_dist, t)) {
+                    if (t < best.t || (t == best.t && face < best.face)) {
+                        best.t = t;
+                        best.face = face;
+                        limit = t;
+                        if (WANT_NORMAL) best.normal_raw = cross3(e1, e2);
+                    }
+                }
+            }
+        }
+    }
+    return best;
+}
+
+ILX_DEV void stage_nodes(const MeshDev& m, Node* cache, int ncache) {
+    // 128-byte nodes copied as float4s by the whole block
+    const float4* src = reinterpret_cast<const float4*>(m.nodes);
+    float4* dst = reinterpret_cast<float4*>(cache);
+    for (int i = threadIdx.x; i < ncache * 8; i += blockDim.x) dst[i] = src[i];
+    __syncthreads();
+}
+
+struct CastArgs {
+    MeshDev mesh;
+    const float* starts;  // (n,3)
+    const float* dirs;    // (n,3)
+    float max_dist;
+    float* hits;          // (n,3)
+    float* dist;          // (n) or null
+    float* normal;        // (n,3) or null
+    int32_t* face;        // (n) or null
+    int64_t n;
+};
+
+ILX_DEV void write_hit(const Hit& h, f3 o, f3 d, float* hits, float* dist, float* normal, int32_t* face, int64_t i) {
+    const float inf = __builtin_inff();
+    const bool ok = h.face >= 0;
+    // kernels.py:69: start + t * dir (no fused multiply-add)
+    const f3 p = ok ? f3{o.x + h.t * d.x, o.y + h.t * d.y, o.z + h.t * d.z} : f3{inf, inf, inf};
+    store3(hits + 3 * i, p);
+    if (dist) dist[i] = ok ? h.t : inf;
+    if (face) face[i] = ok ? h.face : -1;
+    if (normal) store3(normal + 3 * i, ok ? normalize3(h.normal_raw) : f3{inf, inf, inf});
+}
+
+__global__ void __launch_bounds__(kRayBlock) raycast_kernel(CastArgs a) {
+    __shared__ Node cache[kCachedNodes];
+    __shared__ int32_t stack[kStackSlots * kRayBlock];
+    const int ncache = min(a.mesh.num_nodes, kCachedNodes);
+    stage_nodes(a.mesh, cache, ncache);
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * kRayBlock + threadIdx.x; i < a.n;
+         i += static_cast<int64_t>(gridDim.x) * kRayBlock) {
+        const f3 o = load3(a.starts + 3 * i), d = load3(a.dirs + 3 * i);
+        const Hit h = a.normal ? trace<true>(a.mesh, cache, ncache, stack + threadIdx.x, kRayBlock, o, d, a.max_dist)
+                               : trace<false>(a.mesh, cache, ncache, stack + threadIdx.x, kRayBlock, o, d, a.max_dist);
+        write_hit(h, o, d, a.hits, a.dist, a.normal, a.face, i);
+    }
+}
+
+// RayCaster._update_buffers_impl fused with the cast: sensor pose -> world rays -> hits (+ height-scan term).
+struct ScanArgs {
+    MeshDev mesh;
+    const float* pos_w;       // (n,3) sensor position (drift already applied)
+    const float* quat_w;      // (n,4) wxyz
+    const float* ray_starts;  // (r,3) local
+    const float* ray_dirs;    // (r,3) local
+    const uint8_t* env_mask;  // (n) or null: only flagged envs are refreshed
+    int yaw_only;
+    float max_dist;
+    float* ray_hits_w;        // (n,r,3)
+    float* height;            // (n,r) or null: pos_z - hit_z - offset  (observations.py:165-173)
+    float height_offset;
+    int64_t n;
+    int r;
+};
+
+__global__ void __launch_bounds__(kRayBlock) raycaster_update_kernel(ScanArgs a) {
+    __shared__ Node cache[kCachedNodes];
+    __shared__ int32_t stack[kStackSlots * kRayBlock];
+    const int ncache = min(a.mesh.num_nodes, kCachedNodes);
+    stage_nodes(a.mesh, cache, ncache);
+    const int64_t total = a.n * a.r;
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * kRayBlock + threadIdx.x; i < total;
+         i += static_cast<int64_t>(gridDim.x) * kRayBlock) {
+        const int64_t env = i / a.r;
+        const int ray = static_cast<int>(i - env * a.r);
+        if (a.env_mask && !a.env_mask[env]) continue;
+        const f3 pos = load3(a.pos_w + 3 * env);
+        const f4 q = load4(a.quat_w + 4 * env);
+        const f3 ls = load3(a.ray_starts + 3 * ray), ld = load3(a.ray_dirs + 3 * ray);
+        f3 o, d;
+        if (a.yaw_only) {  // ray_caster.py:243-247: starts rotated by yaw only, directions unrotated
+            o = quat_apply_yaw(q, ls);
+            d = ld;
+        } else {  // ray_caster.py:248-252
+            o = quat_apply(q, ls);
+            d = quat_apply(q, ld);
+        }
+        o = {o.x + pos.x, o.y + pos.y, o.z + pos.z};
+        const Hit h = trace<false>(a.mesh, cache, ncache, stack + threadIdx.x, kRayBlock, o, d, a.max_dist);
+        write_hit(h, o, d, a.ray_hits_w, nullptr, nullptr, nullptr, i);
+        if (a.height) {
+            const float hz = (h.face >= 0) ? (o.z + h.t * d.z) : __builtin_inff();
+            a.height[i] = pos.z - hz - a.height_offset;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host-side build
+// ------------------------------------------------------------------------------------------------
+struct Box {
+    float mn[3], mx[3];
+    void reset() {
+        for (int k = 0; k < 3; ++k) mn[k] = std::numeric_limits<float>::infinity(), mx[k] = -mn[k];
+    }
+    void grow(const Box& o) {
+        for (int k = 0; k < 3; ++k) mn[k] = std::min(mn[k], o.mn[k]), mx[k] = std::max(mx[k], o.mx[k]);
+    }
+};
+
+static inline uint64_t spread21(uint64_t v) {
+    v &= 0x1fffff;
+    v = (v | v << 32) & 0x1f00000000ffffULL;
+    v = (v | v << 16) & 0x1f0000ff0000ffULL;
+    v = (v | v << 8) & 0x100f00f00f00f00fULL;
+    v = (v | v << 4) & 0x10c30c30c30c30c3ULL;
+    v = (v | v << 2) & 0x1249249249249249ULL;
+    return v;
+}
+
+struct TmpNode {
+    Box box[4];
+    int32_t ref[4];   // >= 0: index into tmp nodes; leaf encoding otherwise
+};
+
+struct Builder {
+    const std::vector<Box>& tri_box;   // in sorted order
+    std::vector<TmpNode> nodes;
+    int max_depth = 0;
+
+    // builds the node for [lo, hi) (hi - lo > kLeafSize) and returns its index
+    int build(int lo, int hi, int depth, Box& out) {
+        max_depth = std::max(max_depth, depth);
+        const int idx = static_cast<int>(nodes.size());
+        nodes.emplace_back();
+        const int n = hi - lo;
+        out.reset();
+        for (int c = 0; c < 4; ++c) {
+            const int a = lo + static_cast<int>((static_cast<int64_t>(n) * c) / 4);
+            const int b = lo + static_cast<int>((static_cast<int64_t>(n) * (c + 1)) / 4);
+            Box bx;
+            bx.reset();
+            int32_t ref = kEmptyRef;
+            if (b > a) {
+                if (b - a <= kLeafSize) {
+                    for (int t = a; t < b; ++t) bx.grow(tri_box[t]);
+                    ref = -(1 + ((a << 2) | (b - a - 1)));
+                } else {
+                    ref = build(a, b, depth + 1, bx);
+                }
+            }
+            nodes[idx].box[c] = bx;
+            nodes[idx].ref[c] = ref;
+            if (b > a) out.grow(bx);
+        }
+        return idx;
+    }
+};
+
+struct MeshHost {
+    MeshDev dev{};
+    Node* d_nodes = nullptr;
+    float4* d_tris = nullptr;
+    int depth = 0;
+    int64_t num_verts = 0;
+};
+
+}  // namespace ilx
+
+using namespace ilx;
+
+struct ilx_mesh_s {
+    MeshHost h;
+};
+
+extern "C" int ilx_mesh_create(const float* verts_host, int64_t num_verts, const int32_t* tris_host, int64_t num_tris,
+                               ilx_mesh_t* out) {
+    ILX_REQUIRE(out, ILX_EINVAL, "ilx_mesh_create: out is NULL");
+    *out = nullptr;
+    ILX_REQUIRE(verts_host && tris_host, ILX_EINVAL, "ilx_mesh_create: NULL vertex or index array");
+    ILX_REQUIRE(num_verts > 0 && num_tris > 0, ILX_EINVAL, "ilx_mesh_create: empty mesh (%lld vertices, %lld triangles)",
+                (long long)num_verts, (long long)num_tris);
+    ILX_REQUIRE(num_tris < (1 << 28), ILX_ESHAPE, "ilx_mesh_create: %lld triangles (max 2^28)", (long long)num_tris);
+    const int nt = static_cast<int>(num_tris);
+    for (int64_t i = 0; i < 3 * num_tris; ++i)
+        ILX_REQUIRE(tris_host[i] >= 0 && tris_host[i] < num_verts, ILX_EINVAL,
+                    "ilx_mesh_create: triangle index %d outside [0, %lld)", tris_host[i], (long long)num_verts);
+
+    // bounds of the centroids -> Morton keys (uniform scale so that the small z range of a terrain barely splits)
+    std::vector<Box> box(nt);
+    std::vector<float> cen(3 * static_cast<size_t>(nt));
+    float cmin[3] = {INFINITY, INFINITY, INFINITY}, cmax[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int t = 0; t < nt; ++t) {
+        Box b;
+        b.reset();
+        for (int k = 0; k < 3; ++k) {
+            const float* v = verts_host + 3 * static_cast<int64_t>(tris_host[3 * t + k]);
+            for (int a = 0; a < 3; ++a) {
+                ILX_REQUIRE(std::isfinite(v[a]), ILX_EINVAL, "ilx_mesh_create: non-finite vertex coordinate");
+                b.mn[a] = std::min(b.mn[a], v[a]), b.mx[a] = std::max(b.mx[a], v[a]);
+            }
+        }
+        for (int a = 0; a < 3; ++a) {
+            cen[3 * t + a] = 0.5f * (b.mn[a] + b.mx[a]);
+            cmin[a] = std::min(cmin[a], cen[3 * t + a]), cmax[a] = std::max(cmax[a], cen[3 * t + a]);
+            // inflate: the intersection formula may accept points a few ulps outside the exact triangle
+            const float ext = b.mx[a] - b.mn[a];
+            const float pad = 1.0e-4f * std::max(ext, 1.0e-3f) + 4.0e-6f * std::max(std::fabs(b.mn[a]), std::fabs(b.mx[a]));
+            b.mn[a] -= pad, b.mx[a] += pad;
+        }
+        box[t] = b;
+    }
+    const float extent = std::max({cmax[0] - cmin[0], cmax[1] - cmin[1], cmax[2] - cmin[2], 1.0e-12f});
+    std::vector<uint64_t> key(nt);
+    for (int t = 0; t < nt; ++t) {
+        uint64_t k = 0;
+        for (int a = 0; a < 3; ++a) {
+            const double u = (static_cast<double>(cen[3 * t + a]) - cmin[a]) / extent;
+            const uint64_t q = static_cast<uint64_t>(std::min(std::max(u, 0.0), 1.0) * 2097151.0);
+            k |= spread21(q) << a;
+        }
+        key[t] = k;
+    }
+    std::vector<int> order(nt);
+    std::iota(order.begin(), order.end(), 0);
+    std::sort(order.begin(), order.end(), [&](int a, int b) { return key[a] != key[b] ? key[a] < key[b] : a < b; });
+    // inside a leaf the face order must be ascending so that "first strictly smaller t wins" keeps the lowest id;
+    // the kernel compares ids explicitly, so only the boxes need the sorted order here
+    std::vector<Box> sorted_box(nt);
+    for (int i = 0; i < nt; ++i) sorted_box[i] = box[order[i]];
+
+    Builder bld{sorted_box};
+    Box root_box;
+    if (nt <= kLeafSize) {
+        bld.nodes.emplace_back();
+        TmpNode& r = bld.nodes[0];
+        for (int c = 0; c < 4; ++c) r.box[c].reset(), r.ref[c] = kEmptyRef;
+        for (int t = 0; t < nt; ++t) r.box[0].grow(sorted_box[t]);
+        r.ref[0] = -(1 + ((0 << 2) | (nt - 1)));
+    } else {
+        bld.build(0, nt, 0, root_box);
+    }
+    ILX_REQUIRE(bld.max_depth <= kMaxDepth, ILX_ESHAPE, "ilx_mesh_create: tree depth %d exceeds %d", bld.max_depth,
+                kMaxDepth);
+
+    // breadth-first renumbering
+    const int nn = static_cast<int>(bld.nodes.size());
+    std::vector<int> bfs;
+    bfs.reserve(nn);
+    std::vector<int> new_index(nn, -1);
+    bfs.push_back(0);
+    for (size_t head = 0; head < bfs.size(); ++head) {
+        new_index[bfs[head]] = static_cast<int>(head);
+        for (int c = 0; c < 4; ++c)
+            if (bld.nodes[bfs[head]].ref[c] >= 0) bfs.push_back(bld.nodes[bfs[head]].ref[c]);
+    }
+    std::vector<Node> nodes(nn);
+    for (int i = 0; i < nn; ++i) {
+        const TmpNode& s = bld.nodes[bfs[i]];
+        Node& d = nodes[i];
+        std::memset(&d, 0, sizeof(Node));
+        for (int c = 0; c < 4; ++c) {
+            d.minx[c] = s.box[c].mn[0], d.miny[c] = s.box[c].mn[1], d.minz[c] = s.box[c].mn[2];
+            d.maxx[c] = s.box[c].mx[0], d.maxy[c] = s.box[c].mx[1], d.maxz[c] = s.box[c].mx[2];
+            d.ref[c] = s.ref[c] >= 0 ? new_index[s.ref[c]] : s.ref[c];
+        }
+    }
+    std::vector<float4> tris(3 * static_cast<size_t>(nt));
+    for (int i = 0; i < nt; ++i) {
+        const int t = order[i];
+        const float* v0 = verts_host + 3 * static_cast<int64_t>(tris_host[3 * t]);
+        const float* v1 = verts_host + 3 * static_cast<int64_t>(tris_host[3 * t + 1]);
+        const float* v2 = verts_host + 3 * static_cast<int64_t>(tris_host[3 * t + 2]);
+        const float e1[3] = {v1[0] - v0[0], v1[1] - v0[1], v1[2] - v0[2]};
+        const float e2[3] = {v2[0] - v0[0], v2[1] - v0[1], v2[2] - v0[2]};
+        float idbits;
+        std::memcpy(&idbits, &t, sizeof(float));
+        tris[3 * i] = make_float4(v0[0], v0[1], v0[2], e1[0]);
+        tris[3 * i + 1] = make_float4(e1[1], e1[2], e2[0], e2[1]);
+        tris[3 * i + 2] = make_float4(e2[2], idbits, 0.0f, 0.0f);
+    }
+
+    auto* obj = new ilx_mesh_s();
+    MeshHost& h = obj->h;
+    int rc = check_hip(hipMalloc(&h.d_nodes, nodes.size() * sizeof(Node)), "ilx_mesh_create: hipMalloc(nodes)");
+    if (rc == ILX_OK) rc = check_hip(hipMalloc(&h.d_tris, tris.size() * sizeof(float4)), "ilx_mesh_create: hipMalloc(tris)");
+    if (rc == ILX_OK)
+        rc = check_hip(hipMemcpy(h.d_nodes, nodes.data(), nodes.size() * sizeof(Node), hipMemcpyHostToDevice),
+                       "ilx_mesh_create: copy nodes");
+    if (rc == ILX_OK)
+        rc = check_hip(hipMemcpy(h.d_tris, tris.data(), tris.size() * sizeof(float4), hipMemcpyHostToDevice),
+                       "ilx_mesh_create: copy triangles");
+    if (rc != ILX_OK) {
+        if (h.d_nodes) (void)hipFree(h.d_nodes);
+        if (h.d_tris) (void)hipFree(h.d_tris);
+        delete obj;
+        return rc;
+    }
+    h.dev.nodes = h.d_nodes, h.dev.tris = h.d_tris, h.dev.num_nodes = nn, h.dev.num_tris = nt;
+    h.depth = bld.max_depth, h.num_verts = num_verts;
+    *out = obj;
+    return ILX_OK;
+}
+
+extern "C" void ilx_mesh_destroy(ilx_mesh_t mesh) {
+    if (!mesh) return;
+    if (mesh->h.d_nodes) (void)hipFree(mesh->h.d_nodes);
+    if (mesh->h.d_tris) (void)hipFree(mesh->h.d_tris);
+    delete mesh;
+}
+
+extern "C" int ilx_mesh_info(ilx_mesh_t mesh, int64_t* num_tris, int64_t* num_nodes, int32_t* depth) {
+    ILX_REQUIRE(mesh, ILX_EINVAL, "ilx_mesh_info: mesh is NULL");
+    if (num_tris) *num_tris = mesh->h.dev.num_tris;
+    if (num_nodes) *num_nodes = mesh->h.dev.num_nodes;
+    if (depth) *depth = mesh->h.depth;
+    return ILX_OK;
+}
+
+static unsigned ray_grid(int64_t rays) {
+    // enough blocks to fill 256 CUs a few times over; the kernels grid-stride over the rest
+    const int64_t want = (rays + kRayBlock - 1) / kRayBlock;
+    return static_cast<unsigned>(std::min<int64_t>(want, 256 * 12));
+}
+
+extern "C" int ilx_raycast_mesh(ilx_mesh_t mesh, const float* ray_starts, const float* ray_directions, int64_t num_rays,
+                                float max_dist, float* ray_hits, float* ray_distance, float* ray_normal,
+                                int32_t* ray_face_id, void* stream) {
+    ILX_REQUIRE(mesh, ILX_EINVAL, "ilx_raycast_mesh: mesh is NULL");
+    ILX_REQUIRE(num_rays >= 0, ILX_EINVAL, "ilx_raycast_mesh: negative ray count");
+    if (num_rays == 0) return ILX_OK;
+    ILX_REQUIRE(ray_starts && ray_directions && ray_hits, ILX_EINVAL, "ilx_raycast_mesh: NULL operand");
+    CastArgs a{mesh->h.dev, ray_starts, ray_directions, max_dist, ray_hits, ray_distance, ray_normal, ray_face_id, num_rays};
+    hipLaunchKernelGGL(raycast_kernel, dim3(ray_grid(num_rays)), dim3(kRayBlock), 0, as_stream(stream), a);
+    ILX_LAUNCH_CHECK("ilx_raycast_mesh");
+    return ILX_OK;
+}
+
+extern "C" int ilx_raycaster_update(ilx_mesh_t mesh, const float* pos_w, const float* quat_w, const float* ray_starts_local,
+                                    const float* ray_directions_local, const uint8_t* env_mask, int attach_yaw_only,
+                                    float max_dist, float* ray_hits_w, float* height_scan, float height_offset,
+                                    int64_t n, int num_rays, void* stream) {
+    ILX_REQUIRE(mesh, ILX_EINVAL, "ilx_raycaster_update: mesh is NULL");
+    ILX_REQUIRE(n >= 0 && num_rays > 0, ILX_EINVAL, "ilx_raycaster_update: bad shape (%lld, %d)", (long long)n, num_rays);
+    if (n == 0) return ILX_OK;
+    ILX_REQUIRE(pos_w && quat_w && ray_starts_local && ray_directions_local && ray_hits_w, ILX_EINVAL,
+                "ilx_raycaster_update: NULL operand");
+    ILX_REQUIRE((reinterpret_cast<uintptr_t>(quat_w) & 15u) == 0, ILX_EINVAL,
+                "ilx_raycaster_update: quat_w must be 16-byte aligned");
+    ScanArgs a{mesh->h.dev, pos_w, quat_w, ray_starts_local, ray_directions_local, env_mask, attach_yaw_only, max_dist,
+               ray_hits_w, height_scan, height_offset, n, num_rays};
+    hipLaunchKernelGGL(raycaster_update_kernel, dim3(ray_grid(n * num_rays)), dim3(kRayBlock), 0, as_stream(stream), a);
+    ILX_LAUNCH_CHECK("ilx_raycaster_update");
+    return ILX_OK;
+}

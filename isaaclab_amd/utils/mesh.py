@@ -1,0 +1,66 @@
+"""Triangle meshes and ray casting on the HIP BVH kernels (interface of ``isaaclab/utils/warp/ops.py``).
+
+``raycast_mesh`` keeps the reference's signature and return convention (``ops.py:24-32``): a tuple
+``(hits, distance | None, normal | None, face_id | None)`` with ``inf`` / ``-1`` for missed rays.  Unlike the
+reference there is no device-wide synchronisation after the launch; the work is ordered on the current stream.
+"""
+
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+import torch
+
+from .. import _abi
+
+
+class Mesh:
+    """Owns an ``ilx_mesh_t``: the 4-wide BVH and the packed triangles in GPU memory."""
+
+    def __init__(self, points, indices, device="cuda:0"):
+        pts = np.ascontiguousarray(np.asarray(points, dtype=np.float32).reshape(-1, 3))
+        idx = np.ascontiguousarray(np.asarray(indices, dtype=np.int32).reshape(-1, 3))
+        self.device = torch.device(device)
+        self.num_vertices, self.num_triangles = pts.shape[0], idx.shape[0]
+        self.handle = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            _abi.check(_abi.mesh_create(pts.ctypes.data, pts.shape[0], idx.ctypes.data, idx.shape[0],
+                                        ctypes.byref(self.handle)), "ilx_mesh_create")
+        nt, nn, depth = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int32()
+        _abi.check(_abi.mesh_info(self.handle, ctypes.byref(nt), ctypes.byref(nn), ctypes.byref(depth)), "ilx_mesh_info")
+        self.num_nodes, self.depth = nn.value, depth.value
+
+    def __del__(self):
+        h = getattr(self, "handle", None)
+        if h and _abi is not None and getattr(_abi, "lib", None) is not None:
+            _abi.lib.ilx_mesh_destroy(h)
+            self.handle = None
+
+
+def convert_to_mesh(points: np.ndarray, indices: np.ndarray, device: str) -> Mesh:
+    """ops.py:130-145 (``convert_to_warp_mesh``): vertices (V,3) + flat or (F,3) triangle indices -> mesh handle."""
+    return Mesh(points, indices, device)
+
+
+def raycast_mesh(ray_starts: torch.Tensor, ray_directions: torch.Tensor, mesh: Mesh, max_dist: float = 1e6,
+                 return_distance: bool = False, return_normal: bool = False, return_face_id: bool = False):
+    """ops.py:24-127."""
+    shape = ray_starts.shape
+    device = ray_starts.device
+    starts = _abi.f32c(ray_starts.to(mesh.device)).view(-1, 3)
+    dirs = _abi.f32c(ray_directions.to(mesh.device)).view(-1, 3)
+    n = starts.shape[0]
+    hits = torch.empty((n, 3), dtype=torch.float32, device=mesh.device)
+    dist = torch.empty((n,), dtype=torch.float32, device=mesh.device) if return_distance else None
+    normal = torch.empty((n, 3), dtype=torch.float32, device=mesh.device) if return_normal else None
+    face = torch.empty((n,), dtype=torch.int32, device=mesh.device) if return_face_id else None
+    _abi.check(_abi.raycast_mesh(mesh.handle, _abi.ptr(starts), _abi.ptr(dirs), n, float(max_dist), _abi.ptr(hits),
+                                 _abi.ptr(dist), _abi.ptr(normal), _abi.ptr(face), _abi.stream()), "ilx_raycast_mesh")
+    if return_distance:
+        dist = dist.to(device).view(shape[0], shape[1]) if len(shape) == 3 else dist.to(device)
+    if return_normal:
+        normal = normal.to(device).view(shape)
+    if return_face_id:
+        face = face.to(device).view(shape[0], shape[1]) if len(shape) == 3 else face.to(device)
+    return hits.to(device).view(shape), dist, normal, face

@@ -1,0 +1,103 @@
+"""CPU: ray set-up pinned against the reference fixtures; brute-force / C / C-BVH intersection agree."""
+
+import numpy as np
+import torch
+
+from conftest import assert_close, assert_exact, load_golden
+from oracle import raycast as RC
+
+
+def small_mesh(seed=0, n=21, size=2.0, amp=0.2):
+    g = torch.Generator().manual_seed(seed)
+    xs = torch.linspace(0, size, n)
+    gx, gy = torch.meshgrid(xs, xs, indexing="ij")
+    z = torch.rand(n, n, generator=g) * amp
+    verts = torch.stack([gx, gy, z], -1).reshape(-1, 3)
+    idx = torch.arange(n * n).reshape(n, n)
+    a, b, c, d = idx[:-1, :-1].reshape(-1), idx[1:, :-1].reshape(-1), idx[:-1, 1:].reshape(-1), idx[1:, 1:].reshape(-1)
+    tris = torch.cat([torch.stack([a, b, c], -1), torch.stack([b, d, c], -1)]).int()
+    return verts, tris, xs
+
+
+def test_rays(seed=1, n=1500, size=2.0):
+    """Vertical, oblique, edge-aligned and missing rays over the small mesh."""
+    g = torch.Generator().manual_seed(seed)
+    verts, tris, xs = small_mesh()
+    starts = torch.cat([torch.rand(n, 2, generator=g) * (size + 0.2) - 0.1, torch.full((n, 1), 20.0)], -1)
+    dirs = torch.tensor([0.0, 0.0, -1.0]).repeat(n, 1)
+    starts[:40, 0] = xs[torch.randint(0, len(xs), (40,), generator=g)]          # on grid lines (shared edges)
+    starts[40:80, 1] = xs[torch.randint(0, len(xs), (40,), generator=g)]
+    starts[80:100, :2] = verts[torch.randint(0, len(verts), (20,), generator=g), :2]  # through vertices
+    ob = torch.randn(n, 3, generator=g) * 0.3
+    ob[:, 2] = -1.0
+    starts2 = starts.clone()
+    starts2[:, 2] = 1.5
+    return verts, tris, torch.cat([starts, starts2]), torch.cat([dirs, ob])
+
+
+def test_grid_pattern_matches_reference():
+    g = load_golden("ray_caster_rays")
+    s, d = RC.grid_pattern((1.6, 1.0), 0.1)
+    assert_exact(s, g["grid_starts"], "grid starts (xy)")
+    assert_exact(d, g["grid_dirs"], "grid dirs (xy)")
+    assert s.shape == (187, 3) and s[0].tolist() == g["grid_starts"][0].tolist()
+    assert abs(s[1, 0] - s[0, 0] - 0.1) < 1e-6 and s[1, 1] == s[0, 1], "x varies fastest for ordering='xy'"
+    s, d = RC.grid_pattern((1.0, 0.5), 0.25, ordering="yx")
+    assert_exact(s, g["grid_yx_starts"], "grid starts (yx)")
+
+
+def test_world_rays_match_reference():
+    g = load_golden("ray_caster_rays")
+    s0, d0 = RC.grid_pattern((1.6, 1.0), 0.1)
+    s, d = RC.sensor_rays(s0, d0, (0.0, 0.0, 20.0), (1.0, 0.0, 0.0, 0.0))
+    for tag, yaw in (("yaw", True), ("full", False)):
+        assert_exact(s, g[f"{tag}_ray_starts_local"], f"{tag} local starts")
+        assert_exact(d, g[f"{tag}_ray_dirs_local"], f"{tag} local dirs")
+        tf = g["root_transforms_xyzw"]
+        pos = tf[:, :3] + g[f"{tag}_drift"]
+        quat = tf[:, [6, 3, 4, 5]]
+        assert_exact(pos, g[f"{tag}_pos_w"], f"{tag} pos_w")
+        assert_exact(quat, g[f"{tag}_quat_w"], f"{tag} quat_w")
+        sw, dw = RC.world_rays(pos, quat, s, d, yaw)
+        if yaw:
+            assert_close(sw, g[f"{tag}_ray_starts_w"], what=f"{tag} world starts")  # yaw goes through atan2/sin/cos
+            assert_exact(dw, g[f"{tag}_ray_dirs_w"], f"{tag} world dirs")
+        else:
+            # torch.cross switches between fused and unfused forms on large inputs: last-bit differences
+            assert_close(sw, g[f"{tag}_ray_starts_w"], what=f"{tag} world starts")
+            assert_close(dw, g[f"{tag}_ray_dirs_w"], what=f"{tag} world dirs")
+
+
+def test_brute_force_c_and_bvh_agree():
+    verts, tris, starts, dirs = test_rays()
+    h1, t1, f1 = RC.raycast_brute(starts, dirs, verts, tris)
+    mesh = RC.CMesh(verts.numpy(), tris.numpy())
+    h2, t2, f2 = RC.raycast_c(starts, dirs, mesh, brute=True)
+    h3, t3, f3 = RC.raycast_c(starts, dirs, mesh, brute=False)
+    assert_exact(t2, t1, "C brute t")
+    assert_exact(f2, f1, "C brute face")
+    assert_exact(h2, h1, "C brute hits")
+    assert_exact(t3, t1, "C bvh t")
+    assert_exact(f3, f1, "C bvh face")
+    frac = (f1 >= 0).float().mean().item()
+    assert 0.5 < frac < 0.99, f"both hits and misses must occur ({frac})"
+
+
+def test_flat_plane_known_answer():
+    verts = torch.tensor([[-5.0, -5.0, 0.25], [5.0, -5.0, 0.25], [-5.0, 5.0, 0.25], [5.0, 5.0, 0.25]])
+    tris = torch.tensor([[0, 1, 2], [1, 3, 2]], dtype=torch.int32)
+    starts = torch.tensor([[0.3, -0.7, 20.0], [4.0, 4.0, 3.0], [7.0, 0.0, 20.0], [1.0, 1.0, 20.0]])
+    dirs = torch.tensor([[0.0, 0.0, -1.0], [0.0, 0.0, -1.0], [0.0, 0.0, -1.0], [0.0, 0.0, 1.0]])
+    hits, t, f = RC.raycast_brute(starts, dirs, verts, tris)
+    assert torch.equal(hits[0], torch.tensor([0.3, -0.7, 0.25])) and t[0] == 19.75
+    assert f[1] == 1 and t[1] == 2.75
+    assert f[2] == -1 and torch.isinf(hits[2]).all(), "outside the plane"
+    assert f[3] == -1, "pointing away"
+    # max_dist is exclusive and respected
+    _, t2, f2 = RC.raycast_brute(starts[:1], dirs[:1], verts, tris, max_dist=19.75)
+    assert f2[0] == -1
+    # the diagonal is shared by both faces: lowest face index wins
+    _, _, f3 = RC.raycast_brute(torch.tensor([[0.0, 0.0, 1.0]]), torch.tensor([[0.0, 0.0, -1.0]]), verts, tris)
+    assert f3[0] == 0
+    hs = RC.height_scan(torch.tensor([[0.3, -0.7, 0.6]]), hits[None, :1], 0.5)
+    assert_close(hs, torch.tensor([[0.6 - 0.25 - 0.5]]), what="height scan")
