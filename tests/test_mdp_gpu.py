@@ -1,0 +1,160 @@
+"""GPU: the fused MDP kernel (ilx_mdp_step through the C ABI) against the reference-generated manager fixtures and
+the oracle."""
+
+import math
+
+import pytest
+import torch
+
+from conftest import assert_close, assert_exact, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def make_anymal_mdp(dev, n, command=None):
+    from isaaclab_amd.envs.fused_mdp import FusedMdp
+    from isaaclab_amd.tasks import locomotion_velocity as LV
+
+    terms = LV.anymal_c_rough_terms()
+    return FusedMdp(n, dev, num_joints=12, num_bodies=17, num_sensor_bodies=17, history_len=3, num_rays=187, action_dim=12,
+                    command_dim=3, step_dt=LV.STEP_DT, max_episode_length=LV.MAX_EPISODE_LENGTH, command=command, **terms)
+
+
+STATE_FIELDS = ["root_state_w", "joint_pos", "joint_vel", "joint_acc", "applied_torque", "computed_torque",
+                "default_joint_pos", "default_joint_vel", "soft_joint_pos_limits", "soft_joint_vel_limits", "body_state_w",
+                "net_forces_w_history", "current_air_time", "last_air_time", "current_contact_time", "last_contact_time",
+                "ray_hits_w", "sensor_pos_w", "action", "prev_action"]
+
+
+def bind_state(mdp, s, dev):
+    mdp.bind(**{k: s[k].to(dev).contiguous() for k in STATE_FIELDS if k in s})
+
+
+def test_anymal_managers_match_reference(dev):
+    """Three steps of the real Reward/Termination/Observation managers (fixture) vs one fused launch per step."""
+    from isaaclab_amd.envs import fused_mdp as FM
+
+    g = load_golden("managers_anymal")
+    steps, n = g["reward"].shape
+    mdp = make_anymal_mdp(dev, n)
+    assert mdp.obs_dim == 235
+    for k in range(steps):
+        s = {key: v[k] for key, v in g.items() if v.shape[:1] == (steps,)}
+        bind_state(mdp, s, dev)
+        mdp.bind(command=s["command"].to(dev).contiguous(), noise_u=s["noise_u"].to(dev).contiguous())
+        # the fixture's episode_length_buf is the value terminations see, i.e. after the += 1 of the env step
+        mdp.episode_length_buf.copy_((s["episode_length_buf"] - 1).to(dev))
+        mdp.log_sums.zero_()
+        mdp.step(FM.PHASE_TERMINATION | FM.PHASE_REWARD | FM.PHASE_OBSERVATION)
+        assert_exact(mdp.terminated, s["terminated"], f"terminated step {k}")
+        assert_exact(mdp.time_outs, s["time_outs"], f"time_outs step {k}")
+        assert_exact(mdp.reset_buf, s["dones"], f"dones step {k}")
+        assert_exact(mdp.term_dones, s["term_dones"], f"term_dones step {k}")
+        assert_exact(mdp.episode_length_buf, s["episode_length_buf"], f"episode_length_buf step {k}")
+        assert_close(mdp.reward_buf, s["reward"], atol=1e-6, what=f"reward step {k}")
+        assert_close(mdp.step_reward, s["step_reward"], atol=2e-5, what=f"step_reward step {k}")
+        assert_close(mdp.episode_sums, s["episode_sums"], atol=1e-6, what=f"episode_sums step {k}")
+        assert_close(mdp.obs, s["obs"], atol=1e-6, what=f"obs step {k}")
+        # reset bookkeeping: per-term sums over the done envs, termination counts, zeroed sums
+        mdp.step(FM.PHASE_RESET)
+        nd = int(s["dones"].sum())
+        log = mdp.log_sums.cpu()
+        assert log[-1].item() == nd
+        assert_close(log[:11] / nd / 20.0, s["reset_reward_log"], rtol=1e-4, atol=1e-6, what=f"reward log step {k}")
+        assert_exact(log[11:13].long(), s["reset_term_log"], f"termination log step {k}")
+        assert_close(mdp.episode_sums, s["episode_sums_after_reset"], atol=1e-6, what=f"sums after reset step {k}")
+        assert (mdp.episode_length_buf.cpu()[s["dones"]] == 0).all()
+
+
+def test_velocity_command_matches_reference(dev):
+    from isaaclab_amd.envs import fused_mdp as FM
+    from isaaclab_amd.tasks import locomotion_velocity as LV
+
+    g = load_golden("velocity_command")
+    for tag in ("rough", "mixed"):
+        lo, hi, stand, head, stiff = g[f"{tag}_cfg"].tolist()
+        cmd = dict(LV.VELOCITY_COMMAND, resampling_time_range=(lo, hi), rel_standing_envs=stand, rel_heading_envs=head,
+                   heading_control_stiffness=stiff)
+        p = lambda key: g[f"{tag}_pre_{key}"]  # noqa: E731
+        n = p("time_left").shape[0]
+        mdp = make_anymal_mdp(dev, n, command=cmd)
+        # root state whose derived body-frame velocities / heading are the fixture's: identity-free route is to hand
+        # the kernel a state with unit quaternion and the body-frame velocities as world velocities, plus the yaw
+        yaw = p("heading_w")
+        quat = torch.stack([torch.cos(yaw / 2), torch.zeros(n), torch.zeros(n), torch.sin(yaw / 2)], -1)
+        from oracle import mathx as M
+        lin_w = M.quat_rotate(quat, p("root_lin_vel_b"))
+        ang_w = M.quat_rotate(quat, p("root_ang_vel_b"))
+        rs = torch.cat([torch.zeros(n, 3), quat, lin_w, ang_w], -1)
+        mdp.bind(root_state_w=rs.to(dev).contiguous())
+        mdp.command.copy_(p("vel_command_b"))
+        mdp.heading_target.copy_(p("heading_target"))
+        mdp.is_heading_env.copy_(p("is_heading_env"))
+        mdp.is_standing_env.copy_(p("is_standing_env"))
+        mdp.time_left.copy_(p("time_left"))
+        mdp.command_counter.copy_(p("command_counter"))
+        mdp.command_metrics[0].copy_(p("metric_xy"))
+        mdp.command_metrics[1].copy_(p("metric_yaw"))
+        for k in range(g[f"{tag}_samples"].shape[0]):
+            mdp.bind(command_samples=g[f"{tag}_samples"][k].to(dev).contiguous())
+            mdp.step(FM.PHASE_COMMAND)
+            assert_exact(mdp.time_left, g[f"{tag}_time_left"][k], f"{tag} time_left step {k}")
+            assert_exact(mdp.command_counter, g[f"{tag}_command_counter"][k], f"{tag} counter step {k}")
+            assert_exact(mdp.is_heading_env, g[f"{tag}_is_heading_env"][k], f"{tag} is_heading_env step {k}")
+            assert_exact(mdp.is_standing_env, g[f"{tag}_is_standing_env"][k], f"{tag} is_standing_env step {k}")
+            assert_exact(mdp.heading_target, g[f"{tag}_heading_target"][k], f"{tag} heading_target step {k}")
+            # the yaw/velocities went through a rotate/inverse-rotate round trip: 1e-5 absolute on O(1) values
+            assert_close(mdp.command, g[f"{tag}_vel_command_b"][k], atol=2e-5, what=f"{tag} command step {k}")
+            assert_close(mdp.command_metrics[0], g[f"{tag}_metric_xy"][k], atol=1e-6, what=f"{tag} metric xy step {k}")
+            assert_close(mdp.command_metrics[1], g[f"{tag}_metric_yaw"][k], atol=1e-6, what=f"{tag} metric yaw step {k}")
+        # reset of a subset
+        ids = g[f"{tag}_reset_ids"]
+        mdp.terminated.zero_()
+        mdp.time_outs.zero_()
+        mdp.time_outs[ids.to(dev)] = True
+        mdp.term_dones.zero_()
+        before = mdp.command_metrics.cpu().clone()
+        mdp.bind(reset_command_samples=g[f"{tag}_reset_samples"].to(dev).contiguous())
+        mdp.log_sums.zero_()
+        mdp.step(FM.PHASE_RESET)
+        for a, name in (("heading_target",) * 2, ("is_heading_env",) * 2, ("is_standing_env",) * 2, ("time_left",) * 2,
+                        ("command_counter",) * 2):
+            assert_exact(getattr(mdp, a), g[f"{tag}_reset_{name}"], f"{tag} reset {name}")
+        # reset envs carry the injected samples exactly; the others still hold the (tolerance-level) values from above
+        assert_exact(mdp.command.cpu()[ids], g[f"{tag}_reset_vel_command_b"][ids], f"{tag} reset command (reset envs)")
+        assert_close(mdp.command, g[f"{tag}_reset_vel_command_b"], atol=2e-5, what=f"{tag} reset command")
+        assert_close(mdp.command_metrics[0], g[f"{tag}_reset_metric_xy"], atol=1e-6, what=f"{tag} reset metric")
+        assert (mdp.command_metrics.cpu()[:, ids] == 0).all()
+        log = mdp.log_sums.cpu()
+        assert_close(log[13:15].double() / len(ids), g[f"{tag}_reset_extras"], rtol=1e-5, atol=1e-6, what=f"{tag} reset extras")
+        assert torch.equal(before[:, ~mdp.time_outs.cpu()], mdp.command_metrics.cpu()[:, ~mdp.time_outs.cpu()])
+
+
+def test_generated_noise_and_samples_are_in_range_and_reproducible(dev):
+    """Throughput mode: in-kernel counter-based generator (no injected tensors)."""
+    from isaaclab_amd.envs import fused_mdp as FM
+    from isaaclab_amd.tasks import locomotion_velocity as LV
+
+    g = load_golden("managers_anymal")
+    s = {key: v[0] for key, v in g.items() if v.shape[:1] == (g["reward"].shape[0],)}
+    n = s["reward"].shape[0]
+    outs = []
+    for _ in range(2):
+        mdp = make_anymal_mdp(dev, n, command=dict(LV.VELOCITY_COMMAND, resampling_time_range=(0.5, 1.5)))
+        bind_state(mdp, s, dev)
+        mdp.time_left.fill_(0.01)
+        mdp.step(FM.PHASE_COMMAND | FM.PHASE_OBSERVATION, step_index=5)
+        outs.append((mdp.obs.cpu(), mdp.command.cpu(), mdp.time_left.cpu(), mdp.heading_target.cpu()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    obs, cmd, tl, ht = outs[0]
+    clean = make_anymal_mdp(dev, n, command=dict(LV.VELOCITY_COMMAND, resampling_time_range=(0.5, 1.5)))
+    bind_state(clean, s, dev)
+    clean.bind(noise_u=torch.full((n, 235), 0.5, device=dev))  # zero-mean noise at u = 0.5
+    clean.time_left.fill_(0.01)
+    clean.step(FM.PHASE_COMMAND | FM.PHASE_OBSERVATION, step_index=5)
+    diff = (obs - clean.obs.cpu())
+    assert diff[:, 0:3].abs().max() <= 0.1 + 1e-6 and diff[:, 3:6].abs().max() <= 0.2 + 1e-6
+    assert diff[:, 9:12].abs().max() == 0, "commands carry no noise"
+    assert 0.03 < diff[:, 0:3].std() < 0.08, "uniform(-0.1, 0.1) has std 0.0577"
+    assert (tl >= 0.5).all() and (tl <= 1.5).all() and (ht.abs() <= math.pi).all()
+    assert (cmd.abs() <= 1.0).all() and cmd.std() > 0.3
