@@ -1,0 +1,247 @@
+#!/usr/bin/env python3
+"""Benchmark of the non-physics env step (BASELINE.json metric): Isaac-Velocity-Rough-Anymal-C-v0,
+16384 envs per GPU, ActuatorNetMLP + contact bookkeeping + 187-ray height scan + fused managers.
+
+    python bench.py --gpus 1 --steps 200 --warmup 20
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one full env step of the hot path over one batch of synthetic physics state that is already resident
+in HBM: process_action, 4 x (actuator net + joint_acc + contact sensor), height-scan ray cast, and the fused
+termination / reward / reset / command / observation launch.  Prints ONE JSON line (rank 0).
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+NUM_ENVS = 16384
+TERM_EVALS_PER_ENV_STEP = 29  # 8 obs + 9 active rewards + 2 terminations + 1 command + 4 x (actuator + contact) + 1 ray cast
+HBM_PEAK_GBS = 8000.0         # MI355X HBM3E peak (spec); measured float4-copy ceiling is ~6300 GB/s
+
+# Algorithmic bytes per env per launch (each distinct input read once, each output written once; fp32 = 4 B,
+# bool = 1 B, int64 = 8 B; per-joint constants, network weights and the terrain mesh excluded).  J=12, B=17, R=187.
+BYTES = {
+    # read q_des, q, qd (3*48); read+write pos-error / velocity histories (2 * 2 * 144); write computed, applied (2*48)
+    "actuator_net_mlp": 3 * 48 + 4 * 144 + 2 * 48,
+    # read net forces 204, write net_forces_w 204, read+write history 2*612, read+write 4 timers 8*68, clocks 2*9
+    "contact_update": 204 + 204 + 2 * 612 + 8 * 68 + 18,
+    # read vel 48, read+write previous vel 96, write acc 48
+    "joint_acc": 48 + 96 + 48,
+    # read pose 28, write ray hits 187*12
+    "raycaster_update": 28 + 187 * 12,
+    # read root 52, joints (pos, vel, acc, torque, default) 5*48, actions 2*48, contact history 612, timers 2*68,
+    # ray hit z 748, sensor pos 12, command state r+w ~2*41, ep_len r+w 16, noise 880 (parity mode only: not counted);
+    # write obs 940, reward 4, step_reward 44, episode sums r+w 72, flags 5
+    "mdp_step": 52 + 240 + 96 + 612 + 136 + 748 + 12 + 82 + 16 + 940 + 4 + 44 + 72 + 5,
+    "joint_action_process": 48 + 2 * 48 + 48 + 48,
+}
+BYTES_PER_ENV_STEP = (4 * (BYTES["actuator_net_mlp"] + BYTES["contact_update"] + BYTES["joint_acc"]) + BYTES["raycaster_update"]
+                      + BYTES["mdp_step"] + BYTES["joint_action_process"])
+
+
+def build_env(device, num_envs, seed):
+    from isaaclab_amd import synth
+    from isaaclab_amd.envs.locomotion_step import LocomotionVelocityStep
+    from isaaclab_amd.tasks import locomotion_velocity as LV
+    from isaaclab_amd.utils.mesh import convert_to_mesh
+    from isaaclab_amd.utils.string import resolve_matching_names_values
+
+    verts, tris, height_at = synth.rough_terrain_mesh(seed=3)
+    mesh = convert_to_mesh(verts, tris, str(device))
+    ws, bs = synth.actuator_mlp_weights()
+    idx, _, vals = resolve_matching_names_values(LV.ANYMAL_DEFAULT_JOINT_POS, LV.ANYMAL_JOINTS)
+    default = torch.zeros(12)
+    default[idx] = torch.tensor(vals)
+    state = synth.locomotion_state(num_envs, seed, num_joints=12, num_bodies=17, default_joint_pos=default,
+                                   feet_ids=[13, 14, 15, 16], height_at=height_at)
+    env = LocomotionVelocityStep(num_envs, device, mesh, "anymal_c", actuator_net=dict(weights=ws, biases=bs, activation="softsign"),
+                                 seed=seed)
+    env.load_state(state)
+    return env, state, (verts, tris, ws, bs, default)
+
+
+def time_kernels(env, state, device, reps=20):
+    """Average duration of each kernel of the step, measured with events on the stream the kernels run on."""
+    from isaaclab_amd import _abi
+    from isaaclab_amd.envs import fused_mdp as FM
+    from isaaclab_amd.tasks import locomotion_velocity as LV
+    from isaaclab_amd.utils.types import ArticulationActions
+
+    d = env.data
+    raw = state["raw_action"].to(device)
+
+    def actuator():
+        ca = ArticulationActions(joint_positions=d.joint_pos_target, joint_velocities=d.joint_vel_target,
+                                 joint_efforts=d.joint_effort_target)
+        env.actuator.compute(ca, d.joint_pos, d.joint_vel)
+
+    def contact():
+        env.contact._launch(LV.PHYSICS_DT, True)
+
+    def jacc():
+        _abi.check(_abi.joint_acc(_abi.ptr(d.joint_vel), _abi.ptr(d._previous_joint_vel), _abi.ptr(d._joint_acc), 0.005,
+                                  env.n * 12, _abi.stream()))
+
+    def rays():
+        env.scanner._is_outdated.fill_(True)
+        sc = env.scanner
+        _abi.check(_abi.raycaster_update(sc.meshes[sc.cfg.mesh_prim_paths[0]].handle, _abi.ptr(sc._data.pos_w), _abi.ptr(sc._data.quat_w),
+                                         _abi.ptr(sc.ray_starts), _abi.ptr(sc.ray_directions), None, 1, 1e6,
+                                         _abi.ptr(sc._data.ray_hits_w), None, 0.0, env.n, sc.num_rays, _abi.stream()))
+
+    def mdp():
+        env.mdp.step(FM.PHASE_ALL)
+
+    def action():
+        _abi.check(_abi.joint_action_process(_abi.ptr(raw), _abi.ptr(env.action), _abi.ptr(env.prev_action), None, 0.5,
+                                             _abi.ptr(d.default_joint_pos), 0.0, None, _abi.ptr(d.joint_pos_target), env.n, 12,
+                                             _abi.stream()))
+
+    out = {}
+    for name, fn in (("actuator_net_mlp", actuator), ("contact_update", contact), ("joint_acc", jacc),
+                     ("raycaster_update", rays), ("mdp_step", mdp), ("joint_action_process", action)):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+        for a, b in evs:
+            if name == "raycaster_update":
+                env.scanner._is_outdated.fill_(True)
+            a.record()
+            fn()
+            b.record()
+        torch.cuda.synchronize()
+        ts = sorted(a.elapsed_time(b) for a, b in evs)
+        out[name] = ts[len(ts) // 2] * 1e3  # median, microseconds
+    return out
+
+
+def cpu_baseline(seed, sample_envs=2048, steps=3):
+    """The oracle step (unfused PyTorch CPU ops + C ray cast) on a bounded sample of the same workload."""
+    from isaaclab_amd import synth
+    from isaaclab_amd.tasks import locomotion_velocity as LV
+    from isaaclab_amd.utils.string import resolve_matching_names_values
+    from oracle import raycast as RC
+    from oracle.step_locomotion import AnymalRoughOracle
+
+    cores = os.cpu_count() or 1
+    threads = min(cores, 16)
+    torch.set_num_threads(threads)
+    os.environ.setdefault("OMP_NUM_THREADS", str(threads))
+    verts, tris, height_at = synth.rough_terrain_mesh(seed=3)
+    ws, bs = synth.actuator_mlp_weights()
+    idx, _, vals = resolve_matching_names_values(LV.ANYMAL_DEFAULT_JOINT_POS, LV.ANYMAL_JOINTS)
+    default = torch.zeros(12)
+    default[idx] = torch.tensor(vals)
+    state = synth.locomotion_state(sample_envs, seed, num_joints=12, num_bodies=17, default_joint_pos=default,
+                                   feet_ids=[13, 14, 15, 16], height_at=height_at)
+    cm = RC.CMesh(verts, tris)
+    cm.bvh()
+    o = AnymalRoughOracle(sample_envs, state, ws, bs, default, cm)
+    g = torch.Generator().manual_seed(1)
+    noise = torch.rand(sample_envs, 235, generator=g)
+    samples = torch.rand(sample_envs, 7, generator=g)
+    o.step(state["raw_action"], noise, samples, samples)  # warm-up
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        o.step(state["raw_action"], noise, samples, samples)
+    dt = (time.perf_counter() - t0) / steps
+    return {"value": sample_envs / dt, "unit": "env-steps/s", "cores": threads, "kind": "port",
+            "sample": f"{steps} steps of {sample_envs} envs (same step, same terrain mesh of {tris.shape[0]} triangles): "
+                      f"{dt * 1e3:.1f} ms/step; torch {torch.__version__} CPU ops + C BVH ray cast"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--envs", type=int, default=NUM_ENVS, help="environments per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=device)
+
+    env, state, _ = build_env(device, args.envs, seed=3000 + rank)
+    raw = state["raw_action"].to(device)
+    n_log = env.mdp.log_sums.numel()
+
+    def one_step():
+        env.mdp.log_sums.zero_()
+        env.step(raw)
+        if dist is not None:  # episode statistics of the done envs: the only cross-rank exchange of the path
+            dist.all_reduce(env.mdp.log_sums)
+
+    for _ in range(args.warmup):
+        one_step()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    kern = time_kernels(env, state, device)
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        value = args.envs * world * args.steps / elapsed
+        launches = {"actuator_net_mlp": 4, "contact_update": 4, "joint_acc": 4, "raycaster_update": 1, "mdp_step": 1,
+                    "joint_action_process": 1}
+        dominant = max(kern, key=lambda k: kern[k] * launches[k])
+        achieved = BYTES[dominant] * args.envs / (kern[dominant] * 1e-6) / 1e9
+        line = {
+            "metric": "env-steps/sec (non-physics step) ANYmal-C rough", "value": value, "unit": "env-steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "Isaac-Velocity-Rough-Anymal-C-v0 non-physics step", "envs_per_gpu": args.envs,
+                       "decimation": 4, "joints": 12, "bodies": 17, "rays": 187, "obs_dim": 235,
+                       "terrain_triangles": int(env.scanner.meshes["/World/ground"].num_triangles),
+                       "actuator": "ActuatorNetMLP 6-32-32-32-1 softsign (fp32 MFMA)", "parallelism": f"env-shard x{world}"},
+            "env_term_steps_per_s": value * TERM_EVALS_PER_ENV_STEP,
+            "algorithmic_bytes_per_env_step": BYTES_PER_ENV_STEP,
+            "step_hbm_frac": BYTES_PER_ENV_STEP * args.envs / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "launch_us": kern[dominant], "algorithmic_bytes_per_launch": BYTES[dominant] * args.envs},
+            "kernels_us": {k: round(v, 2) for k, v in kern.items()},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline(3000)
+        else:
+            line["cpu_baseline"] = None
+        print(json.dumps(line))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -96,6 +96,14 @@ int ilx_root_frame_derive(const float* root_state, float gx, float gy, float gz,
 int ilx_joint_acc(const float* joint_vel, float* previous_joint_vel, float* joint_acc, float time_elapsed,
                   int64_t count, void* stream);
 
+/* ActionManager.process_action (managers/action_manager.py:318-339) for one JointAction term
+ * (envs/mdp/actions/joint_actions.py:130-139): prev_action <- action, action <- raw_action,
+ * processed = raw * scale + offset, clamped to clip (n,a,2) when given.  scale / offset are (n,a) tensors or
+ * NULL (then the scalar is used).  action / prev_action may be NULL (term-level call without the manager). */
+int ilx_joint_action_process(const float* raw_action, float* action, float* prev_action, const float* scale,
+                             float scale_scalar, const float* offset, float offset_scalar, const float* clip,
+                             float* processed, int64_t n, int a, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Actuators — source/isaaclab/isaaclab/actuators/
  * Per-joint parameters are (j,) when params_per_env == 0, else (n, j) like the reference's buffers.

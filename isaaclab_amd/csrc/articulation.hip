@@ -46,9 +46,39 @@ joint_acc_kernel(const float* __restrict__ vel, float* __restrict__ prev, float*
     prev[i] = v;
 }
 
+// ActionManager.process_action + JointAction.process_actions (action_manager.py:331-332, joint_actions.py:130-139):
+// prev_action <- action; action <- raw; processed = raw * scale + offset [clamped].  One thread per element.
+__global__ void __launch_bounds__(256)
+joint_action_kernel(const float* __restrict__ raw, float* __restrict__ action, float* __restrict__ prev_action,
+                    const float* __restrict__ scale, float scale_scalar, const float* __restrict__ offset,
+                    float offset_scalar, const float* __restrict__ clip, float* __restrict__ processed, int64_t total) {
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const float r = raw[i];
+    if (prev_action) prev_action[i] = action[i];
+    if (action) action[i] = r;
+    float v = r * (scale ? scale[i] : scale_scalar) + (offset ? offset[i] : offset_scalar);
+    if (clip) v = fminf(fmaxf(v, clip[2 * i]), clip[2 * i + 1]);
+    processed[i] = v;
+}
+
 }  // namespace ilx
 
 using namespace ilx;
+
+extern "C" int ilx_joint_action_process(const float* raw_action, float* action, float* prev_action, const float* scale,
+                                        float scale_scalar, const float* offset, float offset_scalar, const float* clip,
+                                        float* processed, int64_t n, int a, void* stream) {
+    ILX_REQUIRE(n >= 0 && a > 0, ILX_EINVAL, "ilx_joint_action_process: bad shape (%lld, %d)", (long long)n, a);
+    if (n == 0) return ILX_OK;
+    ILX_REQUIRE(raw_action && processed, ILX_EINVAL, "ilx_joint_action_process: NULL operand");
+    ILX_REQUIRE(!prev_action || action, ILX_EINVAL, "ilx_joint_action_process: prev_action needs action");
+    const int64_t total = n * a;
+    hipLaunchKernelGGL(joint_action_kernel, dim3(blocks_for(total)), dim3(256), 0, as_stream(stream), raw_action, action,
+                       prev_action, scale, scale_scalar, offset, offset_scalar, clip, processed, total);
+    ILX_LAUNCH_CHECK("ilx_joint_action_process");
+    return ILX_OK;
+}
 
 extern "C" int ilx_root_frame_derive(const float* root_state, float gx, float gy, float gz, float* lin_vel_b,
                                      float* ang_vel_b, float* projected_gravity_b, float* heading_w, int64_t n,

@@ -1,0 +1,151 @@
+"""The non-physics half of one ``ManagerBasedRLEnv.step`` for the rough-terrain velocity tasks, on HIP kernels.
+
+Sequence (``source/isaaclab/isaaclab/envs/manager_based_rl_env.py:152-241`` with ``sim.step`` removed):
+
+    process_action                                  -> ilx_joint_action_process
+    decimation x [ actuator model (write_data_to_sim)  -> ilx_actuator_net_mlp | ilx_actuator_pd
+                   <physics: the caller supplies the next joint state / contact forces>
+                   scene.update: joint_acc, contact    -> ilx_joint_acc, ilx_contact_update ]
+    height scanner refresh (lazy in the reference)  -> ilx_raycaster_update
+    terminations, rewards, manager resets, command, observations -> ilx_mdp_step (one launch)
+
+All buffers have the reference's names and shapes (ArticulationData / ContactSensorData / RayCasterData / manager
+buffers) and are exposed as torch tensors.
+"""
+
+from __future__ import annotations
+
+import torch
+
+from .. import _abi
+from ..actuators import ActuatorNetMLP, ActuatorNetMLPCfg, DCMotor, DCMotorCfg
+from ..assets.articulation_data import ArticulationData
+from ..sensors.contact_sensor import ContactSensor, ContactSensorCfg
+from ..sensors.patterns import GridPatternCfg
+from ..sensors.ray_caster import OffsetCfg, RayCaster, RayCasterCfg
+from ..tasks import locomotion_velocity as LV
+from ..utils.string import resolve_matching_names_values
+from ..utils.types import ArticulationActions
+from . import fused_mdp as FM
+
+
+class LocomotionVelocityStep:
+    def __init__(self, num_envs: int, device, mesh, robot: str = "anymal_c", actuator_net=None, seed: int = 0):
+        self.n, self.device, self.robot = num_envs, torch.device(device), robot
+        n, dev = num_envs, self.device
+        if robot == "anymal_c":
+            joints, bodies = LV.ANYMAL_JOINTS, LV.ANYMAL_BODIES
+            terms = LV.anymal_c_rough_terms()
+            default = LV.ANYMAL_DEFAULT_JOINT_POS
+        elif robot == "h1":
+            joints, bodies = LV.H1_JOINTS, LV.H1_BODIES
+            terms = LV.h1_rough_terms()
+            default = {".*": 0.0}
+        else:
+            raise ValueError(f"unknown robot '{robot}'")
+        self.joint_names, self.body_names = joints, bodies
+        j, b = len(joints), len(bodies)
+        self.data = ArticulationData(n, j, b, dev, joint_names=joints, body_names=bodies)
+        idx, _, vals = resolve_matching_names_values(default, joints)
+        self.data.default_joint_pos[:, idx] = torch.tensor(vals, device=dev)
+        lim = torch.stack([self.data.default_joint_pos - 1.5, self.data.default_joint_pos + 1.5], dim=-1)
+        mean, rng = (lim[..., 0] + lim[..., 1]) / 2, lim[..., 1] - lim[..., 0]
+        self.data.soft_joint_pos_limits[..., 0] = mean - 0.5 * rng * 0.95  # articulation.py:1230-1237
+        self.data.soft_joint_pos_limits[..., 1] = mean + 0.5 * rng * 0.95
+        # actuators (one group over all joints)
+        if robot == "anymal_c":
+            net = actuator_net
+            cfg = ActuatorNetMLPCfg(network=net, **LV.ACTUATOR_NET, **LV.ANYMAL_ACTUATOR)
+            self.actuator = ActuatorNetMLP(cfg, joint_names=joints, joint_ids=slice(None), num_envs=n, device=dev,
+                                           stiffness=0.0, damping=0.0)
+        else:
+            cfg = DCMotorCfg(stiffness=LV.H1_STIFFNESS, damping=LV.H1_DAMPING, effort_limit=LV.H1_EFFORT_LIMIT,
+                             velocity_limit=LV.H1_VELOCITY_LIMIT, saturation_effort=300.0)
+            self.actuator = DCMotor(cfg, joint_names=joints, joint_ids=slice(None), num_envs=n, device=dev)
+        # the group covers every joint: let the actuator write straight into the ArticulationData buffers
+        self.actuator.computed_effort = self.data.computed_torque
+        self.actuator.applied_effort = self.data.applied_torque
+        self.data.soft_joint_vel_limits[:] = self.actuator.velocity_limit
+        # sensors
+        self.contact = ContactSensor(ContactSensorCfg(**LV.CONTACT_SENSOR), n, bodies, dev)
+        hs = LV.HEIGHT_SCAN
+        self.scanner = RayCaster(RayCasterCfg(offset=OffsetCfg(pos=(0.0, 0.0, hs["offset_z"])), attach_yaw_only=True,
+                                              pattern_cfg=GridPatternCfg(resolution=hs["resolution"], size=hs["size"]),
+                                              update_period=hs["update_period"]), n, mesh, dev)
+        # action manager buffers (action_manager.py:318-339) and the JointPositionAction constants (velocity_env_cfg.py:112)
+        self.action = torch.zeros(n, j, device=dev)
+        self.prev_action = torch.zeros(n, j, device=dev)
+        self.action_scale = 0.5
+        # managers: one fused plan
+        self.mdp = FM.FusedMdp(n, dev, num_joints=j, num_bodies=b, num_sensor_bodies=b, history_len=LV.CONTACT_SENSOR["history_length"],
+                               num_rays=self.scanner.num_rays, action_dim=j, command_dim=3, step_dt=LV.STEP_DT,
+                               max_episode_length=LV.MAX_EPISODE_LENGTH, command=LV.VELOCITY_COMMAND, seed=seed, **terms)
+        self._bind()
+
+    def _bind(self):
+        d, c = self.data, self.contact._data
+        self.mdp.bind(root_state_w=d.root_state_w, joint_pos=d.joint_pos, joint_vel=d.joint_vel, joint_acc=d._joint_acc,
+                      applied_torque=d.applied_torque, computed_torque=d.computed_torque, default_joint_pos=d.default_joint_pos,
+                      default_joint_vel=d.default_joint_vel, soft_joint_pos_limits=d.soft_joint_pos_limits,
+                      soft_joint_vel_limits=d.soft_joint_vel_limits, body_state_w=d.body_state_w,
+                      net_forces_w_history=c.net_forces_w_history, current_air_time=c.current_air_time,
+                      last_air_time=c.last_air_time, current_contact_time=c.current_contact_time,
+                      last_contact_time=c.last_contact_time, ray_hits_w=self.scanner._data.ray_hits_w,
+                      sensor_pos_w=self.scanner._data.pos_w, action=self.action, prev_action=self.prev_action)
+
+    def load_state(self, s: dict):
+        """Install persistent buffers from :func:`isaaclab_amd.synth.locomotion_state` (host tensors)."""
+        dev = self.device
+        c = self.contact._data
+        c.net_forces_w_history.copy_(s["net_forces_w_history"])
+        for k in ("current_contact_time", "current_air_time", "last_air_time", "last_contact_time"):
+            getattr(c, k).copy_(s[k])
+        self.action.copy_(s["action"])
+        self.prev_action.copy_(s["prev_action"])
+        self.data._previous_joint_vel.copy_(s["previous_joint_vel"])
+        m = self.mdp
+        m.command.copy_(s["command"])
+        m.heading_target.copy_(s["heading_target"])
+        m.is_heading_env.copy_(s["is_heading_env"])
+        m.is_standing_env.copy_(s["is_standing_env"])
+        m.time_left.copy_(s["time_left"])
+        m.command_counter.copy_(s["command_counter"])
+        m.episode_length_buf.copy_(s["episode_length_buf"])
+        if isinstance(self.actuator, ActuatorNetMLP):
+            self.actuator._joint_pos_error_history.copy_(s["pos_error_history"])
+            self.actuator._joint_vel_history.copy_(s["vel_history"])
+        # clocks as after many steps: every sensor is due
+        self.contact._is_outdated.fill_(False)
+        self.scanner._is_outdated.fill_(False)
+        self.physics = {k: s[k].to(dev).contiguous() for k in ("joint_pos", "joint_vel", "net_forces", "root_state_w")}
+
+    def step(self, raw_action: torch.Tensor, noise_u=None, command_samples=None, reset_command_samples=None):
+        """One env step on the synthetic physics sequence installed by :meth:`load_state`."""
+        d, dev = self.data, self.device
+        n, j = self.n, d._j
+        # -- process_action (manager_based_rl_env.py:172)
+        _abi.check(_abi.joint_action_process(_abi.ptr(raw_action), _abi.ptr(self.action), _abi.ptr(self.prev_action), None,
+                                             self.action_scale, _abi.ptr(d.default_joint_pos), 0.0, None,
+                                             _abi.ptr(d.joint_pos_target), n, j, _abi.stream()), "ilx_joint_action_process")
+        # -- decimation loop (:181-195)
+        for k in range(LV.DECIMATION):
+            d.joint_pos, d.joint_vel = self.physics["joint_pos"][k], self.physics["joint_vel"][k]
+            ca = ArticulationActions(joint_positions=d.joint_pos_target, joint_velocities=d.joint_vel_target,
+                                     joint_efforts=d.joint_effort_target, joint_indices=slice(None))
+            self.actuator.compute(ca, d.joint_pos, d.joint_vel)          # write_data_to_sim
+            # <sim.step would run here; its results for this substep are self.physics[...][k]>
+            d.update(LV.PHYSICS_DT)                                      # scene.update: joint_acc
+            self.contact.set_net_contact_forces(self.physics["net_forces"][k])
+            self.contact.update(LV.PHYSICS_DT)
+            self.scanner.update(LV.PHYSICS_DT)
+        d.set_sim_state(root_state_w=self.physics["root_state_w"])
+        # -- height scanner: refreshed once per env step (update_period = step_dt), lazily in the reference
+        self.scanner.set_pose(d.root_state_w[:, :3].contiguous(), d.root_state_w[:, 3:7].contiguous())
+        self.scanner._update_outdated_buffers()
+        # -- post-physics managers: one launch
+        m = self.mdp
+        m.bind(root_state_w=d.root_state_w, joint_pos=d.joint_pos, joint_vel=d.joint_vel, noise_u=noise_u,
+               command_samples=command_samples, reset_command_samples=reset_command_samples,
+               sensor_pos_w=self.scanner._data.pos_w, ray_hits_w=self.scanner._data.ray_hits_w)
+        m.step(FM.PHASE_ALL)
+        return m.obs, m.reward_buf, m.terminated, m.time_outs

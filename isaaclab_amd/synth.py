@@ -78,3 +78,79 @@ def rough_terrain_mesh(seed: int = 0, rows: int = 10, cols: int = 20, tile: floa
         return h[i, j]
 
     return verts, tris, height_at
+
+
+def _quat_from_rpy(roll, pitch, yaw):
+    cy, sy = torch.cos(yaw * 0.5), torch.sin(yaw * 0.5)
+    cr, sr = torch.cos(roll * 0.5), torch.sin(roll * 0.5)
+    cp, sp = torch.cos(pitch * 0.5), torch.sin(pitch * 0.5)
+    q = torch.stack([cy * cr * cp + sy * sr * sp, cy * sr * cp - sy * cr * sp, cy * cr * sp + sy * sr * cp,
+                     sy * cr * cp - cy * sr * sp], dim=-1)
+    return q / q.norm(dim=-1, keepdim=True)
+
+
+def locomotion_state(n: int, seed: int, *, num_joints: int, num_bodies: int, default_joint_pos: torch.Tensor,
+                     feet_ids, decimation: int = 4, height_at=None, extent=(80.0, 160.0), history_len: int = 3,
+                     max_episode_length: int = 1000, joint_vel_std: float = 2.0):
+    """Seeded stand-in for what PhysX hands the rollout step of a legged robot on rough terrain.
+
+    Per physics substep k < decimation: joint positions / velocities and net contact forces; once per step: root
+    state.  Plus the persistent buffers a running env would hold (previous actions, contact history / timers,
+    command state, episode length), pre-rolled so that every decision branch occurs: feet contact ~50 %, thigh /
+    shank 5 %, base 1 %; ~0.1 % of the envs time out; ~2 % stand still.
+    """
+    g = torch.Generator().manual_seed(seed)
+    j, b, d = num_joints, num_bodies, decimation
+    s = {}
+    xy = torch.rand(n, 2, generator=g) * torch.tensor([extent[0] - 2.0, extent[1] - 2.0]) + 1.0
+    z0 = torch.zeros(n) if height_at is None else torch.from_numpy(np.asarray(height_at(xy[:, 0].numpy(), xy[:, 1].numpy())))
+    pos = torch.cat([xy, (z0 + 0.6 + (torch.rand(n, generator=g) - 0.5) * 0.1).unsqueeze(-1)], dim=-1).float()
+    yaw = (torch.rand(n, generator=g) * 2 - 1) * np.pi
+    rp = torch.randn(n, 2, generator=g) * 0.1
+    quat = _quat_from_rpy(rp[:, 0], rp[:, 1], yaw)
+    s["root_state_w"] = torch.cat([pos, quat, torch.randn(n, 3, generator=g) * 0.5, torch.randn(n, 3, generator=g) * 0.5], dim=-1)
+    dq = default_joint_pos.reshape(1, j)
+    s["joint_pos"] = torch.stack([(dq + torch.randn(n, j, generator=g) * 0.2).clamp(-2.0, 2.0) for _ in range(d)])
+    vel0 = torch.randn(n, j, generator=g) * joint_vel_std
+    s["joint_vel"] = torch.stack([vel0 + torch.randn(n, j, generator=g) * 0.05 * (k + 1) for k in range(d)])
+    s["previous_joint_vel"] = vel0 - torch.randn(n, j, generator=g) * 0.05
+    p_contact = torch.full((b,), 0.05)
+    p_contact[0] = 0.01
+    p_contact[list(feet_ids)] = 0.5
+
+    def forces():
+        on = torch.rand(n, b, generator=g) < p_contact
+        f = torch.randn(n, b, 3, generator=g) * torch.tensor([3.0, 3.0, 60.0])
+        f[..., 2] = f[..., 2].abs()
+        return f * on.unsqueeze(-1)
+
+    s["net_forces"] = torch.stack([forces() for _ in range(d)])
+    s["net_forces_w_history"] = torch.stack([forces() for _ in range(history_len)], dim=1)
+    in_contact = s["net_forces_w_history"][:, 0].norm(dim=-1) > 1.0
+    t = torch.round(torch.rand(n, b, generator=g) * 120) * 0.005
+    s["current_contact_time"] = torch.where(in_contact, t, torch.zeros(()))
+    s["current_air_time"] = torch.where(in_contact, torch.zeros(()), t)
+    s["last_air_time"] = torch.rand(n, b, generator=g) * 0.6
+    s["last_contact_time"] = torch.rand(n, b, generator=g) * 0.6
+    s["action"] = torch.rand(n, j, generator=g) * 2 - 1       # the action of the previous step
+    s["prev_action"] = torch.rand(n, j, generator=g) * 2 - 1
+    s["raw_action"] = torch.rand(n, j, generator=g) * 2 - 1   # this step's policy output
+    s["command"] = torch.rand(n, 3, generator=g) * 2 - 1
+    s["heading_target"] = (torch.rand(n, generator=g) * 2 - 1) * np.pi
+    s["is_heading_env"] = torch.ones(n, dtype=torch.bool)
+    s["is_standing_env"] = torch.rand(n, generator=g) < 0.02
+    s["time_left"] = torch.rand(n, generator=g) * 10.0
+    s["command_counter"] = torch.ones(n, dtype=torch.long)
+    s["episode_length_buf"] = torch.randint(0, max_episode_length, (n,), generator=g)
+    s["pos_error_history"] = torch.randn(n, 3, j, generator=g) * 0.2
+    s["vel_history"] = torch.randn(n, 3, j, generator=g) * joint_vel_std
+    return s
+
+
+def actuator_mlp_weights(seed: int = 7, dims=(6, 32, 32, 32, 1)):
+    """Random-init actuator network (the reference's weight files live on a remote asset server):
+    N(0, 1/sqrt(fan_in)) weights, small biases."""
+    g = torch.Generator().manual_seed(seed)
+    ws = [torch.randn(dims[i + 1], dims[i], generator=g) / dims[i] ** 0.5 for i in range(len(dims) - 1)]
+    bs = [torch.randn(dims[i + 1], generator=g) * 0.1 for i in range(len(dims) - 1)]
+    return ws, bs
