@@ -97,7 +97,7 @@ def time_kernels(env, state, device, reps=20):
         sc = env.scanner
         _abi.check(_abi.raycaster_update(sc.meshes[sc.cfg.mesh_prim_paths[0]].handle, _abi.ptr(sc._data.pos_w), _abi.ptr(sc._data.quat_w),
                                          _abi.ptr(sc.ray_starts), _abi.ptr(sc.ray_directions), None, 1, 1e6,
-                                         _abi.ptr(sc._data.ray_hits_w), None, 0.0, env.n, sc.num_rays, _abi.stream()))
+                                         _abi.ptr(sc._data.ray_hits_w), None, 0.0, env.n, sc.num_rays, sc._hints, _abi.stream()))
 
     def mdp():
         env.mdp.step(FM.PHASE_ALL)

@@ -179,20 +179,29 @@ int ilx_mesh_info(ilx_mesh_t mesh, int64_t* num_tris, int64_t* num_nodes, int32_
 /* raycast_mesh (ops.py:24-127) + raycast_mesh_kernel (kernels.py:13-75): closest hit per ray with
  * 0 <= t < max_dist; ray_hits (n,3) = start + t*dir, +inf on a miss; optional outputs (NULL to skip):
  * ray_distance (n) [+inf], ray_normal (n,3) unit face normal [+inf], ray_face_id (n) int32 [-1].
- * Ties in t go to the lowest face index. */
+ * Ties in t go to the lowest face index.
+ * hints: bit mask of ilx_ray_hint; a hint changes which kernel runs, never the result. */
+enum ilx_ray_hint {
+    ILX_RAYS_Z_PARALLEL = 1 /* the caller expects every direction to be (0, 0, +-z), e.g. a height-scan pattern */
+};
 int ilx_raycast_mesh(ilx_mesh_t mesh, const float* ray_starts, const float* ray_directions, int64_t num_rays,
                      float max_dist, float* ray_hits, float* ray_distance, float* ray_normal, int32_t* ray_face_id,
-                     void* stream);
+                     int hints, void* stream);
+
+/* Diagnostics (no counterpart in the reference): same cast, plus per ray the number of BVH nodes visited and
+ * triangles tested in counters (n,2) int32. */
+int ilx_raycast_mesh_stats(ilx_mesh_t mesh, const float* ray_starts, const float* ray_directions, int64_t num_rays,
+                           float max_dist, float* ray_hits, int32_t* counters, void* stream);
 
 /* RayCaster._update_buffers_impl (ray_caster.py:242-260) in one launch: for every env flagged in env_mask
  * (n) uint8 (NULL = all), rotate the local ray starts (num_rays,3) by the sensor orientation quat_w (n,4)
  * (yaw only when attach_yaw_only, directions then stay unrotated), add pos_w (n,3), cast, and write
  * ray_hits_w (n,num_rays,3).  If height_scan (n,num_rays) is not NULL it receives
- * pos_w.z - hit.z - height_offset (observations.py:165-173). */
+ * pos_w.z - hit.z - height_offset (observations.py:165-173).  hints as in ilx_raycast_mesh. */
 int ilx_raycaster_update(ilx_mesh_t mesh, const float* pos_w, const float* quat_w, const float* ray_starts_local,
                          const float* ray_directions_local, const uint8_t* env_mask, int attach_yaw_only,
                          float max_dist, float* ray_hits_w, float* height_scan, float height_offset, int64_t n,
-                         int num_rays, void* stream);
+                         int num_rays, int hints, void* stream);
 
 #ifdef __cplusplus
 }

@@ -94,6 +94,8 @@ mesh_create = _sig("ilx_mesh_create", P, c_int64, P, c_int64, P)
 lib.ilx_mesh_destroy.argtypes = [P]
 lib.ilx_mesh_destroy.restype = None
 mesh_info = _sig("ilx_mesh_info", P, P, P, P)
-raycast_mesh = _sig("ilx_raycast_mesh", P, P, P, c_int64, c_float, P, P, P, P, P)
-raycaster_update = _sig("ilx_raycaster_update", P, P, P, P, P, P, c_int, c_float, P, P, c_float, c_int64, c_int, P)
+RAYS_Z_PARALLEL = 1
+raycast_mesh = _sig("ilx_raycast_mesh", P, P, P, c_int64, c_float, P, P, P, P, c_int, P)
+raycaster_update = _sig("ilx_raycaster_update", P, P, P, P, P, P, c_int, c_float, P, P, c_float, c_int64, c_int, c_int, P)
 joint_action_process = _sig("ilx_joint_action_process", P, P, P, P, c_float, P, c_float, P, P, c_int64, c_int, P)
+raycast_mesh_stats = _sig("ilx_raycast_mesh_stats", P, P, P, c_int64, c_float, P, P, P)

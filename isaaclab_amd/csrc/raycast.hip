@@ -2,14 +2,21 @@
 // isaaclab/utils/warp/kernels.py:13-75, isaaclab/sensors/ray_caster/ray_caster.py:220-260).
 //
 // Acceleration structure: a 4-wide BVH built on the host at ilx_mesh_create.
-//   * triangles are sorted along a 63-bit Morton curve of their centroids; a node splits its range of the
-//     sorted order into four equal-count children; ranges of <= 4 triangles become leaves;
+//   * top-down object-median splits (longest centroid axis, twice per node -> four children); ranges of
+//     <= 4 triangles become leaves;
 //   * nodes are numbered breadth first, so the top of the tree is one contiguous prefix that every block
 //     stages into LDS once; each node is one 128-byte line: child boxes as SoA float4s + 4 child references;
 //   * leaf triangles are stored in leaf order as (v0, e1, e2, original face id) in three float4s.
 // Traversal: one lane per ray, per-lane stack of child references in LDS ([slot][thread] -> conflict free),
 // children pushed far-to-near.  Box culling is conservative (boxes are inflated at build time and the slab test
 // carries slack), so the result equals testing every triangle: closest t, ties to the lowest face index.
+//
+// Column grid: rays parallel to the z axis (the height scanner's pattern) need no hierarchy at all.  The mesh's
+// xy footprint is cut into square cells and every cell lists the triangles whose (inflated) xy box overlaps it;
+// such a ray tests exactly the triangles of the one cell under its origin.  A caller that knows its rays are
+// z-parallel passes ILX_RAYS_Z_PARALLEL and gets the column kernel (no LDS, full occupancy, ~5x fewer bytes per
+// ray than the tree walk); rays that turn out not to be z-parallel still get the tree walk inside that kernel, so
+// the hint only affects speed, never results.
 #include "common.h"
 #include "raytri.h"
 
@@ -41,7 +48,19 @@ struct MeshDev {
     const float4* tris;  // 3 float4 per triangle, leaf order
     int32_t num_nodes;
     int32_t num_tris;
+    // column grid over the xy footprint (CSR: cell_start[c] .. cell_start[c + 1] index cell_refs)
+    const uint32_t* cell_start;
+    const uint32_t* cell_refs;  // positions in `tris`
+    float gx0, gy0, gx1, gy1, inv_cell;
+    int32_t nx, ny;
 };
+
+// Cell coordinate of x along one axis.  The same expression places triangles at build time and rays at cast
+// time; it is monotone in x, so a ray inside a triangle's box lands in a cell that lists the triangle.
+__host__ __device__ inline int cell_coord(float x, float g0, float inv_cell, int n) {
+    const int c = static_cast<int>(floorf((x - g0) * inv_cell));
+    return c < 0 ? 0 : (c >= n ? n - 1 : c);
+}
 
 struct Hit {
     float t;
@@ -86,7 +105,8 @@ ILX_DEV float ray_box(f3 o, f3 inv, bool zx, bool zy, bool zz, float bminx, floa
 // `cache` holds the first `ncache` nodes (LDS).
 template <bool WANT_NORMAL>
 ILX_DEV Hit trace(const MeshDev& m, const Node* cache, int ncache, int32_t* stack, int stride, f3 o, f3 d,
-                  float max_dist) {
+                  float max_dist, int32_t* counters = nullptr) {
+    int n_nodes = 0, n_tris = 0;
     const float inf = __builtin_inff();
     Hit best{inf, -1, {0.0f, 0.0f, 0.0f}};
     float limit = max_dist;  // candidates must satisfy t < max_dist; afterwards t <= best.t
@@ -98,6 +118,7 @@ ILX_DEV Hit trace(const MeshDev& m, const Node* cache, int ncache, int32_t* stac
     while (sp > 0) {
         const int32_t ref = stack[(--sp) * stride];
         if (ref >= 0) {
+            ++n_nodes;
             const Node* n = (ref < ncache) ? (cache + ref) : (m.nodes + ref);
             const float4 mnx = *reinterpret_cast<const float4*>(n->minx), mny = *reinterpret_cast<const float4*>(n->miny),
                          mnz = *reinterpret_cast<const float4*>(n->minz), mxx = *reinterpret_cast<const float4*>(n->maxx),
@@ -135,6 +156,7 @@ ILX_DEV Hit trace(const MeshDev& m, const Node* cache, int ncache, int32_t* stac
         } else {
             const int32_t code = -(ref + 1);
             const int32_t first = code >> 2, count = (code & 3) + 1;
+            n_tris += count;
             for (int k = 0; k < count; ++k) {
                 const float4* tp = m.tris + 3 * static_cast<int64_t>(first + k);
                 const float4 a = tp[0], b = tp[1], c = tp[2];
@@ -152,7 +174,56 @@ ILX_DEV Hit trace(const MeshDev& m, const Node* cache, int ncache, int32_t* stac
             }
         }
     }
+    if (counters) {
+        counters[0] = n_nodes;
+        counters[1] = n_tris;
+    }
     return best;
+}
+
+ILX_DEV void test_triangle(const MeshDev& m, uint32_t pos, f3 o, f3 d, float max_dist, bool want_normal, Hit& best) {
+    const float4* tp = m.tris + 3 * static_cast<int64_t>(pos);
+    const float4 a = tp[0], b = tp[1], c = tp[2];
+    const f3 v0 = {a.x, a.y, a.z}, e1 = {a.w, b.x, b.y}, e2 = {b.z, b.w, c.x};
+    const int32_t face = __float_as_int(c.y);
+    float t;
+    if (ray_triangle(o, d, v0, e1, e2, max_dist, t)) {
+        if (t < best.t || (t == best.t && face < best.face)) {
+            best.t = t;
+            best.face = face;
+            if (want_normal) best.normal_raw = cross3(e1, e2);
+        }
+    }
+}
+
+// z-parallel ray: every candidate lives in the cell under the origin.
+template <bool WANT_NORMAL>
+ILX_DEV Hit trace_column(const MeshDev& m, f3 o, f3 d, float max_dist) {
+    Hit best{__builtin_inff(), -1, {0.0f, 0.0f, 0.0f}};
+    if (!(o.x >= m.gx0 && o.x <= m.gx1 && o.y >= m.gy0 && o.y <= m.gy1)) return best;
+    const int cx = cell_coord(o.x, m.gx0, m.inv_cell, m.nx), cy = cell_coord(o.y, m.gy0, m.inv_cell, m.ny);
+    const int64_t c = static_cast<int64_t>(cy) * m.nx + cx;
+    uint32_t k = m.cell_start[c];
+    const uint32_t end = m.cell_start[c + 1];
+    // four references per trip so the triangle loads of a trip are in flight together
+    for (; k + 4 <= end; k += 4) {
+        const uint32_t r0 = m.cell_refs[k], r1 = m.cell_refs[k + 1], r2 = m.cell_refs[k + 2], r3 = m.cell_refs[k + 3];
+        test_triangle(m, r0, o, d, max_dist, WANT_NORMAL, best);
+        test_triangle(m, r1, o, d, max_dist, WANT_NORMAL, best);
+        test_triangle(m, r2, o, d, max_dist, WANT_NORMAL, best);
+        test_triangle(m, r3, o, d, max_dist, WANT_NORMAL, best);
+    }
+    for (; k < end; ++k) test_triangle(m, m.cell_refs[k], o, d, max_dist, WANT_NORMAL, best);
+    return best;
+}
+
+// Column kernel body: z-parallel rays take the grid; anything else walks the tree with a private stack and no
+// node cache (slow, but only reached when the caller's hint was wrong for that ray).
+template <bool WANT_NORMAL>
+ILX_DEV Hit trace_hinted(const MeshDev& m, f3 o, f3 d, float max_dist) {
+    if (d.x == 0.0f && d.y == 0.0f && m.cell_start) return trace_column<WANT_NORMAL>(m, o, d, max_dist);
+    int32_t stack[kStackSlots];
+    return trace<WANT_NORMAL>(m, nullptr, 0, stack, 1, o, d, max_dist);
 }
 
 ILX_DEV void stage_nodes(const MeshDev& m, Node* cache, int ncache) {
@@ -173,6 +244,7 @@ struct CastArgs {
     float* normal;        // (n,3) or null
     int32_t* face;        // (n) or null
     int64_t n;
+    int32_t* counters;    // (n,2) or null: nodes visited / triangles tested per ray (diagnostics)
 };
 
 ILX_DEV void write_hit(const Hit& h, f3 o, f3 d, float* hits, float* dist, float* normal, int32_t* face, int64_t i) {
@@ -194,10 +266,19 @@ __global__ void __launch_bounds__(kRayBlock) raycast_kernel(CastArgs a) {
     for (int64_t i = static_cast<int64_t>(blockIdx.x) * kRayBlock + threadIdx.x; i < a.n;
          i += static_cast<int64_t>(gridDim.x) * kRayBlock) {
         const f3 o = load3(a.starts + 3 * i), d = load3(a.dirs + 3 * i);
-        const Hit h = a.normal ? trace<true>(a.mesh, cache, ncache, stack + threadIdx.x, kRayBlock, o, d, a.max_dist)
-                               : trace<false>(a.mesh, cache, ncache, stack + threadIdx.x, kRayBlock, o, d, a.max_dist);
+        int32_t* cnt = a.counters ? a.counters + 2 * i : nullptr;
+        const Hit h = a.normal ? trace<true>(a.mesh, cache, ncache, stack + threadIdx.x, kRayBlock, o, d, a.max_dist, cnt)
+                               : trace<false>(a.mesh, cache, ncache, stack + threadIdx.x, kRayBlock, o, d, a.max_dist, cnt);
         write_hit(h, o, d, a.hits, a.dist, a.normal, a.face, i);
     }
+}
+
+__global__ void __launch_bounds__(kRayBlock) raycast_column_kernel(CastArgs a) {
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * kRayBlock + threadIdx.x;
+    if (i >= a.n) return;
+    const f3 o = load3(a.starts + 3 * i), d = load3(a.dirs + 3 * i);
+    const Hit h = a.normal ? trace_hinted<true>(a.mesh, o, d, a.max_dist) : trace_hinted<false>(a.mesh, o, d, a.max_dist);
+    write_hit(h, o, d, a.hits, a.dist, a.normal, a.face, i);
 }
 
 // RayCaster._update_buffers_impl fused with the cast: sensor pose -> world rays -> hits (+ height-scan term).
@@ -217,6 +298,34 @@ struct ScanArgs {
     int r;
 };
 
+// World ray i = (env, ray) of the sensor; false when the env is masked out.
+ILX_DEV bool sensor_ray(const ScanArgs& a, int64_t i, f3& o, f3& d, float& pos_z) {
+    const int64_t env = i / a.r;
+    const int ray = static_cast<int>(i - env * a.r);
+    if (a.env_mask && !a.env_mask[env]) return false;
+    const f3 pos = load3(a.pos_w + 3 * env);
+    const f4 q = load4(a.quat_w + 4 * env);
+    const f3 ls = load3(a.ray_starts + 3 * ray), ld = load3(a.ray_dirs + 3 * ray);
+    if (a.yaw_only) {  // ray_caster.py:243-247: starts rotated by yaw only, directions unrotated
+        o = quat_apply_yaw(q, ls);
+        d = ld;
+    } else {  // ray_caster.py:248-252
+        o = quat_apply(q, ls);
+        d = quat_apply(q, ld);
+    }
+    o = {o.x + pos.x, o.y + pos.y, o.z + pos.z};
+    pos_z = pos.z;
+    return true;
+}
+
+ILX_DEV void write_scan(const ScanArgs& a, const Hit& h, f3 o, f3 d, float pos_z, int64_t i) {
+    write_hit(h, o, d, a.ray_hits_w, nullptr, nullptr, nullptr, i);
+    if (a.height) {
+        const float hz = (h.face >= 0) ? (o.z + h.t * d.z) : __builtin_inff();
+        a.height[i] = pos_z - hz - a.height_offset;
+    }
+}
+
 __global__ void __launch_bounds__(kRayBlock) raycaster_update_kernel(ScanArgs a) {
     __shared__ Node cache[kCachedNodes];
     __shared__ int32_t stack[kStackSlots * kRayBlock];
@@ -225,28 +334,22 @@ __global__ void __launch_bounds__(kRayBlock) raycaster_update_kernel(ScanArgs a)
     const int64_t total = a.n * a.r;
     for (int64_t i = static_cast<int64_t>(blockIdx.x) * kRayBlock + threadIdx.x; i < total;
          i += static_cast<int64_t>(gridDim.x) * kRayBlock) {
-        const int64_t env = i / a.r;
-        const int ray = static_cast<int>(i - env * a.r);
-        if (a.env_mask && !a.env_mask[env]) continue;
-        const f3 pos = load3(a.pos_w + 3 * env);
-        const f4 q = load4(a.quat_w + 4 * env);
-        const f3 ls = load3(a.ray_starts + 3 * ray), ld = load3(a.ray_dirs + 3 * ray);
         f3 o, d;
-        if (a.yaw_only) {  // ray_caster.py:243-247: starts rotated by yaw only, directions unrotated
-            o = quat_apply_yaw(q, ls);
-            d = ld;
-        } else {  // ray_caster.py:248-252
-            o = quat_apply(q, ls);
-            d = quat_apply(q, ld);
-        }
-        o = {o.x + pos.x, o.y + pos.y, o.z + pos.z};
+        float pos_z;
+        if (!sensor_ray(a, i, o, d, pos_z)) continue;
         const Hit h = trace<false>(a.mesh, cache, ncache, stack + threadIdx.x, kRayBlock, o, d, a.max_dist);
-        write_hit(h, o, d, a.ray_hits_w, nullptr, nullptr, nullptr, i);
-        if (a.height) {
-            const float hz = (h.face >= 0) ? (o.z + h.t * d.z) : __builtin_inff();
-            a.height[i] = pos.z - hz - a.height_offset;
-        }
+        write_scan(a, h, o, d, pos_z, i);
     }
+}
+
+__global__ void __launch_bounds__(kRayBlock) raycaster_update_column_kernel(ScanArgs a) {
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * kRayBlock + threadIdx.x;
+    if (i >= a.n * a.r) return;
+    f3 o, d;
+    float pos_z;
+    if (!sensor_ray(a, i, o, d, pos_z)) return;
+    const Hit h = trace_hinted<false>(a.mesh, o, d, a.max_dist);
+    write_scan(a, h, o, d, pos_z, i);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -262,42 +365,58 @@ struct Box {
     }
 };
 
-static inline uint64_t spread21(uint64_t v) {
-    v &= 0x1fffff;
-    v = (v | v << 32) & 0x1f00000000ffffULL;
-    v = (v | v << 16) & 0x1f0000ff0000ffULL;
-    v = (v | v << 8) & 0x100f00f00f00f00fULL;
-    v = (v | v << 4) & 0x10c30c30c30c30c3ULL;
-    v = (v | v << 2) & 0x1249249249249249ULL;
-    return v;
-}
-
 struct TmpNode {
     Box box[4];
     int32_t ref[4];   // >= 0: index into tmp nodes; leaf encoding otherwise
 };
 
+// Top-down object-median build: a node's range is cut at the median along the longest axis of its centroid
+// bounds, and each half is cut again along its own longest axis, giving four children with compact, barely
+// overlapping boxes (a vertical ray over a terrain then enters about one child per level).
 struct Builder {
-    const std::vector<Box>& tri_box;   // in sorted order
+    std::vector<Box>& tri_box;      // permuted in place together with `order`
+    std::vector<float>& cen;        // centroid (3 floats) per ORIGINAL triangle id
+    std::vector<int>& order;        // order[i] = original triangle id at sorted position i
     std::vector<TmpNode> nodes;
     int max_depth = 0;
+
+    int split(int lo, int hi) {
+        float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (int i = lo; i < hi; ++i)
+            for (int a = 0; a < 3; ++a) {
+                const float c = cen[3 * static_cast<size_t>(order[i]) + a];
+                mn[a] = std::min(mn[a], c), mx[a] = std::max(mx[a], c);
+            }
+        int axis = 0;
+        for (int a = 1; a < 3; ++a)
+            if (mx[a] - mn[a] > mx[axis] - mn[axis]) axis = a;
+        const int mid = lo + (hi - lo) / 2;
+        std::nth_element(order.begin() + lo, order.begin() + mid, order.begin() + hi, [&](int x, int y) {
+            const float cx = cen[3 * static_cast<size_t>(x) + axis], cy = cen[3 * static_cast<size_t>(y) + axis];
+            return cx != cy ? cx < cy : x < y;
+        });
+        return mid;
+    }
 
     // builds the node for [lo, hi) (hi - lo > kLeafSize) and returns its index
     int build(int lo, int hi, int depth, Box& out) {
         max_depth = std::max(max_depth, depth);
         const int idx = static_cast<int>(nodes.size());
         nodes.emplace_back();
-        const int n = hi - lo;
+        int cut[5];
+        cut[0] = lo, cut[4] = hi;
+        cut[2] = split(lo, hi);
+        cut[1] = (cut[2] - lo > 1) ? split(lo, cut[2]) : cut[2];
+        cut[3] = (hi - cut[2] > 1) ? split(cut[2], hi) : hi;
         out.reset();
         for (int c = 0; c < 4; ++c) {
-            const int a = lo + static_cast<int>((static_cast<int64_t>(n) * c) / 4);
-            const int b = lo + static_cast<int>((static_cast<int64_t>(n) * (c + 1)) / 4);
+            const int a = cut[c], b = cut[c + 1];
             Box bx;
             bx.reset();
             int32_t ref = kEmptyRef;
             if (b > a) {
                 if (b - a <= kLeafSize) {
-                    for (int t = a; t < b; ++t) bx.grow(tri_box[t]);
+                    for (int t = a; t < b; ++t) bx.grow(tri_box[order[t]]);
                     ref = -(1 + ((a << 2) | (b - a - 1)));
                 } else {
                     ref = build(a, b, depth + 1, bx);
@@ -315,6 +434,9 @@ struct MeshHost {
     MeshDev dev{};
     Node* d_nodes = nullptr;
     float4* d_tris = nullptr;
+    uint32_t* d_cell_start = nullptr;
+    uint32_t* d_cell_refs = nullptr;
+    int64_t num_cell_refs = 0;
     int depth = 0;
     int64_t num_verts = 0;
 };
@@ -340,10 +462,9 @@ extern "C" int ilx_mesh_create(const float* verts_host, int64_t num_verts, const
         ILX_REQUIRE(tris_host[i] >= 0 && tris_host[i] < num_verts, ILX_EINVAL,
                     "ilx_mesh_create: triangle index %d outside [0, %lld)", tris_host[i], (long long)num_verts);
 
-    // bounds of the centroids -> Morton keys (uniform scale so that the small z range of a terrain barely splits)
+    // per-triangle boxes (inflated) and centroids
     std::vector<Box> box(nt);
     std::vector<float> cen(3 * static_cast<size_t>(nt));
-    float cmin[3] = {INFINITY, INFINITY, INFINITY}, cmax[3] = {-INFINITY, -INFINITY, -INFINITY};
     for (int t = 0; t < nt; ++t) {
         Box b;
         b.reset();
@@ -356,7 +477,6 @@ extern "C" int ilx_mesh_create(const float* verts_host, int64_t num_verts, const
         }
         for (int a = 0; a < 3; ++a) {
             cen[3 * t + a] = 0.5f * (b.mn[a] + b.mx[a]);
-            cmin[a] = std::min(cmin[a], cen[3 * t + a]), cmax[a] = std::max(cmax[a], cen[3 * t + a]);
             // inflate: the intersection formula may accept points a few ulps outside the exact triangle
             const float ext = b.mx[a] - b.mn[a];
             const float pad = 1.0e-4f * std::max(ext, 1.0e-3f) + 4.0e-6f * std::max(std::fabs(b.mn[a]), std::fabs(b.mx[a]));
@@ -364,34 +484,18 @@ extern "C" int ilx_mesh_create(const float* verts_host, int64_t num_verts, const
         }
         box[t] = b;
     }
-    const float extent = std::max({cmax[0] - cmin[0], cmax[1] - cmin[1], cmax[2] - cmin[2], 1.0e-12f});
-    std::vector<uint64_t> key(nt);
-    for (int t = 0; t < nt; ++t) {
-        uint64_t k = 0;
-        for (int a = 0; a < 3; ++a) {
-            const double u = (static_cast<double>(cen[3 * t + a]) - cmin[a]) / extent;
-            const uint64_t q = static_cast<uint64_t>(std::min(std::max(u, 0.0), 1.0) * 2097151.0);
-            k |= spread21(q) << a;
-        }
-        key[t] = k;
-    }
     std::vector<int> order(nt);
     std::iota(order.begin(), order.end(), 0);
-    std::sort(order.begin(), order.end(), [&](int a, int b) { return key[a] != key[b] ? key[a] < key[b] : a < b; });
-    // inside a leaf the face order must be ascending so that "first strictly smaller t wins" keeps the lowest id;
-    // the kernel compares ids explicitly, so only the boxes need the sorted order here
-    std::vector<Box> sorted_box(nt);
-    for (int i = 0; i < nt; ++i) sorted_box[i] = box[order[i]];
-
-    Builder bld{sorted_box};
+    Builder bld{box, cen, order};
     Box root_box;
     if (nt <= kLeafSize) {
         bld.nodes.emplace_back();
         TmpNode& r = bld.nodes[0];
         for (int c = 0; c < 4; ++c) r.box[c].reset(), r.ref[c] = kEmptyRef;
-        for (int t = 0; t < nt; ++t) r.box[0].grow(sorted_box[t]);
+        for (int t = 0; t < nt; ++t) r.box[0].grow(box[t]);
         r.ref[0] = -(1 + ((0 << 2) | (nt - 1)));
     } else {
+        bld.nodes.reserve(static_cast<size_t>(nt) / 2 + 16);
         bld.build(0, nt, 0, root_box);
     }
     ILX_REQUIRE(bld.max_depth <= kMaxDepth, ILX_ESHAPE, "ilx_mesh_create: tree depth %d exceeds %d", bld.max_depth,
@@ -434,9 +538,69 @@ extern "C" int ilx_mesh_create(const float* verts_host, int64_t num_verts, const
         tris[3 * i + 2] = make_float4(e2[2], idbits, 0.0f, 0.0f);
     }
 
+    // column grid: about four cells per triangle over the xy footprint, bounded in cells and in references
+    // (a mesh whose triangles are huge next to the cell size would blow the lists up; then the cells are coarsened,
+    // and a mesh that still does not fit gets no grid -- its z-parallel rays walk the tree).
+    float g0[2] = {INFINITY, INFINITY}, g1[2] = {-INFINITY, -INFINITY};
+    for (int t = 0; t < nt; ++t)
+        for (int a = 0; a < 2; ++a) g0[a] = std::min(g0[a], box[t].mn[a]), g1[a] = std::max(g1[a], box[t].mx[a]);
+    std::vector<uint32_t> cell_start, cell_refs;
+    int gnx = 0, gny = 0;
+    float inv_cell = 0.0f;
+    {
+        const double wx = std::max(double(g1[0]) - g0[0], 1e-6), wy = std::max(double(g1[1]) - g0[1], 1e-6);
+        double cell = std::sqrt(wx * wy / (4.0 * nt));
+        cell = std::max(cell, std::max(wx, wy) / 8192.0);
+        const int64_t max_refs = std::max<int64_t>(int64_t(64) * nt, 1 << 16);
+        for (int attempt = 0; attempt < 12; ++attempt, cell *= 2.0) {
+            inv_cell = static_cast<float>(1.0 / cell);
+            gnx = std::max(1, cell_coord(g1[0], g0[0], inv_cell, 1 << 20) + 1);
+            gny = std::max(1, cell_coord(g1[1], g0[1], inv_cell, 1 << 20) + 1);
+            if (static_cast<int64_t>(gnx) * gny > (int64_t(1) << 26)) continue;
+            cell_start.assign(static_cast<size_t>(gnx) * gny + 1, 0u);
+            int64_t total = 0;
+            for (int i = 0; i < nt && total <= max_refs; ++i) {
+                const Box& b = box[order[i]];
+                const int x0 = cell_coord(b.mn[0], g0[0], inv_cell, gnx), x1 = cell_coord(b.mx[0], g0[0], inv_cell, gnx);
+                const int y0 = cell_coord(b.mn[1], g0[1], inv_cell, gny), y1 = cell_coord(b.mx[1], g0[1], inv_cell, gny);
+                total += static_cast<int64_t>(x1 - x0 + 1) * (y1 - y0 + 1);
+                if (total > max_refs) break;
+                for (int y = y0; y <= y1; ++y)
+                    for (int x = x0; x <= x1; ++x) ++cell_start[static_cast<size_t>(y) * gnx + x + 1];
+            }
+            if (total > max_refs) {
+                cell_start.clear();
+                continue;
+            }
+            for (size_t c = 1; c < cell_start.size(); ++c) cell_start[c] += cell_start[c - 1];
+            cell_refs.resize(static_cast<size_t>(total));
+            std::vector<uint32_t> fill(cell_start.begin(), cell_start.end() - 1);
+            for (int i = 0; i < nt; ++i) {
+                const Box& b = box[order[i]];
+                const int x0 = cell_coord(b.mn[0], g0[0], inv_cell, gnx), x1 = cell_coord(b.mx[0], g0[0], inv_cell, gnx);
+                const int y0 = cell_coord(b.mn[1], g0[1], inv_cell, gny), y1 = cell_coord(b.mx[1], g0[1], inv_cell, gny);
+                for (int y = y0; y <= y1; ++y)
+                    for (int x = x0; x <= x1; ++x) cell_refs[fill[static_cast<size_t>(y) * gnx + x]++] = static_cast<uint32_t>(i);
+            }
+            break;
+        }
+    }
+
     auto* obj = new ilx_mesh_s();
     MeshHost& h = obj->h;
     int rc = check_hip(hipMalloc(&h.d_nodes, nodes.size() * sizeof(Node)), "ilx_mesh_create: hipMalloc(nodes)");
+    if (rc == ILX_OK && !cell_start.empty()) {
+        rc = check_hip(hipMalloc(&h.d_cell_start, cell_start.size() * sizeof(uint32_t)), "ilx_mesh_create: hipMalloc(cells)");
+        if (rc == ILX_OK)
+            rc = check_hip(hipMalloc(&h.d_cell_refs, std::max<size_t>(cell_refs.size(), 1) * sizeof(uint32_t)),
+                           "ilx_mesh_create: hipMalloc(cell refs)");
+        if (rc == ILX_OK)
+            rc = check_hip(hipMemcpy(h.d_cell_start, cell_start.data(), cell_start.size() * sizeof(uint32_t),
+                                     hipMemcpyHostToDevice), "ilx_mesh_create: copy cells");
+        if (rc == ILX_OK && !cell_refs.empty())
+            rc = check_hip(hipMemcpy(h.d_cell_refs, cell_refs.data(), cell_refs.size() * sizeof(uint32_t),
+                                     hipMemcpyHostToDevice), "ilx_mesh_create: copy cell refs");
+    }
     if (rc == ILX_OK) rc = check_hip(hipMalloc(&h.d_tris, tris.size() * sizeof(float4)), "ilx_mesh_create: hipMalloc(tris)");
     if (rc == ILX_OK)
         rc = check_hip(hipMemcpy(h.d_nodes, nodes.data(), nodes.size() * sizeof(Node), hipMemcpyHostToDevice),
@@ -447,10 +611,16 @@ extern "C" int ilx_mesh_create(const float* verts_host, int64_t num_verts, const
     if (rc != ILX_OK) {
         if (h.d_nodes) (void)hipFree(h.d_nodes);
         if (h.d_tris) (void)hipFree(h.d_tris);
+        if (h.d_cell_start) (void)hipFree(h.d_cell_start);
+        if (h.d_cell_refs) (void)hipFree(h.d_cell_refs);
         delete obj;
         return rc;
     }
     h.dev.nodes = h.d_nodes, h.dev.tris = h.d_tris, h.dev.num_nodes = nn, h.dev.num_tris = nt;
+    h.dev.cell_start = h.d_cell_start, h.dev.cell_refs = h.d_cell_refs;
+    h.dev.gx0 = g0[0], h.dev.gy0 = g0[1], h.dev.gx1 = g1[0], h.dev.gy1 = g1[1], h.dev.inv_cell = inv_cell;
+    h.dev.nx = gnx, h.dev.ny = gny;
+    h.num_cell_refs = static_cast<int64_t>(cell_refs.size());
     h.depth = bld.max_depth, h.num_verts = num_verts;
     *out = obj;
     return ILX_OK;
@@ -460,6 +630,8 @@ extern "C" void ilx_mesh_destroy(ilx_mesh_t mesh) {
     if (!mesh) return;
     if (mesh->h.d_nodes) (void)hipFree(mesh->h.d_nodes);
     if (mesh->h.d_tris) (void)hipFree(mesh->h.d_tris);
+    if (mesh->h.d_cell_start) (void)hipFree(mesh->h.d_cell_start);
+    if (mesh->h.d_cell_refs) (void)hipFree(mesh->h.d_cell_refs);
     delete mesh;
 }
 
@@ -477,23 +649,41 @@ static unsigned ray_grid(int64_t rays) {
     return static_cast<unsigned>(std::min<int64_t>(want, 256 * 12));
 }
 
+static unsigned column_grid(int64_t rays) { return static_cast<unsigned>((rays + kRayBlock - 1) / kRayBlock); }
+
 extern "C" int ilx_raycast_mesh(ilx_mesh_t mesh, const float* ray_starts, const float* ray_directions, int64_t num_rays,
                                 float max_dist, float* ray_hits, float* ray_distance, float* ray_normal,
-                                int32_t* ray_face_id, void* stream) {
+                                int32_t* ray_face_id, int hints, void* stream) {
     ILX_REQUIRE(mesh, ILX_EINVAL, "ilx_raycast_mesh: mesh is NULL");
     ILX_REQUIRE(num_rays >= 0, ILX_EINVAL, "ilx_raycast_mesh: negative ray count");
     if (num_rays == 0) return ILX_OK;
     ILX_REQUIRE(ray_starts && ray_directions && ray_hits, ILX_EINVAL, "ilx_raycast_mesh: NULL operand");
-    CastArgs a{mesh->h.dev, ray_starts, ray_directions, max_dist, ray_hits, ray_distance, ray_normal, ray_face_id, num_rays};
-    hipLaunchKernelGGL(raycast_kernel, dim3(ray_grid(num_rays)), dim3(kRayBlock), 0, as_stream(stream), a);
+    ILX_REQUIRE(num_rays < (int64_t(1) << 31) * kRayBlock, ILX_ESHAPE, "ilx_raycast_mesh: too many rays");
+    CastArgs a{mesh->h.dev, ray_starts, ray_directions, max_dist, ray_hits, ray_distance, ray_normal, ray_face_id, num_rays,
+               nullptr};
+    if ((hints & ILX_RAYS_Z_PARALLEL) && mesh->h.d_cell_start)
+        hipLaunchKernelGGL(raycast_column_kernel, dim3(column_grid(num_rays)), dim3(kRayBlock), 0, as_stream(stream), a);
+    else
+        hipLaunchKernelGGL(raycast_kernel, dim3(ray_grid(num_rays)), dim3(kRayBlock), 0, as_stream(stream), a);
     ILX_LAUNCH_CHECK("ilx_raycast_mesh");
+    return ILX_OK;
+}
+
+extern "C" int ilx_raycast_mesh_stats(ilx_mesh_t mesh, const float* ray_starts, const float* ray_directions,
+                                      int64_t num_rays, float max_dist, float* ray_hits, int32_t* counters, void* stream) {
+    ILX_REQUIRE(mesh, ILX_EINVAL, "ilx_raycast_mesh_stats: mesh is NULL");
+    if (num_rays <= 0) return ILX_OK;
+    ILX_REQUIRE(ray_starts && ray_directions && ray_hits && counters, ILX_EINVAL, "ilx_raycast_mesh_stats: NULL operand");
+    CastArgs a{mesh->h.dev, ray_starts, ray_directions, max_dist, ray_hits, nullptr, nullptr, nullptr, num_rays, counters};
+    hipLaunchKernelGGL(raycast_kernel, dim3(ray_grid(num_rays)), dim3(kRayBlock), 0, as_stream(stream), a);
+    ILX_LAUNCH_CHECK("ilx_raycast_mesh_stats");
     return ILX_OK;
 }
 
 extern "C" int ilx_raycaster_update(ilx_mesh_t mesh, const float* pos_w, const float* quat_w, const float* ray_starts_local,
                                     const float* ray_directions_local, const uint8_t* env_mask, int attach_yaw_only,
                                     float max_dist, float* ray_hits_w, float* height_scan, float height_offset,
-                                    int64_t n, int num_rays, void* stream) {
+                                    int64_t n, int num_rays, int hints, void* stream) {
     ILX_REQUIRE(mesh, ILX_EINVAL, "ilx_raycaster_update: mesh is NULL");
     ILX_REQUIRE(n >= 0 && num_rays > 0, ILX_EINVAL, "ilx_raycaster_update: bad shape (%lld, %d)", (long long)n, num_rays);
     if (n == 0) return ILX_OK;
@@ -503,7 +693,11 @@ extern "C" int ilx_raycaster_update(ilx_mesh_t mesh, const float* pos_w, const f
                 "ilx_raycaster_update: quat_w must be 16-byte aligned");
     ScanArgs a{mesh->h.dev, pos_w, quat_w, ray_starts_local, ray_directions_local, env_mask, attach_yaw_only, max_dist,
                ray_hits_w, height_scan, height_offset, n, num_rays};
-    hipLaunchKernelGGL(raycaster_update_kernel, dim3(ray_grid(n * num_rays)), dim3(kRayBlock), 0, as_stream(stream), a);
+    if ((hints & ILX_RAYS_Z_PARALLEL) && mesh->h.d_cell_start)
+        hipLaunchKernelGGL(raycaster_update_column_kernel, dim3(column_grid(n * num_rays)), dim3(kRayBlock), 0,
+                           as_stream(stream), a);
+    else
+        hipLaunchKernelGGL(raycaster_update_kernel, dim3(ray_grid(n * num_rays)), dim3(kRayBlock), 0, as_stream(stream), a);
     ILX_LAUNCH_CHECK("ilx_raycaster_update");
     return ILX_OK;
 }

@@ -71,6 +71,10 @@ class RayCaster:
         offset_quat = torch.tensor(list(cfg.offset.rot), device=dev)
         self.ray_directions = math_utils.quat_apply(offset_quat.repeat(self.num_rays, 1), self.ray_directions)
         self.ray_starts = self.ray_starts + offset_pos
+        # z-parallel world rays (a yaw-only scanner looking straight down) take the column-grid kernel
+        self._hints = 0
+        if cfg.attach_yaw_only and bool((self.ray_directions[:, :2] == 0).all()):
+            self._hints = _abi.RAYS_Z_PARALLEL
         self.drift = torch.zeros(n, 3, device=dev)
         self._data = RayCasterData(pos_w=torch.zeros(n, 3, device=dev), quat_w=torch.zeros(n, 4, device=dev),
                                    ray_hits_w=torch.zeros(n, self.num_rays, 3, device=dev))
@@ -132,7 +136,8 @@ class RayCaster:
         _abi.check(_abi.raycaster_update(
             mesh.handle, _abi.ptr(d.pos_w), _abi.ptr(d.quat_w), _abi.ptr(self.ray_starts), _abi.ptr(self.ray_directions),
             mask.data_ptr(), int(self.cfg.attach_yaw_only), float(self.cfg.max_distance), _abi.ptr(d.ray_hits_w),
-            _abi.ptr(height_out), float(height_offset), self._num_envs, self.num_rays, _abi.stream()),
+            _abi.ptr(height_out), float(height_offset), self._num_envs, self.num_rays, self._hints,
+            _abi.stream()),
             "ilx_raycaster_update")
         self._timestamp_last_update = torch.where(mask, self._timestamp, self._timestamp_last_update)
         self._is_outdated = torch.zeros_like(mask)

@@ -44,8 +44,10 @@ def convert_to_mesh(points: np.ndarray, indices: np.ndarray, device: str) -> Mes
 
 
 def raycast_mesh(ray_starts: torch.Tensor, ray_directions: torch.Tensor, mesh: Mesh, max_dist: float = 1e6,
-                 return_distance: bool = False, return_normal: bool = False, return_face_id: bool = False):
-    """ops.py:24-127."""
+                 return_distance: bool = False, return_normal: bool = False, return_face_id: bool = False,
+                 z_parallel_hint: bool = False):
+    """ops.py:24-127.  ``z_parallel_hint`` (no counterpart in the reference) tells the library that the directions
+    are expected to be (0, 0, +-z); it selects the column-grid kernel and never changes the result."""
     shape = ray_starts.shape
     device = ray_starts.device
     starts = _abi.f32c(ray_starts.to(mesh.device)).view(-1, 3)
@@ -56,7 +58,8 @@ def raycast_mesh(ray_starts: torch.Tensor, ray_directions: torch.Tensor, mesh: M
     normal = torch.empty((n, 3), dtype=torch.float32, device=mesh.device) if return_normal else None
     face = torch.empty((n,), dtype=torch.int32, device=mesh.device) if return_face_id else None
     _abi.check(_abi.raycast_mesh(mesh.handle, _abi.ptr(starts), _abi.ptr(dirs), n, float(max_dist), _abi.ptr(hits),
-                                 _abi.ptr(dist), _abi.ptr(normal), _abi.ptr(face), _abi.stream()), "ilx_raycast_mesh")
+                                 _abi.ptr(dist), _abi.ptr(normal), _abi.ptr(face),
+                                 _abi.RAYS_Z_PARALLEL if z_parallel_hint else 0, _abi.stream()), "ilx_raycast_mesh")
     if return_distance:
         dist = dist.to(device).view(shape[0], shape[1]) if len(shape) == 3 else dist.to(device)
     if return_normal:

@@ -38,6 +38,35 @@ def test_small_mesh_all_outputs(dev):
     assert out[0].shape == (3, 200, 3) and out[1].shape == (3, 200)
 
 
+def test_z_parallel_hint_never_changes_results(dev):
+    """The column-grid kernel (z-parallel hint) must return what the tree walk returns -- for z-parallel rays (grid
+    look-up), for rays that break the hint (in-kernel tree walk), on seams, vertices and outside the footprint."""
+    from isaaclab_amd.utils.mesh import convert_to_mesh, raycast_mesh
+
+    verts, tris, starts, dirs = make_rays()
+    mesh = convert_to_mesh(verts.numpy(), tris.numpy().reshape(-1), str(dev))
+    gen = torch.Generator().manual_seed(5)
+    lo, hi = verts.min(0).values, verts.max(0).values
+    m = 4096
+    xy = lo[:2] - 0.5 + torch.rand(m, 2, generator=gen) * (hi[:2] - lo[:2] + 1.0)
+    xy[:verts.shape[0]] = verts[:, :2][:m]                       # straight through mesh vertices
+    mid = 0.5 * (verts[tris[:, 0].long()] + verts[tris[:, 1].long()])[:, :2]
+    xy[1024:1024 + min(1024, mid.shape[0])] = mid[:1024]         # on triangle edges
+    down = torch.cat([xy, torch.full((m, 1), float(hi[2]) + 3.0)], -1)
+    up = torch.cat([xy, torch.full((m, 1), float(lo[2]) - 3.0)], -1)
+    s_all = torch.cat([down, up, starts])
+    d_all = torch.cat([torch.tensor([[0.0, 0.0, -1.0]]).repeat(m, 1), torch.tensor([[0.0, 0.0, 2.5]]).repeat(m, 1), dirs])
+    ref = raycast_mesh(s_all.to(dev), d_all.to(dev), mesh, return_distance=True, return_normal=True, return_face_id=True)
+    got = raycast_mesh(s_all.to(dev), d_all.to(dev), mesh, return_distance=True, return_normal=True, return_face_id=True,
+                       z_parallel_hint=True)
+    for a, b, what in zip(got, ref, ("hits", "distance", "normal", "face")):
+        assert_exact(a, b, f"{what} with the z-parallel hint")
+    h, t, f = RC.raycast_brute(s_all[:2 * m], d_all[:2 * m], verts, tris)
+    assert_exact(got[3][:2 * m], f, "column-grid face ids vs brute force")
+    assert_exact(got[1][:2 * m], t, "column-grid distances vs brute force")
+    assert (f >= 0).float().mean() > 0.5
+
+
 def test_tiny_and_degenerate_meshes(dev):
     from isaaclab_amd.utils.mesh import convert_to_mesh, raycast_mesh
 
@@ -53,6 +82,10 @@ def test_tiny_and_degenerate_meshes(dev):
     assert face.cpu().tolist() == [0, 1, -1, -1, 0]
     _, _, _, f2 = raycast_mesh(starts[:1].to(dev), dirs[:1].to(dev), mesh, max_dist=19.75, return_face_id=True)
     assert f2.item() == -1, "max_dist is exclusive"
+    hz, dz, _, fz = raycast_mesh(starts.to(dev), dirs.to(dev), mesh, return_distance=True, return_face_id=True,
+                                 z_parallel_hint=True)
+    assert_exact(fz, f, "face (column grid)")
+    assert_exact(hz, h, "hits (column grid)")
     # empty ray set
     out = raycast_mesh(torch.zeros(0, 3, device=dev), torch.zeros(0, 3, device=dev), mesh)
     assert out[0].shape == (0, 3)
@@ -177,6 +210,20 @@ def test_full_size_terrain_sample(dev):
     hb, tb, fb = RC.raycast_c(sw_k.view(-1, 3)[sub], dw.reshape(-1, 3)[sub], cm, brute=True)
     assert_exact(face, fb, "face ids vs brute force")
     assert_exact(dist, tb, "distance vs brute force")
+    # all sensor rays again through both kernels of the generic entry point
+    for hint in (False, True):
+        ha, ta, _, fa = raycast_mesh(sw_k.view(-1, 3).to(dev), dw.reshape(-1, 3).to(dev), mesh, return_distance=True,
+                                     return_face_id=True, z_parallel_hint=hint)
+        assert_exact(fa, f, f"face ids, hint={hint}")
+        assert_exact(ta, t, f"distances, hint={hint}")
+    # rays exactly on the 0.1 m lattice (shared edges and vertices: ties between up to six faces)
+    k = torch.randint(0, 800, (2048, 2), generator=gen)
+    lat = torch.cat([k[:, :1] * 0.1, k[:, 1:] * 0.2, torch.full((2048, 1), 25.0)], -1)
+    dl = torch.tensor([[0.0, 0.0, -1.0]]).repeat(2048, 1)
+    _, tl, _, fl = raycast_mesh(lat.to(dev), dl.to(dev), mesh, return_distance=True, return_face_id=True, z_parallel_hint=True)
+    _, tlc, flc = RC.raycast_c(lat, dl, cm)
+    assert_exact(fl, flc, "lattice face ids (column grid)")
+    assert_exact(tl, tlc, "lattice distances (column grid)")
     # oblique rays through the terrain
     o = torch.cat([torch.rand(512, 2, generator=gen) * torch.tensor([80.0, 160.0]), torch.full((512, 1), 3.0)], -1)
     dd = torch.randn(512, 3, generator=gen)
