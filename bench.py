@@ -183,6 +183,8 @@ def main():
 
         dist.init_process_group("nccl", device_id=device)
 
+    from isaaclab_amd.distributed import all_reduce_log_sums
+
     env, state, _ = build_env(device, args.envs, seed=3000 + rank)
     raw = state["raw_action"].to(device)
     n_log = env.mdp.log_sums.numel()
@@ -191,7 +193,7 @@ def main():
         env.mdp.log_sums.zero_()
         env.step(raw)
         if dist is not None:  # episode statistics of the done envs: the only cross-rank exchange of the path
-            dist.all_reduce(env.mdp.log_sums)
+            all_reduce_log_sums(env.mdp.log_sums)
 
     for _ in range(args.warmup):
         one_step()
