@@ -7,7 +7,7 @@
         bench.py --gpus N --steps K --warmup W
 
 A "step" is one full env step of the hot path over one batch of synthetic physics state that is already resident
-in HBM: process_action, 4 x (actuator net + joint_acc + contact sensor), height-scan ray cast, and the fused
+in HBM: process_action, 4 x (actuator net + scene update: joint_acc, contact sensor, clocks), height-scan ray cast, and the fused
 termination / reward / reset / command / observation launch.  Prints ONE JSON line (rank 0).
 """
 
@@ -33,19 +33,19 @@ HBM_PEAK_GBS = 8000.0         # MI355X HBM3E peak (spec); measured float4-copy c
 BYTES = {
     # read q_des, q, qd (3*48); read+write pos-error / velocity histories (2 * 2 * 144); write computed, applied (2*48)
     "actuator_net_mlp": 3 * 48 + 4 * 144 + 2 * 48,
-    # read net forces 204, write net_forces_w 204, read+write history 2*612, read+write 4 timers 8*68, clocks 2*9
-    "contact_update": 204 + 204 + 2 * 612 + 8 * 68 + 18,
-    # read vel 48, read+write previous vel 96, write acc 48
-    "joint_acc": 48 + 96 + 48,
-    # read pose 28, write ray hits 187*12
-    "raycaster_update": 28 + 187 * 12,
+    # InteractiveScene.update in one launch -- contact: read net forces 204, write net_forces_w 204, read+write
+    # history 2*612, read+write 4 timers 8*68, clock 18; joint_acc: read vel 48, read+write previous vel 96, write acc 48;
+    # scanner clock 18
+    "scene_update": 204 + 204 + 2 * 612 + 8 * 68 + 18 + 48 + 96 + 48 + 18,
+    # read pose 28 + clock 9, write pose 28, ray hits 187*12, clock 5
+    "raycaster_refresh": 28 + 9 + 28 + 187 * 12 + 5,
     # read root 52, joints (pos, vel, acc, torque, default) 5*48, actions 2*48, contact history 612, timers 2*68,
     # ray hit z 748, sensor pos 12, command state r+w ~2*41, ep_len r+w 16, noise 880 (parity mode only: not counted);
     # write obs 940, reward 4, step_reward 44, episode sums r+w 72, flags 5
     "mdp_step": 52 + 240 + 96 + 612 + 136 + 748 + 12 + 82 + 16 + 940 + 4 + 44 + 72 + 5,
     "joint_action_process": 48 + 2 * 48 + 48 + 48,
 }
-BYTES_PER_ENV_STEP = (4 * (BYTES["actuator_net_mlp"] + BYTES["contact_update"] + BYTES["joint_acc"]) + BYTES["raycaster_update"]
+BYTES_PER_ENV_STEP = (4 * (BYTES["actuator_net_mlp"] + BYTES["scene_update"]) + BYTES["raycaster_refresh"]
                       + BYTES["mdp_step"] + BYTES["joint_action_process"])
 
 
@@ -85,19 +85,11 @@ def time_kernels(env, state, device, reps=20):
                                  joint_efforts=d.joint_effort_target)
         env.actuator.compute(ca, d.joint_pos, d.joint_vel)
 
-    def contact():
-        env.contact._launch(LV.PHYSICS_DT, True)
-
-    def jacc():
-        _abi.check(_abi.joint_acc(_abi.ptr(d.joint_vel), _abi.ptr(d._previous_joint_vel), _abi.ptr(d._joint_acc), 0.005,
-                                  env.n * 12, _abi.stream()))
+    def scene():
+        env.scene.update(LV.PHYSICS_DT)
 
     def rays():
-        env.scanner._is_outdated.fill_(True)
-        sc = env.scanner
-        _abi.check(_abi.raycaster_update(sc.meshes[sc.cfg.mesh_prim_paths[0]].handle, _abi.ptr(sc._data.pos_w), _abi.ptr(sc._data.quat_w),
-                                         _abi.ptr(sc.ray_starts), _abi.ptr(sc.ray_directions), None, 1, 1e6,
-                                         _abi.ptr(sc._data.ray_hits_w), None, 0.0, env.n, sc.num_rays, sc._hints, _abi.stream()))
+        env.scanner._update_outdated_buffers()
 
     def mdp():
         env.mdp.step(FM.PHASE_ALL)
@@ -108,15 +100,15 @@ def time_kernels(env, state, device, reps=20):
                                              _abi.stream()))
 
     out = {}
-    for name, fn in (("actuator_net_mlp", actuator), ("contact_update", contact), ("joint_acc", jacc),
-                     ("raycaster_update", rays), ("mdp_step", mdp), ("joint_action_process", action)):
+    for name, fn in (("actuator_net_mlp", actuator), ("scene_update", scene), ("raycaster_refresh", rays), ("mdp_step", mdp),
+                     ("joint_action_process", action)):
         for _ in range(3):
             fn()
         torch.cuda.synchronize()
         evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
         for a, b in evs:
-            if name == "raycaster_update":
-                env.scanner._is_outdated.fill_(True)
+            if name == "raycaster_refresh":
+                env.scanner._is_outdated.fill_(True)  # every env is due, as once per env step
             a.record()
             fn()
             b.record()
@@ -216,8 +208,7 @@ def main():
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         value = args.envs * world * args.steps / elapsed
-        launches = {"actuator_net_mlp": 4, "contact_update": 4, "joint_acc": 4, "raycaster_update": 1, "mdp_step": 1,
-                    "joint_action_process": 1}
+        launches = {"actuator_net_mlp": 4, "scene_update": 4, "raycaster_refresh": 1, "mdp_step": 1, "joint_action_process": 1}
         dominant = max(kern, key=lambda k: kern[k] * launches[k])
         achieved = BYTES[dominant] * args.envs / (kern[dominant] * 1e-6) / 1e9
         line = {

@@ -162,6 +162,45 @@ int ilx_contact_update(const float* net_forces_in, float* net_forces_w, float* h
                        float* timestamp, float* timestamp_last_update, uint8_t* is_outdated, int advance_clock,
                        float dt, float update_period, float force_threshold, int64_t n, int b, int h, void* stream);
 
+/* InteractiveScene.update(dt) in ONE launch (scene/interactive_scene.py:496-513) for a scene with up to one
+ * articulation, one contact sensor and one ray caster:
+ *   articulation : joint_acc = (joint_vel - previous_joint_vel) / joint_acc_elapsed; previous <- joint_vel
+ *                  (articulation_data.py:77-82, 445-455)
+ *   contact      : clock += dt, then the bookkeeping of ilx_contact_update for the envs that are due
+ *                  (contact_lazy != 0: only flag them, as a sensor without history does under lazy_sensor_update)
+ *   ray caster   : clock += dt and flag the envs that are due (sensor_base.py:197-205); the rays themselves are cast
+ *                  by ilx_raycaster_update when the data is read.
+ * A group whose first pointer (joint_vel / net_forces_in / ray_timestamp) is NULL is skipped. */
+typedef struct ilx_scene {
+    int64_t num_envs;
+    float dt;
+    /* articulation */
+    const float* joint_vel;          /* (n,j) */
+    float* previous_joint_vel;       /* (n,j) */
+    float* joint_acc;                /* (n,j) */
+    int32_t num_joints;
+    float joint_acc_elapsed;
+    /* contact sensor: same meaning as the arguments of ilx_contact_update */
+    const float* net_forces_in;      /* (n,b,3) */
+    float* net_forces_w;
+    float* net_forces_w_history;     /* (n,h,b,3) or NULL */
+    float* current_air_time;
+    float* last_air_time;
+    float* current_contact_time;
+    float* last_contact_time;
+    float* contact_timestamp;
+    float* contact_timestamp_last_update;
+    uint8_t* contact_is_outdated;
+    float contact_update_period, force_threshold;
+    int32_t num_bodies, history_length, contact_lazy;
+    /* ray caster clock */
+    float* ray_timestamp;
+    float* ray_timestamp_last_update;
+    uint8_t* ray_is_outdated;
+    float ray_update_period;
+} ilx_scene;
+int ilx_scene_update(const ilx_scene* scene, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Mesh ray casting — source/isaaclab/isaaclab/utils/warp/ops.py, utils/warp/kernels.py,
  * sensors/ray_caster/ray_caster.py
@@ -202,6 +241,34 @@ int ilx_raycaster_update(ilx_mesh_t mesh, const float* pos_w, const float* quat_
                          const float* ray_directions_local, const uint8_t* env_mask, int attach_yaw_only,
                          float max_dist, float* ray_hits_w, float* height_scan, float height_offset, int64_t n,
                          int num_rays, int hints, void* stream);
+
+/* SensorBase._update_outdated_buffers + RayCaster._update_buffers_impl (sensor_base.py:284-293,
+ * ray_caster.py:220-260) for the envs flagged in is_outdated, in two launches and without temporaries:
+ *   pos_w <- pose_pos + drift, quat_w <- pose_quat (flagged envs only), world rays, cast, ray_hits_w [, height_scan];
+ *   then timestamp_last_update <- timestamp and is_outdated <- 0 for those envs.
+ * pose_pos / pose_quat are strided views (row stride in floats), e.g. root_state_w and root_state_w + 3 with
+ * stride 13; quaternion (w,x,y,z). */
+typedef struct ilx_raycaster {
+    ilx_mesh_t mesh;
+    int64_t num_envs;
+    int32_t num_rays, attach_yaw_only, hints;
+    float max_distance;
+    const float* pose_pos;
+    const float* pose_quat;
+    int64_t pose_pos_stride, pose_quat_stride;
+    const float* drift;                 /* (n,3) or NULL */
+    const float* ray_starts_local;      /* (r,3) */
+    const float* ray_directions_local;  /* (r,3) */
+    float* pos_w;                       /* RayCasterData (ray_caster_data.py:10-30) */
+    float* quat_w;
+    float* ray_hits_w;
+    float* height_scan;                 /* (n,r) or NULL: pos_w.z - hit.z - height_offset */
+    float height_offset;
+    float* timestamp;                   /* sensor clock (sensor_base.py) */
+    float* timestamp_last_update;
+    uint8_t* is_outdated;
+} ilx_raycaster;
+int ilx_raycaster_refresh(const ilx_raycaster* rc, void* stream);
 
 #ifdef __cplusplus
 }

@@ -99,3 +99,48 @@ raycast_mesh = _sig("ilx_raycast_mesh", P, P, P, c_int64, c_float, P, P, P, P, c
 raycaster_update = _sig("ilx_raycaster_update", P, P, P, P, P, P, c_int, c_float, P, P, c_float, c_int64, c_int, c_int, P)
 joint_action_process = _sig("ilx_joint_action_process", P, P, P, P, c_float, P, c_float, P, P, c_int64, c_int, P)
 raycast_mesh_stats = _sig("ilx_raycast_mesh_stats", P, P, P, c_int64, c_float, P, P, P)
+
+
+class Scene(ctypes.Structure):
+    """Mirror of ``ilx_scene`` (include/isaaclab_amd.h)."""
+
+    _fields_ = [
+        ("num_envs", c_int64), ("dt", c_float),
+        ("joint_vel", c_void_p), ("previous_joint_vel", c_void_p), ("joint_acc", c_void_p),
+        ("num_joints", ctypes.c_int32), ("joint_acc_elapsed", c_float),
+        ("net_forces_in", c_void_p), ("net_forces_w", c_void_p), ("net_forces_w_history", c_void_p),
+        ("current_air_time", c_void_p), ("last_air_time", c_void_p), ("current_contact_time", c_void_p),
+        ("last_contact_time", c_void_p), ("contact_timestamp", c_void_p), ("contact_timestamp_last_update", c_void_p),
+        ("contact_is_outdated", c_void_p), ("contact_update_period", c_float), ("force_threshold", c_float),
+        ("num_bodies", ctypes.c_int32), ("history_length", ctypes.c_int32), ("contact_lazy", ctypes.c_int32),
+        ("ray_timestamp", c_void_p), ("ray_timestamp_last_update", c_void_p), ("ray_is_outdated", c_void_p),
+        ("ray_update_period", c_float),
+    ]
+
+
+class RayCasterDesc(ctypes.Structure):
+    """Mirror of ``ilx_raycaster`` (include/isaaclab_amd.h)."""
+
+    _fields_ = [
+        ("mesh", c_void_p), ("num_envs", c_int64), ("num_rays", ctypes.c_int32), ("attach_yaw_only", ctypes.c_int32),
+        ("hints", ctypes.c_int32), ("max_distance", c_float),
+        ("pose_pos", c_void_p), ("pose_quat", c_void_p), ("pose_pos_stride", c_int64), ("pose_quat_stride", c_int64),
+        ("drift", c_void_p), ("ray_starts_local", c_void_p), ("ray_directions_local", c_void_p),
+        ("pos_w", c_void_p), ("quat_w", c_void_p), ("ray_hits_w", c_void_p), ("height_scan", c_void_p),
+        ("height_offset", c_float), ("timestamp", c_void_p), ("timestamp_last_update", c_void_p), ("is_outdated", c_void_p),
+    ]
+
+
+scene_update = _sig("ilx_scene_update", ctypes.POINTER(Scene), P)
+raycaster_refresh = _sig("ilx_raycaster_refresh", ctypes.POINTER(RayCasterDesc), P)
+
+
+def row_view(t: torch.Tensor, width: int):
+    """(pointer, row stride in floats) of an (n, width) float32 GPU view whose rows are contiguous (e.g. a column
+    slice of ``root_state_w``)."""
+    if not t.is_cuda:
+        raise IlxError("isaaclab_amd kernels need GPU tensors (got a CPU tensor); there is no CPU fallback")
+    if t.dtype != torch.float32 or t.dim() != 2 or t.shape[1] != width or t.stride(1) != 1:
+        raise IlxError(f"expected an (n, {width}) float32 view with contiguous rows, got {tuple(t.shape)} {t.dtype} "
+                       f"strides {t.stride()}")
+    return t.data_ptr(), t.stride(0)

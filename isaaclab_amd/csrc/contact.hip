@@ -30,6 +30,59 @@ struct ContactArgs {
     int envs_per_block;
 };
 
+// Sensor clock of one env (sensor_base.py:197-205): returns whether the env is refreshed in this launch.
+// tick: advance the clock by dt; lazy: only flag outdated envs, refresh nothing.
+struct Clock {
+    float ts_new, last;
+    bool refresh;
+};
+ILX_DEV Clock read_clock(const float* ts, const float* ts_last, const uint8_t* outdated, int64_t env, int tick, float dt,
+                         float period) {
+    Clock c{ts[env], ts_last[env], outdated[env] != 0};
+    if (tick) {
+        c.ts_new = c.ts_new + dt;                                              // sensor_base.py:199
+        c.refresh = c.refresh || ((c.ts_new - c.last + 1e-6f) >= period);      // sensor_base.py:200
+    }
+    return c;
+}
+ILX_DEV void write_clock(float* ts, float* ts_last, uint8_t* outdated, int64_t env, const Clock& c, bool lazy) {
+    ts[env] = c.ts_new;
+    if (lazy) {
+        outdated[env] = c.refresh;
+    } else {
+        if (c.refresh) ts_last[env] = c.ts_new;  // sensor_base.py:291
+        outdated[env] = 0;                       // refreshed now, or it was not outdated to begin with
+    }
+}
+
+// contact_sensor.py:324-373 for one (env, body).
+ILX_DEV void contact_body(const ContactArgs& a, int64_t env, int body, float elapsed) {
+    const int64_t eb = env * a.b + body;
+    const f3 f = load3(a.in + 3 * eb);
+    store3(a.net + 3 * eb, f);  // contact_sensor.py:324
+    if (a.hist) {               // contact_sensor.py:326-328
+        const int64_t hb = (env * a.h) * a.b + body;
+        f3 old[kMaxContactHistory - 1];
+#pragma unroll
+        for (int k = 0; k < kMaxContactHistory - 1; ++k)
+            if (k < a.h - 1) old[k] = load3(a.hist + 3 * (hb + static_cast<int64_t>(k) * a.b));
+        store3(a.hist + 3 * hb, f);
+#pragma unroll
+        for (int k = 0; k < kMaxContactHistory - 1; ++k)
+            if (k < a.h - 1) store3(a.hist + 3 * (hb + static_cast<int64_t>(k + 1) * a.b), old[k]);
+    }
+    if (a.cur_air) {  // contact_sensor.py:346-373
+        const bool contact = norm3(f) > a.thr;
+        const float ca = a.cur_air[eb], cc = a.cur_contact[eb];
+        const bool first_contact = (ca > 0.0f) && contact;
+        const bool first_detached = (cc > 0.0f) && !contact;
+        if (first_contact) a.last_air[eb] = ca + elapsed;
+        a.cur_air[eb] = contact ? 0.0f : ca + elapsed;
+        if (first_detached) a.last_contact[eb] = cc + elapsed;
+        a.cur_contact[eb] = contact ? cc + elapsed : 0.0f;
+    }
+}
+
 __global__ void __launch_bounds__(256) contact_update_kernel(ContactArgs a) {
     const int t = threadIdx.x;
     const bool wide = a.b > 256;  // more bodies than threads: one env per block, threads stride over bodies
@@ -38,52 +91,68 @@ __global__ void __launch_bounds__(256) contact_update_kernel(ContactArgs a) {
     const int64_t env = static_cast<int64_t>(blockIdx.x) * a.envs_per_block + le;
     const bool active = le < a.envs_per_block && env < a.n;
 
-    float ts_new = 0.0f, last = 0.0f;
-    bool refresh = false;
-    if (active) {
-        ts_new = a.ts[env];
-        last = a.ts_last[env];
-        refresh = a.outdated[env] != 0;
-        if (a.tick) {
-            ts_new = ts_new + a.dt;                                          // sensor_base.py:199
-            refresh = refresh || ((ts_new - last + 1e-6f) >= a.period);      // sensor_base.py:200
-        }
-    }
+    Clock c{0.0f, 0.0f, false};
+    if (active) c = read_clock(a.ts, a.ts_last, a.outdated, env, a.tick, a.dt, a.period);
     __syncthreads();
-    if (active && b0 == 0) {
-        a.ts[env] = ts_new;
-        if (refresh) a.ts_last[env] = ts_new;  // sensor_base.py:291
-        a.outdated[env] = 0;                   // refreshed now, or it was not outdated to begin with
-    }
-    if (!active || !refresh) return;
-
-    const float elapsed = ts_new - last;  // contact_sensor.py:349
+    if (active && b0 == 0) write_clock(a.ts, a.ts_last, a.outdated, env, c, false);
+    if (!active || !c.refresh) return;
+    const float elapsed = c.ts_new - c.last;  // contact_sensor.py:349
     for (int body = b0; body < a.b; body += 256) {
-        const int64_t eb = env * a.b + body;
-        const f3 f = load3(a.in + 3 * eb);
-        store3(a.net + 3 * eb, f);  // contact_sensor.py:324
-        if (a.hist) {               // contact_sensor.py:326-328
-            const int64_t hb = (env * a.h) * a.b + body;
-            f3 old[kMaxContactHistory - 1];
-#pragma unroll
-            for (int k = 0; k < kMaxContactHistory - 1; ++k)
-                if (k < a.h - 1) old[k] = load3(a.hist + 3 * (hb + static_cast<int64_t>(k) * a.b));
-            store3(a.hist + 3 * hb, f);
-#pragma unroll
-            for (int k = 0; k < kMaxContactHistory - 1; ++k)
-                if (k < a.h - 1) store3(a.hist + 3 * (hb + static_cast<int64_t>(k + 1) * a.b), old[k]);
-        }
-        if (a.cur_air) {  // contact_sensor.py:346-373
-            const bool contact = norm3(f) > a.thr;
-            const float ca = a.cur_air[eb], cc = a.cur_contact[eb];
-            const bool first_contact = (ca > 0.0f) && contact;
-            const bool first_detached = (cc > 0.0f) && !contact;
-            if (first_contact) a.last_air[eb] = ca + elapsed;
-            a.cur_air[eb] = contact ? 0.0f : ca + elapsed;
-            if (first_detached) a.last_contact[eb] = cc + elapsed;
-            a.cur_contact[eb] = contact ? cc + elapsed : 0.0f;
-        }
+        contact_body(a, env, body, elapsed);
         if (!wide) break;
+    }
+}
+
+// InteractiveScene.update(dt) for the usual locomotion scene in ONE launch (scene/interactive_scene.py:496-513):
+// articulation -> joint_acc (articulation_data.py:77-82, 445-455); contact sensor -> clock + bookkeeping;
+// ray caster -> clock only (its buffers refresh lazily, on the next read).  Thread layout as above: a block owns
+// whole envs, `width` threads per env.
+struct SceneArgs {
+    ContactArgs c;          // c.in == nullptr: no contact sensor
+    int contact_lazy;       // history_length == 0 and lazy updates: flag, do not refresh
+    const float* joint_vel; // nullptr: no articulation
+    float* prev_joint_vel;
+    float* joint_acc;
+    int j;
+    float joint_elapsed;
+    float* ray_ts;          // nullptr: no ray caster
+    float* ray_ts_last;
+    uint8_t* ray_outdated;
+    float ray_period;
+    int width;
+};
+
+__global__ void __launch_bounds__(256) scene_update_kernel(SceneArgs s) {
+    const ContactArgs& a = s.c;
+    const int t = threadIdx.x;
+    const int le = t / s.width;
+    const int k0 = t - le * s.width;
+    const int64_t env = static_cast<int64_t>(blockIdx.x) * a.envs_per_block + le;
+    const bool active = le < a.envs_per_block && env < a.n;
+    const bool has_contact = a.in != nullptr;
+
+    Clock c{0.0f, 0.0f, false};
+    if (active && has_contact) c = read_clock(a.ts, a.ts_last, a.outdated, env, 1, a.dt, a.period);
+    __syncthreads();
+    if (!active) return;
+    if (k0 == 0) {
+        if (has_contact) write_clock(a.ts, a.ts_last, a.outdated, env, c, s.contact_lazy != 0);
+        if (s.ray_ts) {
+            const Clock r = read_clock(s.ray_ts, s.ray_ts_last, s.ray_outdated, env, 1, a.dt, s.ray_period);
+            write_clock(s.ray_ts, s.ray_ts_last, s.ray_outdated, env, r, true);
+        }
+    }
+    if (s.joint_vel) {
+        for (int j = k0; j < s.j; j += s.width) {
+            const int64_t i = env * s.j + j;
+            const float v = s.joint_vel[i];
+            s.joint_acc[i] = div_(v - s.prev_joint_vel[i], s.joint_elapsed);
+            s.prev_joint_vel[i] = v;
+        }
+    }
+    if (has_contact && c.refresh && !s.contact_lazy) {
+        const float elapsed = c.ts_new - c.last;
+        for (int body = k0; body < a.b; body += s.width) contact_body(a, env, body, elapsed);
     }
 }
 
@@ -113,5 +182,55 @@ extern "C" int ilx_contact_update(const float* net_forces_in, float* net_forces_
     const unsigned blocks = static_cast<unsigned>((n + a.envs_per_block - 1) / a.envs_per_block);
     hipLaunchKernelGGL(contact_update_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), a);
     ILX_LAUNCH_CHECK("ilx_contact_update");
+    return ILX_OK;
+}
+
+extern "C" int ilx_scene_update(const ilx_scene* scene, void* stream) {
+    ILX_REQUIRE(scene, ILX_EINVAL, "ilx_scene_update: scene is NULL");
+    const ilx_scene& d = *scene;
+    ILX_REQUIRE(d.num_envs >= 0, ILX_EINVAL, "ilx_scene_update: negative env count");
+    if (d.num_envs == 0) return ILX_OK;
+    SceneArgs s{};
+    int width = 1;
+    if (d.joint_vel) {
+        ILX_REQUIRE(d.previous_joint_vel && d.joint_acc && d.num_joints > 0, ILX_EINVAL,
+                    "ilx_scene_update: articulation needs previous_joint_vel, joint_acc and num_joints > 0");
+        ILX_REQUIRE(d.joint_acc_elapsed > 0.0f, ILX_EINVAL, "ilx_scene_update: joint_acc_elapsed must be positive");
+        s.joint_vel = d.joint_vel, s.prev_joint_vel = d.previous_joint_vel, s.joint_acc = d.joint_acc;
+        s.j = d.num_joints, s.joint_elapsed = d.joint_acc_elapsed;
+        width = d.num_joints;
+    }
+    ContactArgs& a = s.c;
+    a.n = d.num_envs, a.dt = d.dt;
+    if (d.net_forces_in) {
+        const int b = d.num_bodies, h = d.history_length;
+        ILX_REQUIRE(b > 0 && h >= 0, ILX_EINVAL, "ilx_scene_update: bad contact shape (b=%d, h=%d)", b, h);
+        ILX_REQUIRE(h <= kMaxContactHistory, ILX_ESHAPE, "ilx_scene_update: history length %d (max %d)", h, kMaxContactHistory);
+        ILX_REQUIRE(d.net_forces_w && d.contact_timestamp && d.contact_timestamp_last_update && d.contact_is_outdated,
+                    ILX_EINVAL, "ilx_scene_update: NULL contact operand");
+        ILX_REQUIRE((h == 0) == (d.net_forces_w_history == nullptr), ILX_EINVAL,
+                    "ilx_scene_update: history must be NULL iff history_length == 0");
+        const int timers = (d.current_air_time != nullptr) + (d.last_air_time != nullptr) +
+                           (d.current_contact_time != nullptr) + (d.last_contact_time != nullptr);
+        ILX_REQUIRE(timers == 0 || timers == 4, ILX_EINVAL, "ilx_scene_update: pass all four timers or none");
+        a.in = d.net_forces_in, a.net = d.net_forces_w, a.hist = d.net_forces_w_history;
+        a.cur_air = d.current_air_time, a.last_air = d.last_air_time, a.cur_contact = d.current_contact_time;
+        a.last_contact = d.last_contact_time;
+        a.ts = d.contact_timestamp, a.ts_last = d.contact_timestamp_last_update, a.outdated = d.contact_is_outdated;
+        a.period = d.contact_update_period, a.thr = d.force_threshold, a.tick = 1, a.b = b, a.h = h;
+        s.contact_lazy = d.contact_lazy;
+        width = b;
+    }
+    if (d.ray_timestamp) {
+        ILX_REQUIRE(d.ray_timestamp_last_update && d.ray_is_outdated, ILX_EINVAL, "ilx_scene_update: NULL ray caster clock");
+        s.ray_ts = d.ray_timestamp, s.ray_ts_last = d.ray_timestamp_last_update, s.ray_outdated = d.ray_is_outdated;
+        s.ray_period = d.ray_update_period;
+    }
+    if (width > 256) width = 256;
+    s.width = width;
+    a.envs_per_block = 256 / width;
+    const unsigned blocks = static_cast<unsigned>((d.num_envs + a.envs_per_block - 1) / a.envs_per_block);
+    hipLaunchKernelGGL(scene_update_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), s);
+    ILX_LAUNCH_CHECK("ilx_scene_update");
     return ILX_OK;
 }

@@ -284,8 +284,12 @@ __global__ void __launch_bounds__(kRayBlock) raycast_column_kernel(CastArgs a) {
 // RayCaster._update_buffers_impl fused with the cast: sensor pose -> world rays -> hits (+ height-scan term).
 struct ScanArgs {
     MeshDev mesh;
-    const float* pos_w;       // (n,3) sensor position (drift already applied)
-    const float* quat_w;      // (n,4) wxyz
+    const float* pos_w;       // sensor parent position, row stride pos_stride floats
+    const float* quat_w;      // wxyz, row stride quat_stride floats
+    int64_t pos_stride, quat_stride;
+    const float* drift;       // (n,3) added to the position, or null
+    float* pos_out;           // (n,3) / (n,4): RayCasterData.pos_w / quat_w of the refreshed envs, or null
+    float* quat_out;
     const float* ray_starts;  // (r,3) local
     const float* ray_dirs;    // (r,3) local
     const uint8_t* env_mask;  // (n) or null: only flagged envs are refreshed
@@ -303,8 +307,17 @@ ILX_DEV bool sensor_ray(const ScanArgs& a, int64_t i, f3& o, f3& d, float& pos_z
     const int64_t env = i / a.r;
     const int ray = static_cast<int>(i - env * a.r);
     if (a.env_mask && !a.env_mask[env]) return false;
-    const f3 pos = load3(a.pos_w + 3 * env);
-    const f4 q = load4(a.quat_w + 4 * env);
+    f3 pos = load3(a.pos_w + a.pos_stride * env);
+    const f4 q = load4u(a.quat_w + a.quat_stride * env);
+    if (a.drift) {  // ray_caster.py:233-240
+        const f3 dr = load3(a.drift + 3 * env);
+        pos = {pos.x + dr.x, pos.y + dr.y, pos.z + dr.z};
+    }
+    if (a.pos_out && ray == 0) {
+        store3(a.pos_out + 3 * env, pos);
+        float* qo = a.quat_out + 4 * env;
+        qo[0] = q.w, qo[1] = q.x, qo[2] = q.y, qo[3] = q.z;
+    }
     const f3 ls = load3(a.ray_starts + 3 * ray), ld = load3(a.ray_dirs + 3 * ray);
     if (a.yaw_only) {  // ray_caster.py:243-247: starts rotated by yaw only, directions unrotated
         o = quat_apply_yaw(q, ls);
@@ -350,6 +363,15 @@ __global__ void __launch_bounds__(kRayBlock) raycaster_update_column_kernel(Scan
     if (!sensor_ray(a, i, o, d, pos_z)) return;
     const Hit h = trace_hinted<false>(a.mesh, o, d, a.max_dist);
     write_scan(a, h, o, d, pos_z, i);
+}
+
+// sensor_base.py:284-293 after the refresh: the refreshed envs record the time and are no longer outdated.
+__global__ void __launch_bounds__(256)
+sensor_refreshed_kernel(const float* __restrict__ ts, float* __restrict__ ts_last, uint8_t* __restrict__ outdated, int64_t n) {
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= n || !outdated[i]) return;
+    ts_last[i] = ts[i];
+    outdated[i] = 0;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -649,6 +671,7 @@ static unsigned ray_grid(int64_t rays) {
     return static_cast<unsigned>(std::min<int64_t>(want, 256 * 12));
 }
 
+static void launch_scan(ilx_mesh_t mesh, const ScanArgs& a, int hints, void* stream);
 static unsigned column_grid(int64_t rays) { return static_cast<unsigned>((rays + kRayBlock - 1) / kRayBlock); }
 
 extern "C" int ilx_raycast_mesh(ilx_mesh_t mesh, const float* ray_starts, const float* ray_directions, int64_t num_rays,
@@ -689,15 +712,39 @@ extern "C" int ilx_raycaster_update(ilx_mesh_t mesh, const float* pos_w, const f
     if (n == 0) return ILX_OK;
     ILX_REQUIRE(pos_w && quat_w && ray_starts_local && ray_directions_local && ray_hits_w, ILX_EINVAL,
                 "ilx_raycaster_update: NULL operand");
-    ILX_REQUIRE((reinterpret_cast<uintptr_t>(quat_w) & 15u) == 0, ILX_EINVAL,
-                "ilx_raycaster_update: quat_w must be 16-byte aligned");
-    ScanArgs a{mesh->h.dev, pos_w, quat_w, ray_starts_local, ray_directions_local, env_mask, attach_yaw_only, max_dist,
-               ray_hits_w, height_scan, height_offset, n, num_rays};
-    if ((hints & ILX_RAYS_Z_PARALLEL) && mesh->h.d_cell_start)
-        hipLaunchKernelGGL(raycaster_update_column_kernel, dim3(column_grid(n * num_rays)), dim3(kRayBlock), 0,
-                           as_stream(stream), a);
-    else
-        hipLaunchKernelGGL(raycaster_update_kernel, dim3(ray_grid(n * num_rays)), dim3(kRayBlock), 0, as_stream(stream), a);
+    ScanArgs a{mesh->h.dev, pos_w, quat_w, 3, 4, nullptr, nullptr, nullptr, ray_starts_local, ray_directions_local, env_mask,
+               attach_yaw_only, max_dist, ray_hits_w, height_scan, height_offset, n, num_rays};
+    launch_scan(mesh, a, hints, stream);
     ILX_LAUNCH_CHECK("ilx_raycaster_update");
     return ILX_OK;
+}
+
+extern "C" int ilx_raycaster_refresh(const ilx_raycaster* rc, void* stream) {
+    ILX_REQUIRE(rc, ILX_EINVAL, "ilx_raycaster_refresh: descriptor is NULL");
+    const ilx_raycaster& d = *rc;
+    ILX_REQUIRE(d.mesh, ILX_EINVAL, "ilx_raycaster_refresh: mesh is NULL");
+    ILX_REQUIRE(d.num_envs >= 0 && d.num_rays > 0, ILX_EINVAL, "ilx_raycaster_refresh: bad shape (%lld, %d)",
+                (long long)d.num_envs, d.num_rays);
+    if (d.num_envs == 0) return ILX_OK;
+    ILX_REQUIRE(d.pose_pos && d.pose_quat && d.ray_starts_local && d.ray_directions_local && d.pos_w && d.quat_w &&
+                    d.ray_hits_w && d.timestamp && d.timestamp_last_update && d.is_outdated,
+                ILX_EINVAL, "ilx_raycaster_refresh: NULL operand");
+    ILX_REQUIRE(d.pose_pos_stride >= 3 && d.pose_quat_stride >= 4, ILX_EINVAL, "ilx_raycaster_refresh: bad pose strides");
+    ScanArgs a{d.mesh->h.dev, d.pose_pos, d.pose_quat, d.pose_pos_stride, d.pose_quat_stride, d.drift, d.pos_w, d.quat_w,
+               d.ray_starts_local, d.ray_directions_local, d.is_outdated, d.attach_yaw_only, d.max_distance, d.ray_hits_w,
+               d.height_scan, d.height_offset, d.num_envs, d.num_rays};
+    launch_scan(d.mesh, a, d.hints, stream);
+    ILX_LAUNCH_CHECK("ilx_raycaster_refresh");
+    hipLaunchKernelGGL(sensor_refreshed_kernel, dim3(blocks_for(d.num_envs)), dim3(256), 0, as_stream(stream), d.timestamp,
+                       d.timestamp_last_update, d.is_outdated, d.num_envs);
+    ILX_LAUNCH_CHECK("ilx_raycaster_refresh");
+    return ILX_OK;
+}
+
+static void launch_scan(ilx_mesh_t mesh, const ScanArgs& a, int hints, void* stream) {
+    const int64_t rays = a.n * a.r;
+    if ((hints & ILX_RAYS_Z_PARALLEL) && mesh->h.d_cell_start)
+        hipLaunchKernelGGL(raycaster_update_column_kernel, dim3(column_grid(rays)), dim3(kRayBlock), 0, as_stream(stream), a);
+    else
+        hipLaunchKernelGGL(raycaster_update_kernel, dim3(ray_grid(rays)), dim3(kRayBlock), 0, as_stream(stream), a);
 }

@@ -22,6 +22,7 @@ from ..actuators import ActuatorNetMLP, ActuatorNetMLPCfg, DCMotor, DCMotorCfg
 from ..assets.articulation_data import ArticulationData
 from ..sensors.contact_sensor import ContactSensor, ContactSensorCfg
 from ..sensors.patterns import GridPatternCfg
+from ..scene import InteractiveScene
 from ..sensors.ray_caster import OffsetCfg, RayCaster, RayCasterCfg
 from ..tasks import locomotion_velocity as LV
 from ..utils.string import resolve_matching_names_values
@@ -72,6 +73,10 @@ class LocomotionVelocityStep:
         self.scanner = RayCaster(RayCasterCfg(offset=OffsetCfg(pos=(0.0, 0.0, hs["offset_z"])), attach_yaw_only=True,
                                               pattern_cfg=GridPatternCfg(resolution=hs["resolution"], size=hs["size"]),
                                               update_period=hs["update_period"]), n, mesh, dev)
+        self.scene = InteractiveScene(n, dev)
+        self.scene.articulations["robot"] = self.data
+        self.scene.sensors["contact_forces"] = self.contact
+        self.scene.sensors["height_scanner"] = self.scanner
         # action manager buffers (action_manager.py:318-339) and the JointPositionAction constants (velocity_env_cfg.py:112)
         self.action = torch.zeros(n, j, device=dev)
         self.prev_action = torch.zeros(n, j, device=dev)
@@ -134,13 +139,11 @@ class LocomotionVelocityStep:
                                      joint_efforts=d.joint_effort_target, joint_indices=slice(None))
             self.actuator.compute(ca, d.joint_pos, d.joint_vel)          # write_data_to_sim
             # <sim.step would run here; its results for this substep are self.physics[...][k]>
-            d.update(LV.PHYSICS_DT)                                      # scene.update: joint_acc
             self.contact.set_net_contact_forces(self.physics["net_forces"][k])
-            self.contact.update(LV.PHYSICS_DT)
-            self.scanner.update(LV.PHYSICS_DT)
+            self.scene.update(LV.PHYSICS_DT)                             # joint_acc, contact sensor, scanner clock: one launch
         d.set_sim_state(root_state_w=self.physics["root_state_w"])
         # -- height scanner: refreshed once per env step (update_period = step_dt), lazily in the reference
-        self.scanner.set_pose(d.root_state_w[:, :3].contiguous(), d.root_state_w[:, 3:7].contiguous())
+        self.scanner.set_pose(d.root_state_w[:, :3], d.root_state_w[:, 3:7])
         self.scanner._update_outdated_buffers()
         # -- post-physics managers: one launch
         m = self.mdp

@@ -1,0 +1,76 @@
+"""``InteractiveScene.update(dt)`` (``isaaclab/scene/interactive_scene.py:496-513``) as ONE launch.
+
+The reference loops over the scene entities: ``articulation.update(dt)`` (joint accelerations), then every sensor's
+``update(dt, force_recompute=not lazy_sensor_update)`` (clocks; eager refresh for sensors with a history).  For the
+usual locomotion scene -- one articulation, one contact sensor, one ray caster -- ``ilx_scene_update`` does all of it
+in a single kernel; any other composition falls back to the entities' own ``update`` methods (one launch each).
+"""
+
+from __future__ import annotations
+
+import ctypes
+
+from . import _abi
+from .assets.articulation_data import ArticulationData
+from .sensors.contact_sensor import ContactSensor
+from .sensors.ray_caster import RayCaster
+
+
+class InteractiveScene:
+    def __init__(self, num_envs: int, device, lazy_sensor_update: bool = True):
+        self.num_envs, self.device = num_envs, device
+        self.lazy_sensor_update = lazy_sensor_update
+        self.articulations: dict[str, ArticulationData] = {}
+        self.sensors: dict[str, object] = {}
+
+    def __getitem__(self, key: str):
+        """interactive_scene.py:547-570: assets and sensors share one namespace."""
+        if key in self.articulations:
+            return self.articulations[key]
+        if key in self.sensors:
+            return self.sensors[key]
+        raise KeyError(f"Scene entity with key '{key}' not found. Available Entities: '{self.keys()}'")
+
+    def keys(self) -> list[str]:
+        return list(self.articulations) + list(self.sensors)
+
+    def update(self, dt: float) -> None:
+        arts = list(self.articulations.values())
+        contacts = [s for s in self.sensors.values() if isinstance(s, ContactSensor)]
+        rays = [s for s in self.sensors.values() if isinstance(s, RayCaster)]
+        fusable = len(arts) <= 1 and len(contacts) <= 1 and len(rays) <= 1 and len(contacts) + len(rays) == len(self.sensors)
+        if not fusable:
+            for a in arts:
+                a.update(dt)
+            for s in self.sensors.values():
+                s.update(dt, force_recompute=not self.lazy_sensor_update)
+            return
+        force = not self.lazy_sensor_update
+        sc = _abi.Scene(num_envs=self.num_envs, dt=float(dt))
+        if arts:
+            d = arts[0]
+            d._sim_timestamp += dt                                   # articulation_data.py:77-82
+            sc.joint_vel, sc.previous_joint_vel = _abi.ptr(d.joint_vel), _abi.ptr(d._previous_joint_vel)
+            sc.joint_acc, sc.num_joints = _abi.ptr(d._joint_acc), d._j
+            sc.joint_acc_elapsed = float(d._sim_timestamp - d._joint_acc_timestamp)
+            d._joint_acc_timestamp = d._sim_timestamp
+        if contacts:
+            c = contacts[0]
+            cd, h, t = c._data, c.cfg.history_length, c.cfg.track_air_time
+            sc.net_forces_in, sc.net_forces_w = _abi.ptr(c._forces_in), _abi.ptr(cd.net_forces_w)
+            sc.net_forces_w_history = _abi.ptr(cd.net_forces_w_history) if h > 0 else None
+            if t:
+                sc.current_air_time, sc.last_air_time = _abi.ptr(cd.current_air_time), _abi.ptr(cd.last_air_time)
+                sc.current_contact_time, sc.last_contact_time = _abi.ptr(cd.current_contact_time), _abi.ptr(cd.last_contact_time)
+            sc.contact_timestamp, sc.contact_timestamp_last_update = _abi.ptr(c._timestamp), _abi.ptr(c._timestamp_last_update)
+            sc.contact_is_outdated = c._is_outdated.data_ptr()
+            sc.contact_update_period, sc.force_threshold = float(c.cfg.update_period), float(c.cfg.force_threshold)
+            sc.num_bodies, sc.history_length = c.num_bodies, h
+            sc.contact_lazy = int(not (force or h > 0))                # sensor_base.py:203-205
+        if rays:
+            r = rays[0]
+            sc.ray_timestamp, sc.ray_timestamp_last_update = _abi.ptr(r._timestamp), _abi.ptr(r._timestamp_last_update)
+            sc.ray_is_outdated, sc.ray_update_period = r._is_outdated.data_ptr(), float(r.cfg.update_period)
+        _abi.check(_abi.scene_update(ctypes.byref(sc), _abi.stream()), "ilx_scene_update")
+        if rays and (force or rays[0].cfg.history_length > 0):
+            rays[0]._update_outdated_buffers()

@@ -9,6 +9,7 @@ a device-wide synchronise).
 
 from __future__ import annotations
 
+import ctypes
 from collections.abc import Sequence
 from dataclasses import dataclass, field
 
@@ -76,6 +77,7 @@ class RayCaster:
         if cfg.attach_yaw_only and bool((self.ray_directions[:, :2] == 0).all()):
             self._hints = _abi.RAYS_Z_PARALLEL
         self.drift = torch.zeros(n, 3, device=dev)
+        self._has_drift = cfg.drift_range[0] != 0.0 or cfg.drift_range[1] != 0.0
         self._data = RayCasterData(pos_w=torch.zeros(n, 3, device=dev), quat_w=torch.zeros(n, 4, device=dev),
                                    ray_hits_w=torch.zeros(n, self.num_rays, 3, device=dev))
         self._pose_pos = torch.zeros(n, 3, device=dev)
@@ -97,8 +99,10 @@ class RayCaster:
 
     # -- physics hand-over
     def set_pose(self, pos_w: torch.Tensor, quat_w: torch.Tensor):
-        """Sensor parent pose in the world frame, quaternion (w, x, y, z)."""
-        self._pose_pos, self._pose_quat = _abi.f32c(pos_w), _abi.f32c(quat_w)
+        """Sensor parent pose in the world frame, quaternion (w, x, y, z).  Column slices of a wider state tensor
+        (``root_state_w[:, :3]``, ``root_state_w[:, 3:7]``) are taken as they are: the kernel reads strided rows."""
+        self._pose_pos = pos_w if (pos_w.dtype == torch.float32 and pos_w.stride(-1) == 1) else _abi.f32c(pos_w)
+        self._pose_quat = quat_w if (quat_w.dtype == torch.float32 and quat_w.stride(-1) == 1) else _abi.f32c(quat_w)
 
     def set_root_transforms(self, root_transforms_xyzw: torch.Tensor):
         """What ``ArticulationView.get_root_transforms`` returns: (N,7) with an xyzw quaternion (ray_caster.py:225-227)."""
@@ -114,7 +118,7 @@ class RayCaster:
         self._timestamp_last_update[env_ids] = 0.0
         self._is_outdated[env_ids] = True
         lo, hi = self.cfg.drift_range
-        if lo != 0.0 or hi != 0.0:
+        if self._has_drift:
             self.drift[env_ids] = self.drift[env_ids].uniform_(lo, hi)
 
     def update(self, dt: float, force_recompute: bool = False):
@@ -125,19 +129,18 @@ class RayCaster:
             self._update_outdated_buffers()
 
     def _update_outdated_buffers(self, height_out: torch.Tensor | None = None, height_offset: float = 0.0):
-        """sensor_base.py:284-293 + ray_caster.py:220-260 (the env subset is a mask consumed by the kernel)."""
-        mask = self._is_outdated
+        """sensor_base.py:284-293 + ray_caster.py:220-260: the flagged envs take the new pose (+ drift), cast their
+        rays and record the refresh time -- two launches, the env subset is the ``_is_outdated`` mask on the device."""
         d = self._data
-        # ray_caster.py:233-240: pose (+drift) of the refreshed sensors
-        pos = self._pose_pos + self.drift
-        d.pos_w = torch.where(mask.unsqueeze(-1), pos, d.pos_w)
-        d.quat_w = torch.where(mask.unsqueeze(-1), self._pose_quat, d.quat_w)
         mesh = self.meshes[self.cfg.mesh_prim_paths[0]]
-        _abi.check(_abi.raycaster_update(
-            mesh.handle, _abi.ptr(d.pos_w), _abi.ptr(d.quat_w), _abi.ptr(self.ray_starts), _abi.ptr(self.ray_directions),
-            mask.data_ptr(), int(self.cfg.attach_yaw_only), float(self.cfg.max_distance), _abi.ptr(d.ray_hits_w),
-            _abi.ptr(height_out), float(height_offset), self._num_envs, self.num_rays, self._hints,
-            _abi.stream()),
-            "ilx_raycaster_update")
-        self._timestamp_last_update = torch.where(mask, self._timestamp, self._timestamp_last_update)
-        self._is_outdated = torch.zeros_like(mask)
+        pp, ps = _abi.row_view(self._pose_pos, 3)
+        qp, qs = _abi.row_view(self._pose_quat, 4)
+        rc = _abi.RayCasterDesc(
+            mesh=mesh.handle, num_envs=self._num_envs, num_rays=self.num_rays, attach_yaw_only=int(self.cfg.attach_yaw_only),
+            hints=self._hints, max_distance=float(self.cfg.max_distance), pose_pos=pp, pose_quat=qp, pose_pos_stride=ps,
+            pose_quat_stride=qs, drift=_abi.ptr(self.drift),
+            ray_starts_local=_abi.ptr(self.ray_starts), ray_directions_local=_abi.ptr(self.ray_directions),
+            pos_w=_abi.ptr(d.pos_w), quat_w=_abi.ptr(d.quat_w), ray_hits_w=_abi.ptr(d.ray_hits_w),
+            height_scan=_abi.ptr(height_out), height_offset=float(height_offset), timestamp=_abi.ptr(self._timestamp),
+            timestamp_last_update=_abi.ptr(self._timestamp_last_update), is_outdated=self._is_outdated.data_ptr())
+        _abi.check(_abi.raycaster_refresh(ctypes.byref(rc), _abi.stream()), "ilx_raycaster_refresh")
