@@ -42,7 +42,7 @@ class MlpHandle:
 
     def __del__(self):
         h = getattr(self, "handle", None)
-        if h:
+        if h and _abi is not None and getattr(_abi, "lib", None) is not None:  # module globals are gone at shutdown
             _abi.lib.ilx_mlp_destroy(h)
             self.handle = None
 

@@ -1,18 +1,19 @@
 // Fused MDP step: termination / reward / reset-bookkeeping / command / observation managers in ONE launch.
 //
-// Mapping: one 64-lane wavefront per environment, four environments per 256-thread block.  Rows of the
-// ArticulationData arrays ((N,J), (N,B,3), (N,CB) ...) are contiguous per env, so lane k reading element k of the
-// env's row is a coalesced access without any AoS->SoA staging.
-//
-// Schedule per wave: (1) GATHER -- every load any active term needs is issued back to back into registers (lane j
-// holds joint j's nine values, lane b body b's contact timers / peak force / velocity, lane i reward term i's
-// episode sum, ...), so the wave pays ONE memory round trip instead of one per term; (2) the term tables, staged
-// in LDS once per block, are interpreted from registers: sums over joints / bodies are shuffle butterflies,
-// index lists are lane permutes, decisions are ballots; (3) SCATTER -- outputs leave in a few coalesced stores.
+// A 256-thread block owns kE = 16 consecutive environments and works in three stages:
+//   STAGE   every row the active terms read (joint arrays, action, contact timers, command, root state, episode
+//           sums ...) is one contiguous chunk for 16 consecutive envs, so the block copies the chunks into LDS
+//           with fully coalesced loads, all issued back to back: one memory round trip for the whole step.  The
+//           peak contact force per body (max over the history of |F|) is reduced on the way in.
+//   DECIDE  one LANE per environment (16 lanes of each of the 4 waves): per-env scalar math -- root-frame
+//           velocities, terminations, rewards, reset bookkeeping, command update -- runs once per env instead of
+//           once per lane of a wave.  The four waves split the reward terms round-robin.
+//   EMIT    all 256 threads write the observation rows (16 threads x 4 consecutive columns per env and trip,
+//           one Philox4x32 call per 4 noisy columns), episode sums, per-term rewards and termination flags from
+//           LDS: coalesced stores.
 // The chain termination -> reward -> reset -> command -> observation never round-trips through memory.
-//
-// `kind` is uniform across the wave, so the dispatch is scalar control flow.  Term formulas cite the reference
-// file:line; op order for decisions follows math_dev.h.
+// Term tables are data (`kind` dispatch); term formulas cite the reference file:line; op order for decisions
+// follows math_dev.h.
 #include "common.h"
 #include "math_dev.h"
 
@@ -24,66 +25,54 @@
 namespace ilx {
 
 constexpr int kMaxTerms = 32;      // per manager
-constexpr int kMaxIds = 1024;      // index-list entries staged in LDS
-constexpr int kMaxRow = 64;        // joints / bodies / sensor bodies / action / command columns: one per lane
-constexpr int kRayRegs = 4;        // ray z values prefetched per lane (num_rays <= 256; beyond that: direct loads)
+constexpr int kE = 16;             // environments per block
+constexpr int kMaxLdsBytes = 64 * 1024;
 
 enum Need : uint32_t {
     kNeedJoint = 1u, kNeedForces = 2u, kNeedTimers = 4u, kNeedBodyVel = 8u, kNeedBodyAcc = 16u, kNeedAction = 32u,
     kNeedRays = 64u,
 };
 
+// Word (4-byte) offsets into the block's LDS image; rows are [env][column] unless stated.
+struct Layout {
+    int terms, ids;
+    int q, qd, qdd, tau_a, tau_c, q0, qd0, vlim, lim;  // joints (lim: 2 per joint)
+    int act, pact;                                     // action columns
+    int air, last_air, contact_t, fpeak;               // sensor bodies
+    int bvx, bvy, bacc;                                // asset bodies
+    int cmd, root;                                     // command row, 13-wide root state
+    int eps, srew;                                     // episode sums [term][env], step reward [env][term]
+    int ptotal;                                        // reward partial totals [wave][env]
+    int derived;                                       // [env][kDerived]
+    int bits;                                          // term bit mask per env, then done flag per env
+    int logp;                                          // per-block partial sums of the logging vector
+    int colterm, tstart;                               // observation columns: term index per column (u8), first column per term
+    int total;
+};
+constexpr int kDerived = 10;  // lin_b(3) ang_b(3) grav_b(3) sensor_z
+
 struct MdpDev {
     ilx_mdp d;                // by-value copy; the HOST pointers inside are nulled
     const ilx_term* terms;    // device: [terminations | rewards | observations]
     const int32_t* ids;       // device
+    const uint32_t* cols;     // device: [ceil(obs_dim / 4) packed u8 term indices | first column per obs term]
     uint32_t need;
+    int any_noise;            // some observation term draws noise
+    Layout L;
 };
 
-// Cross-lane moves inside the VALU (data-parallel primitives): no LDS round trip.  Called with all 64 lanes active.
-template <int CTRL>
-ILX_DEV float dpp(float v) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
-}
-constexpr int kQuadXor1 = 0xB1, kQuadXor2 = 0x4E, kRowHalfMirror = 0x141, kRowMirror = 0x140;
-ILX_DEV float lane_const(float v, int src) {  // src uniform
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
-}
-// Sum / min over the 64 lanes, result uniform.  Four in-row steps, then the four row totals are combined.
-ILX_DEV float wave_sum(float v) {
-    v += dpp<kQuadXor1>(v);
-    v += dpp<kQuadXor2>(v);
-    v += dpp<kRowHalfMirror>(v);
-    v += dpp<kRowMirror>(v);
-    return (lane_const(v, 0) + lane_const(v, 16)) + (lane_const(v, 32) + lane_const(v, 48));
-}
-ILX_DEV float wave_min(float v) {
-    v = fminf(v, dpp<kQuadXor1>(v));
-    v = fminf(v, dpp<kQuadXor2>(v));
-    v = fminf(v, dpp<kRowHalfMirror>(v));
-    v = fminf(v, dpp<kRowMirror>(v));
-    return fminf(fminf(lane_const(v, 0), lane_const(v, 16)), fminf(lane_const(v, 32), lane_const(v, 48)));
-}
-ILX_DEV bool wave_any(bool p) { return __ballot(p) != 0ull; }
-// Column selector of a term entry: `identity` (uniform) short-cuts the permute when the column is the lane itself.
-struct Sel {
-    int c;
-    bool identity;
+// Philox4x32-10 (counter based): reproducible per (seed, step, env, element block) whatever the launch geometry.
+struct u4 {
+    uint32_t x, y, z, w;
 };
-ILX_DEV float lane_get(float v, Sel s) { return s.identity ? v : __shfl(v, s.c, 64); }
-ILX_DEV float uni(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
-ILX_DEV int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
-
-// Philox4x32-10 (counter based): reproducible per (seed, step, env, element) whatever the launch geometry.
-ILX_DEV uint32_t mulhi32(uint32_t a, uint32_t b) { return __umulhi(a, b); }
-ILX_DEV float philox_uniform(uint64_t seed, uint64_t step, uint64_t env, uint32_t elem) {
+ILX_DEV u4 philox4(uint64_t seed, uint64_t step, uint64_t env, uint32_t elem) {
     uint32_t c0 = elem, c1 = static_cast<uint32_t>(env), c2 = static_cast<uint32_t>(env >> 32) ^ static_cast<uint32_t>(step),
              c3 = static_cast<uint32_t>(step >> 32);
     uint32_t k0 = static_cast<uint32_t>(seed), k1 = static_cast<uint32_t>(seed >> 32);
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
-        const uint32_t hi0 = mulhi32(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-        const uint32_t hi1 = mulhi32(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
         c0 = hi1 ^ c1 ^ k0;
         c1 = lo1;
         c2 = hi0 ^ c3 ^ k1;
@@ -91,108 +80,89 @@ ILX_DEV float philox_uniform(uint64_t seed, uint64_t step, uint64_t env, uint32_
         k0 += 0x9E3779B9u;
         k1 += 0xBB67AE85u;
     }
-    return static_cast<float>(c0 >> 8) * (1.0f / 16777216.0f);  // 24 random mantissa bits, [0, 1)
+    return u4{c0, c1, c2, c3};
+}
+ILX_DEV float u01(uint32_t bits) { return static_cast<float>(bits >> 8) * (1.0f / 16777216.0f); }  // [0, 1), 24 bits
+ILX_DEV float philox_uniform(uint64_t seed, uint64_t step, uint64_t env, uint32_t elem) {
+    return u01(philox4(seed, step, env, elem).x);
 }
 
-// A term with its fields in scalar registers.
-struct Term {
-    int kind, flags;
-    float weight, p0, p1, p2, p3, aux;
-    int ids_off, ids_cnt, ids2_off, ids2_cnt;
-};
-ILX_DEV Term fetch_term(const ilx_term* lds) {
-    const ilx_term t = *lds;
-    return Term{uni(t.kind), uni(t.flags), uni(t.weight), uni(t.p[0]), uni(t.p[1]), uni(t.p[2]), uni(t.p[3]), uni(t.aux),
-                uni(t.ids_off), uni(t.ids_cnt), uni(t.ids2_off), uni(t.ids2_cnt)};
-}
-
-// Per-lane slice of one environment's state (lane k owns column k of every row).
-struct Row {
-    float q = 0, qd = 0, qdd = 0, tau_a = 0, tau_c = 0, q0 = 0, qd0 = 0, lim_lo = 0, lim_hi = 0, vlim = 0;  // joint k
-    float act = 0, pact = 0;                                                                           // action column k
-    float air = 0, last_air = 0, contact_t = 0, fpeak = 0;  // sensor body k: timers, max_h |F_h| (rewards.py:266)
-    float bvx = 0, bvy = 0, bacc = 0;                       // asset body k: lin vel xy, |lin acc|
-    float cmd = 0;                                          // command column k
-};
-
+// One environment as seen by its lane in the DECIDE stage.
 struct Env {
     const MdpDev& m;
+    const float* S;      // LDS image
     const int32_t* ids;  // LDS copy of the index lists
+    int e;               // env slot in the block
     int64_t env;
-    int lane;
-    Row r;
     f3 pos, lin_w, ang_w, lin_b, ang_b, grav_b;
     f4 quat;
     float heading;
-    float time_left = 0.0f;
-    int64_t command_counter = 0;
+    float time_left;
+    int64_t command_counter;
 
-    // register-file column a term's k-th entry refers to (ids list, or identity for slice(None))
-    ILX_DEV Sel col(const Term& t, int n) const {
-        if (t.ids_cnt < 0) return Sel{lane, true};
-        return Sel{lane < n ? ids[t.ids_off + lane] : 0, false};
-    }
-    ILX_DEV Sel col2(const Term& t, int n) const {
-        if (t.ids2_cnt < 0) return Sel{lane, true};
-        return Sel{lane < n ? ids[t.ids2_off + lane] : 0, false};
-    }
-    ILX_DEV int jcount(const Term& t) const { return t.ids_cnt < 0 ? m.d.num_joints : t.ids_cnt; }
-    ILX_DEV int bcount_sensor(const Term& t) const { return t.ids_cnt < 0 ? m.d.num_sensor_bodies : t.ids_cnt; }
-    ILX_DEV int bcount_asset(const Term& t) const { return t.ids_cnt < 0 ? m.d.num_bodies : t.ids_cnt; }
-    ILX_DEV float cmd(int k) const { return lane_const(r.cmd, k); }
-    // sum over the listed joints of f(column)
+    ILX_DEV int id(const ilx_term& t, int k) const { return t.ids_cnt < 0 ? k : ids[t.ids_off + k]; }
+    ILX_DEV int id2(const ilx_term& t, int k) const { return t.ids2_cnt < 0 ? k : ids[t.ids2_off + k]; }
+    ILX_DEV int jcount(const ilx_term& t) const { return t.ids_cnt < 0 ? m.d.num_joints : t.ids_cnt; }
+    ILX_DEV int bcount_sensor(const ilx_term& t) const { return t.ids_cnt < 0 ? m.d.num_sensor_bodies : t.ids_cnt; }
+    ILX_DEV int bcount_asset(const ilx_term& t) const { return t.ids_cnt < 0 ? m.d.num_bodies : t.ids_cnt; }
+    ILX_DEV float joint(int off, int j) const { return S[off + e * m.d.num_joints + j]; }
+    ILX_DEV float sbody(int off, int b) const { return S[off + e * m.d.num_sensor_bodies + b]; }
+    ILX_DEV float abody(int off, int b) const { return S[off + e * m.d.num_bodies + b]; }
+    ILX_DEV float cmd(int k) const { return S[m.L.cmd + e * m.d.command_dim + k]; }
     template <typename F>
-    ILX_DEV float joint_sum(const Term& t, F f) const {
+    ILX_DEV float joint_sum(const ilx_term& t, F f) const {
         const int n = jcount(t);
-        const float v = f(col(t, n));
-        return wave_sum(lane < n ? v : 0.0f);
+        float acc = 0.0f;
+        for (int k = 0; k < n; ++k) acc += f(id(t, k));
+        return acc;
     }
     template <typename F>
-    ILX_DEV bool joint_any(const Term& t, F f) const {
+    ILX_DEV bool joint_any(const ilx_term& t, F f) const {
         const int n = jcount(t);
-        const bool v = f(col(t, n));
-        return wave_any(lane < n && v);
+        bool hit = false;
+        for (int k = 0; k < n; ++k) hit = hit || f(id(t, k));
+        return hit;
     }
 };
 
 // --------------------------------------------------------------------------------------------------
-ILX_DEV bool eval_termination(const Env& e, const Term& t, int64_t ep_len) {
+ILX_DEV bool eval_termination(const Env& e, const ilx_term& t, int64_t ep_len) {
     const ilx_mdp& d = e.m.d;
-    const Row& r = e.r;
+    const Layout& L = e.m.L;
     switch (t.kind) {
         case ILX_TERM_TIME_OUT:  // terminations.py:30-32
             return ep_len >= d.max_episode_length;
         case ILX_TERM_COMMAND_RESAMPLE:  // :35-42
-            return (e.time_left <= t.p0) && (e.command_counter == static_cast<int64_t>(t.p1));
+            return (e.time_left <= t.p[0]) && (e.command_counter == static_cast<int64_t>(t.p[1]));
         case ILX_TERM_BAD_ORIENTATION:  // :50-59
-            return fabsf(acosf(-e.grav_b.z)) > t.p0;
+            return fabsf(acosf(-e.grav_b.z)) > t.p[0];
         case ILX_TERM_ROOT_HEIGHT_BELOW_MINIMUM:  // :62-72
-            return e.pos.z < t.p0;
+            return e.pos.z < t.p[0];
         case ILX_TERM_JOINT_POS_OUT_OF_MANUAL_LIMIT:  // :90-105
-            return e.joint_any(t, [&](Sel c) { const float q = lane_get(r.q, c); return (q > t.p1) || (q < t.p0); });
+            return e.joint_any(t, [&](int j) { const float q = e.joint(L.q, j); return (q > t.p[1]) || (q < t.p[0]); });
         case ILX_TERM_JOINT_VEL_OUT_OF_LIMIT:  // :108-114
-            return e.joint_any(t, [&](Sel c) { return fabsf(lane_get(r.qd, c)) > lane_get(r.vlim, c); });
+            return e.joint_any(t, [&](int j) { return fabsf(e.joint(L.qd, j)) > e.joint(L.vlim, j); });
         case ILX_TERM_JOINT_VEL_OUT_OF_MANUAL_LIMIT:  // :117-124
-            return e.joint_any(t, [&](Sel c) { return fabsf(lane_get(r.qd, c)) > t.p0; });
+            return e.joint_any(t, [&](int j) { return fabsf(e.joint(L.qd, j)) > t.p[0]; });
         case ILX_TERM_JOINT_EFFORT_OUT_OF_LIMIT:  // :127-142, torch.isclose(rtol=1e-5, atol=1e-8)
-            return e.joint_any(t, [&](Sel c) {
-                const float a = lane_get(r.tau_c, c), b = lane_get(r.tau_a, c);
+            return e.joint_any(t, [&](int j) {
+                const float a = e.joint(L.tau_c, j), b = e.joint(L.tau_a, j);
                 return (a == b) || (fabsf(a - b) <= (1.0e-8f + 1.0e-5f * fabsf(b)));
             });
         case ILX_TERM_ILLEGAL_CONTACT: {  // :150-158
             const int n = e.bcount_sensor(t);
-            const float f = lane_get(r.fpeak, e.col(t, n));
-            return wave_any(e.lane < n && f > t.p0);
+            bool hit = false;
+            for (int k = 0; k < n; ++k) hit = hit || (e.sbody(L.fpeak, e.id(t, k)) > t.p[0]);
+            return hit;
         }
     }
     return false;
 }
 
-ILX_DEV float eval_reward(const Env& e, const Term& t, bool terminated, bool time_out, uint32_t term_bits) {
+ILX_DEV float eval_reward(const Env& e, const ilx_term& t, bool terminated, bool time_out, uint32_t term_bits) {
     const ilx_mdp& d = e.m.d;
-    const Row& r = e.r;
+    const Layout& L = e.m.L;
     const int B = d.num_bodies, A = d.action_dim;
-    const int lane = e.lane;
     switch (t.kind) {
         case ILX_REW_IS_ALIVE: return terminated ? 0.0f : 1.0f;       // rewards.py:31-33
         case ILX_REW_IS_TERMINATED: return terminated ? 1.0f : 0.0f;  // :36-38
@@ -202,97 +172,122 @@ ILX_DEV float eval_reward(const Env& e, const Term& t, bool terminated, bool tim
         case ILX_REW_ANG_VEL_XY_L2: return e.ang_b.x * e.ang_b.x + e.ang_b.y * e.ang_b.y;    // :83-87
         case ILX_REW_FLAT_ORIENTATION_L2: return e.grav_b.x * e.grav_b.x + e.grav_b.y * e.grav_b.y;  // :90-97
         case ILX_REW_BASE_HEIGHT_L2: {  // :100-122
-            float target = t.p0;
+            float target = t.p[0];
             if (t.flags & 1) {
                 float acc = 0.0f;
-                for (int k = lane; k < d.num_rays; k += 64) acc += d.ray_hits_w[3 * (e.env * d.num_rays + k) + 2];
-                target = t.p0 + div_(wave_sum(acc), static_cast<float>(d.num_rays));
+                for (int k = 0; k < d.num_rays; ++k) acc += d.ray_hits_w[3 * (e.env * d.num_rays + k) + 2];
+                target = t.p[0] + div_(acc, static_cast<float>(d.num_rays));
             }
             const float dz = e.pos.z - target;
             return dz * dz;
         }
         case ILX_REW_BODY_LIN_ACC_L2: {  // :125-128
             const int n = e.bcount_asset(t);
-            const float a = lane_get(r.bacc, e.col(t, n));
-            return wave_sum(lane < n ? a : 0.0f);
+            float acc = 0.0f;
+            for (int k = 0; k < n; ++k) acc += e.abody(L.bacc, e.id(t, k));
+            return acc;
         }
         case ILX_REW_JOINT_TORQUES_L2:  // :136-143
-            return e.joint_sum(t, [&](Sel c) { const float v = lane_get(r.tau_a, c); return v * v; });
+            return e.joint_sum(t, [&](int j) { const float v = e.joint(L.tau_a, j); return v * v; });
         case ILX_REW_JOINT_VEL_L1:  // :146-150
-            return e.joint_sum(t, [&](Sel c) { return fabsf(lane_get(r.qd, c)); });
+            return e.joint_sum(t, [&](int j) { return fabsf(e.joint(L.qd, j)); });
         case ILX_REW_JOINT_VEL_L2:  // :153-160
-            return e.joint_sum(t, [&](Sel c) { const float v = lane_get(r.qd, c); return v * v; });
+            return e.joint_sum(t, [&](int j) { const float v = e.joint(L.qd, j); return v * v; });
         case ILX_REW_JOINT_ACC_L2:  // :163-170
-            return e.joint_sum(t, [&](Sel c) { const float v = lane_get(r.qdd, c); return v * v; });
+            return e.joint_sum(t, [&](int j) { const float v = e.joint(L.qdd, j); return v * v; });
         case ILX_REW_JOINT_DEVIATION_L1:  // :173-179
-            return e.joint_sum(t, [&](Sel c) { return fabsf(lane_get(r.q, c) - lane_get(r.q0, c)); });
+            return e.joint_sum(t, [&](int j) { return fabsf(e.joint(L.q, j) - e.joint(L.q0, j)); });
         case ILX_REW_JOINT_POS_LIMITS:  // :182-196
-            return e.joint_sum(t, [&](Sel c) {
-                const float q = lane_get(r.q, c);
-                return -fminf(q - lane_get(r.lim_lo, c), 0.0f) + fmaxf(q - lane_get(r.lim_hi, c), 0.0f);
+            return e.joint_sum(t, [&](int j) {
+                const float q = e.joint(L.q, j);
+                const float lo = e.S[L.lim + 2 * (e.e * d.num_joints + j)], hi = e.S[L.lim + 2 * (e.e * d.num_joints + j) + 1];
+                return -fminf(q - lo, 0.0f) + fmaxf(q - hi, 0.0f);
             });
         case ILX_REW_JOINT_VEL_LIMITS:  // :199-218
-            return e.joint_sum(t, [&](Sel c) {
-                return fminf(fmaxf(fabsf(lane_get(r.qd, c)) - lane_get(r.vlim, c) * t.p0, 0.0f), 1.0f);
+            return e.joint_sum(t, [&](int j) {
+                return fminf(fmaxf(fabsf(e.joint(L.qd, j)) - e.joint(L.vlim, j) * t.p[0], 0.0f), 1.0f);
             });
         case ILX_REW_APPLIED_TORQUE_LIMITS:  // :226-242
-            return e.joint_sum(t, [&](Sel c) { return fabsf(lane_get(r.tau_a, c) - lane_get(r.tau_c, c)); });
+            return e.joint_sum(t, [&](int j) { return fabsf(e.joint(L.tau_a, j) - e.joint(L.tau_c, j)); });
         case ILX_REW_ACTION_RATE_L2: {  // :245-247
-            const float v = r.act - r.pact;
-            return wave_sum(lane < A ? v * v : 0.0f);
+            float acc = 0.0f;
+            for (int k = 0; k < A; ++k) {
+                const float v = e.S[L.act + e.e * A + k] - e.S[L.pact + e.e * A + k];
+                acc += v * v;
+            }
+            return acc;
         }
-        case ILX_REW_ACTION_L2:  // :250-252
-            return wave_sum(lane < A ? r.act * r.act : 0.0f);
+        case ILX_REW_ACTION_L2: {  // :250-252
+            float acc = 0.0f;
+            for (int k = 0; k < A; ++k) {
+                const float v = e.S[L.act + e.e * A + k];
+                acc += v * v;
+            }
+            return acc;
+        }
         case ILX_REW_UNDESIRED_CONTACTS: {  // :260-268 (count of bodies above the threshold)
             const int n = e.bcount_sensor(t);
-            const float f = lane_get(r.fpeak, e.col(t, n));
-            return wave_sum((lane < n && f > t.p0) ? 1.0f : 0.0f);
+            float acc = 0.0f;
+            for (int k = 0; k < n; ++k) acc += (e.sbody(L.fpeak, e.id(t, k)) > t.p[0]) ? 1.0f : 0.0f;
+            return acc;
         }
         case ILX_REW_CONTACT_FORCES: {  // :271-279
             const int n = e.bcount_sensor(t);
-            const float f = lane_get(r.fpeak, e.col(t, n));
-            return wave_sum(lane < n ? fmaxf(f - t.p0, 0.0f) : 0.0f);
+            float acc = 0.0f;
+            for (int k = 0; k < n; ++k) acc += fmaxf(e.sbody(L.fpeak, e.id(t, k)) - t.p[0], 0.0f);
+            return acc;
         }
         case ILX_REW_TRACK_LIN_VEL_XY_EXP: {  // :287-298
             const float dx = e.cmd(0) - e.lin_b.x, dy = e.cmd(1) - e.lin_b.y;
-            return expf(div_(-(dx * dx + dy * dy), t.p0));
+            return expf(div_(-(dx * dx + dy * dy), t.p[0]));
         }
         case ILX_REW_TRACK_ANG_VEL_Z_EXP: {  // :301-309
             const float dz = e.cmd(2) - e.ang_b.z;
-            return expf(div_(-(dz * dz), t.p0));
+            return expf(div_(-(dz * dz), t.p[0]));
         }
         case ILX_REW_FEET_AIR_TIME: {  // velocity/mdp/rewards.py:25-44
             const int n = e.bcount_sensor(t);
-            const Sel c = e.col(t, n);
-            const float cc = lane_get(r.contact_t, c), la = lane_get(r.last_air, c);
-            const bool first = (cc > 0.0f) && (cc < t.p1);  // contact_sensor.py:200-203
-            const float acc = wave_sum(lane < n ? (la - t.p0) * (first ? 1.0f : 0.0f) : 0.0f);
+            float acc = 0.0f;
+            for (int k = 0; k < n; ++k) {
+                const int b = e.id(t, k);
+                const float cc = e.sbody(L.contact_t, b);
+                const bool first = (cc > 0.0f) && (cc < t.p[1]);  // contact_sensor.py:200-203
+                acc += (e.sbody(L.last_air, b) - t.p[0]) * (first ? 1.0f : 0.0f);
+            }
             return acc * ((norm2(e.cmd(0), e.cmd(1)) > 0.1f) ? 1.0f : 0.0f);
         }
         case ILX_REW_FEET_AIR_TIME_POSITIVE_BIPED: {  // velocity/mdp/rewards.py:47-66
             const int n = e.bcount_sensor(t);
-            const Sel c = e.col(t, n);
-            const float cc = lane_get(r.contact_t, c), ca = lane_get(r.air, c);
-            const bool single = wave_sum((lane < n && cc > 0.0f) ? 1.0f : 0.0f) == 1.0f;
-            const float mode = (cc > 0.0f) ? cc : ca;
-            const float mn = wave_min(lane < n ? (single ? mode : 0.0f) : __builtin_inff());
-            return fminf(mn, t.p0) * ((norm2(e.cmd(0), e.cmd(1)) > 0.1f) ? 1.0f : 0.0f);
+            float cnt = 0.0f;
+            for (int k = 0; k < n; ++k) cnt += (e.sbody(L.contact_t, e.id(t, k)) > 0.0f) ? 1.0f : 0.0f;
+            const bool single = cnt == 1.0f;
+            float mn = __builtin_inff();
+            for (int k = 0; k < n; ++k) {
+                const int b = e.id(t, k);
+                const float cc = e.sbody(L.contact_t, b);
+                const float mode = (cc > 0.0f) ? cc : e.sbody(L.air, b);
+                mn = fminf(mn, single ? mode : 0.0f);
+            }
+            return fminf(mn, t.p[0]) * ((norm2(e.cmd(0), e.cmd(1)) > 0.1f) ? 1.0f : 0.0f);
         }
         case ILX_REW_FEET_SLIDE: {  // velocity/mdp/rewards.py:69-83
             const int n = e.bcount_sensor(t);
-            const bool contact = lane_get(r.fpeak, e.col(t, n)) > 1.0f;
-            const Sel ab = e.col2(t, n);
-            const float sp = norm2(lane_get(r.bvx, ab), lane_get(r.bvy, ab));
-            return wave_sum(lane < n ? sp * (contact ? 1.0f : 0.0f) : 0.0f);
+            float acc = 0.0f;
+            for (int k = 0; k < n; ++k) {
+                const bool contact = e.sbody(L.fpeak, e.id(t, k)) > 1.0f;
+                const int ab = e.id2(t, k);
+                acc += norm2(e.abody(L.bvx, ab), e.abody(L.bvy, ab)) * (contact ? 1.0f : 0.0f);
+            }
+            return acc;
         }
         case ILX_REW_TRACK_LIN_VEL_XY_YAW_FRAME_EXP: {  // velocity/mdp/rewards.py:86-96
             const f3 v = quat_rotate_inverse(yaw_quat(e.quat), e.lin_w);
             const float dx = e.cmd(0) - v.x, dy = e.cmd(1) - v.y;
-            return expf(div_(-(dx * dx + dy * dy), t.p0));
+            return expf(div_(-(dx * dx + dy * dy), t.p[0]));
         }
         case ILX_REW_TRACK_ANG_VEL_Z_WORLD_EXP: {  // velocity/mdp/rewards.py:99-106
             const float dz = e.cmd(2) - e.ang_w.z;
-            return expf(div_(-(dz * dz), t.p0));
+            return expf(div_(-(dz * dz), t.p[0]));
         }
         case ILX_REW_POSITION_COMMAND_ERROR:
         case ILX_REW_POSITION_COMMAND_ERROR_TANH: {  // reach/mdp/rewards.py:19-52
@@ -300,7 +295,7 @@ ILX_DEV float eval_reward(const Env& e, const Term& t, bool terminated, bool tim
             const f3 des = {e.pos.x + rr.x, e.pos.y + rr.y, e.pos.z + rr.z};
             const float* b = d.body_state_w + 13 * (e.env * B + e.ids[t.ids_off]);
             const float dist = norm3(b[0] - des.x, b[1] - des.y, b[2] - des.z);
-            return t.kind == ILX_REW_POSITION_COMMAND_ERROR ? dist : (1.0f - tanhf(div_(dist, t.p0)));
+            return t.kind == ILX_REW_POSITION_COMMAND_ERROR ? dist : (1.0f - tanhf(div_(dist, t.p[0])));
         }
         case ILX_REW_ORIENTATION_COMMAND_ERROR: {  // reach/mdp/rewards.py:55-69
             const f4 des = quat_mul(e.quat, f4{e.cmd(3), e.cmd(4), e.cmd(5), e.cmd(6)});
@@ -308,12 +303,12 @@ ILX_DEV float eval_reward(const Env& e, const Term& t, bool terminated, bool tim
             return quat_error_magnitude(f4{b[0], b[1], b[2], b[3]}, des);
         }
         case ILX_REW_JOINT_POS_TARGET_L2:  // cartpole/mdp/rewards.py:19-26
-            return e.joint_sum(t, [&](Sel c) { const float v = wrap_to_pi(lane_get(r.q, c)) - t.p0; return v * v; });
+            return e.joint_sum(t, [&](int j) { const float v = wrap_to_pi(e.joint(L.q, j)) - t.p[0]; return v * v; });
     }
     return 0.0f;
 }
 
-ILX_DEV int obs_dim_of(const ilx_mdp& d, const Term& t) {
+ILX_DEV int obs_dim_of(const ilx_mdp& d, const ilx_term& t) {
     const int nj = t.ids_cnt < 0 ? d.num_joints : t.ids_cnt;
     switch (t.kind) {
         case ILX_OBS_BASE_POS_Z: return 1;
@@ -336,48 +331,51 @@ ILX_DEV int obs_dim_of(const ilx_mdp& d, const Term& t) {
     return 0;
 }
 
-// Column k = lane of a term that is at most 64 wide (everything except the height scan).
-ILX_DEV float eval_obs_row(const Env& e, const Term& t, int dim) {
-    const ilx_mdp& d = e.m.d;
-    const Row& r = e.r;
-    const int k = e.lane;
-    auto pick3 = [](f3 v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : v.z); };
+// Column k of an observation term for env slot e (EMIT stage; everything except the height scan comes from LDS).
+ILX_DEV float eval_obs(const MdpDev& m, const float* S, const int32_t* ids, int e, int64_t env, const ilx_term& t, int k) {
+    const ilx_mdp& d = m.d;
+    const Layout& L = m.L;
+    const int J = d.num_joints;
+    const float* root = S + L.root + 13 * e;
+    const float* der = S + L.derived + kDerived * e;
+    auto jid = [&](int kk) { return e * J + (t.ids_cnt < 0 ? kk : ids[t.ids_off + kk]); };
     switch (t.kind) {
-        case ILX_OBS_BASE_POS_Z: return e.pos.z;                 // observations.py:33-37
-        case ILX_OBS_BASE_LIN_VEL: return pick3(e.lin_b, k);      // :40-44
-        case ILX_OBS_BASE_ANG_VEL: return pick3(e.ang_b, k);      // :47-51
-        case ILX_OBS_PROJECTED_GRAVITY: return pick3(e.grav_b, k);  // :54-58
-        case ILX_OBS_ROOT_POS_W:                                  // :61-65
-            return pick3(e.pos, k) - ((d.env_origins && k < 3) ? d.env_origins[3 * e.env + k] : 0.0f);
+        case ILX_OBS_BASE_POS_Z: return root[2];                 // observations.py:33-37
+        case ILX_OBS_BASE_LIN_VEL: return der[k];                 // :40-44
+        case ILX_OBS_BASE_ANG_VEL: return der[3 + k];             // :47-51
+        case ILX_OBS_PROJECTED_GRAVITY: return der[6 + k];        // :54-58
+        case ILX_OBS_ROOT_POS_W: return root[k] - (d.env_origins ? d.env_origins[3 * env + k] : 0.0f);  // :61-65
         case ILX_OBS_ROOT_QUAT_W: {  // :68-82
-            const f4 q = (t.flags & ILX_OBS_FLAG_QUAT_UNIQUE) ? quat_unique(e.quat) : e.quat;
-            return k == 0 ? q.w : (k == 1 ? q.x : (k == 2 ? q.y : q.z));
+            const float v = root[3 + k];
+            return ((t.flags & ILX_OBS_FLAG_QUAT_UNIQUE) && root[3] < 0.0f) ? -v : v;
         }
-        case ILX_OBS_ROOT_LIN_VEL_W: return pick3(e.lin_w, k);  // :85-89
-        case ILX_OBS_ROOT_ANG_VEL_W: return pick3(e.ang_w, k);  // :92-96
-        case ILX_OBS_JOINT_POS: return lane_get(r.q, e.col(t, dim));  // :104-111
-        case ILX_OBS_JOINT_POS_REL: {                                   // :114-121
-            const Sel c = e.col(t, dim);
-            return lane_get(r.q, c) - lane_get(r.q0, c);
+        case ILX_OBS_ROOT_LIN_VEL_W: return root[7 + k];   // :85-89
+        case ILX_OBS_ROOT_ANG_VEL_W: return root[10 + k];  // :92-96
+        case ILX_OBS_JOINT_POS: return S[L.q + jid(k)];    // :104-111
+        case ILX_OBS_JOINT_POS_REL: {                      // :114-121
+            const int i = jid(k);
+            return S[L.q + i] - S[L.q0 + i];
         }
         case ILX_OBS_JOINT_POS_LIMIT_NORMALIZED: {  // :124-137 (math.py:23-40)
-            const Sel c = e.col(t, dim);
-            const float lo = lane_get(r.lim_lo, c), hi = lane_get(r.lim_hi, c);
+            const int i = jid(k);
+            const float lo = S[L.lim + 2 * i], hi = S[L.lim + 2 * i + 1];
             const float off = (lo + hi) * 0.5f;
-            return div_(2.0f * (lane_get(r.q, c) - off), hi - lo);
+            return div_(2.0f * (S[L.q + i] - off), hi - lo);
         }
-        case ILX_OBS_JOINT_VEL: return lane_get(r.qd, e.col(t, dim));  // :140-147
-        case ILX_OBS_JOINT_VEL_REL: {                                    // :150-157
-            const Sel c = e.col(t, dim);
-            return lane_get(r.qd, c) - lane_get(r.qd0, c);
+        case ILX_OBS_JOINT_VEL: return S[L.qd + jid(k)];  // :140-147
+        case ILX_OBS_JOINT_VEL_REL: {                     // :150-157
+            const int i = jid(k);
+            return S[L.qd + i] - S[L.qd0 + i];
         }
-        case ILX_OBS_LAST_ACTION: return r.act;          // :512-521
-        case ILX_OBS_GENERATED_COMMANDS: return r.cmd;   // :529-531
+        case ILX_OBS_HEIGHT_SCAN:  // :165-173
+            return der[9] - d.ray_hits_w[3 * (env * d.num_rays + k) + 2] - t.aux;
+        case ILX_OBS_LAST_ACTION: return S[L.act + e * d.action_dim + k];          // :512-521
+        case ILX_OBS_GENERATED_COMMANDS: return S[L.cmd + e * d.command_dim + k];  // :529-531
     }
     return 0.0f;
 }
 
-// Command term state of one env, uniform across the wave (lane 0 stores it).
+// Command term state of one env (held by the env's lane).
 struct CmdState {
     float time_left = 0.0f, metric0 = 0.0f, metric1 = 0.0f, heading_target = 0.0f;
     int64_t counter = 0;
@@ -417,220 +415,235 @@ ILX_DEV void command_resample(const ilx_mdp& d, int64_t env, const float* inject
     }
 }
 
+// coalesced copy of the block's chunk of an [env][width] array into LDS
+ILX_DEV void stage_rows(float* dst, const float* src, int64_t env0, int ne, int width) {
+    const float* p = src + env0 * width;
+    for (int i = threadIdx.x; i < ne * width; i += 256) dst[i] = p[i];
+}
+
 __global__ void __launch_bounds__(256) mdp_step_kernel(MdpDev m) {
-    __shared__ ilx_term s_terms[3 * kMaxTerms];
-    __shared__ int32_t s_ids[kMaxIds];
+    extern __shared__ float S[];
     const ilx_mdp& d = m.d;
+    const Layout& L = m.L;
     const int NT = d.num_terminations, NR = d.num_rewards, NO = d.num_observations;
-    const int lane = threadIdx.x & 63;
     const int64_t N = d.num_envs;
-    const int64_t wave_env = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
-    const int64_t env = wave_env < N ? wave_env : N - 1;  // a surplus wave gathers a valid row, then leaves
+    const int64_t env0 = static_cast<int64_t>(blockIdx.x) * kE;
+    const int ne = static_cast<int>(N - env0 < kE ? N - env0 : kE);
     const int J = d.num_joints, B = d.num_bodies, CB = d.num_sensor_bodies, A = d.action_dim, CD = d.command_dim;
-    const int R = d.num_rays;
+    const int tid = threadIdx.x;
     const bool ph_term = d.phases & ILX_PHASE_TERMINATION, ph_rew = d.phases & ILX_PHASE_REWARD,
                ph_reset = d.phases & ILX_PHASE_RESET, ph_obs = d.phases & ILX_PHASE_OBSERVATION;
     const bool has_cmd_term = d.command_kind != ILX_CMD_NONE;
     const bool ph_cmd = (d.phases & ILX_PHASE_COMMAND) && has_cmd_term;
     const bool cmd_state = has_cmd_term && (d.phases & (ILX_PHASE_COMMAND | ILX_PHASE_RESET));
+    const ilx_term* terms = reinterpret_cast<const ilx_term*>(S + L.terms);
+    const int32_t* ids = reinterpret_cast<const int32_t*>(S + L.ids);
 
-    // ================= GATHER: every load is issued before the first use =================
-    Env e{m, s_ids, env, lane};
-    Row& r = e.r;
-    const float* rs = d.root_state_w + 13 * env;
-    const float rs_lane = lane < 13 ? rs[lane] : 0.0f;
-    if ((m.need & kNeedJoint) && lane < J) {
-        const int64_t i = env * J + lane;
-        r.q = d.joint_pos[i], r.qd = d.joint_vel[i], r.qdd = d.joint_acc[i];
-        r.tau_a = d.applied_torque[i], r.tau_c = d.computed_torque[i];
-        r.q0 = d.default_joint_pos[i], r.qd0 = d.default_joint_vel[i];
-        const float2 lim = *reinterpret_cast<const float2*>(d.soft_joint_pos_limits + 2 * i);
-        r.lim_lo = lim.x, r.lim_hi = lim.y;
-        r.vlim = d.soft_joint_vel_limits[i];
-    }
-    if ((m.need & kNeedAction) && lane < A) {
-        r.act = d.action[env * A + lane];
-        if (d.prev_action) r.pact = d.prev_action[env * A + lane];
-    }
-    if ((m.need & kNeedTimers) && lane < CB) {
-        const int64_t i = env * CB + lane;
-        r.air = d.current_air_time[i], r.last_air = d.last_air_time[i], r.contact_t = d.current_contact_time[i];
-    }
-    if ((m.need & kNeedBodyVel) && lane < B) {
-        const float* v = d.body_state_w + 13 * (env * B + lane) + 7;
-        r.bvx = v[0], r.bvy = v[1];
-    }
-    f3 bacc = {0, 0, 0};
-    if ((m.need & kNeedBodyAcc) && lane < B) bacc = load3(d.body_lin_acc_w + 3 * (env * B + lane));
-    if (d.command && lane < CD) r.cmd = d.command[env * CD + lane];
-    float ep_sum = 0.0f;  // lane i: episode sum of reward term i
-    if ((ph_rew || ph_reset) && lane < NR) ep_sum = d.episode_sums[static_cast<int64_t>(lane) * N + env];
-    float rz[kRayRegs] = {0, 0, 0, 0};
-    float sensor_z = 0.0f;
-    if (m.need & kNeedRays) {
-        sensor_z = d.sensor_pos_w[3 * env + 2];
-#pragma unroll
-        for (int it = 0; it < kRayRegs; ++it) {
-            const int k = it * 64 + lane;
-            if (k < R) rz[it] = d.ray_hits_w[3 * (env * R + k) + 2];
-        }
-    }
-    int64_t ep_len = d.episode_length_buf ? d.episode_length_buf[env] : 0;
-    CmdState cs;
-    if (d.time_left) cs.time_left = d.time_left[env];
-    if (d.command_counter) cs.counter = d.command_counter[env];
-    if (cmd_state) {
-        cs.metric0 = d.command_metrics[env], cs.metric1 = d.command_metrics[N + env];
-        if (d.command_kind == ILX_CMD_VELOCITY) {
-            cs.heading_target = d.heading_target[env];
-            cs.is_heading = d.is_heading_env[env] != 0;
-            cs.is_standing = d.is_standing_env[env] != 0;
-        }
-    }
-    // peak contact force over the history per sensor body (last: the longest dependent chain of the gather)
-    if ((m.need & kNeedForces) && lane < CB) {
-        const int H = d.history_len;
-        float mx = -__builtin_inff();
-#pragma unroll 4
-        for (int h = 0; h < H; ++h) {
-            const float* f = d.net_forces_w_history + 3 * ((env * H + h) * CB + lane);
-            mx = fmaxf(mx, norm3(f[0], f[1], f[2]));
-        }
-        r.fpeak = mx;
-    }
-    r.bacc = norm3(bacc);
-
-    // term tables and index lists -> LDS; their loads are in flight together with the gather above
+    // ================= STAGE =================
     {
         const int32_t* src = reinterpret_cast<const int32_t*>(m.terms);
-        int32_t* dst = reinterpret_cast<int32_t*>(s_terms);
+        int32_t* dst = reinterpret_cast<int32_t*>(S + L.terms);
         const int words = (NT + NR + NO) * static_cast<int>(sizeof(ilx_term) / 4);
-        for (int i = threadIdx.x; i < words; i += 256) dst[i] = src[i];
-        for (int i = threadIdx.x; i < d.num_ids; i += 256) s_ids[i] = m.ids[i];
+        for (int i = tid; i < words; i += 256) dst[i] = src[i];
+        int32_t* idst = reinterpret_cast<int32_t*>(S + L.ids);
+        for (int i = tid; i < d.num_ids; i += 256) idst[i] = m.ids[i];
+        uint32_t* cdst = reinterpret_cast<uint32_t*>(S + L.colterm);  // colterm and tstart are adjacent
+        const int cwords = ((d.obs_dim + 3) >> 2) + NO;
+        if (ph_obs)
+            for (int i = tid; i < cwords; i += 256) cdst[i] = m.cols[i];
+        for (int i = tid; i < NR + NT + 3; i += 256) S[L.logp + i] = 0.0f;
     }
-    __syncthreads();
-    if (wave_env >= N) return;  // wave-uniform
-
-    // root frame quantities (articulation_data.py:411-425, 502-518), uniform across the wave
-    e.pos = {lane_const(rs_lane, 0), lane_const(rs_lane, 1), lane_const(rs_lane, 2)};
-    e.quat = {lane_const(rs_lane, 3), lane_const(rs_lane, 4), lane_const(rs_lane, 5), lane_const(rs_lane, 6)};
-    e.lin_w = {lane_const(rs_lane, 7), lane_const(rs_lane, 8), lane_const(rs_lane, 9)};
-    e.ang_w = {lane_const(rs_lane, 10), lane_const(rs_lane, 11), lane_const(rs_lane, 12)};
-    e.lin_b = quat_rotate_inverse(e.quat, e.lin_w);
-    e.ang_b = quat_rotate_inverse(e.quat, e.ang_w);
-    e.grav_b = quat_rotate_inverse(e.quat, f3{d.gravity_dir[0], d.gravity_dir[1], d.gravity_dir[2]});
-    {
-        const f3 fwd = quat_apply(e.quat, f3{1.0f, 0.0f, 0.0f});
-        e.heading = atan2f(fwd.y, fwd.x);
+    stage_rows(S + L.root, d.root_state_w, env0, ne, 13);
+    if (m.need & kNeedJoint) {
+        stage_rows(S + L.q, d.joint_pos, env0, ne, J);
+        stage_rows(S + L.qd, d.joint_vel, env0, ne, J);
+        stage_rows(S + L.qdd, d.joint_acc, env0, ne, J);
+        stage_rows(S + L.tau_a, d.applied_torque, env0, ne, J);
+        stage_rows(S + L.tau_c, d.computed_torque, env0, ne, J);
+        stage_rows(S + L.q0, d.default_joint_pos, env0, ne, J);
+        stage_rows(S + L.qd0, d.default_joint_vel, env0, ne, J);
+        stage_rows(S + L.vlim, d.soft_joint_vel_limits, env0, ne, J);
+        stage_rows(S + L.lim, d.soft_joint_pos_limits, env0, ne, 2 * J);
     }
-    e.time_left = cs.time_left, e.command_counter = cs.counter;
-    if (has_cmd_term) {
-#pragma unroll
-        for (int k = 0; k < 7; ++k) cs.c[k] = lane_const(r.cmd, k);
+    if (m.need & kNeedAction) {
+        stage_rows(S + L.act, d.action, env0, ne, A);
+        if (d.prev_action) stage_rows(S + L.pact, d.prev_action, env0, ne, A);
     }
-    const float dt = d.step_dt;
-
-    // ================= terminations (manager_based_rl_env.py:199-202, termination_manager.py:151-174)
+    if (m.need & kNeedTimers) {
+        stage_rows(S + L.air, d.current_air_time, env0, ne, CB);
+        stage_rows(S + L.last_air, d.last_air_time, env0, ne, CB);
+        stage_rows(S + L.contact_t, d.current_contact_time, env0, ne, CB);
+    }
+    if (d.command) stage_rows(S + L.cmd, d.command, env0, ne, CD);
+    if (ph_rew || ph_reset) {  // episode sums: [term][env] in memory and in LDS
+        for (int i = tid; i < NR * kE; i += 256) {
+            const int term = i / kE, e = i - term * kE;
+            if (e < ne) S[L.eps + i] = d.episode_sums[static_cast<int64_t>(term) * N + env0 + e];
+        }
+    }
+    if (m.need & kNeedBodyVel) {
+        for (int i = tid; i < ne * B; i += 256) {
+            const float* v = d.body_state_w + 13 * (env0 * B + i) + 7;
+            S[L.bvx + i] = v[0], S[L.bvy + i] = v[1];
+        }
+    }
+    if (m.need & kNeedBodyAcc) {
+        for (int i = tid; i < ne * B; i += 256) S[L.bacc + i] = norm3(load3(d.body_lin_acc_w + 3 * (env0 * B + i)));
+    }
+    if (m.need & kNeedForces) {  // max over the history of |F| per (env, body): rewards.py:266 / terminations.py:157
+        const int H = d.history_len;
+        for (int i = tid; i < ne * CB; i += 256) {
+            const int e = i / CB, b = i - e * CB;
+            float mx = -__builtin_inff();
+#pragma unroll 4
+            for (int h = 0; h < H; ++h) mx = fmaxf(mx, norm3(load3(d.net_forces_w_history + 3 * (((env0 + e) * H + h) * CB + b))));
+            S[L.fpeak + i] = mx;
+        }
+    }
+    // per-env scalars of the DECIDE lanes (coalesced over the 16 lanes), loaded before the barrier
+    const int wave = tid >> 6, lane = tid & 63;
+    const bool decide = lane < ne;
+    const int e = lane;
+    const int64_t env = env0 + (decide ? e : 0);
+    int64_t ep_len = 0;
+    CmdState cs;
+    float sensor_z = 0.0f;
     bool terminated = false, time_out = false;
     uint32_t term_bits = 0;
-    if (ph_term) {
-        ep_len += 1;
-        for (int i = 0; i < NT; ++i) {
-            const Term t = fetch_term(s_terms + i);
-            const bool v = eval_termination(e, t, ep_len);
-            term_bits |= v ? (1u << i) : 0u;
-            if (t.flags & 1) time_out = time_out || v; else terminated = terminated || v;
+    if (decide) {
+        if (d.episode_length_buf) ep_len = d.episode_length_buf[env];
+        if (d.time_left) cs.time_left = d.time_left[env];
+        if (d.command_counter) cs.counter = d.command_counter[env];
+        if (cmd_state && wave == 0) {
+            cs.metric0 = d.command_metrics[env], cs.metric1 = d.command_metrics[N + env];
+            if (d.command_kind == ILX_CMD_VELOCITY) {
+                cs.heading_target = d.heading_target[env];
+                cs.is_heading = d.is_heading_env[env] != 0;
+                cs.is_standing = d.is_standing_env[env] != 0;
+            }
         }
-        if (lane < NT) d.term_dones[static_cast<int64_t>(lane) * N + env] = (term_bits >> lane) & 1u;
-        if (lane == 0) {
+        if ((m.need & kNeedRays) && wave == 0) sensor_z = d.sensor_pos_w[3 * env + 2];
+        if (!ph_term && d.terminated) {
+            terminated = d.terminated[env] != 0;
+            time_out = d.time_outs[env] != 0;
+            for (int i = 0; i < NT; ++i) term_bits |= d.term_dones[static_cast<int64_t>(i) * N + env] ? (1u << i) : 0u;
+        }
+    }
+    __syncthreads();
+
+    // ================= DECIDE: one lane per env; the four waves split the reward terms =================
+    Env en{m, S, ids, e, env};
+    const float dt = d.step_dt;
+    if (decide) {
+        const float* rs = S + L.root + 13 * e;
+        en.pos = {rs[0], rs[1], rs[2]};
+        en.quat = {rs[3], rs[4], rs[5], rs[6]};
+        en.lin_w = {rs[7], rs[8], rs[9]};
+        en.ang_w = {rs[10], rs[11], rs[12]};
+        // articulation_data.py:411-425, 502-518
+        en.lin_b = quat_rotate_inverse(en.quat, en.lin_w);
+        en.ang_b = quat_rotate_inverse(en.quat, en.ang_w);
+        en.grav_b = quat_rotate_inverse(en.quat, f3{d.gravity_dir[0], d.gravity_dir[1], d.gravity_dir[2]});
+        en.time_left = cs.time_left, en.command_counter = cs.counter;
+        // ---- terminations (manager_based_rl_env.py:199-202, termination_manager.py:151-174); every wave needs the result
+        if (ph_term) {
+            ep_len += 1;
+            for (int i = 0; i < NT; ++i) {
+                const ilx_term t = terms[i];
+                const bool v = eval_termination(en, t, ep_len);
+                term_bits |= v ? (1u << i) : 0u;
+                if (t.flags & 1) time_out = time_out || v; else terminated = terminated || v;
+            }
+        }
+        // ---- rewards (reward_manager.py:128-157): this wave's share of the terms
+        if (ph_rew) {
+            float partial = 0.0f;
+            for (int i = wave; i < NR; i += 4) {
+                const ilx_term t = terms[NT + i];
+                if (t.weight == 0.0f) continue;  // :145-146 (episode sums and step_reward keep their values)
+                const float value = eval_reward(en, t, terminated, time_out, term_bits) * t.weight * dt;
+                partial += value;
+                S[L.eps + i * kE + e] += value;
+                S[L.srew + e * NR + i] = div_(value, dt);
+            }
+            S[L.ptotal + wave * kE + e] = partial;
+        }
+    }
+    __syncthreads();
+    if (decide && wave == 0) {
+        const bool done = terminated || time_out;
+        if (ph_term) {
             d.terminated[env] = terminated;
             d.time_outs[env] = time_out;
-            if (d.reset_buf) d.reset_buf[env] = terminated || time_out;
+            if (d.reset_buf) d.reset_buf[env] = done;
         }
-    } else if (d.terminated) {
-        terminated = d.terminated[env] != 0;
-        time_out = d.time_outs[env] != 0;
-        const bool mine = lane < NT && d.term_dones[static_cast<int64_t>(lane) * N + env] != 0;
-        term_bits = static_cast<uint32_t>(__ballot(mine));
-    }
-    const bool done = terminated || time_out;
-
-    // ================= rewards (reward_manager.py:128-157)
-    bool sum_dirty = false;
-    if (ph_rew) {
-        float total = 0.0f, my_step = 0.0f;
-        for (int i = 0; i < NR; ++i) {
-            const Term t = fetch_term(s_terms + NT + i);
-            if (t.weight == 0.0f) continue;  // :145-146 (episode sums and step_reward keep their values)
-            const float value = eval_reward(e, t, terminated, time_out, term_bits) * t.weight * dt;
-            total += value;
-            if (lane == i) {
-                ep_sum += value;
-                my_step = div_(value, dt);
-                sum_dirty = true;
+        if (ph_rew)
+            d.reward_buf[env] = ((S[L.ptotal + e] + S[L.ptotal + kE + e]) + S[L.ptotal + 2 * kE + e]) + S[L.ptotal + 3 * kE + e];
+        reinterpret_cast<uint32_t*>(S + L.bits)[e] = term_bits;
+        reinterpret_cast<uint32_t*>(S + L.bits)[kE + e] = done ? 1u : 0u;
+        if (has_cmd_term) {
+#pragma unroll
+            for (int k = 0; k < 7; ++k)
+                if (k < CD) cs.c[k] = en.cmd(k);
+        }
+        // ---- reset bookkeeping of the managers for done envs (manager_based_rl_env.py:364-391)
+        bool cmd_dirty = false;
+        if (ph_reset && done) {
+            // logging sums go through per-block partials in LDS (ds_add_f32), one global atomic per entry and block
+            float* logp = S + L.logp;
+            for (int i = 0; i < NR; ++i) {  // reward_manager.py:115-121
+                atomicAdd(logp + i, S[L.eps + i * kE + e]);
+                S[L.eps + i * kE + e] = 0.0f;
             }
+            for (int i = 0; i < NT; ++i)  // termination_manager.py:142-144
+                if (term_bits & (1u << i)) atomicAdd(logp + NR + i, 1.0f);
+            atomicAdd(logp + NR + NT + 2, 1.0f);
+            if (has_cmd_term) {  // command_manager.py:120-149
+                atomicAdd(logp + NR + NT, cs.metric0);
+                atomicAdd(logp + NR + NT + 1, cs.metric1);
+                cs.metric0 = cs.metric1 = 0.0f;
+                cs.counter = 0;
+                command_resample(d, env, d.reset_command_samples, 16u, cs);
+                cmd_dirty = true;
+            }
+            ep_len = 0;  // manager_based_rl_env.py:391
         }
-        if (sum_dirty) d.step_reward[env * NR + lane] = my_step;
-        if (lane == 0) d.reward_buf[env] = total;
-    }
-
-    // ================= reset bookkeeping of the managers for done envs (manager_based_rl_env.py:364-391)
-    bool cmd_dirty = false;
-    if (ph_reset && done) {
-        if (lane < NR) {  // reward_manager.py:115-121
-            if (d.log_sums) atomicAdd(d.log_sums + lane, ep_sum);
-            ep_sum = 0.0f;
-            sum_dirty = true;
-        }
-        if (d.log_sums) {
-            if (lane < NT && ((term_bits >> lane) & 1u)) atomicAdd(d.log_sums + NR + lane, 1.0f);  // termination_manager.py:142-144
-            if (lane == 0) atomicAdd(d.log_sums + NR + NT + 2, 1.0f);
-        }
-        if (has_cmd_term) {  // command_manager.py:120-149
-            if (d.log_sums && lane < 2) atomicAdd(d.log_sums + NR + NT + lane, lane == 0 ? cs.metric0 : cs.metric1);
-            cs.metric0 = cs.metric1 = 0.0f;
-            cs.counter = 0;
-            command_resample(d, env, d.reset_command_samples, 16u, cs);
+        if (d.episode_length_buf && (ph_term || (ph_reset && done))) d.episode_length_buf[env] = ep_len;
+        // ---- command term (command_manager.py:151-166)
+        if (ph_cmd) {
+            if (d.command_kind == ILX_CMD_VELOCITY) {  // velocity_command.py:111-121
+                cs.metric0 = cs.metric0 + div_(norm2(cs.c[0] - en.lin_b.x, cs.c[1] - en.lin_b.y), d.max_command_step);
+                cs.metric1 = cs.metric1 + div_(fabsf(cs.c[2] - en.ang_b.z), d.max_command_step);
+            } else {  // pose_command.py:92-108 (metrics are overwritten each step)
+                f3 pw;
+                f4 qw;
+                combine_frame_transforms(en.pos, en.quat, f3{cs.c[0], cs.c[1], cs.c[2]}, f4{cs.c[3], cs.c[4], cs.c[5], cs.c[6]}, pw, qw);
+                const float* b = d.body_state_w + 13 * (env * B + d.pose_body_index);
+                const f3 aa = axis_angle_from_quat(quat_error(qw, f4{b[3], b[4], b[5], b[6]}));
+                cs.metric0 = norm3(b[0] - pw.x, b[1] - pw.y, b[2] - pw.z);
+                cs.metric1 = norm3(aa);
+            }
+            cs.time_left = cs.time_left - dt;
+            if (cs.time_left <= 0.0f) command_resample(d, env, d.command_samples, 0u, cs);
+            if (d.command_kind == ILX_CMD_VELOCITY) {  // velocity_command.py:140-160
+                if (d.heading_command && cs.is_heading) {
+                    const f3 fwd = quat_apply(en.quat, f3{1.0f, 0.0f, 0.0f});  // articulation_data.py:416-425
+                    const float err = wrap_to_pi(cs.heading_target - atan2f(fwd.y, fwd.x));
+                    cs.c[2] = fminf(fmaxf(d.heading_control_stiffness * err, d.cmd_range[3][0]), d.cmd_range[3][1]);
+                }
+                if (cs.is_standing) cs.c[0] = cs.c[1] = cs.c[2] = 0.0f;
+            }
             cmd_dirty = true;
         }
-        ep_len = 0;  // manager_based_rl_env.py:391
-    }
-    if (sum_dirty) d.episode_sums[static_cast<int64_t>(lane) * N + env] = ep_sum;
-    if (lane == 0 && d.episode_length_buf && (ph_term || (ph_reset && done))) d.episode_length_buf[env] = ep_len;
-
-    // ================= command term (command_manager.py:151-166)
-    if (ph_cmd) {
-        if (d.command_kind == ILX_CMD_VELOCITY) {  // velocity_command.py:111-121
-            cs.metric0 = cs.metric0 + div_(norm2(cs.c[0] - e.lin_b.x, cs.c[1] - e.lin_b.y), d.max_command_step);
-            cs.metric1 = cs.metric1 + div_(fabsf(cs.c[2] - e.ang_b.z), d.max_command_step);
-        } else {  // pose_command.py:92-108 (metrics are overwritten each step)
-            f3 pw;
-            f4 qw;
-            combine_frame_transforms(e.pos, e.quat, f3{cs.c[0], cs.c[1], cs.c[2]}, f4{cs.c[3], cs.c[4], cs.c[5], cs.c[6]}, pw, qw);
-            const float* b = d.body_state_w + 13 * (env * B + d.pose_body_index);
-            const f3 aa = axis_angle_from_quat(quat_error(qw, f4{b[3], b[4], b[5], b[6]}));
-            cs.metric0 = norm3(b[0] - pw.x, b[1] - pw.y, b[2] - pw.z);
-            cs.metric1 = norm3(aa);
-        }
-        cs.time_left = cs.time_left - dt;
-        if (cs.time_left <= 0.0f) command_resample(d, env, d.command_samples, 0u, cs);
-        if (d.command_kind == ILX_CMD_VELOCITY) {  // velocity_command.py:140-160
-            if (d.heading_command && cs.is_heading) {
-                const float err = wrap_to_pi(cs.heading_target - e.heading);
-                cs.c[2] = fminf(fmaxf(d.heading_control_stiffness * err, d.cmd_range[3][0]), d.cmd_range[3][1]);
-            }
-            if (cs.is_standing) cs.c[0] = cs.c[1] = cs.c[2] = 0.0f;
-        }
-        cmd_dirty = true;
-    }
-    if (cmd_dirty) {
-        const int width = d.command_kind == ILX_CMD_VELOCITY ? 3 : 7;
-        float mine = r.cmd;
+        if (cmd_dirty) {
+            const int width = d.command_kind == ILX_CMD_VELOCITY ? 3 : 7;
 #pragma unroll
-        for (int k = 0; k < 7; ++k) mine = (lane == k && k < width) ? cs.c[k] : mine;
-        r.cmd = mine;
-        if (lane < width) d.command[env * CD + lane] = mine;
-        if (lane == 0) {
+            for (int k = 0; k < 7; ++k) {
+                if (k < width) {
+                    S[L.cmd + e * CD + k] = cs.c[k];
+                    d.command[env * CD + k] = cs.c[k];
+                }
+            }
             d.time_left[env] = cs.time_left;
             d.command_counter[env] = cs.counter;
             d.command_metrics[env] = cs.metric0;
@@ -641,38 +654,79 @@ __global__ void __launch_bounds__(256) mdp_step_kernel(MdpDev m) {
                 d.is_standing_env[env] = cs.is_standing;
             }
         }
+        float* der = S + L.derived + kDerived * e;
+        der[0] = en.lin_b.x, der[1] = en.lin_b.y, der[2] = en.lin_b.z;
+        der[3] = en.ang_b.x, der[4] = en.ang_b.y, der[5] = en.ang_b.z;
+        der[6] = en.grav_b.x, der[7] = en.grav_b.y, der[8] = en.grav_b.z;
+        der[9] = sensor_z;
     }
+    __syncthreads();
 
-    // ================= observations (observation_manager.py:260-335)
-    if (ph_obs) {
-        int col = 0;
-        float* row = d.obs + env * d.obs_dim;
-        for (int i = 0; i < NO; ++i) {
-            const Term t = fetch_term(s_terms + NT + NR + i);
-            const int dim = obs_dim_of(d, t);
-            auto finish = [&](float v, int k) {
-                if (t.flags & ILX_OBS_FLAG_NOISE) {  // noise_model.py:63-64: data + rand * (max - min) + min
-                    const float u = d.noise_u ? d.noise_u[env * d.obs_dim + col + k]
-                                              : philox_uniform(d.seed, d.step_index, static_cast<uint64_t>(env), col + k);
-                    v = v + u * t.p1 + t.p0;
-                }
-                if (t.flags & ILX_OBS_FLAG_CLIP) v = fminf(fmaxf(v, t.p2), t.p3);  // :315-316
-                if (t.flags & ILX_OBS_FLAG_SCALE) v = v * t.weight;                // :317-318
-                row[col + k] = v;
-            };
-            if (t.kind == ILX_OBS_HEIGHT_SCAN) {  // observations.py:165-173
-#pragma unroll
-                for (int it = 0; it < kRayRegs; ++it) {
-                    const int k = it * 64 + lane;
-                    if (k < dim) finish(sensor_z - rz[it] - t.aux, k);
-                }
-                for (int k = kRayRegs * 64 + lane; k < dim; k += 64)
-                    finish(sensor_z - d.ray_hits_w[3 * (env * R + k) + 2] - t.aux, k);
-            } else {
-                const float v = eval_obs_row(e, t, dim);
-                if (lane < dim) finish(v, lane);
+    // ================= EMIT =================
+    const uint32_t* bits = reinterpret_cast<const uint32_t*>(S + L.bits);
+    if (ph_term) {
+        for (int i = tid; i < NT * kE; i += 256) {
+            const int term = i / kE, ee = i - term * kE;
+            if (ee < ne) d.term_dones[static_cast<int64_t>(term) * N + env0 + ee] = (bits[ee] >> term) & 1u;
+        }
+    }
+    if (ph_rew || ph_reset) {
+        for (int i = tid; i < NR * kE; i += 256) {
+            const int term = i / kE, ee = i - term * kE;
+            if (ee >= ne) continue;
+            const bool active = ph_rew && terms[NT + term].weight != 0.0f;
+            if (active || (ph_reset && bits[kE + ee])) d.episode_sums[static_cast<int64_t>(term) * N + env0 + ee] = S[L.eps + i];
+        }
+        if (ph_rew) {
+            for (int i = tid; i < ne * NR; i += 256) {
+                const int term = i % NR;
+                if (terms[NT + term].weight != 0.0f) d.step_reward[env0 * NR + i] = S[L.srew + i];
             }
-            col += dim;
+        }
+    }
+    if (ph_reset && d.log_sums && tid < NR + NT + 3) {
+        const float v = S[L.logp + tid];
+        if (v != 0.0f) unsafeAtomicAdd(d.log_sums + tid, v);  // hardware float add at L2, no return value
+    }
+    // ---- observations (observation_manager.py:260-335).  The concatenated row is cut into groups of 4 columns;
+    // 16 threads per env take group g, g + 16, ...; a group's noise is one Philox4x32 call.
+    if (ph_obs) {
+        const int ee = tid >> 4, g = tid & 15;
+        if (ee < ne) {
+            const int64_t oenv = env0 + ee;
+            const int O = d.obs_dim;
+            float* row = d.obs + oenv * O;
+            const uint32_t* colterm = reinterpret_cast<const uint32_t*>(S + L.colterm);
+            const int32_t* tstart = reinterpret_cast<const int32_t*>(S + L.tstart);
+            const ilx_term* oterms = terms + NT + NR;
+            for (int cg = g; 4 * cg < O; cg += 16) {
+                const uint32_t packed = colterm[cg];
+                int cur = static_cast<int>(packed & 255u);
+                ilx_term t = oterms[cur];
+                float u[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+                if (!d.noise_u && m.any_noise) {
+                    const u4 r = philox4(d.seed, d.step_index, static_cast<uint64_t>(oenv), static_cast<uint32_t>(cg));
+                    u[0] = u01(r.x), u[1] = u01(r.y), u[2] = u01(r.z), u[3] = u01(r.w);
+                }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int col = 4 * cg + c;
+                    if (col >= O) break;
+                    const int ti = static_cast<int>((packed >> (8 * c)) & 255u);
+                    if (ti != cur) {
+                        cur = ti;
+                        t = oterms[cur];
+                    }
+                    float v = eval_obs(m, S, ids, ee, oenv, t, col - tstart[cur]);
+                    if (t.flags & ILX_OBS_FLAG_NOISE) {  // noise_model.py:63-64: data + rand * (max - min) + min
+                        const float uu = d.noise_u ? d.noise_u[oenv * O + col] : u[c];
+                        v = v + uu * t.p[1] + t.p[0];
+                    }
+                    if (t.flags & ILX_OBS_FLAG_CLIP) v = fminf(fmaxf(v, t.p[2]), t.p[3]);  // :315-316
+                    if (t.flags & ILX_OBS_FLAG_SCALE) v = v * t.weight;                    // :317-318
+                    row[col] = v;
+                }
+            }
         }
     }
 }
@@ -684,6 +738,8 @@ using namespace ilx;
 struct ilx_mdp_plan_s {
     ilx_term* d_terms = nullptr;  // [terminations | rewards | observations]
     int32_t* d_ids = nullptr;
+    uint32_t* d_cols = nullptr;  // packed term index per observation column, then the first column of every term
+    bool any_noise = false;
     int nt = 0, nr = 0, no = 0, nids = 0;
     int obs_dim = 0;
     // data the term tables read, per phase group (checked against NULL at every step)
@@ -769,8 +825,8 @@ extern "C" int ilx_mdp_plan_create(const ilx_mdp* desc, ilx_mdp_plan_t* out) {
     *out = nullptr;
     const ilx_mdp& d = *desc;
     ILX_REQUIRE(d.num_ids == 0 || d.ids, ILX_EINVAL, "ilx_mdp_plan_create: ids is NULL");
-    ILX_REQUIRE(d.num_ids >= 0 && d.num_ids <= kMaxIds, ILX_ESHAPE, "ilx_mdp_plan_create: %d index-list entries (max %d)",
-                d.num_ids, kMaxIds);
+    ILX_REQUIRE(d.num_ids >= 0 && d.num_ids <= 4096, ILX_ESHAPE, "ilx_mdp_plan_create: %d index-list entries (max 4096)",
+                d.num_ids);
     int rc = validate_terms(d);
     if (rc != ILX_OK) return rc;
     auto* p = new ilx_mdp_plan_s();
@@ -819,6 +875,22 @@ extern "C" int ilx_mdp_plan_create(const ilx_mdp* desc, ilx_mdp_plan_t* out) {
             rc = check_hip(hipMemcpy(p->d_ids, d.ids, d.num_ids * sizeof(int32_t), hipMemcpyHostToDevice),
                            "ilx_mdp_plan_create: hipMemcpy");
     }
+    if (rc == ILX_OK && d.num_observations > 0) {
+        ILX_REQUIRE(d.obs_dim <= 16384, ILX_ESHAPE, "ilx_mdp_plan_create: %d observation columns (max 16384)", d.obs_dim);
+        const int groups = (d.obs_dim + 3) / 4;
+        std::vector<uint32_t> cols(static_cast<size_t>(groups) + d.num_observations, 0u);
+        int col = 0;
+        for (int i = 0; i < d.num_observations; ++i) {
+            cols[groups + i] = static_cast<uint32_t>(col);
+            const int dim = host_obs_dim(d, d.observations[i]);
+            for (int k = 0; k < dim; ++k, ++col) cols[col >> 2] |= static_cast<uint32_t>(i) << (8 * (col & 3));
+            p->any_noise |= (d.observations[i].flags & ILX_OBS_FLAG_NOISE) != 0;
+        }
+        rc = check_hip(hipMalloc(&p->d_cols, cols.size() * sizeof(uint32_t)), "ilx_mdp_plan_create: hipMalloc");
+        if (rc == ILX_OK)
+            rc = check_hip(hipMemcpy(p->d_cols, cols.data(), cols.size() * sizeof(uint32_t), hipMemcpyHostToDevice),
+                           "ilx_mdp_plan_create: hipMemcpy");
+    }
     if (rc != ILX_OK) {
         ilx_mdp_plan_destroy(p);
         return rc;
@@ -831,6 +903,7 @@ extern "C" void ilx_mdp_plan_destroy(ilx_mdp_plan_t plan) {
     if (!plan) return;
     if (plan->d_terms) (void)hipFree(plan->d_terms);
     if (plan->d_ids) (void)hipFree(plan->d_ids);
+    if (plan->d_cols) (void)hipFree(plan->d_cols);
     delete plan;
 }
 
@@ -843,13 +916,9 @@ extern "C" int ilx_mdp_step(ilx_mdp_plan_t plan, const ilx_mdp* desc, void* stre
                 ILX_EINVAL, "ilx_mdp_step: term counts differ from the plan");
     if (d.num_envs == 0 || d.phases == 0) return ILX_OK;
     ILX_REQUIRE(d.root_state_w, ILX_EINVAL, "ilx_mdp_step: root_state_w is NULL");
-    // one register-file column per joint / body / action / command entry
-    ILX_REQUIRE(d.num_joints >= 0 && d.num_joints <= kMaxRow && d.num_bodies >= 0 && d.num_bodies <= kMaxRow &&
-                    d.num_sensor_bodies >= 0 && d.num_sensor_bodies <= kMaxRow && d.action_dim >= 0 &&
-                    d.action_dim <= kMaxRow && d.command_dim >= 0 && d.command_dim <= kMaxRow,
-                ILX_ESHAPE, "ilx_mdp_step: joints / bodies / sensor bodies / action / command widths above %d are not supported",
-                kMaxRow);
-    ILX_REQUIRE(d.history_len >= 0 && d.num_rays >= 0, ILX_EINVAL, "ilx_mdp_step: negative history length or ray count");
+    ILX_REQUIRE(d.num_joints >= 0 && d.num_bodies >= 0 && d.num_sensor_bodies >= 0 && d.action_dim >= 0 &&
+                    d.command_dim >= 0 && d.history_len >= 0 && d.num_rays >= 0,
+                ILX_EINVAL, "ilx_mdp_step: negative size");
     if (d.command_kind != ILX_CMD_NONE)
         ILX_REQUIRE(d.command_dim >= (d.command_kind == ILX_CMD_VELOCITY ? 3 : 7), ILX_ESHAPE,
                     "ilx_mdp_step: command_dim %d too small for the command term", d.command_dim);
@@ -896,6 +965,8 @@ extern "C" int ilx_mdp_step(ilx_mdp_plan_t plan, const ilx_mdp* desc, void* stre
     m.d = d;
     m.terms = plan->d_terms;
     m.ids = plan->d_ids;
+    m.cols = plan->d_cols;
+    m.any_noise = plan->any_noise;
     m.need = 0;
     if ((pt && plan->t_joint) || (pr && plan->r_joint) || (po && plan->o_joint)) m.need |= kNeedJoint;
     if ((pt && plan->t_contact) || (pr && plan->r_contact)) m.need |= kNeedForces;
@@ -904,10 +975,39 @@ extern "C" int ilx_mdp_step(ilx_mdp_plan_t plan, const ilx_mdp* desc, void* stre
     if (pr && plan->r_body_acc) m.need |= kNeedBodyAcc;
     if ((pr && plan->r_action) || (po && plan->o_action)) m.need |= kNeedAction;
     if (po && plan->o_rays) m.need |= kNeedRays;
+    // LDS image of one block (kE envs)
+    Layout& L = m.L;
+    int w = 0;
+    auto take = [&](int words) { const int at = w; w += (words + 3) & ~3; return at; };
+    const int J = d.num_joints, B = d.num_bodies, CB = d.num_sensor_bodies, A = d.action_dim, CD = d.command_dim;
+    L.terms = take((plan->nt + plan->nr + plan->no) * static_cast<int>(sizeof(ilx_term) / 4));
+    L.ids = take(plan->nids);
+    const bool nj = m.need & kNeedJoint;
+    L.q = take(nj ? kE * J : 0), L.qd = take(nj ? kE * J : 0), L.qdd = take(nj ? kE * J : 0);
+    L.tau_a = take(nj ? kE * J : 0), L.tau_c = take(nj ? kE * J : 0), L.q0 = take(nj ? kE * J : 0);
+    L.qd0 = take(nj ? kE * J : 0), L.vlim = take(nj ? kE * J : 0), L.lim = take(nj ? 2 * kE * J : 0);
+    const bool na = m.need & kNeedAction;
+    L.act = take(na ? kE * A : 0), L.pact = take(na ? kE * A : 0);
+    const bool ntm = m.need & kNeedTimers;
+    L.air = take(ntm ? kE * CB : 0), L.last_air = take(ntm ? kE * CB : 0), L.contact_t = take(ntm ? kE * CB : 0);
+    L.fpeak = take((m.need & kNeedForces) ? kE * CB : 0);
+    L.bvx = take((m.need & kNeedBodyVel) ? kE * B : 0), L.bvy = take((m.need & kNeedBodyVel) ? kE * B : 0);
+    L.bacc = take((m.need & kNeedBodyAcc) ? kE * B : 0);
+    L.cmd = take(kE * CD), L.root = take(kE * 13);
+    L.eps = take(kE * plan->nr), L.srew = take(kE * plan->nr), L.ptotal = take(4 * kE);
+    L.derived = take(kE * kDerived), L.bits = take(2 * kE);
+    L.logp = take(plan->nr + plan->nt + 3);
+    L.colterm = take((plan->obs_dim + 3) / 4 + plan->no);  // one block: tstart follows the packed term indices directly
+    L.tstart = L.colterm + (plan->obs_dim + 3) / 4;
+    L.total = w;
+    const size_t lds_bytes = static_cast<size_t>(w) * 4;
+    ILX_REQUIRE(lds_bytes <= kMaxLdsBytes, ILX_ESHAPE,
+                "ilx_mdp_step: %zu bytes of per-block state (16 envs x row widths) exceed the %d-byte LDS budget", lds_bytes,
+                kMaxLdsBytes);
     m.d.terminations = m.d.rewards = m.d.observations = nullptr;
     m.d.ids = nullptr;
-    const unsigned blocks = static_cast<unsigned>((d.num_envs + 3) / 4);
-    hipLaunchKernelGGL(mdp_step_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), m);
+    const unsigned blocks = static_cast<unsigned>((d.num_envs + kE - 1) / kE);
+    hipLaunchKernelGGL(mdp_step_kernel, dim3(blocks), dim3(256), lds_bytes, as_stream(stream), m);
     ILX_LAUNCH_CHECK("ilx_mdp_step");
     return ILX_OK;
 }
