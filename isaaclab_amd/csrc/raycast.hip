@@ -50,7 +50,9 @@ struct MeshDev {
     int32_t num_tris;
     // column grid over the xy footprint (CSR: cell_start[c] .. cell_start[c + 1] index cell_refs)
     const uint32_t* cell_start;
-    const uint32_t* cell_refs;  // positions in `tris`
+    const uint32_t* cell_refs;  // positions in `tris` (padded with 4 entries so that 4-wide reads stay in bounds)
+    const float4* tri_xy;       // 2 float4 per triangle: (v0x, v0y, e1x, e1y), (e2x, e2y, v0z, e1z)
+    const float2* tri_z;        // per triangle: (e2z, face id bits)
     float gx0, gy0, gx1, gy1, inv_cell;
     int32_t nx, ny;
 };
@@ -181,18 +183,21 @@ ILX_DEV Hit trace(const MeshDev& m, const Node* cache, int ncache, int32_t* stac
     return best;
 }
 
-ILX_DEV void test_triangle(const MeshDev& m, uint32_t pos, f3 o, f3 d, float max_dist, bool want_normal, Hit& best) {
-    const float4* tp = m.tris + 3 * static_cast<int64_t>(pos);
-    const float4 a = tp[0], b = tp[1], c = tp[2];
-    const f3 v0 = {a.x, a.y, a.z}, e1 = {a.w, b.x, b.y}, e2 = {b.z, b.w, c.x};
-    const int32_t face = __float_as_int(c.y);
+// Candidate `pos` of a z-parallel ray: the barycentric decision reads 32 bytes, only an accepted candidate reads
+// the rest.
+template <bool WANT_NORMAL>
+ILX_DEV void test_column_triangle(const MeshDev& m, uint32_t pos, f3 o, float dz, float max_dist, Hit& best) {
+    const float4 a = m.tri_xy[2 * static_cast<int64_t>(pos)], b = m.tri_xy[2 * static_cast<int64_t>(pos) + 1];
+    ColumnHit h;
+    if (!ray_triangle_z_inside(o.x, o.y, dz, a.x, a.y, a.z, a.w, b.x, b.y, h)) return;
+    const float2 c = m.tri_z[pos];
     float t;
-    if (ray_triangle(o, d, v0, e1, e2, max_dist, t)) {
-        if (t < best.t || (t == best.t && face < best.face)) {
-            best.t = t;
-            best.face = face;
-            if (want_normal) best.normal_raw = cross3(e1, e2);
-        }
+    if (!ray_triangle_z_distance(h, o.z, b.z, a.z, a.w, b.w, b.x, b.y, c.x, max_dist, t)) return;
+    const int32_t face = __float_as_int(c.y);
+    if (t < best.t || (t == best.t && face < best.face)) {
+        best.t = t;
+        best.face = face;
+        if (WANT_NORMAL) best.normal_raw = cross3(f3{a.z, a.w, b.w}, f3{b.x, b.y, c.x});
     }
 }
 
@@ -202,29 +207,21 @@ ILX_DEV Hit trace_column(const MeshDev& m, f3 o, f3 d, float max_dist) {
     Hit best{__builtin_inff(), -1, {0.0f, 0.0f, 0.0f}};
     if (!(o.x >= m.gx0 && o.x <= m.gx1 && o.y >= m.gy0 && o.y <= m.gy1)) return best;
     const int cx = cell_coord(o.x, m.gx0, m.inv_cell, m.nx), cy = cell_coord(o.y, m.gy0, m.inv_cell, m.ny);
-    const int64_t c = static_cast<int64_t>(cy) * m.nx + cx;
-    uint32_t k = m.cell_start[c];
-    const uint32_t end = m.cell_start[c + 1];
-    // four references per trip so the triangle loads of a trip are in flight together
-    for (; k + 4 <= end; k += 4) {
-        const uint32_t r0 = m.cell_refs[k], r1 = m.cell_refs[k + 1], r2 = m.cell_refs[k + 2], r3 = m.cell_refs[k + 3];
-        test_triangle(m, r0, o, d, max_dist, WANT_NORMAL, best);
-        test_triangle(m, r1, o, d, max_dist, WANT_NORMAL, best);
-        test_triangle(m, r2, o, d, max_dist, WANT_NORMAL, best);
-        test_triangle(m, r3, o, d, max_dist, WANT_NORMAL, best);
+    const uint32_t* cs = m.cell_start + (static_cast<int64_t>(cy) * m.nx + cx);
+    const uint32_t begin = cs[0], end = cs[1];
+    for (uint32_t k = begin; k < end; k += 4) {
+        // four references per trip (the list is padded), so the triangle loads of a trip are in flight together
+        const uint32_t* rp = m.cell_refs + k;
+        const uint32_t r0 = rp[0], r1 = rp[1], r2 = rp[2], r3 = rp[3];
+        test_column_triangle<WANT_NORMAL>(m, r0, o, d.z, max_dist, best);
+        if (k + 1 < end) test_column_triangle<WANT_NORMAL>(m, r1, o, d.z, max_dist, best);
+        if (k + 2 < end) test_column_triangle<WANT_NORMAL>(m, r2, o, d.z, max_dist, best);
+        if (k + 3 < end) test_column_triangle<WANT_NORMAL>(m, r3, o, d.z, max_dist, best);
     }
-    for (; k < end; ++k) test_triangle(m, m.cell_refs[k], o, d, max_dist, WANT_NORMAL, best);
     return best;
 }
 
-// Column kernel body: z-parallel rays take the grid; anything else walks the tree with a private stack and no
-// node cache (slow, but only reached when the caller's hint was wrong for that ray).
-template <bool WANT_NORMAL>
-ILX_DEV Hit trace_hinted(const MeshDev& m, f3 o, f3 d, float max_dist) {
-    if (d.x == 0.0f && d.y == 0.0f && m.cell_start) return trace_column<WANT_NORMAL>(m, o, d, max_dist);
-    int32_t stack[kStackSlots];
-    return trace<WANT_NORMAL>(m, nullptr, 0, stack, 1, o, d, max_dist);
-}
+ILX_DEV bool z_parallel(f3 d) { return d.x == 0.0f && d.y == 0.0f; }
 
 ILX_DEV void stage_nodes(const MeshDev& m, Node* cache, int ncache) {
     // 128-byte nodes copied as float4s by the whole block
@@ -245,6 +242,8 @@ struct CastArgs {
     int32_t* face;        // (n) or null
     int64_t n;
     int32_t* counters;    // (n,2) or null: nodes visited / triangles tested per ray (diagnostics)
+    int32_t* off_grid;    // column kernel: set to 1 when a ray was not z-parallel; tree kernel: null = all rays,
+                          // else only the rays the column kernel left out (and nothing at all while the flag is 0)
 };
 
 ILX_DEV void write_hit(const Hit& h, f3 o, f3 d, float* hits, float* dist, float* normal, int32_t* face, int64_t i) {
@@ -261,11 +260,13 @@ ILX_DEV void write_hit(const Hit& h, f3 o, f3 d, float* hits, float* dist, float
 __global__ void __launch_bounds__(kRayBlock) raycast_kernel(CastArgs a) {
     __shared__ Node cache[kCachedNodes];
     __shared__ int32_t stack[kStackSlots * kRayBlock];
+    if (a.off_grid && *a.off_grid == 0) return;  // mop-up launch with nothing to mop up
     const int ncache = min(a.mesh.num_nodes, kCachedNodes);
     stage_nodes(a.mesh, cache, ncache);
     for (int64_t i = static_cast<int64_t>(blockIdx.x) * kRayBlock + threadIdx.x; i < a.n;
          i += static_cast<int64_t>(gridDim.x) * kRayBlock) {
         const f3 o = load3(a.starts + 3 * i), d = load3(a.dirs + 3 * i);
+        if (a.off_grid && z_parallel(d)) continue;
         int32_t* cnt = a.counters ? a.counters + 2 * i : nullptr;
         const Hit h = a.normal ? trace<true>(a.mesh, cache, ncache, stack + threadIdx.x, kRayBlock, o, d, a.max_dist, cnt)
                                : trace<false>(a.mesh, cache, ncache, stack + threadIdx.x, kRayBlock, o, d, a.max_dist, cnt);
@@ -277,7 +278,11 @@ __global__ void __launch_bounds__(kRayBlock) raycast_column_kernel(CastArgs a) {
     const int64_t i = static_cast<int64_t>(blockIdx.x) * kRayBlock + threadIdx.x;
     if (i >= a.n) return;
     const f3 o = load3(a.starts + 3 * i), d = load3(a.dirs + 3 * i);
-    const Hit h = a.normal ? trace_hinted<true>(a.mesh, o, d, a.max_dist) : trace_hinted<false>(a.mesh, o, d, a.max_dist);
+    if (!z_parallel(d)) {  // left to the tree kernel that follows
+        *a.off_grid = 1;
+        return;
+    }
+    const Hit h = a.normal ? trace_column<true>(a.mesh, o, d, a.max_dist) : trace_column<false>(a.mesh, o, d, a.max_dist);
     write_hit(h, o, d, a.hits, a.dist, a.normal, a.face, i);
 }
 
@@ -300,6 +305,7 @@ struct ScanArgs {
     float height_offset;
     int64_t n;
     int r;
+    int32_t* off_grid;        // as in CastArgs
 };
 
 // World ray i = (env, ray) of the sensor; false when the env is masked out.
@@ -342,6 +348,7 @@ ILX_DEV void write_scan(const ScanArgs& a, const Hit& h, f3 o, f3 d, float pos_z
 __global__ void __launch_bounds__(kRayBlock) raycaster_update_kernel(ScanArgs a) {
     __shared__ Node cache[kCachedNodes];
     __shared__ int32_t stack[kStackSlots * kRayBlock];
+    if (a.off_grid && *a.off_grid == 0) return;  // mop-up launch with nothing to mop up
     const int ncache = min(a.mesh.num_nodes, kCachedNodes);
     stage_nodes(a.mesh, cache, ncache);
     const int64_t total = a.n * a.r;
@@ -350,6 +357,7 @@ __global__ void __launch_bounds__(kRayBlock) raycaster_update_kernel(ScanArgs a)
         f3 o, d;
         float pos_z;
         if (!sensor_ray(a, i, o, d, pos_z)) continue;
+        if (a.off_grid && z_parallel(d)) continue;
         const Hit h = trace<false>(a.mesh, cache, ncache, stack + threadIdx.x, kRayBlock, o, d, a.max_dist);
         write_scan(a, h, o, d, pos_z, i);
     }
@@ -361,7 +369,11 @@ __global__ void __launch_bounds__(kRayBlock) raycaster_update_column_kernel(Scan
     f3 o, d;
     float pos_z;
     if (!sensor_ray(a, i, o, d, pos_z)) return;
-    const Hit h = trace_hinted<false>(a.mesh, o, d, a.max_dist);
+    if (!z_parallel(d)) {  // left to the tree kernel that follows
+        *a.off_grid = 1;
+        return;
+    }
+    const Hit h = trace_column<false>(a.mesh, o, d, a.max_dist);
     write_scan(a, h, o, d, pos_z, i);
 }
 
@@ -459,6 +471,9 @@ struct MeshHost {
     uint32_t* d_cell_start = nullptr;
     uint32_t* d_cell_refs = nullptr;
     int64_t num_cell_refs = 0;
+    float4* d_tri_xy = nullptr;
+    float2* d_tri_z = nullptr;
+    int32_t* d_off_grid = nullptr;  // flag raised by a column kernel for the tree kernel launched right after it
     int depth = 0;
     int64_t num_verts = 0;
 };
@@ -563,6 +578,8 @@ extern "C" int ilx_mesh_create(const float* verts_host, int64_t num_verts, const
     // column grid: about four cells per triangle over the xy footprint, bounded in cells and in references
     // (a mesh whose triangles are huge next to the cell size would blow the lists up; then the cells are coarsened,
     // and a mesh that still does not fit gets no grid -- its z-parallel rays walk the tree).
+    // A cell lists a triangle when the triangle's xy projection, grown by the same pad as its box, overlaps the cell
+    // grown by the rounding slack of cell_coord: box range first, then the three edge half-planes (separating axes).
     float g0[2] = {INFINITY, INFINITY}, g1[2] = {-INFINITY, -INFINITY};
     for (int t = 0; t < nt; ++t)
         for (int a = 0; a < 2; ++a) g0[a] = std::min(g0[a], box[t].mn[a]), g1[a] = std::max(g1[a], box[t].mx[a]);
@@ -571,6 +588,8 @@ extern "C" int ilx_mesh_create(const float* verts_host, int64_t num_verts, const
     float inv_cell = 0.0f;
     {
         const double wx = std::max(double(g1[0]) - g0[0], 1e-6), wy = std::max(double(g1[1]) - g0[1], 1e-6);
+        const double span = std::max(std::max(std::fabs(double(g0[0])), std::fabs(double(g1[0]))),
+                                     std::max(std::fabs(double(g0[1])), std::fabs(double(g1[1]))));
         double cell = std::sqrt(wx * wy / (4.0 * nt));
         cell = std::max(cell, std::max(wx, wy) / 8192.0);
         const int64_t max_refs = std::max<int64_t>(int64_t(64) * nt, 1 << 16);
@@ -579,38 +598,83 @@ extern "C" int ilx_mesh_create(const float* verts_host, int64_t num_verts, const
             gnx = std::max(1, cell_coord(g1[0], g0[0], inv_cell, 1 << 20) + 1);
             gny = std::max(1, cell_coord(g1[1], g0[1], inv_cell, 1 << 20) + 1);
             if (static_cast<int64_t>(gnx) * gny > (int64_t(1) << 26)) continue;
-            cell_start.assign(static_cast<size_t>(gnx) * gny + 1, 0u);
-            int64_t total = 0;
-            for (int i = 0; i < nt && total <= max_refs; ++i) {
-                const Box& b = box[order[i]];
+            const double cw = 1.0 / double(inv_cell);
+            const double half = 0.5 * cw + 4e-3 * cw + 2e-5 * span;  // half cell + slack of the float cell mapping
+            // visits the cells of sorted triangle i; fn(cell index)
+            auto for_cells = [&](int i, auto&& fn) {
+                const int t = order[i];
+                const Box& b = box[t];
                 const int x0 = cell_coord(b.mn[0], g0[0], inv_cell, gnx), x1 = cell_coord(b.mx[0], g0[0], inv_cell, gnx);
                 const int y0 = cell_coord(b.mn[1], g0[1], inv_cell, gny), y1 = cell_coord(b.mx[1], g0[1], inv_cell, gny);
-                total += static_cast<int64_t>(x1 - x0 + 1) * (y1 - y0 + 1);
-                if (total > max_refs) break;
-                for (int y = y0; y <= y1; ++y)
-                    for (int x = x0; x <= x1; ++x) ++cell_start[static_cast<size_t>(y) * gnx + x + 1];
-            }
+                if (x1 - x0 < 2 && y1 - y0 < 2) {  // nothing to gain from the edge tests
+                    for (int y = y0; y <= y1; ++y)
+                        for (int x = x0; x <= x1; ++x) fn(static_cast<size_t>(y) * gnx + x);
+                    return;
+                }
+                double P[3][2];
+                for (int k = 0; k < 3; ++k)
+                    for (int a = 0; a < 2; ++a) P[k][a] = verts_host[3 * static_cast<int64_t>(tris_host[3 * t + k]) + a];
+                // pad of the box (the larger of x and y), recovered from the inflated box
+                double pad = 0.0;
+                for (int a = 0; a < 2; ++a) {
+                    const double lo = std::min(P[0][a], std::min(P[1][a], P[2][a]));
+                    pad = std::max(pad, lo - double(b.mn[a]));
+                }
+                double nx[3], ny[3], off[3], reach[3];
+                bool use[3];
+                for (int k = 0; k < 3; ++k) {
+                    const double* A = P[k];
+                    const double* Bv = P[(k + 1) % 3];
+                    const double* C = P[(k + 2) % 3];
+                    double ex = -(Bv[1] - A[1]), ey = Bv[0] - A[0];
+                    const double side = ex * (C[0] - A[0]) + ey * (C[1] - A[1]);
+                    const double len = std::sqrt(ex * ex + ey * ey);
+                    use[k] = len > 0.0 && std::fabs(side) > 1e-12 * len * len;  // degenerate projection: no culling
+                    if (side < 0.0) ex = -ex, ey = -ey;
+                    nx[k] = ex, ny[k] = ey;
+                    off[k] = ex * A[0] + ey * A[1];
+                    reach[k] = half * (std::fabs(ex) + std::fabs(ey)) + pad * len;
+                }
+                for (int y = y0; y <= y1; ++y) {
+                    const double cy = double(g0[1]) + (y + 0.5) * cw;
+                    for (int x = x0; x <= x1; ++x) {
+                        const double cx = double(g0[0]) + (x + 0.5) * cw;
+                        bool hit = true;
+                        for (int k = 0; k < 3 && hit; ++k)
+                            if (use[k]) hit = (nx[k] * cx + ny[k] * cy - off[k]) + reach[k] >= 0.0;
+                        if (hit) fn(static_cast<size_t>(y) * gnx + x);
+                    }
+                }
+            };
+            cell_start.assign(static_cast<size_t>(gnx) * gny + 1, 0u);
+            int64_t total = 0;
+            for (int i = 0; i < nt && total <= max_refs; ++i) for_cells(i, [&](size_t c) { ++cell_start[c + 1], ++total; });
             if (total > max_refs) {
                 cell_start.clear();
                 continue;
             }
             for (size_t c = 1; c < cell_start.size(); ++c) cell_start[c] += cell_start[c - 1];
-            cell_refs.resize(static_cast<size_t>(total));
+            cell_refs.assign(static_cast<size_t>(total) + 4, 0u);  // 4 entries of padding for the 4-wide reads
             std::vector<uint32_t> fill(cell_start.begin(), cell_start.end() - 1);
-            for (int i = 0; i < nt; ++i) {
-                const Box& b = box[order[i]];
-                const int x0 = cell_coord(b.mn[0], g0[0], inv_cell, gnx), x1 = cell_coord(b.mx[0], g0[0], inv_cell, gnx);
-                const int y0 = cell_coord(b.mn[1], g0[1], inv_cell, gny), y1 = cell_coord(b.mx[1], g0[1], inv_cell, gny);
-                for (int y = y0; y <= y1; ++y)
-                    for (int x = x0; x <= x1; ++x) cell_refs[fill[static_cast<size_t>(y) * gnx + x]++] = static_cast<uint32_t>(i);
-            }
+            for (int i = 0; i < nt; ++i) for_cells(i, [&](size_t c) { cell_refs[fill[c]++] = static_cast<uint32_t>(i); });
             break;
         }
+    }
+    // split triangle records for the column kernel
+    std::vector<float4> tri_xy(cell_start.empty() ? 0 : 2 * static_cast<size_t>(nt));
+    std::vector<float2> tri_z(cell_start.empty() ? 0 : static_cast<size_t>(nt));
+    for (size_t i = 0; i < tri_z.size(); ++i) {
+        const float4 a = tris[3 * i], b = tris[3 * i + 1], c = tris[3 * i + 2];  // (v0, e1x) (e1y, e1z, e2x, e2y) (e2z, id)
+        tri_xy[2 * i] = make_float4(a.x, a.y, a.w, b.x);
+        tri_xy[2 * i + 1] = make_float4(b.z, b.w, a.z, b.y);
+        tri_z[i] = make_float2(c.x, c.y);
     }
 
     auto* obj = new ilx_mesh_s();
     MeshHost& h = obj->h;
     int rc = check_hip(hipMalloc(&h.d_nodes, nodes.size() * sizeof(Node)), "ilx_mesh_create: hipMalloc(nodes)");
+    if (rc == ILX_OK) rc = check_hip(hipMalloc(&h.d_off_grid, sizeof(int32_t)), "ilx_mesh_create: hipMalloc(flag)");
+    if (rc == ILX_OK) rc = check_hip(hipMemset(h.d_off_grid, 0, sizeof(int32_t)), "ilx_mesh_create: hipMemset(flag)");
     if (rc == ILX_OK && !cell_start.empty()) {
         rc = check_hip(hipMalloc(&h.d_cell_start, cell_start.size() * sizeof(uint32_t)), "ilx_mesh_create: hipMalloc(cells)");
         if (rc == ILX_OK)
@@ -622,6 +686,14 @@ extern "C" int ilx_mesh_create(const float* verts_host, int64_t num_verts, const
         if (rc == ILX_OK && !cell_refs.empty())
             rc = check_hip(hipMemcpy(h.d_cell_refs, cell_refs.data(), cell_refs.size() * sizeof(uint32_t),
                                      hipMemcpyHostToDevice), "ilx_mesh_create: copy cell refs");
+        if (rc == ILX_OK) rc = check_hip(hipMalloc(&h.d_tri_xy, tri_xy.size() * sizeof(float4)), "ilx_mesh_create: hipMalloc(xy)");
+        if (rc == ILX_OK) rc = check_hip(hipMalloc(&h.d_tri_z, tri_z.size() * sizeof(float2)), "ilx_mesh_create: hipMalloc(z)");
+        if (rc == ILX_OK)
+            rc = check_hip(hipMemcpy(h.d_tri_xy, tri_xy.data(), tri_xy.size() * sizeof(float4), hipMemcpyHostToDevice),
+                           "ilx_mesh_create: copy xy records");
+        if (rc == ILX_OK)
+            rc = check_hip(hipMemcpy(h.d_tri_z, tri_z.data(), tri_z.size() * sizeof(float2), hipMemcpyHostToDevice),
+                           "ilx_mesh_create: copy z records");
     }
     if (rc == ILX_OK) rc = check_hip(hipMalloc(&h.d_tris, tris.size() * sizeof(float4)), "ilx_mesh_create: hipMalloc(tris)");
     if (rc == ILX_OK)
@@ -635,11 +707,15 @@ extern "C" int ilx_mesh_create(const float* verts_host, int64_t num_verts, const
         if (h.d_tris) (void)hipFree(h.d_tris);
         if (h.d_cell_start) (void)hipFree(h.d_cell_start);
         if (h.d_cell_refs) (void)hipFree(h.d_cell_refs);
+        if (h.d_off_grid) (void)hipFree(h.d_off_grid);
+        if (h.d_tri_xy) (void)hipFree(h.d_tri_xy);
+        if (h.d_tri_z) (void)hipFree(h.d_tri_z);
         delete obj;
         return rc;
     }
     h.dev.nodes = h.d_nodes, h.dev.tris = h.d_tris, h.dev.num_nodes = nn, h.dev.num_tris = nt;
     h.dev.cell_start = h.d_cell_start, h.dev.cell_refs = h.d_cell_refs;
+    h.dev.tri_xy = h.d_tri_xy, h.dev.tri_z = h.d_tri_z;
     h.dev.gx0 = g0[0], h.dev.gy0 = g0[1], h.dev.gx1 = g1[0], h.dev.gy1 = g1[1], h.dev.inv_cell = inv_cell;
     h.dev.nx = gnx, h.dev.ny = gny;
     h.num_cell_refs = static_cast<int64_t>(cell_refs.size());
@@ -654,6 +730,9 @@ extern "C" void ilx_mesh_destroy(ilx_mesh_t mesh) {
     if (mesh->h.d_tris) (void)hipFree(mesh->h.d_tris);
     if (mesh->h.d_cell_start) (void)hipFree(mesh->h.d_cell_start);
     if (mesh->h.d_cell_refs) (void)hipFree(mesh->h.d_cell_refs);
+    if (mesh->h.d_off_grid) (void)hipFree(mesh->h.d_off_grid);
+    if (mesh->h.d_tri_xy) (void)hipFree(mesh->h.d_tri_xy);
+    if (mesh->h.d_tri_z) (void)hipFree(mesh->h.d_tri_z);
     delete mesh;
 }
 
@@ -671,7 +750,7 @@ static unsigned ray_grid(int64_t rays) {
     return static_cast<unsigned>(std::min<int64_t>(want, 256 * 12));
 }
 
-static void launch_scan(ilx_mesh_t mesh, const ScanArgs& a, int hints, void* stream);
+static int launch_scan(ilx_mesh_t mesh, ScanArgs a, int hints, void* stream);
 static unsigned column_grid(int64_t rays) { return static_cast<unsigned>((rays + kRayBlock - 1) / kRayBlock); }
 
 extern "C" int ilx_raycast_mesh(ilx_mesh_t mesh, const float* ray_starts, const float* ray_directions, int64_t num_rays,
@@ -683,11 +762,16 @@ extern "C" int ilx_raycast_mesh(ilx_mesh_t mesh, const float* ray_starts, const 
     ILX_REQUIRE(ray_starts && ray_directions && ray_hits, ILX_EINVAL, "ilx_raycast_mesh: NULL operand");
     ILX_REQUIRE(num_rays < (int64_t(1) << 31) * kRayBlock, ILX_ESHAPE, "ilx_raycast_mesh: too many rays");
     CastArgs a{mesh->h.dev, ray_starts, ray_directions, max_dist, ray_hits, ray_distance, ray_normal, ray_face_id, num_rays,
-               nullptr};
-    if ((hints & ILX_RAYS_Z_PARALLEL) && mesh->h.d_cell_start)
+               nullptr, nullptr};
+    if ((hints & ILX_RAYS_Z_PARALLEL) && mesh->h.d_cell_start) {
+        // column kernel, then the tree kernel for whatever rays were not z-parallel after all (it leaves at once
+        // when the column kernel raised no flag)
+        a.off_grid = mesh->h.d_off_grid;
+        ILX_REQUIRE(hipMemsetAsync(a.off_grid, 0, sizeof(int32_t), as_stream(stream)) == hipSuccess, ILX_EHIP,
+                    "ilx_raycast_mesh: hipMemsetAsync failed");
         hipLaunchKernelGGL(raycast_column_kernel, dim3(column_grid(num_rays)), dim3(kRayBlock), 0, as_stream(stream), a);
-    else
-        hipLaunchKernelGGL(raycast_kernel, dim3(ray_grid(num_rays)), dim3(kRayBlock), 0, as_stream(stream), a);
+    }
+    hipLaunchKernelGGL(raycast_kernel, dim3(ray_grid(num_rays)), dim3(kRayBlock), 0, as_stream(stream), a);
     ILX_LAUNCH_CHECK("ilx_raycast_mesh");
     return ILX_OK;
 }
@@ -697,7 +781,8 @@ extern "C" int ilx_raycast_mesh_stats(ilx_mesh_t mesh, const float* ray_starts, 
     ILX_REQUIRE(mesh, ILX_EINVAL, "ilx_raycast_mesh_stats: mesh is NULL");
     if (num_rays <= 0) return ILX_OK;
     ILX_REQUIRE(ray_starts && ray_directions && ray_hits && counters, ILX_EINVAL, "ilx_raycast_mesh_stats: NULL operand");
-    CastArgs a{mesh->h.dev, ray_starts, ray_directions, max_dist, ray_hits, nullptr, nullptr, nullptr, num_rays, counters};
+    CastArgs a{mesh->h.dev, ray_starts, ray_directions, max_dist, ray_hits, nullptr, nullptr, nullptr, num_rays, counters,
+               nullptr};
     hipLaunchKernelGGL(raycast_kernel, dim3(ray_grid(num_rays)), dim3(kRayBlock), 0, as_stream(stream), a);
     ILX_LAUNCH_CHECK("ilx_raycast_mesh_stats");
     return ILX_OK;
@@ -713,8 +798,9 @@ extern "C" int ilx_raycaster_update(ilx_mesh_t mesh, const float* pos_w, const f
     ILX_REQUIRE(pos_w && quat_w && ray_starts_local && ray_directions_local && ray_hits_w, ILX_EINVAL,
                 "ilx_raycaster_update: NULL operand");
     ScanArgs a{mesh->h.dev, pos_w, quat_w, 3, 4, nullptr, nullptr, nullptr, ray_starts_local, ray_directions_local, env_mask,
-               attach_yaw_only, max_dist, ray_hits_w, height_scan, height_offset, n, num_rays};
-    launch_scan(mesh, a, hints, stream);
+               attach_yaw_only, max_dist, ray_hits_w, height_scan, height_offset, n, num_rays, nullptr};
+    const int rc = launch_scan(mesh, a, hints, stream);
+    if (rc != ILX_OK) return rc;
     ILX_LAUNCH_CHECK("ilx_raycaster_update");
     return ILX_OK;
 }
@@ -732,8 +818,9 @@ extern "C" int ilx_raycaster_refresh(const ilx_raycaster* rc, void* stream) {
     ILX_REQUIRE(d.pose_pos_stride >= 3 && d.pose_quat_stride >= 4, ILX_EINVAL, "ilx_raycaster_refresh: bad pose strides");
     ScanArgs a{d.mesh->h.dev, d.pose_pos, d.pose_quat, d.pose_pos_stride, d.pose_quat_stride, d.drift, d.pos_w, d.quat_w,
                d.ray_starts_local, d.ray_directions_local, d.is_outdated, d.attach_yaw_only, d.max_distance, d.ray_hits_w,
-               d.height_scan, d.height_offset, d.num_envs, d.num_rays};
-    launch_scan(d.mesh, a, d.hints, stream);
+               d.height_scan, d.height_offset, d.num_envs, d.num_rays, nullptr};
+    const int status = launch_scan(d.mesh, a, d.hints, stream);
+    if (status != ILX_OK) return status;
     ILX_LAUNCH_CHECK("ilx_raycaster_refresh");
     hipLaunchKernelGGL(sensor_refreshed_kernel, dim3(blocks_for(d.num_envs)), dim3(256), 0, as_stream(stream), d.timestamp,
                        d.timestamp_last_update, d.is_outdated, d.num_envs);
@@ -741,10 +828,15 @@ extern "C" int ilx_raycaster_refresh(const ilx_raycaster* rc, void* stream) {
     return ILX_OK;
 }
 
-static void launch_scan(ilx_mesh_t mesh, const ScanArgs& a, int hints, void* stream) {
+// Column kernel + tree kernel for the rays it left out (a no-op launch when there are none), or the tree kernel alone.
+static int launch_scan(ilx_mesh_t mesh, ScanArgs a, int hints, void* stream) {
     const int64_t rays = a.n * a.r;
-    if ((hints & ILX_RAYS_Z_PARALLEL) && mesh->h.d_cell_start)
+    if ((hints & ILX_RAYS_Z_PARALLEL) && mesh->h.d_cell_start) {
+        a.off_grid = mesh->h.d_off_grid;
+        ILX_REQUIRE(hipMemsetAsync(a.off_grid, 0, sizeof(int32_t), as_stream(stream)) == hipSuccess, ILX_EHIP,
+                    "raycaster: hipMemsetAsync failed");
         hipLaunchKernelGGL(raycaster_update_column_kernel, dim3(column_grid(rays)), dim3(kRayBlock), 0, as_stream(stream), a);
-    else
-        hipLaunchKernelGGL(raycaster_update_kernel, dim3(ray_grid(rays)), dim3(kRayBlock), 0, as_stream(stream), a);
+    }
+    hipLaunchKernelGGL(raycaster_update_kernel, dim3(ray_grid(rays)), dim3(kRayBlock), 0, as_stream(stream), a);
+    return ILX_OK;
 }

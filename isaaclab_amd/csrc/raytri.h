@@ -33,4 +33,37 @@ ILX_DEV bool ray_triangle(f3 o, f3 d, f3 v0, f3 e1, f3 e2, float max_dist, float
     return true;
 }
 
+// The same test for a ray parallel to the z axis (d.x == d.y == 0), split so that the barycentric decision needs
+// only the xy parts of the triangle: with those two components zero, p.z, the z terms of det / u and the x, y terms
+// of v are products with zero, so every value computed below is the value ray_triangle computes (a zero may carry
+// the other sign, which no comparison and no output can tell).  Stage 1 rejects or yields (qz, inv); stage 2 needs
+// the z parts and produces t.
+struct ColumnHit {
+    float sx, sy, qz, inv;
+};
+ILX_DEV bool ray_triangle_z_inside(float ox, float oy, float dz, float v0x, float v0y, float e1x, float e1y, float e2x,
+                                   float e2y, ColumnHit& h) {
+    const float px = -(dz * e2y), py = dz * e2x;
+    const float det = e1x * px + e1y * py;
+    if (!(det != 0.0f)) return false;
+    const float inv = div_(1.0f, det);
+    const float sx = ox - v0x, sy = oy - v0y;
+    const float u = (sx * px + sy * py) * inv;
+    if (!(u >= -kBaryEps && u <= 1.0f + kBaryEps)) return false;
+    const float qz = fmaf_(sx, e1y, -(sy * e1x));
+    const float v = (dz * qz) * inv;
+    if (!(v >= -kBaryEps && (u + v) <= 1.0f + kBaryEps)) return false;
+    h = ColumnHit{sx, sy, qz, inv};
+    return true;
+}
+ILX_DEV bool ray_triangle_z_distance(const ColumnHit& h, float oz, float v0z, float e1x, float e1y, float e1z, float e2x,
+                                     float e2y, float e2z, float max_dist, float& t_out) {
+    const float sz = oz - v0z;
+    const float qx = fmaf_(h.sy, e1z, -(sz * e1y)), qy = fmaf_(sz, e1x, -(h.sx * e1z));
+    const float t = ((e2x * qx + e2y * qy) + e2z * h.qz) * h.inv;
+    if (!(t >= 0.0f && t < max_dist)) return false;
+    t_out = t;
+    return true;
+}
+
 }  // namespace ilx
