@@ -211,6 +211,16 @@ def main():
         launches = {"actuator_net_mlp": 4, "scene_update": 4, "raycaster_refresh": 1, "mdp_step": 1, "joint_action_process": 1}
         dominant = max(kern, key=lambda k: kern[k] * launches[k])
         achieved = BYTES[dominant] * args.envs / (kern[dominant] * 1e-6) / 1e9
+        # HBM-side bytes per launch of that kernel from the committed counter passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
+        # of this same command, corrected as stated in the file); only meaningful for the env count it was taken at
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r1_hbm_traffic.json")) as f:
+                prof = json.load(f)
+            if prof.get("envs") == args.envs:
+                traffic = prof["kernels"][dominant]["hbm_bytes_per_launch"]
+        except (OSError, KeyError, ValueError):
+            pass
         line = {
             "metric": "env-steps/sec (non-physics step) ANYmal-C rough", "value": value, "unit": "env-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
@@ -223,7 +233,7 @@ def main():
             "algorithmic_bytes_per_env_step": BYTES_PER_ENV_STEP,
             "step_hbm_frac": BYTES_PER_ENV_STEP * args.envs / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "launch_us": kern[dominant], "algorithmic_bytes_per_launch": BYTES[dominant] * args.envs},
             "kernels_us": {k: round(v, 2) for k, v in kern.items()},
         }
