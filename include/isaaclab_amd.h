@@ -270,6 +270,63 @@ typedef struct ilx_raycaster {
 } ilx_raycaster;
 int ilx_raycaster_refresh(const ilx_raycaster* rc, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Differential inverse kinematics — source/isaaclab/isaaclab/controllers/differential_ik.py and the action term
+ * source/isaaclab/isaaclab/envs/mdp/actions/task_space_actions.py
+ * ------------------------------------------------------------------------------------------------ */
+#define ILX_IK_POSITION 0 /* command_type "position" (differential_ik_cfg.py:22-27) */
+#define ILX_IK_POSE 1     /* command_type "pose" */
+enum ilx_ik_method {      /* ik_method (differential_ik_cfg.py:37-38) */
+    ILX_IK_PINV = 0,      /* differential_ik.py:197-203  k_val */
+    ILX_IK_SVD = 1,       /* :204-219  k_val, min_singular_value */
+    ILX_IK_TRANS = 2,     /* :220-226  k_val */
+    ILX_IK_DLS = 3        /* :227-236  lambda_val */
+};
+
+/* Where the controlled frame is.  root_pos == NULL: ee_pos / ee_quat already are the frame pose the controller works
+ * in (the plain DifferentialIKController interface, differential_ik.py:97-174).  root_pos != NULL: the action term's
+ * _compute_frame_pose (task_space_actions.py:190-209): ee_* are the WORLD pose of the body, root_* the world pose of
+ * the articulation root, and the optional fixed offset (body_offset cfg) is applied in the body frame; the Jacobian
+ * handed to ilx_diff_ik_compute is then the WORLD Jacobian of that body and goes through jacobian_b (:140-149) and
+ * _compute_frame_jacobian (:211-229) inside the kernel.  All pointers are strided row views (stride in floats),
+ * quaternions (w,x,y,z). */
+typedef struct ilx_ik_frame {
+    const float* ee_pos;
+    const float* ee_quat;
+    int64_t ee_pos_stride, ee_quat_stride;
+    const float* root_pos;
+    const float* root_quat;
+    int64_t root_pos_stride, root_quat_stride;
+    int32_t has_offset;
+    float offset_pos[3];
+    float offset_rot[4];
+} ilx_ik_frame;
+
+/* DifferentialInverseKinematicsAction.process_actions (task_space_actions.py:155-167) fused with
+ * DifferentialIKController.set_command (differential_ik.py:97-147):
+ *   raw_actions != NULL: raw_store <- raw; processed <- clamp(raw * scale_host[k], clip) ; command = processed
+ *   command != NULL    : the controller interface alone (command already in task space)
+ *   -> ee_pos_des (n,3), ee_quat_des (n,4).  The action width follows action_dim (:79-86): 3, 6 (relative pose)
+ *   or 7.  scale_host: HOST array of that width.  clip: (n,width,2) device or NULL.  frame may be NULL for an
+ *   absolute pose command. */
+int ilx_diff_ik_set_command(const ilx_ik_frame* frame, int command_type, int use_relative_mode, const float* raw_actions,
+                            float* raw_store, float* processed, const float* scale_host, const float* clip,
+                            const float* command, float* ee_pos_des, float* ee_quat_des, int64_t n, void* stream);
+
+/* DifferentialIKController.compute (differential_ik.py:148-240), and with a world frame description the whole of
+ * DifferentialInverseKinematicsAction.apply_actions (task_space_actions.py:169-181), in one launch:
+ *   joint_pos_des[:, ids] = joint_pos[:, ids] + dq,  dq from the pose error and the 6 x num_joints Jacobian.
+ * Jacobian element (env, row, col) is read at env * jacobian_env_stride + row * jacobian_row_stride +
+ * (jacobian_cols ? jacobian_cols[col] : col), so a slice [:, body, :, joint_ids] of the simulator's Jacobian tensor
+ * needs no copy.  joint_ids (device int32, or NULL for 0..num_joints-1) index joint_pos and joint_pos_des rows.
+ * The 6x6 solves run in float64. */
+int ilx_diff_ik_compute(const ilx_ik_frame* frame, int command_type, int ik_method, float k_val, float lambda_val,
+                        float min_singular_value, const float* jacobian, int64_t jacobian_env_stride,
+                        int64_t jacobian_row_stride, const int32_t* jacobian_cols, const float* joint_pos,
+                        int64_t joint_pos_stride, const int32_t* joint_ids, const float* ee_pos_des,
+                        const float* ee_quat_des, float* joint_pos_des, int64_t joint_pos_des_stride, int64_t n,
+                        int num_joints, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -144,3 +144,35 @@ def row_view(t: torch.Tensor, width: int):
         raise IlxError(f"expected an (n, {width}) float32 view with contiguous rows, got {tuple(t.shape)} {t.dtype} "
                        f"strides {t.stride()}")
     return t.data_ptr(), t.stride(0)
+
+
+class IkFrame(ctypes.Structure):
+    """Mirror of ``ilx_ik_frame`` (include/isaaclab_amd.h)."""
+
+    _fields_ = [
+        ("ee_pos", c_void_p), ("ee_quat", c_void_p), ("ee_pos_stride", c_int64), ("ee_quat_stride", c_int64),
+        ("root_pos", c_void_p), ("root_quat", c_void_p), ("root_pos_stride", c_int64), ("root_quat_stride", c_int64),
+        ("has_offset", ctypes.c_int32), ("offset_pos", c_float * 3), ("offset_rot", c_float * 4),
+    ]
+
+
+IK_POSITION, IK_POSE = 0, 1
+IK_METHODS = {"pinv": 0, "svd": 1, "trans": 2, "dls": 3}
+diff_ik_set_command = _sig("ilx_diff_ik_set_command", ctypes.POINTER(IkFrame), c_int, c_int, P, P, P, P, P, P, P, P, c_int64, P)
+diff_ik_compute = _sig("ilx_diff_ik_compute", ctypes.POINTER(IkFrame), c_int, c_int, c_float, c_float, c_float, P, c_int64,
+                       c_int64, P, P, c_int64, P, P, P, P, c_int64, c_int64, c_int, P)
+
+
+def ik_frame(ee_pos, ee_quat, root_pos=None, root_quat=None, offset_pos=None, offset_rot=None) -> IkFrame:
+    """Describe the controlled frame from (possibly strided) row views."""
+    f = IkFrame()
+    f.ee_pos, f.ee_pos_stride = row_view(ee_pos, 3)
+    f.ee_quat, f.ee_quat_stride = row_view(ee_quat, 4)
+    if root_pos is not None:
+        f.root_pos, f.root_pos_stride = row_view(root_pos, 3)
+        f.root_quat, f.root_quat_stride = row_view(root_quat, 4)
+        if offset_pos is not None:
+            f.has_offset = 1
+            f.offset_pos = (c_float * 3)(*[float(v) for v in offset_pos])
+            f.offset_rot = (c_float * 4)(*[float(v) for v in offset_rot])
+    return f

@@ -1,0 +1,1 @@
+from .differential_ik import DifferentialIKController, DifferentialIKControllerCfg  # noqa: F401

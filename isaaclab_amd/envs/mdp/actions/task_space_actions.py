@@ -1,0 +1,151 @@
+"""DifferentialIK action term (interface of ``isaaclab/envs/mdp/actions/task_space_actions.py:30-229`` and
+``actions_cfg.py``'s ``DifferentialInverseKinematicsActionCfg``).
+
+``process_actions`` (scale, clip, frame pose, controller command) is one launch and ``apply_actions`` (frame pose,
+Jacobian into the root frame + offset correction, pose error, 6x6 solve, joint targets) is one launch; the
+simulator's Jacobian tensor and ``body_state_w`` are read in place through strided views.
+
+The asset is duck-typed: ``find_joints``, ``find_bodies``, ``is_fixed_base``, ``num_joints``, ``data`` (an
+:class:`isaaclab_amd.assets.ArticulationData`), ``get_jacobians()`` (what ``root_physx_view.get_jacobians()`` returns:
+``(N, bodies[-1 if fixed base], 6, joints[+6 if floating base])``) and ``set_joint_position_target``.
+"""
+
+from __future__ import annotations
+
+import ctypes
+from collections.abc import Sequence
+from dataclasses import dataclass, field
+
+import torch
+
+from .... import _abi
+from ....controllers.differential_ik import DifferentialIKController, DifferentialIKControllerCfg
+from ....utils import string as string_utils
+
+
+@dataclass
+class OffsetCfg:
+    pos: tuple[float, float, float] = (0.0, 0.0, 0.0)
+    rot: tuple[float, float, float, float] = (1.0, 0.0, 0.0, 0.0)
+
+
+@dataclass
+class DifferentialInverseKinematicsActionCfg:
+    """actions_cfg.py (DifferentialInverseKinematicsActionCfg)."""
+
+    asset_name: str = "robot"
+    joint_names: list[str] = field(default_factory=lambda: [".*"])
+    body_name: str = ""
+    body_offset: OffsetCfg | None = None
+    scale: float | tuple[float, ...] = 1.0
+    clip: dict | None = None
+    controller: DifferentialIKControllerCfg = field(default_factory=DifferentialIKControllerCfg)
+    debug_vis: bool = False
+
+
+class DifferentialInverseKinematicsAction:
+    def __init__(self, cfg: DifferentialInverseKinematicsActionCfg, env):
+        self.cfg, self._env = cfg, env
+        self._asset = env.scene[cfg.asset_name]
+        self.num_envs, self.device = env.num_envs, torch.device(env.device)
+        a = self._asset
+        self._joint_ids, self._joint_names = a.find_joints(cfg.joint_names)
+        self._num_joints = len(self._joint_ids)
+        body_ids, body_names = a.find_bodies(cfg.body_name)
+        if len(body_ids) != 1:
+            raise ValueError(f"Expected one match for the body name: {cfg.body_name}. Found {len(body_ids)}: {body_names}.")
+        self._body_idx, self._body_name = body_ids[0], body_names[0]
+        if a.is_fixed_base:  # task_space_actions.py:72-77
+            self._jacobi_body_idx, self._jacobi_joint_ids = self._body_idx - 1, list(self._joint_ids)
+        else:
+            self._jacobi_body_idx, self._jacobi_joint_ids = self._body_idx, [i + 6 for i in self._joint_ids]
+        dev = self.device
+        self._joint_ids_dev = torch.tensor(self._joint_ids, dtype=torch.int32, device=dev)
+        self._jacobi_cols_dev = torch.tensor(self._jacobi_joint_ids, dtype=torch.int32, device=dev)
+        if self._num_joints == a.num_joints:
+            self._joint_ids = slice(None)
+        self._ik_controller = DifferentialIKController(cfg.controller, self.num_envs, dev)
+        dim = self.action_dim
+        self._raw_actions = torch.zeros(self.num_envs, dim, device=dev)
+        self._processed_actions = torch.zeros_like(self._raw_actions)
+        self._scale = torch.zeros(self.num_envs, dim, device=dev)
+        self._scale[:] = torch.tensor(cfg.scale, device=dev)
+        scale = [float(cfg.scale)] * dim if isinstance(cfg.scale, (int, float)) else [float(v) for v in cfg.scale]
+        if len(scale) != dim:
+            raise ValueError(f"scale has {len(scale)} entries, the action is {dim} wide")
+        self._scale_host = (ctypes.c_float * dim)(*scale)
+        if cfg.body_offset is not None:
+            self._offset_pos = torch.tensor(cfg.body_offset.pos, device=dev).repeat(self.num_envs, 1)
+            self._offset_rot = torch.tensor(cfg.body_offset.rot, device=dev).repeat(self.num_envs, 1)
+        else:
+            self._offset_pos, self._offset_rot = None, None
+        self._clip = None
+        if cfg.clip is not None:
+            if not isinstance(cfg.clip, dict):
+                raise ValueError(f"Unsupported clip type: {type(cfg.clip)}. Supported types are dict.")
+            self._clip = torch.tensor([[-float("inf"), float("inf")]], device=dev).repeat(self.num_envs, dim, 1)
+            index_list, _, value_list = string_utils.resolve_matching_names_values(cfg.clip, self._joint_names)
+            self._clip[:, index_list] = torch.tensor(value_list, device=dev)
+        self._pose_is_live = False
+
+    # -- properties
+    @property
+    def action_dim(self) -> int:
+        return self._ik_controller.action_dim
+
+    @property
+    def raw_actions(self) -> torch.Tensor:
+        return self._raw_actions
+
+    @property
+    def processed_actions(self) -> torch.Tensor:
+        return self._processed_actions
+
+    def _frame(self) -> _abi.IkFrame:
+        d = self._asset.data
+        body = d.body_state_w[:, self._body_idx]
+        off = self.cfg.body_offset
+        return _abi.ik_frame(body[:, 0:3], body[:, 3:7], d.root_state_w[:, 0:3], d.root_state_w[:, 3:7],
+                             off.pos if off else None, off.rot if off else None)
+
+    # -- operations
+    def process_actions(self, actions: torch.Tensor):
+        """task_space_actions.py:155-167."""
+        c = self._ik_controller
+        frame = self._frame()
+        _abi.check(_abi.diff_ik_set_command(ctypes.byref(frame), c._type, int(c.cfg.use_relative_mode),
+                                            _abi.ptr(_abi.f32c(actions)), _abi.ptr(self._raw_actions),
+                                            _abi.ptr(self._processed_actions), self._scale_host, _abi.ptr(self._clip), None,
+                                            _abi.ptr(c.ee_pos_des), _abi.ptr(c.ee_quat_des), self.num_envs, _abi.stream()),
+                   "ilx_diff_ik_set_command")
+        c._command = self._processed_actions
+
+    def apply_actions(self):
+        """task_space_actions.py:169-181.  The reference skips the update while the simulator still reports all-zero
+        orientations (``ee_quat.norm() != 0``, a device-to-host sync on every call); here that is checked until the
+        first non-zero pose is seen and never again."""
+        d = self._asset.data
+        if not self._pose_is_live:
+            if float(d.body_state_w[:, self._body_idx, 3:7].norm()) == 0.0:
+                self._asset.set_joint_position_target(d.joint_pos[:, self._joint_ids].clone(), self._joint_ids)
+                return
+            self._pose_is_live = True
+        c = self._ik_controller
+        jac = self._asset.get_jacobians()
+        if jac.dtype != torch.float32 or not jac.is_contiguous():
+            jac = _abi.f32c(jac)
+        nb, cols = jac.shape[1], jac.shape[3]
+        body_jac = jac[:, self._jacobi_body_idx]  # (N, 6, cols) view
+        target = d.joint_pos_target
+        p = c.cfg.ik_params
+        frame = self._frame()
+        _abi.check(_abi.diff_ik_compute(ctypes.byref(frame), c._type, _abi.IK_METHODS[c.cfg.ik_method],
+                                        float(p.get("k_val", 1.0)), float(p.get("lambda_val", 0.0)),
+                                        float(p.get("min_singular_value", 0.0)), body_jac.data_ptr(), nb * 6 * cols, cols,
+                                        _abi.ptr(self._jacobi_cols_dev), _abi.ptr(d.joint_pos), d.joint_pos.shape[1],
+                                        _abi.ptr(self._joint_ids_dev), _abi.ptr(c.ee_pos_des), _abi.ptr(c.ee_quat_des),
+                                        _abi.ptr(target), target.shape[1], self.num_envs, self._num_joints, _abi.stream()),
+                   "ilx_diff_ik_compute")
+
+    def reset(self, env_ids: Sequence[int] | None = None) -> None:
+        self._raw_actions[env_ids] = 0.0

@@ -154,3 +154,81 @@ def actuator_mlp_weights(seed: int = 7, dims=(6, 32, 32, 32, 1)):
     ws = [torch.randn(dims[i + 1], dims[i], generator=g) / dims[i] ** 0.5 for i in range(len(dims) - 1)]
     bs = [torch.randn(dims[i + 1], generator=g) * 0.1 for i in range(len(dims) - 1)]
     return ws, bs
+
+
+# ---- manipulator kinematics for the DifferentialIK fixtures ---------------------------------------------------------
+# xArm6 revolute chain (joint origins xyz / rpy, every axis = local z), from the robot description the reference
+# ships (ROBOT/xarm/xarm6_with_gripper.urdf:79-225).  Data only; the forward kinematics below is the textbook product.
+XARM6_JOINT_ORIGINS = (
+    ((0.0, 0.0, 0.267), (0.0, 0.0, 0.0)),
+    ((0.0, 0.0, 0.0), (-1.5708, 0.0, 0.0)),
+    ((0.0535, -0.2845, 0.0), (0.0, 0.0, 0.0)),
+    ((0.0775, 0.3425, 0.0), (-1.5708, 0.0, 0.0)),
+    ((0.0, 0.0, 0.0), (1.5708, 0.0, 0.0)),
+    ((0.076, 0.097, 0.0), (-1.5708, 0.0, 0.0)),
+)
+XARM6_DEFAULT_JOINT_POS = (0.0, -1.22, -0.78, 0.0, 1.30, 0.0)
+
+
+def _rot_rpy(r, p, y):
+    cr, sr, cp, sp, cy, sy = np.cos(r), np.sin(r), np.cos(p), np.sin(p), np.cos(y), np.sin(y)
+    rx = np.array([[1, 0, 0], [0, cr, -sr], [0, sr, cr]])
+    ry = np.array([[cp, 0, sp], [0, 1, 0], [-sp, 0, cp]])
+    rz = np.array([[cy, -sy, 0], [sy, cy, 0], [0, 0, 1]])
+    return rz @ ry @ rx
+
+
+def _quat_from_matrix(m):
+    """(…,3,3) rotation matrices -> wxyz quaternions with w >= 0 (float64)."""
+    w = np.sqrt(np.maximum(0.0, 1.0 + m[..., 0, 0] + m[..., 1, 1] + m[..., 2, 2])) / 2
+    x = np.sqrt(np.maximum(0.0, 1.0 + m[..., 0, 0] - m[..., 1, 1] - m[..., 2, 2])) / 2
+    y = np.sqrt(np.maximum(0.0, 1.0 - m[..., 0, 0] + m[..., 1, 1] - m[..., 2, 2])) / 2
+    z = np.sqrt(np.maximum(0.0, 1.0 - m[..., 0, 0] - m[..., 1, 1] + m[..., 2, 2])) / 2
+    x = np.copysign(x, m[..., 2, 1] - m[..., 1, 2])
+    y = np.copysign(y, m[..., 0, 2] - m[..., 2, 0])
+    z = np.copysign(z, m[..., 1, 0] - m[..., 0, 1])
+    return np.stack([w, x, y, z], -1)
+
+
+def serial_arm_kinematics(joint_pos: np.ndarray, root_pos: np.ndarray, root_quat: np.ndarray, origins=XARM6_JOINT_ORIGINS):
+    """World pose of the last link and its geometric Jacobian (N,6,J) for a z-axis revolute chain (float64 inside).
+
+    Returns ``ee_pos_w (N,3), ee_quat_w (N,4 wxyz), jacobian_w (N,6,J)`` as float32 arrays: what a fixed-base
+    articulation's ``body_pos_w/body_quat_w`` and ``root_physx_view.get_jacobians()`` would hold for that link."""
+    q = np.asarray(joint_pos, dtype=np.float64)
+    n, nj = q.shape
+    w, x, y, z = (np.asarray(root_quat, dtype=np.float64)[:, k] for k in range(4))
+    rot = np.stack([np.stack([1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)], -1),
+                    np.stack([2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)], -1),
+                    np.stack([2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)], -1)], -2)
+    pos = np.asarray(root_pos, dtype=np.float64).copy()
+    axes, anchors = [], []
+    for k in range(nj):
+        xyz, rpy = origins[k]
+        pos = pos + np.einsum("nij,j->ni", rot, np.array(xyz))
+        rot = rot @ _rot_rpy(*rpy)
+        axes.append(rot[:, :, 2].copy())
+        anchors.append(pos.copy())
+        c, s = np.cos(q[:, k]), np.sin(q[:, k])
+        rz = np.zeros((n, 3, 3))
+        rz[:, 0, 0], rz[:, 0, 1], rz[:, 1, 0], rz[:, 1, 1], rz[:, 2, 2] = c, -s, s, c, 1.0
+        rot = rot @ rz
+    jac = np.zeros((n, 6, nj))
+    for k in range(nj):
+        jac[:, 0:3, k] = np.cross(axes[k], pos - anchors[k])
+        jac[:, 3:6, k] = axes[k]
+    return pos.astype(np.float32), _quat_from_matrix(rot).astype(np.float32), jac.astype(np.float32)
+
+
+def reach_ik_state(n: int, seed: int, spread: float = 0.3):
+    """Synthetic state of a fixed-base 6-DOF arm for the DifferentialIK action term: joint positions around the
+    default pose, root pose, end-effector pose and world Jacobian from the kinematics above, raw actions U(-1, 1)."""
+    g = torch.Generator().manual_seed(seed)
+    q = torch.tensor(XARM6_DEFAULT_JOINT_POS).repeat(n, 1) + spread * torch.randn(n, 6, generator=g)
+    root_pos = torch.cat([torch.rand(n, 2, generator=g) * 20 - 10, torch.zeros(n, 1)], -1)
+    yaw = torch.rand(n, generator=g) * 6.28 - 3.14
+    root_quat = torch.stack([torch.cos(yaw / 2), torch.zeros(n), torch.zeros(n), torch.sin(yaw / 2)], -1)
+    ee_pos, ee_quat, jac = serial_arm_kinematics(q.numpy(), root_pos.numpy(), root_quat.numpy())
+    return dict(joint_pos=q, root_pos_w=root_pos, root_quat_w=root_quat, ee_pos_w=torch.from_numpy(ee_pos),
+                ee_quat_w=torch.from_numpy(ee_quat), jacobian_w=torch.from_numpy(jac),
+                raw_action_pose_rel=torch.rand(n, 6, generator=g) * 2 - 1)
