@@ -1,0 +1,71 @@
+/*
+ * isaaclab_amd — in-hand manipulation direct env (Shadow / Allegro hand): the non-physics part of DirectRLEnv.step
+ * for source/isaaclab_tasks/isaaclab_tasks/direct/inhand_manipulation/inhand_manipulation_env.py
+ * (cfg: direct/shadow_hand/shadow_hand_env_cfg.py:117-227).
+ *
+ *   ilx_inhand_apply_action : _apply_action                                  (:97-117), once per physics substep
+ *   ilx_inhand_step         : episode_length_buf += 1, _get_dones (:179-199), compute_rewards per env (:349-420),
+ *                             goal resets (:168-171, :249-262), the env-reset bookkeeping that does not write into the
+ *                             simulator (goal, successes, episode length), compute_full_observations (:298-322);
+ *                             adds this GPU's (num_resets, sum successes*resets) to stats[2]
+ *   ilx_inhand_finish       : consecutive_successes from stats (:422-431), then stats <- 0.  Between step and finish a
+ *                             multi-GPU run all-reduces stats (2 floats) so that every rank tracks the global value.
+ */
+#ifndef ISAACLAB_AMD_INHAND_H
+#define ISAACLAB_AMD_INHAND_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ilx_inhand {
+    int64_t num_envs;
+    int32_t num_joints, num_bodies, num_actuated, num_fingertips;
+    const int32_t* actuated_ids;     /* device (num_actuated): sorted joint indices (:37-41) */
+    const int32_t* fingertip_ids;    /* device (num_fingertips): sorted body indices (:44-48) */
+    /* simulator state of this step */
+    const float* joint_pos;          /* (n,j) */
+    const float* joint_vel;          /* (n,j) */
+    const float* lower_limits;       /* (n,j) hand_dof_lower_limits */
+    const float* upper_limits;       /* (n,j) */
+    const float* body_state_w;       /* (n,b,13) hand bodies: pos, quat wxyz, lin vel, ang vel */
+    const float* object_state_w;     /* (n,13) */
+    const float* env_origins;        /* (n,3) */
+    const float* in_hand_pos;        /* (n,3) */
+    const float* actions;            /* (n,num_actuated) */
+    /* env buffers (read and written) */
+    float* cur_targets;              /* (n,j) */
+    float* prev_targets;             /* (n,j) */
+    float* goal_rot;                 /* (n,4) */
+    float* successes;                /* (n) */
+    uint8_t* reset_goal_buf;         /* (n) */
+    int64_t* episode_length_buf;     /* (n) */
+    float* consecutive_successes;    /* (1) */
+    float* stats;                    /* (2) partial sums, zeroed by ilx_inhand_finish */
+    /* outputs */
+    float* obs;                      /* (n, 2j + 24 + 13*fingertips + num_actuated) */
+    float* reward;                   /* (n) */
+    uint8_t* terminated;             /* (n) out_of_reach */
+    uint8_t* time_outs;              /* (n) */
+    uint8_t* reset_buf;              /* (n) terminated | time_outs */
+    /* cfg (shadow_hand_env_cfg.py:208-227) */
+    float dist_reward_scale, rot_reward_scale, rot_eps, action_penalty_scale, reach_goal_bonus, fall_penalty, fall_dist,
+        vel_obs_scale, success_tolerance, av_factor, one_minus_av_factor, act_moving_average, one_minus_act_moving_average;
+    int32_t max_consecutive_success;
+    int64_t max_episode_length;
+    /* random draws of _reset_target_pose, U(-1,1): (n,2) each, or NULL -> counter-based generator (seed, step_index) */
+    const float* goal_samples;
+    const float* reset_goal_samples;
+    uint64_t seed, step_index;
+} ilx_inhand;
+
+int ilx_inhand_apply_action(const ilx_inhand* env, void* stream);
+int ilx_inhand_step(const ilx_inhand* env, void* stream);
+int ilx_inhand_finish(const ilx_inhand* env, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ISAACLAB_AMD_INHAND_H */

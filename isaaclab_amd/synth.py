@@ -232,3 +232,48 @@ def reach_ik_state(n: int, seed: int, spread: float = 0.3):
     return dict(joint_pos=q, root_pos_w=root_pos, root_quat_w=root_quat, ee_pos_w=torch.from_numpy(ee_pos),
                 ee_quat_w=torch.from_numpy(ee_quat), jacobian_w=torch.from_numpy(jac),
                 raw_action_pose_rel=torch.rand(n, 6, generator=g) * 2 - 1)
+
+
+def inhand_state(n: int, seed: int, num_joints: int = 24, num_bodies: int = 26, num_actuated: int = 20, num_fingertips: int = 5,
+                 max_episode_length: int = 600):
+    """Synthetic state of the in-hand manipulation direct env (Shadow hand shapes: 24 DOF, 20 actuated, 5 fingertips):
+    object position = in-hand position + N(0, 0.1) so that a few percent of the envs exceed the fall distance,
+    ~3 % of the goal rotations close to the object's (successes), episode lengths up to the limit."""
+    g = torch.Generator().manual_seed(seed)
+
+    def quat(k):
+        q = torch.randn(k, 4, generator=g)
+        return q / q.norm(dim=-1, keepdim=True)
+
+    lower = -0.3 - torch.rand(num_joints, generator=g)
+    upper = 0.3 + torch.rand(num_joints, generator=g)
+    lower, upper = lower.repeat(n, 1), upper.repeat(n, 1)
+    env_origins = torch.cat([torch.rand(n, 2, generator=g) * 60 - 30, torch.zeros(n, 1)], -1)
+    in_hand = torch.tensor([0.0, -0.39, 0.56]).repeat(n, 1)
+    obj = torch.zeros(n, 13)
+    obj[:, 0:3] = in_hand + env_origins + 0.1 * torch.randn(n, 3, generator=g)
+    obj[:, 3:7] = quat(n)
+    obj[:, 7:13] = torch.randn(n, 6, generator=g)
+    goal = quat(n)
+    near = torch.rand(n, generator=g) < 0.03
+    small = torch.cat([torch.ones(n, 1), 0.03 * torch.randn(n, 3, generator=g)], -1)
+    small = small / small.norm(dim=-1, keepdim=True)
+    # goal = small rotation * object orientation on the "near" envs (quaternion product written out)
+    w1, x1, y1, z1 = small.unbind(-1)
+    w2, x2, y2, z2 = obj[:, 3:7].unbind(-1)
+    prod = torch.stack([w1 * w2 - x1 * x2 - y1 * y2 - z1 * z2, w1 * x2 + x1 * w2 + y1 * z2 - z1 * y2,
+                        w1 * y2 - x1 * z2 + y1 * w2 + z1 * x2, w1 * z2 + x1 * y2 - y1 * x2 + z1 * w2], -1)
+    goal = torch.where(near.unsqueeze(-1), prod, goal)
+    body = torch.zeros(n, num_bodies, 13)
+    body[..., 0:3] = env_origins.unsqueeze(1) + torch.randn(n, num_bodies, 3, generator=g) * 0.1
+    body[..., 3:7] = quat(n * num_bodies).view(n, num_bodies, 4)
+    body[..., 7:13] = torch.randn(n, num_bodies, 6, generator=g)
+    q = lower + (upper - lower) * torch.rand(n, num_joints, generator=g)
+    actuated = sorted(torch.randperm(num_joints, generator=g)[:num_actuated].tolist())
+    fingers = sorted(torch.randperm(num_bodies, generator=g)[:num_fingertips].tolist())
+    return dict(joint_pos=q, joint_vel=torch.randn(n, num_joints, generator=g), lower=lower, upper=upper, env_origins=env_origins,
+                in_hand_pos=in_hand, object_state=obj, goal_rot=goal, body_state=body,
+                cur_targets=q.clone(), prev_targets=q + 0.05 * torch.randn(n, num_joints, generator=g),
+                successes=torch.randint(0, 5, (n,), generator=g).float(), reset_goal_buf=torch.zeros(n, dtype=torch.bool),
+                consecutive_successes=torch.tensor([1.5]), episode_length_buf=torch.randint(0, max_episode_length, (n,), generator=g),
+                actions=torch.rand(n, num_actuated, generator=g) * 2 - 1, actuated=actuated, fingers=fingers)

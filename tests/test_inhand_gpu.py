@@ -1,0 +1,78 @@
+"""GPU: the in-hand manipulation (Shadow hand) non-physics step against the reference's outputs and the oracle."""
+
+import pytest
+import torch
+
+from conftest import assert_close, assert_exact, load_golden
+from oracle import inhand as IH
+from test_oracle_inhand import VARIANTS, load_case
+
+pytestmark = pytest.mark.gpu
+
+
+def make_env(dev, s, ema, max_succ):
+    from isaaclab_amd.envs.inhand_step import InHandManipulationCfg, InHandManipulationStep
+
+    n = s["joint_pos"].shape[0]
+    cfg = InHandManipulationCfg(act_moving_average=ema, max_consecutive_success=max_succ)
+    env = InHandManipulationStep(cfg, n, dev, num_joints=24, num_bodies=26, actuated_dof_indices=[int(i) for i in s["actuated"]],
+                                 finger_bodies=[int(i) for i in s["fingers"]], lower_limits=s["lower"], upper_limits=s["upper"],
+                                 in_hand_pos=s["in_hand_pos"], env_origins=s["env_origins"])
+    assert env.max_episode_length == 600 and env.obs_dim == 157
+    for k in ("cur_targets", "prev_targets", "goal_rot", "successes", "consecutive_successes", "episode_length_buf"):
+        getattr(env, k).copy_(s[k])
+    env.set_sim_state(s["joint_pos"].to(dev), s["joint_vel"].to(dev), s["body_state"].to(dev), s["object_state"].to(dev))
+    return env
+
+
+def test_inhand_step_matches_reference(dev):
+    g = load_golden("inhand")
+    for tag, (ema, max_succ) in VARIANTS.items():
+        s = load_case(g, tag)
+        env = make_env(dev, s, ema, max_succ)
+        obs, reward, terminated, time_outs = env.step(s["actions"].to(dev), g[f"{tag}_goal_samples"].to(dev),
+                                                      g[f"{tag}_reset_goal_samples"].to(dev))
+        assert_exact(env.cur_targets, g[f"{tag}_cur_targets"], f"{tag} cur_targets")
+        assert_exact(env.prev_targets, g[f"{tag}_prev_targets"], f"{tag} prev_targets")
+        assert_exact(terminated, g[f"{tag}_terminated"], f"{tag} terminated")
+        assert_exact(time_outs, g[f"{tag}_time_outs"], f"{tag} time_outs")
+        assert_exact(env.successes, g[f"{tag}_successes"], f"{tag} successes")
+        assert_exact(env.episode_length_buf, g[f"{tag}_episode_length_buf"], f"{tag} episode_length_buf")
+        assert not env.reset_goal_buf.any()
+        assert_close(reward, g[f"{tag}_reward"], rtol=1e-5, atol=1e-5, what=f"{tag} reward")
+        assert_close(env.consecutive_successes, g[f"{tag}_consecutive_successes"], rtol=1e-5, what=f"{tag} consecutive successes")
+        assert_close(env.goal_rot, g[f"{tag}_goal_rot"], rtol=1e-5, atol=1e-6, what=f"{tag} goal_rot")
+        assert_close(obs, g[f"{tag}_obs"], rtol=1e-5, atol=2e-6, what=f"{tag} observations")
+        assert (env.stats == 0).all(), "the partial sums are cleared for the next step"
+
+
+def test_inhand_second_step_and_generator(dev):
+    """Two consecutive steps against the oracle (state carried over), then the in-kernel generator: new goals are unit
+    quaternions and reproducible."""
+    g = load_golden("inhand")
+    s = load_case(g, "shadow_ema")
+    env = make_env(dev, s, 0.8, 50)
+    cfg = IH.InHandCfg(act_moving_average=0.8, max_consecutive_success=50)
+    o = IH.InHandOracle(cfg, s, s["actuated"].tolist(), s["fingers"].tolist())
+    gen = torch.Generator().manual_seed(3)
+    for step in range(2):
+        actions = s["actions"] if step == 0 else torch.rand_like(s["actions"]) * 2 - 1
+        gs, rs = torch.rand(512, 2, generator=gen) * 2 - 1, torch.rand(512, 2, generator=gen) * 2 - 1
+        r = o.step(actions, gs, rs)
+        obs, reward, terminated, time_outs = env.step(actions.to(dev), gs.to(dev), rs.to(dev))
+        assert_exact(terminated, r["terminated"], f"terminated step {step}")
+        assert_exact(time_outs, r["time_outs"], f"time_outs step {step}")
+        assert_exact(env.successes, o.s["successes"], f"successes step {step}")
+        assert_exact(env.cur_targets, o.s["cur_targets"], f"targets step {step}")
+        assert_close(reward, r["reward"], rtol=1e-5, atol=1e-5, what=f"reward step {step}")
+        assert_close(obs, r["obs"], rtol=1e-5, atol=2e-6, what=f"obs step {step}")
+        assert_close(env.consecutive_successes, o.s["consecutive_successes"], rtol=1e-5, what=f"consecutive successes step {step}")
+    outs = []
+    for _ in range(2):
+        e2 = make_env(dev, s, 1.0, 0)
+        e2.step(s["actions"].to(dev))
+        outs.append(e2.goal_rot.cpu())
+    assert torch.equal(outs[0], outs[1])
+    changed = (outs[0] != s["goal_rot"]).any(dim=1)
+    assert changed.sum() > 10
+    assert_close(outs[0].norm(dim=1), torch.ones(512), rtol=1e-5, what="generated goals are unit quaternions")
