@@ -1,0 +1,45 @@
+"""Term configuration records (interface of ``isaaclab/managers/manager_term_cfg.py``)."""
+
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Callable
+
+
+@dataclass
+class ManagerTermBaseCfg:
+    func: Callable = None
+    params: dict = field(default_factory=dict)
+
+
+@dataclass
+class RewardTermCfg(ManagerTermBaseCfg):
+    weight: float = 0.0
+
+
+@dataclass
+class TerminationTermCfg(ManagerTermBaseCfg):
+    time_out: bool = False
+
+
+@dataclass
+class UniformNoiseCfg:
+    """``isaaclab/utils/noise/noise_cfg.py`` (UniformNoiseCfg, operation "add")."""
+    n_min: float = -1.0
+    n_max: float = 1.0
+    operation: str = "add"
+
+
+@dataclass
+class ObservationTermCfg(ManagerTermBaseCfg):
+    noise: UniformNoiseCfg | None = None
+    clip: tuple[float, float] | None = None
+    scale: float | None = None
+    history_length: int = 0
+
+
+@dataclass
+class ObservationGroupCfg:
+    """A group is any object whose attributes (or a dict whose values) are :class:`ObservationTermCfg`."""
+    concatenate_terms: bool = True
+    enable_corruption: bool = False
