@@ -35,6 +35,8 @@ constexpr int kMaxDepth = 12;
 constexpr int kCachedNodes = 85;      // levels 0..3 of the 4-wide tree
 constexpr int kRayBlock = 256;
 constexpr int kEmptyRef = INT32_MIN;
+constexpr double kGridCellsPerTriangle = 8.0;  // column grid resolution (measured: 2 -> 170 us, 4 -> 136, 8 -> 122, 16 -> 122)
+constexpr int kGridTile = 16;                  // column records are stored in tiles of 16 x 16 cells
 
 struct alignas(16) Node {
     float minx[4], miny[4], minz[4], maxx[4], maxy[4], maxz[4];
@@ -575,7 +577,7 @@ extern "C" int ilx_mesh_create(const float* verts_host, int64_t num_verts, const
         tris[3 * i + 2] = make_float4(e2[2], idbits, 0.0f, 0.0f);
     }
 
-    // column grid: about four cells per triangle over the xy footprint, bounded in cells and in references
+    // column grid: about eight cells per triangle over the xy footprint, bounded in cells and in references
     // (a mesh whose triangles are huge next to the cell size would blow the lists up; then the cells are coarsened,
     // and a mesh that still does not fit gets no grid -- its z-parallel rays walk the tree).
     // A cell lists a triangle when the triangle's xy projection, grown by the same pad as its box, overlaps the cell
@@ -590,7 +592,7 @@ extern "C" int ilx_mesh_create(const float* verts_host, int64_t num_verts, const
         const double wx = std::max(double(g1[0]) - g0[0], 1e-6), wy = std::max(double(g1[1]) - g0[1], 1e-6);
         const double span = std::max(std::max(std::fabs(double(g0[0])), std::fabs(double(g1[0]))),
                                      std::max(std::fabs(double(g0[1])), std::fabs(double(g1[1]))));
-        double cell = std::sqrt(wx * wy / (4.0 * nt));
+        double cell = std::sqrt(wx * wy / (kGridCellsPerTriangle * nt));
         cell = std::max(cell, std::max(wx, wy) / 8192.0);
         const int64_t max_refs = std::max<int64_t>(int64_t(64) * nt, 1 << 16);
         for (int attempt = 0; attempt < 12; ++attempt, cell *= 2.0) {
@@ -663,11 +665,35 @@ extern "C" int ilx_mesh_create(const float* verts_host, int64_t num_verts, const
     // split triangle records for the column kernel
     std::vector<float4> tri_xy(cell_start.empty() ? 0 : 2 * static_cast<size_t>(nt));
     std::vector<float2> tri_z(cell_start.empty() ? 0 : static_cast<size_t>(nt));
-    for (size_t i = 0; i < tri_z.size(); ++i) {
-        const float4 a = tris[3 * i], b = tris[3 * i + 1], c = tris[3 * i + 2];  // (v0, e1x) (e1y, e1z, e2x, e2y) (e2z, id)
-        tri_xy[2 * i] = make_float4(a.x, a.y, a.w, b.x);
-        tri_xy[2 * i + 1] = make_float4(b.z, b.w, a.z, b.y);
-        tri_z[i] = make_float2(c.x, c.y);
+    {
+        // the column records are stored in tile order of the cell under each triangle's centroid (tiles of T x T
+        // cells, row-major inside), so that the candidates of neighbouring rays share cache lines
+        const int T = kGridTile;
+        std::vector<uint32_t> pos(tri_z.size());
+        std::iota(pos.begin(), pos.end(), 0u);
+        if (T > 0 && !tri_z.empty()) {
+            const int ntx = (gnx + T - 1) / T;
+            std::vector<uint64_t> key(tri_z.size());
+            for (size_t i = 0; i < tri_z.size(); ++i) {
+                const int t = order[i];
+                const int cx = cell_coord(cen[3 * static_cast<size_t>(t)], g0[0], inv_cell, gnx);
+                const int cy = cell_coord(cen[3 * static_cast<size_t>(t) + 1], g0[1], inv_cell, gny);
+                key[i] = (static_cast<uint64_t>(cy / T) * ntx + cx / T) * (T * T) + (cy % T) * T + cx % T;
+            }
+            std::vector<uint32_t> by_key(tri_z.size());
+            std::iota(by_key.begin(), by_key.end(), 0u);
+            std::stable_sort(by_key.begin(), by_key.end(), [&](uint32_t a, uint32_t b) { return key[a] < key[b]; });
+            for (size_t r = 0; r < by_key.size(); ++r) pos[by_key[r]] = static_cast<uint32_t>(r);
+            for (size_t k = 0; k + 4 < cell_refs.size() + 0; ++k) cell_refs[k] = pos[cell_refs[k]];
+            for (size_t c = 0; c + 1 < cell_start.size(); ++c)
+                std::sort(cell_refs.begin() + cell_start[c], cell_refs.begin() + cell_start[c + 1]);
+        }
+        for (size_t i = 0; i < tri_z.size(); ++i) {
+            const float4 a = tris[3 * i], b = tris[3 * i + 1], c = tris[3 * i + 2];  // (v0, e1x) (e1y, e1z, e2x, e2y) (e2z, id)
+            tri_xy[2 * static_cast<size_t>(pos[i])] = make_float4(a.x, a.y, a.w, b.x);
+            tri_xy[2 * static_cast<size_t>(pos[i]) + 1] = make_float4(b.z, b.w, a.z, b.y);
+            tri_z[pos[i]] = make_float2(c.x, c.y);
+        }
     }
 
     auto* obj = new ilx_mesh_s();

@@ -35,3 +35,4 @@ print("identical:", bool((a[1] == b[1]).all()), bool((a[3] == b[3]).all()))
 pv = np.array([[-100, -100, 0], [300, -100, 0], [-100, 300, 0], [300, 300, 0]], dtype=np.float32)
 plane = convert_to_mesh(pv, np.array([[0, 1, 2], [1, 3, 2]], dtype=np.int32), "cuda:0")
 print("plane cast us", timeit(lambda: raycast_mesh(starts, dirs, plane)))
+print("plane cast (column grid) us", timeit(lambda: raycast_mesh(starts, dirs, plane, z_parallel_hint=True)))
