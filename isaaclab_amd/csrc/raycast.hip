@@ -310,8 +310,19 @@ struct ScanArgs {
     int32_t* off_grid;        // as in CastArgs
 };
 
+// Workgroups are dealt to the 8 XCDs round-robin (block b runs on XCD b % 8), each with its own L2.  This maps the
+// hardware block index to a logical one such that consecutive logical blocks -- neighbouring rays, which read the
+// same cells and triangles -- share an XCD.
+ILX_DEV unsigned xcd_block(unsigned b, unsigned nblocks) {
+    constexpr unsigned kXcds = 8;
+    const unsigned per = nblocks / kXcds, full = per * kXcds;
+    if (b >= full) return b;  // the ragged tail keeps its place
+    return (b % kXcds) * per + b / kXcds;
+}
+
 // World ray i = (env, ray) of the sensor; false when the env is masked out.
-ILX_DEV bool sensor_ray(const ScanArgs& a, int64_t i, f3& o, f3& d, float& pos_z) {
+// `yaw` (optional): this env's yaw-only quaternion, precomputed once per env of the block.
+ILX_DEV bool sensor_ray(const ScanArgs& a, int64_t i, f3& o, f3& d, float& pos_z, const f4* yaw = nullptr) {
     const int64_t env = i / a.r;
     const int ray = static_cast<int>(i - env * a.r);
     if (a.env_mask && !a.env_mask[env]) return false;
@@ -328,7 +339,7 @@ ILX_DEV bool sensor_ray(const ScanArgs& a, int64_t i, f3& o, f3& d, float& pos_z
     }
     const f3 ls = load3(a.ray_starts + 3 * ray), ld = load3(a.ray_dirs + 3 * ray);
     if (a.yaw_only) {  // ray_caster.py:243-247: starts rotated by yaw only, directions unrotated
-        o = quat_apply_yaw(q, ls);
+        o = yaw ? quat_apply(*yaw, ls) : quat_apply_yaw(q, ls);
         d = ld;
     } else {  // ray_caster.py:248-252
         o = quat_apply(q, ls);
@@ -366,11 +377,23 @@ __global__ void __launch_bounds__(kRayBlock) raycaster_update_kernel(ScanArgs a)
 }
 
 __global__ void __launch_bounds__(kRayBlock) raycaster_update_column_kernel(ScanArgs a) {
-    const int64_t i = static_cast<int64_t>(blockIdx.x) * kRayBlock + threadIdx.x;
-    if (i >= a.n * a.r) return;
+    // the yaw-only rotation (atan2, sin, cos, normalise) is per env, not per ray: the first threads of the block
+    // compute it for the envs the block's rays belong to (at most one env per thread)
+    __shared__ f4 yaw_q[kRayBlock];
+    const int64_t first = static_cast<int64_t>(xcd_block(blockIdx.x, gridDim.x)) * kRayBlock;
+    const int64_t total = a.n * a.r;
+    const int64_t env0 = first / a.r;
+    if (a.yaw_only) {
+        const int64_t last = (first + kRayBlock - 1 < total ? first + kRayBlock - 1 : total - 1) / a.r;
+        const int64_t e = env0 + threadIdx.x;
+        if (e <= last) yaw_q[threadIdx.x] = yaw_quat(load4u(a.quat_w + a.quat_stride * e));
+        __syncthreads();
+    }
+    const int64_t i = first + threadIdx.x;
+    if (i >= total) return;
     f3 o, d;
     float pos_z;
-    if (!sensor_ray(a, i, o, d, pos_z)) return;
+    if (!sensor_ray(a, i, o, d, pos_z, a.yaw_only ? &yaw_q[i / a.r - env0] : nullptr)) return;
     if (!z_parallel(d)) {  // left to the tree kernel that follows
         *a.off_grid = 1;
         return;
