@@ -158,3 +158,42 @@ def test_generated_noise_and_samples_are_in_range_and_reproducible(dev):
     assert 0.03 < diff[:, 0:3].std() < 0.08, "uniform(-0.1, 0.1) has std 0.0577"
     assert (tl >= 0.5).all() and (tl <= 1.5).all() and (ht.abs() <= math.pi).all()
     assert (cmd.abs() <= 1.0).all() and cmd.std() > 0.3
+
+
+def test_pose_command_matches_reference(dev):
+    """UniformPoseCommand through the fused kernel's COMMAND / RESET phases against the reference class."""
+    from isaaclab_amd.envs import fused_mdp as FM
+
+    g = load_golden("pose_command")
+    for tag in ("reach", "unique"):
+        v = g[f"{tag}_cfg"].tolist()
+        cmd_cfg = dict(kind="pose", resampling_time_range=(v[0], v[1]), ranges=[(v[2], v[3]), (v[4], v[5]), (v[6], v[7]), (v[8], v[9]),
+                                                                              (v[10], v[11]), (v[12], v[13])],
+                       body_index=8, make_quat_unique=bool(v[14]))
+        n = g[f"{tag}_pre_time_left"].shape[0]
+        mdp = FM.FusedMdp(n, dev, num_joints=7, num_bodies=11, command_dim=7, step_dt=1 / 30, command=cmd_cfg)
+        mdp.bind(root_state_w=g[f"{tag}_root_state_w"].to(dev).contiguous(), body_state_w=g[f"{tag}_body_state_w"].to(dev).contiguous())
+        mdp.command.copy_(g[f"{tag}_pre_pose_command_b"])
+        mdp.time_left.copy_(g[f"{tag}_pre_time_left"])
+        mdp.command_counter.copy_(g[f"{tag}_pre_command_counter"])
+        for k in range(3):
+            mdp.bind(command_samples=g[f"{tag}_samples"][k].to(dev).contiguous())
+            mdp.step(FM.PHASE_COMMAND)
+            assert_exact(mdp.time_left, g[f"{tag}_time_left"][k], f"{tag} time_left step {k}")
+            assert_exact(mdp.command_counter, g[f"{tag}_command_counter"][k], f"{tag} counter step {k}")
+            assert_close(mdp.command, g[f"{tag}_pose_command_b"][k], atol=1e-6, what=f"{tag} command step {k}")
+            assert_close(mdp.command_metrics[0], g[f"{tag}_position_error"][k], atol=1e-6, what=f"{tag} position error step {k}")
+            assert_close(mdp.command_metrics[1], g[f"{tag}_orientation_error"][k], atol=3e-6, what=f"{tag} orientation error step {k}")
+        ids = g[f"{tag}_reset_ids"]
+        mdp.time_outs.zero_()
+        mdp.terminated.zero_()
+        mdp.time_outs[ids.to(dev)] = True
+        mdp.bind(reset_command_samples=g[f"{tag}_reset_samples"].to(dev).contiguous())
+        mdp.log_sums.zero_()
+        mdp.step(FM.PHASE_RESET)
+        assert_exact(mdp.time_left, g[f"{tag}_reset_time_left"], f"{tag} reset time_left")
+        assert_exact(mdp.command_counter, g[f"{tag}_reset_command_counter"], f"{tag} reset counter")
+        assert_close(mdp.command, g[f"{tag}_reset_pose_command_b"], atol=1e-6, what=f"{tag} reset command")
+        assert_close(mdp.command_metrics[0], g[f"{tag}_reset_position_error"], atol=1e-6, what=f"{tag} reset metric")
+        log = mdp.log_sums.cpu()
+        assert_close(log[0:2].double() / len(ids), g[f"{tag}_reset_extras"], rtol=1e-5, atol=1e-6, what=f"{tag} reset extras")

@@ -216,3 +216,28 @@ def test_managers_anymal():
         assert_exact(MG.termination_reset_counts(term_dones, dones), s["reset_term_log"], f"reset termination log step {k}")
         assert_close(episode_sums, s["episode_sums_after_reset"], what=f"episode sums after reset step {k}")
         assert dones.any()
+
+
+def _pose_cfg(g, tag):
+    v = g[f"{tag}_cfg"].tolist()
+    return C.PoseCommandCfg(resampling_time_range=(v[0], v[1]), pos_x=(v[2], v[3]), pos_y=(v[4], v[5]), pos_z=(v[6], v[7]),
+                            roll=(v[8], v[9]), pitch=(v[10], v[11]), yaw=(v[12], v[13]), make_quat_unique=bool(v[14]))
+
+
+def test_pose_command():
+    """UniformPoseCommand (pose_command.py:92-127 under command_manager.py:151-187) against the reference class."""
+    g = load_golden("pose_command")
+    for tag in ("reach", "unique"):
+        cfg = _pose_cfg(g, tag)
+        cmd, tl, cnt = g[f"{tag}_pre_pose_command_b"], g[f"{tag}_pre_time_left"], g[f"{tag}_pre_command_counter"]
+        root, body = g[f"{tag}_root_state_w"], g[f"{tag}_body_state_w"][:, 8]
+        for k in range(3):
+            pe, oe, pw = C.pose_metrics(cmd, root, body[:, :3], body[:, 3:7])   # metrics come before the resample
+            assert_close(pe, g[f"{tag}_position_error"][k], atol=1e-6, what=f"{tag} position error step {k}")
+            assert_close(oe, g[f"{tag}_orientation_error"][k], atol=2e-6, what=f"{tag} orientation error step {k}")
+            cmd, tl, cnt, mask = C.pose_compute(cfg, cmd, tl, cnt, 1 / 30, g[f"{tag}_samples"][k])
+            assert_exact(mask, g[f"{tag}_resampled"][k], f"{tag} resample mask step {k}")
+            assert_exact(tl, g[f"{tag}_time_left"][k], f"{tag} time_left step {k}")
+            assert_exact(cnt, g[f"{tag}_command_counter"][k], f"{tag} counter step {k}")
+            assert_close(cmd, g[f"{tag}_pose_command_b"][k], atol=1e-6, what=f"{tag} command step {k}")
+            assert mask.sum() > 10
