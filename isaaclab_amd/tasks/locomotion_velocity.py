@@ -105,13 +105,12 @@ def h1_rough_terms(joints=H1_JOINTS, bodies=H1_BODIES):
     jd_arms = _ids([".*_shoulder_.*", ".*_elbow"], joints)
     jd_torso = _ids("torso", joints)
     ankles = _ids(".*_ankle", joints)
-    legs = _ids([".*_hip_.*", ".*_knee"], joints)
     rewards = [
         TermSpec("track_lin_vel_xy_yaw_frame_exp", 1.0, (0.5 ** 2, 0, 0, 0), name="track_lin_vel_xy_exp"),
         TermSpec("track_ang_vel_z_world_exp", 1.0, (0.5 ** 2, 0, 0, 0), name="track_ang_vel_z_exp"),
         TermSpec("ang_vel_xy_l2", -0.05, name="ang_vel_xy_l2"),
         TermSpec("joint_torques_l2", 0.0, name="dof_torques_l2"),
-        TermSpec("joint_acc_l2", -1.25e-7, ids=legs, name="dof_acc_l2"),
+        TermSpec("joint_acc_l2", -1.25e-7, name="dof_acc_l2"),
         TermSpec("action_rate_l2", -0.005, name="action_rate_l2"),
         TermSpec("feet_air_time_positive_biped", 0.25, (0.4, 0, 0, 0), ids=feet, name="feet_air_time"),
         TermSpec("flat_orientation_l2", -1.0, name="flat_orientation_l2"),

@@ -197,3 +197,69 @@ def test_pose_command_matches_reference(dev):
         assert_close(mdp.command_metrics[0], g[f"{tag}_reset_position_error"], atol=1e-6, what=f"{tag} reset metric")
         log = mdp.log_sums.cpu()
         assert_close(log[0:2].double() / len(ids), g[f"{tag}_reset_extras"], rtol=1e-5, atol=1e-6, what=f"{tag} reset extras")
+
+
+def _managers_case(dev, tag, mdp, n_rewards, n_terms, max_len_s, obs_atol=1e-6):
+    """Three steps of the reference's real managers (fixture) vs one fused launch per step, plus the reset bookkeeping."""
+    from isaaclab_amd.envs import fused_mdp as FM
+
+    g = load_golden(f"managers_{tag}")
+    steps = g["reward"].shape[0]
+    for k in range(steps):
+        s = {key: v[k] for key, v in g.items() if v.shape[:1] == (steps,)}
+        bind_state(mdp, s, dev)
+        mdp.bind(command=s["command"].to(dev).contiguous(), noise_u=s["noise_u"].to(dev).contiguous())
+        mdp.episode_length_buf.copy_((s["episode_length_buf"] - 1).to(dev))
+        mdp.log_sums.zero_()
+        mdp.step(FM.PHASE_TERMINATION | FM.PHASE_REWARD | FM.PHASE_OBSERVATION)
+        assert_exact(mdp.terminated, s["terminated"], f"{tag} terminated step {k}")
+        assert_exact(mdp.time_outs, s["time_outs"], f"{tag} time_outs step {k}")
+        assert_exact(mdp.term_dones, s["term_dones"], f"{tag} term_dones step {k}")
+        assert_close(mdp.reward_buf, s["reward"], atol=2e-6, what=f"{tag} reward step {k}")
+        assert_close(mdp.step_reward, s["step_reward"], atol=5e-5, what=f"{tag} step_reward step {k}")
+        assert_close(mdp.episode_sums, s["episode_sums"], atol=2e-6, what=f"{tag} episode_sums step {k}")
+        assert_close(mdp.obs, s["obs"], atol=obs_atol, what=f"{tag} obs step {k}")
+        mdp.step(FM.PHASE_RESET)
+        nd = int(s["dones"].sum())
+        log = mdp.log_sums.cpu()
+        assert log[-1].item() == nd and nd > 0
+        assert_close(log[:n_rewards] / nd / max_len_s, s["reset_reward_log"], rtol=1e-4, atol=1e-6, what=f"{tag} reward log step {k}")
+        assert_exact(log[n_rewards:n_rewards + n_terms].long(), s["reset_term_log"], f"{tag} termination log step {k}")
+        assert_close(mdp.episode_sums, s["episode_sums_after_reset"], atol=2e-6, what=f"{tag} sums after reset step {k}")
+    return g
+
+
+def test_h1_managers_match_reference(dev):
+    """Unitree H1 rough (h1/rough_env_cfg.py): biped air time, feet slide, yaw-frame tracking, termination penalty,
+    joint deviation groups, torso contact termination."""
+    from isaaclab_amd.envs.fused_mdp import FusedMdp
+    from isaaclab_amd.tasks import locomotion_velocity as LV
+
+    mdp = FusedMdp(128, dev, num_joints=19, num_bodies=20, num_sensor_bodies=20, history_len=3, num_rays=187, action_dim=19,
+                   command_dim=3, step_dt=LV.STEP_DT, max_episode_length=LV.MAX_EPISODE_LENGTH, **LV.h1_rough_terms())
+    assert mdp.obs_dim == 256
+    g = _managers_case(dev, "h1", mdp, 14, 2, 20.0)
+    assert 0.1 < g["terminated"].float().mean() < 0.95
+
+
+def test_cartpole_managers_match_reference(dev):
+    from isaaclab_amd.envs.fused_mdp import FusedMdp
+    from isaaclab_amd.tasks import cartpole as CP
+
+    assert CP.MAX_EPISODE_LENGTH == 300
+    mdp = FusedMdp(256, dev, num_joints=2, num_bodies=3, action_dim=1, command_dim=3, step_dt=CP.STEP_DT,
+                   max_episode_length=CP.MAX_EPISODE_LENGTH, **CP.cartpole_terms())
+    assert mdp.obs_dim == 4
+    g = _managers_case(dev, "cartpole", mdp, 5, 2, CP.MAX_EPISODE_LENGTH * CP.STEP_DT)
+    assert g["terminated"].any() and g["time_outs"].any()
+
+
+def test_reach_managers_match_reference(dev):
+    from isaaclab_amd.envs.fused_mdp import FusedMdp
+    from isaaclab_amd.tasks import reach as RE
+
+    assert RE.MAX_EPISODE_LENGTH == 360
+    mdp = FusedMdp(256, dev, num_joints=9, num_bodies=11, action_dim=7, command_dim=7, step_dt=RE.STEP_DT,
+                   max_episode_length=RE.MAX_EPISODE_LENGTH, **RE.reach_terms())
+    assert mdp.obs_dim == 32
+    _managers_case(dev, "reach", mdp, 5, 1, RE.MAX_EPISODE_LENGTH * RE.STEP_DT, obs_atol=2e-6)
