@@ -1,0 +1,208 @@
+"""Non-physics half of ``ManagerBasedRLEnv.step`` (``isaaclab/envs/manager_based_rl_env.py:152-241``) for a scene with
+one articulation, as a small base class plus the Cartpole and Franka-Reach configurations.
+
+    process_action                                   -> ilx_joint_action_process | ilx_diff_ik_set_command
+    decimation x [ apply_action + actuator model     -> ilx_diff_ik_compute, ilx_actuator_pd
+                   <physics: the caller supplies the next joint state>
+                   scene.update                      -> ilx_scene_update ]
+    terminations, rewards, manager resets, command, observations -> ilx_mdp_step (one launch)
+
+The rough-terrain locomotion configs (contact sensor, ray caster, actuator net) are
+:class:`isaaclab_amd.envs.locomotion_step.LocomotionVelocityStep`.
+"""
+
+from __future__ import annotations
+
+import types
+
+import torch
+
+from .. import _abi
+from ..actuators import ImplicitActuator, ImplicitActuatorCfg
+from ..assets.articulation_data import ArticulationData
+from ..controllers.differential_ik import DifferentialIKControllerCfg
+from ..scene import InteractiveScene
+from ..tasks import cartpole as CP
+from ..tasks import reach as RE
+from ..utils.string import resolve_matching_names
+from ..utils.types import ArticulationActions
+from . import fused_mdp as FM
+from .mdp.actions import DifferentialInverseKinematicsAction, DifferentialInverseKinematicsActionCfg, OffsetCfg
+
+
+class _Asset:
+    """What the action terms need from an articulation (names, data, Jacobian, target setter)."""
+
+    is_fixed_base = True
+
+    def __init__(self, data: ArticulationData):
+        self.data = data
+        self.joint_names, self.body_names = data.joint_names, data.body_names
+        self.num_joints, self.num_bodies = len(self.joint_names), len(self.body_names)
+        self.jacobians = None
+
+    def find_joints(self, names, preserve_order=False):
+        return resolve_matching_names(names, self.joint_names, preserve_order)
+
+    def find_bodies(self, names, preserve_order=False):
+        return resolve_matching_names(names, self.body_names, preserve_order)
+
+    def get_jacobians(self):
+        return self.jacobians
+
+    def set_joint_position_target(self, target, joint_ids=None):
+        self.data.joint_pos_target[:, joint_ids if joint_ids is not None else slice(None)] = target
+
+
+class ManagerBasedStep:
+    """Shared sequence; subclasses provide the action term and the actuator groups."""
+
+    def __init__(self, num_envs: int, device, joints, bodies, terms: dict, *, action_dim: int, step_dt: float, physics_dt: float,
+                 decimation: int, max_episode_length: int, command: dict | None = None, command_dim: int = 0, seed: int = 0):
+        self.n, self.device = num_envs, torch.device(device)
+        self.step_dt, self.physics_dt, self.decimation = step_dt, physics_dt, decimation
+        n, dev = num_envs, self.device
+        self.data = ArticulationData(n, len(joints), len(bodies), dev, joint_names=joints, body_names=bodies)
+        self.asset = _Asset(self.data)
+        self.scene = InteractiveScene(n, dev)
+        self.scene.articulations["robot"] = self.data
+        self.action = torch.zeros(n, action_dim, device=dev)        # action_manager.py:318-339
+        self.prev_action = torch.zeros(n, action_dim, device=dev)
+        self.mdp = FM.FusedMdp(n, dev, num_joints=len(joints), num_bodies=len(bodies), action_dim=action_dim,
+                               command_dim=command_dim, step_dt=step_dt, max_episode_length=max_episode_length, command=command,
+                               seed=seed, **terms)
+        self.physics = None
+
+    def load_physics(self, physics: dict):
+        """Synthetic simulator output of one env step: ``joint_pos`` / ``joint_vel`` (decimation, N, J) per substep,
+        ``root_state_w`` (N,13), ``body_state_w`` (N,B,13) and optionally ``jacobians`` at the end of the step."""
+        dev = self.device
+        self.physics = {k: v.to(dev).contiguous() for k, v in physics.items()}
+
+    def process_action(self, raw):
+        raise NotImplementedError
+
+    def apply_action(self):
+        raise NotImplementedError
+
+    def step(self, raw_action: torch.Tensor, noise_u=None, command_samples=None, reset_command_samples=None):
+        d, ph = self.data, self.physics
+        self.process_action(raw_action)
+        for k in range(self.decimation):
+            self.apply_action()                              # action terms' apply_actions + write_data_to_sim (actuators)
+            d.joint_pos, d.joint_vel = ph["joint_pos"][k], ph["joint_vel"][k]   # <sim.step>
+            self.scene.update(self.physics_dt)
+        d.set_sim_state(root_state_w=ph["root_state_w"], body_state_w=ph.get("body_state_w"))
+        m = self.mdp
+        m.bind(root_state_w=d.root_state_w, joint_pos=d.joint_pos, joint_vel=d.joint_vel, joint_acc=d._joint_acc,
+               applied_torque=d.applied_torque, computed_torque=d.computed_torque, default_joint_pos=d.default_joint_pos,
+               default_joint_vel=d.default_joint_vel, soft_joint_pos_limits=d.soft_joint_pos_limits,
+               soft_joint_vel_limits=d.soft_joint_vel_limits, body_state_w=d.body_state_w, action=self.action,
+               prev_action=self.prev_action, noise_u=noise_u, command_samples=command_samples,
+               reset_command_samples=reset_command_samples)
+        m.step(FM.PHASE_ALL)
+        return m.obs, m.reward_buf, m.terminated, m.time_outs
+
+    def _actuate(self, actuators):
+        """articulation.py:1399-1436 for actuator groups that together cover every joint."""
+        d = self.data
+        for act, ids in actuators:
+            ca = ArticulationActions(joint_positions=d.joint_pos_target[:, ids].contiguous(),
+                                     joint_velocities=d.joint_vel_target[:, ids].contiguous(),
+                                     joint_efforts=d.joint_effort_target[:, ids].contiguous(), joint_indices=ids)
+            act.compute(ca, d.joint_pos[:, ids].contiguous(), d.joint_vel[:, ids].contiguous())
+            d.computed_torque[:, ids] = act.computed_effort
+            d.applied_torque[:, ids] = act.applied_effort
+
+
+class CartpoleStep(ManagerBasedStep):
+    """Isaac-Cartpole-v0 (cartpole_env_cfg.py): JointEffortAction on the cart (scale 100), implicit actuators
+    (isaaclab_assets/robots/cartpole.py:39-50), five rewards, two terminations, 4-wide observation."""
+
+    def __init__(self, num_envs: int, device, seed: int = 0):
+        super().__init__(num_envs, device, CP.JOINTS, CP.BODIES, CP.cartpole_terms(), action_dim=1, step_dt=CP.STEP_DT,
+                         physics_dt=CP.PHYSICS_DT, decimation=CP.DECIMATION, max_episode_length=CP.MAX_EPISODE_LENGTH, seed=seed)
+        cfg = ImplicitActuatorCfg(effort_limit=400.0, velocity_limit=100.0, stiffness=0.0, damping={"slider_to_cart": 10.0, "cart_to_pole": 0.0})
+        self.actuator = ImplicitActuator(cfg, joint_names=CP.JOINTS, joint_ids=slice(None), num_envs=num_envs, device=self.device)
+        self.actuator.computed_effort, self.actuator.applied_effort = self.data.computed_torque, self.data.applied_torque
+        self._effort = torch.zeros(num_envs, 1, device=self.device)
+
+    def process_action(self, raw):  # joint_actions.py:130-139, 214-225 (JointEffortAction, no offset)
+        _abi.check(_abi.joint_action_process(_abi.ptr(_abi.f32c(raw)), _abi.ptr(self.action), _abi.ptr(self.prev_action), None,
+                                             CP.ACTION_SCALE, None, 0.0, None, _abi.ptr(self._effort), self.n, 1, _abi.stream()),
+                   "ilx_joint_action_process")
+
+    def apply_action(self):
+        d = self.data
+        d.joint_effort_target[:, 0:1] = self._effort          # set_joint_effort_target(processed, joint_ids=[cart])
+        ca = ArticulationActions(joint_positions=d.joint_pos_target, joint_velocities=d.joint_vel_target,
+                                 joint_efforts=d.joint_effort_target, joint_indices=slice(None))
+        self.actuator.compute(ca, d.joint_pos, d.joint_vel)
+
+
+class ReachStep(ManagerBasedStep):
+    """Isaac-Reach-Franka-v0 and its IK variants (reach_env_cfg.py + config/franka/*): arm action = JointPositionAction
+    (scale 0.5, default offset) or the DifferentialIK action term (relative / absolute pose, DLS), implicit actuators
+    (isaaclab_assets/robots/franka.py:50-72), UniformPoseCommand, five rewards, time-out, 32-wide observation
+    (9 + 9 + 7 + arm action width)."""
+
+    def __init__(self, num_envs: int, device, arm_action: str = "joint_pos", seed: int = 0):
+        if arm_action not in ("joint_pos", "ik_rel", "ik_abs"):
+            raise ValueError(f"unknown arm action '{arm_action}'")
+        self.arm_action = arm_action
+        adim = {"joint_pos": 7, "ik_rel": 6, "ik_abs": 7}[arm_action]
+        cmd = dict(RE.POSE_COMMAND, body_index=RE.FRANKA_BODIES.index(RE.EE_BODY))
+        super().__init__(num_envs, device, RE.FRANKA_JOINTS, RE.FRANKA_BODIES, RE.reach_terms(), action_dim=adim, step_dt=RE.STEP_DT,
+                         physics_dt=RE.PHYSICS_DT, decimation=RE.DECIMATION, max_episode_length=RE.MAX_EPISODE_LENGTH,
+                         command=cmd, command_dim=7, seed=seed)
+        n, dev = num_envs, self.device
+        arm = resolve_matching_names(["panda_joint.*"], RE.FRANKA_JOINTS)[0]
+        self._arm = arm
+        cfg = ImplicitActuatorCfg(effort_limit={"panda_joint[1-4]": 87.0, "panda_joint[5-7]": 12.0, "panda_finger_joint.*": 200.0},
+                                  velocity_limit={"panda_joint[1-4]": 2.175, "panda_joint[5-7]": 2.61, "panda_finger_joint.*": 0.2},
+                                  stiffness={"panda_joint.*": 80.0, "panda_finger_joint.*": 2e3},
+                                  damping={"panda_joint.*": 4.0, "panda_finger_joint.*": 1e2})
+        self.actuator = ImplicitActuator(cfg, joint_names=RE.FRANKA_JOINTS, joint_ids=slice(None), num_envs=n, device=dev)
+        self.actuator.computed_effort, self.actuator.applied_effort = self.data.computed_torque, self.data.applied_torque
+        self._arm_target = torch.zeros(n, 7, device=dev)
+        self._arm_default = torch.zeros(n, 7, device=dev)
+        self.ik = None
+        if arm_action != "joint_pos":
+            env = types.SimpleNamespace(num_envs=n, device=dev, scene={"robot": self.asset})
+            ik_cfg = DifferentialInverseKinematicsActionCfg(
+                joint_names=["panda_joint.*"], body_name=RE.EE_BODY, body_offset=OffsetCfg(*RE.IK_BODY_OFFSET),
+                scale=0.5 if arm_action == "ik_rel" else 1.0,   # ik_rel_env_cfg.py:29-36 / ik_abs_env_cfg.py:29-34
+                controller=DifferentialIKControllerCfg("pose", arm_action == "ik_rel", "dls"))
+            self.ik = DifferentialInverseKinematicsAction(ik_cfg, env)
+
+    def set_default_joint_pos(self, default: torch.Tensor):
+        self.data.default_joint_pos[:] = default.to(self.device)
+        self._arm_default = self.data.default_joint_pos[:, self._arm].contiguous()
+
+    def load_physics(self, physics: dict):
+        super().load_physics(physics)
+        # the pose the action terms see while this step's actions are processed is the one of the previous step's end
+        if "body_state_w" in self.physics:
+            self.data.set_sim_state(root_state_w=self.physics["root_state_w"], body_state_w=self.physics["body_state_w"])
+        self.asset.jacobians = self.physics.get("jacobians")
+
+    def process_action(self, raw):
+        raw = _abi.f32c(raw)
+        if self.ik is None:  # JointPositionAction: processed = raw * 0.5 + default (joint_actions.py:145-160)
+            _abi.check(_abi.joint_action_process(_abi.ptr(raw), _abi.ptr(self.action), _abi.ptr(self.prev_action), None,
+                                                 RE.ARM_ACTION_SCALE, _abi.ptr(self._arm_default), 0.0, None,
+                                                 _abi.ptr(self._arm_target), self.n, 7, _abi.stream()), "ilx_joint_action_process")
+        else:  # ActionManager bookkeeping (action_manager.py:331-332), then the term
+            self.prev_action.copy_(self.action)
+            self.action.copy_(raw)
+            self.ik.process_actions(raw)
+
+    def apply_action(self):
+        d = self.data
+        if self.ik is None:
+            d.joint_pos_target[:, self._arm] = self._arm_target
+        else:
+            self.ik.apply_actions()
+        ca = ArticulationActions(joint_positions=d.joint_pos_target, joint_velocities=d.joint_vel_target,
+                                 joint_efforts=d.joint_effort_target, joint_indices=slice(None))
+        self.actuator.compute(ca, d.joint_pos, d.joint_vel)

@@ -1,0 +1,208 @@
+"""GPU: end-to-end non-physics env steps of Isaac-Cartpole-v0 and Isaac-Reach-Franka-v0 (joint-position and
+DifferentialIK arm actions) against a composition of the oracle's pieces in the reference's step order
+(manager_based_rl_env.py:152-241).  The pieces themselves are pinned to the reference by the golden fixtures."""
+
+import math
+
+import pytest
+import torch
+
+from conftest import assert_close, assert_exact
+from oracle import actuators as A
+from oracle import articulation as AD
+from oracle import command as C
+from oracle import ik as IK
+from oracle import managers as MG
+from oracle import mathx as M
+from oracle import terms as T
+
+pytestmark = pytest.mark.gpu
+
+
+def test_cartpole_step(dev):
+    from isaaclab_amd.envs.manager_based_step import CartpoleStep
+    from isaaclab_amd.tasks import cartpole as CP
+
+    n = 512
+    g = torch.Generator().manual_seed(1001)
+    env = CartpoleStep(n, dev)
+    q0 = torch.stack([torch.rand(n, generator=g) * 6.4 - 3.2, (torch.rand(n, generator=g) * 2 - 1) * math.pi], -1)
+    qd0 = torch.randn(n, 2, generator=g)
+    env.data.joint_pos, env.data.joint_vel = q0.to(dev), qd0.to(dev)
+    env.data._previous_joint_vel.copy_(qd0)
+    ep = torch.randint(0, 300, (n,), generator=g)
+    ep[:3] = 298
+    env.mdp.episode_length_buf.copy_(ep)
+    kd = torch.tensor([10.0, 0.0]).repeat(n, 1)
+    q, qd, prev_qd = q0, qd0, qd0.clone()
+    action, prev_action = torch.zeros(n, 1), torch.zeros(n, 1)
+    sums, step_reward = torch.zeros(5, n), torch.zeros(n, 5)
+    sim_time, acc_time = 0.0, -1.0
+    for step in range(3):
+        raw = torch.rand(n, 1, generator=g) * 2 - 1
+        phys = dict(joint_pos=torch.stack([q0 + 0.3 * torch.randn(n, 2, generator=g) for _ in range(2)]),
+                    joint_vel=torch.stack([torch.randn(n, 2, generator=g) for _ in range(2)]), root_state_w=torch.zeros(n, 13))
+        phys["root_state_w"][:, 3] = 1.0
+        env.load_physics(phys)
+        obs, reward, terminated, time_outs = env.step(raw.to(dev))
+        # ---- oracle composition
+        prev_action, action = action, raw.clone()
+        tau_ff = torch.cat([raw * 100.0, torch.zeros(n, 1)], -1)
+        for k in range(2):
+            comp = A.pd_torque(torch.zeros(n, 2), torch.zeros(n, 2), tau_ff, q, qd, torch.zeros(n, 2), kd)
+            app = A.clip_effort(comp, torch.full((n, 2), 400.0))
+            q, qd = phys["joint_pos"][k], phys["joint_vel"][k]
+            sim_time += CP.PHYSICS_DT
+            acc, prev_qd = AD.joint_acc(qd, prev_qd, sim_time - acc_time)
+            acc_time = sim_time
+        ep = ep + 1
+        dones, term, trunc, term_dones = MG.termination_compute(
+            [T.time_out(ep, CP.MAX_EPISODE_LENGTH), T.joint_pos_out_of_manual_limit(q, (-3.0, 3.0), [0])], [True, False])
+        vals = [T.is_alive(term), T.is_terminated(term), T.joint_pos_target_l2(q, 0.0, [1]), T.joint_vel_l1(qd, [0]), T.joint_vel_l1(qd, [1])]
+        ref_reward = MG.reward_compute(vals, [1.0, -2.0, -1.0, -0.01, -0.005], CP.STEP_DT, sums, step_reward)
+        MG.reward_reset(sums, dones, CP.MAX_EPISODE_LENGTH * CP.STEP_DT)
+        ep = torch.where(dones, torch.zeros_like(ep), ep)
+        ref_obs = torch.cat([q, qd], -1)   # defaults are zero
+        assert_exact(terminated, term, f"terminated step {step}")
+        assert_exact(time_outs, trunc, f"time_outs step {step}")
+        assert_exact(env.mdp.episode_length_buf, ep, f"episode_length_buf step {step}")
+        assert_exact(env.data.computed_torque, comp, f"computed torque step {step}")
+        assert_exact(env.data.applied_torque, app, f"applied torque step {step}")
+        assert_exact(env.data.joint_acc, acc, f"joint_acc step {step}")
+        assert_exact(obs, ref_obs, f"obs step {step}")
+        assert_close(reward, ref_reward, atol=1e-6, what=f"reward step {step}")
+        assert_close(env.mdp.episode_sums, sums, atol=1e-6, what=f"episode sums step {step}")
+        assert_exact(env.action, action, "action")
+        assert_exact(env.prev_action, prev_action, "prev_action")
+        assert term.any()
+
+
+def _reach_physics(g, n, q_mean):
+    root = torch.zeros(n, 13)
+    root[:, :3] = torch.randn(n, 3, generator=g)
+    yaw = torch.rand(n, generator=g) * 6.28 - 3.14
+    root[:, 3], root[:, 6] = torch.cos(yaw / 2), torch.sin(yaw / 2)
+    body = torch.zeros(n, 11, 13)
+    body[..., :3] = root[:, None, :3] + 0.4 * torch.randn(n, 11, 3, generator=g)
+    body[..., 3:7] = M.normalize(torch.randn(n, 11, 4, generator=g))
+    # Jacobians of the 10 moving links: well-conditioned 6x7 arm blocks (sigma in [0.2, 1.5]) + finger columns
+    U, _ = torch.linalg.qr(torch.randn(n, 10, 6, 6, generator=g))
+    V, _ = torch.linalg.qr(torch.randn(n, 10, 7, 7, generator=g))
+    S = 0.2 + 1.3 * torch.rand(n, 10, 6, generator=g)
+    jac = torch.zeros(n, 10, 6, 9)
+    jac[..., :7] = U @ torch.diag_embed(S) @ V[..., :6].transpose(-1, -2)
+    jac[..., 7:] = 0.1 * torch.randn(n, 10, 6, 2, generator=g)
+    return dict(joint_pos=torch.stack([q_mean + 0.2 * torch.randn(n, 9, generator=g) for _ in range(2)]),
+                joint_vel=torch.stack([0.5 * torch.randn(n, 9, generator=g) for _ in range(2)]), root_state_w=root,
+                body_state_w=body, jacobians=jac)
+
+
+@pytest.mark.parametrize("arm_action", ["joint_pos", "ik_rel", "ik_abs"])
+def test_reach_step(dev, arm_action):
+    from isaaclab_amd.envs.manager_based_step import ReachStep
+    from isaaclab_amd.tasks import reach as RE
+
+    n = 384
+    g = torch.Generator().manual_seed(2002)
+    env = ReachStep(n, dev, arm_action=arm_action)
+    default = torch.tensor([0.0, -0.569, 0.0, -2.81, 0.0, 3.037, 0.741, 0.04, 0.04]).repeat(n, 1)   # franka.py:38-48
+    env.set_default_joint_pos(default)
+    adim = env.action.shape[1]
+    q, qd = default + 0.1 * torch.randn(n, 9, generator=g), torch.zeros(n, 9)
+    env.data.joint_pos, env.data.joint_vel = q.to(dev), qd.to(dev)
+    ep = torch.randint(0, 360, (n,), generator=g)
+    ep[:4] = 358
+    env.mdp.episode_length_buf.copy_(ep)
+    cmd_state = dict(cmd=torch.cat([torch.rand(n, 3, generator=g) * 0.5, M.normalize(torch.randn(n, 4, generator=g))], -1),
+                     time_left=torch.rand(n, generator=g) * 0.1, counter=torch.zeros(n, dtype=torch.long))
+    env.mdp.command.copy_(cmd_state["cmd"])
+    env.mdp.time_left.copy_(cmd_state["time_left"])
+    cfg = C.PoseCommandCfg()
+    kp = torch.tensor([80.0] * 7 + [2e3] * 2).repeat(n, 1)
+    kd = torch.tensor([4.0] * 7 + [1e2] * 2).repeat(n, 1)
+    lim = torch.tensor([87.0] * 4 + [12.0] * 3 + [200.0] * 2).repeat(n, 1)
+    prev_qd = torch.zeros(n, 9)
+    action, prev_action = torch.zeros(n, adim), torch.zeros(n, adim)
+    sums, step_reward = torch.zeros(5, n), torch.zeros(n, 5)
+    target = torch.zeros(n, 9)
+    sim_time, acc_time = 0.0, -1.0
+    op, orot = torch.tensor([RE.IK_BODY_OFFSET[0]]), torch.tensor([RE.IK_BODY_OFFSET[1]])
+    phys = _reach_physics(g, n, default)
+    for step in range(2):
+        env.load_physics(phys)       # pose / Jacobian the action terms see = end of the previous step
+        if arm_action == "ik_abs":   # a reachable absolute pose near the current one, in the root frame
+            pb, qb = IK.frame_pose(phys["root_state_w"][:, :3], phys["root_state_w"][:, 3:7], phys["body_state_w"][:, 8, :3],
+                                   phys["body_state_w"][:, 8, 3:7], op, orot)
+            tp, tq = M.apply_delta_pose(pb, qb, torch.cat([0.05 * torch.randn(n, 3, generator=g), 0.2 * torch.randn(n, 3, generator=g)], -1))
+            raw = torch.cat([tp, tq], -1)
+        else:
+            raw = torch.rand(n, adim, generator=g) * 2 - 1
+        noise_u = torch.rand(n, env.mdp.obs_dim, generator=g)
+        samples = torch.rand(n, 7, generator=g)
+        samples[:, 0] = 4.0
+        new_phys = _reach_physics(g, n, default)
+        step_phys = dict(phys, joint_pos=new_phys["joint_pos"], joint_vel=new_phys["joint_vel"])
+        env.load_physics(step_phys)
+        obs, reward, terminated, time_outs = env.step(raw.to(dev), noise_u.to(dev), samples.to(dev), samples.to(dev))
+        # ---- oracle composition
+        prev_action, action = action, raw.clone()
+        rp, rq = phys["root_state_w"][:, :3], phys["root_state_w"][:, 3:7]
+        ep_w, eq_w, jac_w = phys["body_state_w"][:, 8, :3], phys["body_state_w"][:, 8, 3:7], phys["jacobians"][:, 7][:, :, :7]
+        if arm_action == "joint_pos":
+            arm_target = raw * 0.5 + default[:, :7]
+        else:
+            scale = 0.5 if arm_action == "ik_rel" else 1.0
+            _, pdes, qdes = IK.process_actions(raw, scale, None, rp, rq, ep_w, eq_w, op, orot, "pose", arm_action == "ik_rel")
+        for k in range(2):
+            if arm_action != "joint_pos":
+                arm_target = IK.apply_actions(rp, rq, ep_w, eq_w, jac_w, q[:, :7], pdes, qdes, op, orot, "pose", "dls",
+                                              {"lambda_val": 0.01}, f64=True)
+            target = torch.cat([arm_target, target[:, 7:]], -1)
+            comp = A.pd_torque(target, torch.zeros(n, 9), torch.zeros(n, 9), q, qd, kp, kd)
+            app = A.clip_effort(comp, lim)
+            q, qd = step_phys["joint_pos"][k], step_phys["joint_vel"][k]
+            sim_time += RE.PHYSICS_DT
+            acc, prev_qd = AD.joint_acc(qd, prev_qd, sim_time - acc_time)
+            acc_time = sim_time
+        ep = ep + 1
+        rs, bs = phys["root_state_w"], phys["body_state_w"]
+        dones, term, trunc, _ = MG.termination_compute([T.time_out(ep, RE.MAX_EPISODE_LENGTH)], [True])
+        cmd = cmd_state["cmd"]
+        vals = [T.position_command_error(cmd, rs, bs[:, 8, :3]), T.position_command_error_tanh(cmd, rs, bs[:, 8, :3], 0.1),
+                T.orientation_command_error(cmd, rs, bs[:, 8, 3:7]), T.action_rate_l2(action, prev_action), T.joint_vel_l2(qd)]
+        ref_reward = MG.reward_compute(vals, [-0.2, 0.1, -0.1, -0.0001, -0.0001], RE.STEP_DT, sums, step_reward)
+        MG.reward_reset(sums, dones, RE.MAX_EPISODE_LENGTH * RE.STEP_DT)
+        # command: reset of the done envs (resample), then compute(dt)
+        if dones.any():
+            c2, tl2, cnt2, _ = C.pose_compute(cfg, cmd, torch.where(dones, torch.full((n,), -1.0), cmd_state["time_left"] + RE.STEP_DT),
+                                              torch.where(dones, torch.zeros(n, dtype=torch.long), cmd_state["counter"]), RE.STEP_DT, samples)
+            cmd = torch.where(dones.unsqueeze(-1), c2, cmd)
+            cmd_state["time_left"] = torch.where(dones, samples[:, 0], cmd_state["time_left"])
+            cmd_state["counter"] = torch.where(dones, torch.ones(n, dtype=torch.long), cmd_state["counter"])
+        cmd, cmd_state["time_left"], cmd_state["counter"], _ = C.pose_compute(cfg, cmd, cmd_state["time_left"], cmd_state["counter"],
+                                                                             RE.STEP_DT, samples)
+        cmd_state["cmd"] = cmd
+        ep = torch.where(dones, torch.zeros_like(ep), ep)
+        parts = [(T.joint_pos_rel(q, default), (-0.01, 0.01)), (T.joint_vel_rel(qd, torch.zeros(n, 9)), (-0.01, 0.01)), (cmd, None),
+                 (action, None)]
+        cols, col = [], 0
+        for val, noise in parts:
+            w = val.shape[1]
+            cols.append(T.apply_obs_pipeline(val, noise_u[:, col:col + w], noise, None))
+            col += w
+        ref_obs = MG.observation_concat(cols)
+        assert_exact(time_outs, trunc, f"time_outs step {step}")
+        assert not terminated.any()
+        assert_exact(env.mdp.episode_length_buf, ep, f"episode_length_buf step {step}")
+        assert_exact(env.mdp.time_left, cmd_state["time_left"], f"command time_left step {step}")
+        assert_exact(env.mdp.command_counter, cmd_state["counter"], f"command counter step {step}")
+        assert_close(env.mdp.command, cmd, atol=1e-6, what=f"command step {step}")
+        tol = 1e-6 if arm_action == "joint_pos" else 2e-5   # the IK update goes through a 6x6 solve
+        assert_close(env.data.joint_pos_target[:, :7], arm_target, rtol=1e-5, atol=tol, what=f"arm joint targets step {step}")
+        assert_close(env.data.computed_torque, comp, rtol=1e-5, atol=2e-3 if arm_action != "joint_pos" else 1e-5, what=f"computed torque step {step}")
+        assert_exact(env.data.joint_acc, acc, f"joint_acc step {step}")
+        assert_close(obs, ref_obs, atol=2e-6, what=f"obs step {step}")
+        assert_close(reward, ref_reward, atol=2e-6, what=f"reward step {step}")
+        assert_close(env.mdp.episode_sums, sums, atol=2e-6, what=f"episode sums step {step}")
+        assert trunc.any() or step > 0
+        phys = dict(new_phys)
