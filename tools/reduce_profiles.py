@@ -1,0 +1,84 @@
+#!/usr/bin/env python3
+"""Reduce the rocprofv3 outputs of tools/profile_bench.sh into the summaries kept under profiles/:
+
+    python tools/reduce_profiles.py <tag> [envs]
+
+profiles/<tag>_bench_kernel_stats.csv  the --kernel-trace --stats table, as rocprofv3 wrote it
+profiles/<tag>_bench_line.json         the bench line of the same tree
+profiles/<tag>_hbm_traffic.json        per-kernel FETCH_SIZE / WRITE_SIZE per launch (KB; FETCH_SIZE doubled: gfx950 tallies its
+                                       128-byte requests as 64 bytes) -> bytes that crossed the L2 <-> fabric boundary
+"""
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KERNELS = {  # substring of the kernel symbol -> bench kernel name (launches of one bench kernel are summed per call)
+    "joint_action_kernel": "joint_action_process", "mlp_mfma_kernel": "actuator_net_mlp", "scene_update_kernel": "scene_update",
+    "raycaster_update": "raycaster_refresh", "sensor_refreshed_kernel": "raycaster_refresh", "mdp_step_kernel": "mdp_step",
+}
+PRIMARY = {"joint_action_process": "joint_action_kernel", "actuator_net_mlp": "mlp_mfma_kernel", "scene_update": "scene_update_kernel",
+           "raycaster_refresh": "raycaster_update_column_kernel", "mdp_step": "mdp_step_kernel"}
+
+
+def counter_per_launch(path, counter):
+    """Sum of `counter` over the launches that belong to one call of each bench kernel, divided by the number of calls
+    (= launches of the kernel's primary symbol), at full grid size only (the bench's 16384-env launches)."""
+    rows = list(csv.DictReader(open(path)))
+    total, calls, grid = {}, {}, {}
+    for r in rows:
+        if r["Counter_Name"] != counter:
+            continue
+        for sub, name in KERNELS.items():
+            if sub in r["Kernel_Name"]:
+                if PRIMARY[name] in r["Kernel_Name"]:
+                    grid[name] = max(grid.get(name, 0), int(r["Grid_Size"]))
+    for r in rows:
+        if r["Counter_Name"] != counter:
+            continue
+        for sub, name in KERNELS.items():
+            if sub in r["Kernel_Name"]:
+                primary = PRIMARY[name] in r["Kernel_Name"]
+                if primary and int(r["Grid_Size"]) != grid[name]:
+                    continue  # smaller launches belong to the CPU-baseline-free set-up, not to the step
+                total[name] = total.get(name, 0.0) + float(r["Counter_Value"])
+                if primary:
+                    calls[name] = calls.get(name, 0) + 1
+    return {k: (total[k] / calls[k], calls[k]) for k in total if calls.get(k)}
+
+
+def main():
+    tag = sys.argv[1]
+    envs = int(sys.argv[2]) if len(sys.argv) > 2 else 16384
+    src = os.path.join(ROOT, "gpurun_out", tag)
+    dst = os.path.join(ROOT, "profiles")
+    os.makedirs(dst, exist_ok=True)
+    stats = glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True)
+    if stats:
+        shutil.copy(stats[0], os.path.join(dst, f"{tag}_bench_kernel_stats.csv"))
+    if os.path.exists(os.path.join(src, "bench_line.json")):
+        shutil.copy(os.path.join(src, "bench_line.json"), os.path.join(dst, f"{tag}_bench_line.json"))
+    fetch = glob.glob(os.path.join(src, "pmc_fetch", "**", "*counter_collection.csv"), recursive=True)
+    write = glob.glob(os.path.join(src, "pmc_write", "**", "*counter_collection.csv"), recursive=True)
+    if fetch and write:
+        f = counter_per_launch(fetch[0], "FETCH_SIZE")
+        w = counter_per_launch(write[0], "WRITE_SIZE")
+        out = {"command": "rocprofv3 --pmc FETCH_SIZE -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline  (and a separate pass "
+                          "with --pmc WRITE_SIZE)",
+               "correction": "FETCH_SIZE doubled (gfx950 tallies 128-byte requests at 64 bytes); counts L2 fabric-side requests, "
+                             "Infinity Cache hits included",
+               "envs": envs, "kernels": {}}
+        for k in f:
+            fk, n = f[k]
+            wk = w.get(k, (0.0, 0))[0]
+            out["kernels"][k] = {"FETCH_SIZE_KB_per_launch": round(2.0 * fk, 1), "launches_sampled": n,
+                                 "WRITE_SIZE_KB_per_launch": round(wk, 1), "hbm_bytes_per_launch": int((2.0 * fk + wk) * 1024)}
+        json.dump(out, open(os.path.join(dst, f"{tag}_hbm_traffic.json"), "w"), indent=1)
+    print("profiles written for", tag)
+
+
+if __name__ == "__main__":
+    main()
