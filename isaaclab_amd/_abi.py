@@ -94,6 +94,7 @@ mesh_create = _sig("ilx_mesh_create", P, c_int64, P, c_int64, P)
 lib.ilx_mesh_destroy.argtypes = [P]
 lib.ilx_mesh_destroy.restype = None
 mesh_info = _sig("ilx_mesh_info", P, P, P, P)
+mesh_grid_stats = _sig("ilx_mesh_grid_stats", P, P)
 RAYS_Z_PARALLEL = 1
 raycast_mesh = _sig("ilx_raycast_mesh", P, P, P, c_int64, c_float, P, P, P, P, c_int, P)
 raycaster_update = _sig("ilx_raycaster_update", P, P, P, P, P, P, c_int, c_float, P, P, c_float, c_int64, c_int, c_int, P)

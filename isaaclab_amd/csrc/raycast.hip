@@ -12,19 +12,24 @@
 // carries slack), so the result equals testing every triangle: closest t, ties to the lowest face index.
 //
 // Column grid: rays parallel to the z axis (the height scanner's pattern) need no hierarchy at all.  The mesh's
-// xy footprint is cut into square cells and every cell lists the triangles whose (inflated) xy box overlaps it;
-// such a ray tests exactly the triangles of the one cell under its origin.  A caller that knows its rays are
-// z-parallel passes ILX_RAYS_Z_PARALLEL and gets the column kernel (no LDS, full occupancy, ~5x fewer bytes per
-// ray than the tree walk); rays that turn out not to be z-parallel still get the tree walk inside that kernel, so
-// the hint only affects speed, never results.
+// xy footprint is cut into square cells and every cell knows the triangles whose (inflated) xy projection overlaps
+// it; such a ray tests exactly the triangles of the one cell under its origin.  A cell is one 32-bit word: most
+// cells see one to three triangles that are neighbours in the record array and name that run directly, the others
+// point at a shared candidate list (cells with the same candidates share one list).  Cell words and triangle
+// records are both stored in tiles of 16 x 16 cells, so the rays of one wavefront (a patch of one env's scan
+// pattern) touch few cache lines whatever the sensor's yaw.  A caller that knows its rays are z-parallel passes
+// ILX_RAYS_Z_PARALLEL and gets the column kernel (no LDS, full occupancy); rays that turn out not to be z-parallel
+// are left to a tree-walk launch that follows, so the hint only affects speed, never results.
 #include "common.h"
 #include "raytri.h"
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <numeric>
+#include <unordered_map>
 #include <vector>
 
 namespace ilx {
@@ -35,8 +40,15 @@ constexpr int kMaxDepth = 12;
 constexpr int kCachedNodes = 85;      // levels 0..3 of the 4-wide tree
 constexpr int kRayBlock = 256;
 constexpr int kEmptyRef = INT32_MIN;
-constexpr double kGridCellsPerTriangle = 8.0;  // column grid resolution (measured: 2 -> 170 us, 4 -> 136, 8 -> 122, 16 -> 122)
-constexpr int kGridTile = 16;                  // column records are stored in tiles of 16 x 16 cells
+constexpr double kGridCellsPerTriangle = 8.0;  // column grid resolution
+constexpr int kGridTile = 16;                  // cell words, column triangles and vertices are stored in tiles of 16 x 16 cells
+constexpr double kGridPhase = 0.5;             // the grid starts this fraction of a cell before the mesh: triangle edges
+                                               // of a regular height field then run through cells, not along cell borders
+// Cell word: 0xFFFFFFFF = empty; otherwise bits 31..30 = k and bits 29..0 = p.  k < 3: the candidates are the k + 1
+// records p .. p + k.  k = 3: a list starts at the 16-byte word cell_lists[p] = (count, r0, r1, r2), followed by
+// (r3, r4, r5, r6) ... for as long as the count says.
+constexpr uint32_t kCellEmpty = 0xFFFFFFFFu;
+constexpr uint32_t kCellIndexMask = 0x3FFFFFFFu;
 
 struct alignas(16) Node {
     float minx[4], miny[4], minz[4], maxx[4], maxy[4], maxz[4];
@@ -50,14 +62,20 @@ struct MeshDev {
     const float4* tris;  // 3 float4 per triangle, leaf order
     int32_t num_nodes;
     int32_t num_tris;
-    // column grid over the xy footprint (CSR: cell_start[c] .. cell_start[c + 1] index cell_refs)
-    const uint32_t* cell_start;
-    const uint32_t* cell_refs;  // positions in `tris` (padded with 4 entries so that 4-wide reads stay in bounds)
-    const float4* tri_xy;       // 2 float4 per triangle: (v0x, v0y, e1x, e1y), (e2x, e2y, v0z, e1z)
-    const float2* tri_z;        // per triangle: (e2z, face id bits)
+    // column grid over the xy footprint
+    const uint32_t* cells;       // one word per cell, tile order (cell_slot)
+    const uint4* cell_lists;     // candidate lists of the cells whose candidates are not one short run
+    const uint4* col_tris;       // per triangle, column order: three positions in col_verts, original face id
+    const float4* col_verts;     // vertices (x, y, z, -) in tile order of their xy: neighbouring triangles share them
     float gx0, gy0, gx1, gy1, inv_cell;
-    int32_t nx, ny;
+    int32_t nx, ny, ntx;         // cells per axis, tiles per row
 };
+
+// Slot of cell (cx, cy) in `cells`: tiles row-major, cells row-major inside a tile.
+__host__ __device__ inline int64_t cell_slot(int cx, int cy, int ntx) {
+    return ((static_cast<int64_t>(cy / kGridTile) * ntx + cx / kGridTile) * (kGridTile * kGridTile)) +
+           (cy % kGridTile) * kGridTile + cx % kGridTile;
+}
 
 // Cell coordinate of x along one axis.  The same expression places triangles at build time and rays at cast
 // time; it is monotone in x, so a ray inside a triangle's box lands in a cell that lists the triangle.
@@ -185,40 +203,66 @@ ILX_DEV Hit trace(const MeshDev& m, const Node* cache, int ncache, int32_t* stac
     return best;
 }
 
-// Candidate `pos` of a z-parallel ray: the barycentric decision reads 32 bytes, only an accepted candidate reads
-// the rest.
+// A candidate of a z-parallel ray, given by its three vertices.  The edges are the same float subtractions the tree's
+// triangle records were built with, so both paths evaluate ray_triangle on identical operands.
 template <bool WANT_NORMAL>
-ILX_DEV void test_column_triangle(const MeshDev& m, uint32_t pos, f3 o, float dz, float max_dist, Hit& best) {
-    const float4 a = m.tri_xy[2 * static_cast<int64_t>(pos)], b = m.tri_xy[2 * static_cast<int64_t>(pos) + 1];
+ILX_DEV void test_column_vertices(f3 v0, f3 v1, f3 v2, int32_t face, f3 o, float dz, float max_dist, Hit& best) {
+    const f3 e1 = {v1.x - v0.x, v1.y - v0.y, v1.z - v0.z}, e2 = {v2.x - v0.x, v2.y - v0.y, v2.z - v0.z};
     ColumnHit h;
-    if (!ray_triangle_z_inside(o.x, o.y, dz, a.x, a.y, a.z, a.w, b.x, b.y, h)) return;
-    const float2 c = m.tri_z[pos];
+    if (!ray_triangle_z_inside(o.x, o.y, dz, v0.x, v0.y, e1.x, e1.y, e2.x, e2.y, h)) return;
     float t;
-    if (!ray_triangle_z_distance(h, o.z, b.z, a.z, a.w, b.w, b.x, b.y, c.x, max_dist, t)) return;
-    const int32_t face = __float_as_int(c.y);
+    if (!ray_triangle_z_distance(h, o.z, v0.z, e1.x, e1.y, e1.z, e2.x, e2.y, e2.z, max_dist, t)) return;
     if (t < best.t || (t == best.t && face < best.face)) {
         best.t = t;
         best.face = face;
-        if (WANT_NORMAL) best.normal_raw = cross3(f3{a.z, a.w, b.w}, f3{b.x, b.y, c.x});
+        if (WANT_NORMAL) best.normal_raw = cross3(e1, e2);
     }
 }
 
-// z-parallel ray: every candidate lives in the cell under the origin.
+ILX_DEV f3 column_vertex(const MeshDev& m, uint32_t i) {
+    const float4 v = m.col_verts[i];
+    return {v.x, v.y, v.z};
+}
+
+template <bool WANT_NORMAL>
+ILX_DEV void test_column_triangle(const MeshDev& m, uint32_t pos, f3 o, float dz, float max_dist, Hit& best) {
+    const uint4 t = m.col_tris[pos];
+    test_column_vertices<WANT_NORMAL>(column_vertex(m, t.x), column_vertex(m, t.y), column_vertex(m, t.z), static_cast<int32_t>(t.w),
+                                      o, dz, max_dist, best);
+}
+
+// z-parallel ray: every candidate lives in the cell under the origin.  The kernel's time is fabric traffic, so the
+// structures are small (4 bytes per cell, 16 per triangle, 16 per shared vertex); a wavefront's chain of dependent
+// loads is cell word -> (list header) -> vertex indices of the first three candidates -> their vertices, each step
+// with all its loads in flight together.  Only cells with more than three candidates go round a loop.
 template <bool WANT_NORMAL>
 ILX_DEV Hit trace_column(const MeshDev& m, f3 o, f3 d, float max_dist) {
     Hit best{__builtin_inff(), -1, {0.0f, 0.0f, 0.0f}};
     if (!(o.x >= m.gx0 && o.x <= m.gx1 && o.y >= m.gy0 && o.y <= m.gy1)) return best;
     const int cx = cell_coord(o.x, m.gx0, m.inv_cell, m.nx), cy = cell_coord(o.y, m.gy0, m.inv_cell, m.ny);
-    const uint32_t* cs = m.cell_start + (static_cast<int64_t>(cy) * m.nx + cx);
-    const uint32_t begin = cs[0], end = cs[1];
-    for (uint32_t k = begin; k < end; k += 4) {
-        // four references per trip (the list is padded), so the triangle loads of a trip are in flight together
-        const uint32_t* rp = m.cell_refs + k;
-        const uint32_t r0 = rp[0], r1 = rp[1], r2 = rp[2], r3 = rp[3];
-        test_column_triangle<WANT_NORMAL>(m, r0, o, d.z, max_dist, best);
-        if (k + 1 < end) test_column_triangle<WANT_NORMAL>(m, r1, o, d.z, max_dist, best);
-        if (k + 2 < end) test_column_triangle<WANT_NORMAL>(m, r2, o, d.z, max_dist, best);
-        if (k + 3 < end) test_column_triangle<WANT_NORMAL>(m, r3, o, d.z, max_dist, best);
+    const uint32_t word = m.cells[cell_slot(cx, cy, m.ntx)];
+    if (word == kCellEmpty) return best;
+    const uint32_t kind = word >> 30, p = word & kCellIndexMask;
+    uint32_t n = kind + 1, p0 = p, p1 = p + 1, p2 = p + 2;
+    if (kind == 3) {
+        const uint4 head = m.cell_lists[p];
+        n = head.x, p0 = head.y, p1 = head.z, p2 = head.w;
+    }
+    p1 = n > 1 ? p1 : p0;  // absent candidates repeat the first one: the loads below need no branch
+    p2 = n > 2 ? p2 : p0;
+    const uint4 t0 = m.col_tris[p0], t1 = m.col_tris[p1], t2 = m.col_tris[p2];
+    const f3 a0 = column_vertex(m, t0.x), a1 = column_vertex(m, t0.y), a2 = column_vertex(m, t0.z);
+    const f3 b0 = column_vertex(m, t1.x), b1 = column_vertex(m, t1.y), b2 = column_vertex(m, t1.z);
+    const f3 c0 = column_vertex(m, t2.x), c1 = column_vertex(m, t2.y), c2 = column_vertex(m, t2.z);
+    test_column_vertices<WANT_NORMAL>(a0, a1, a2, static_cast<int32_t>(t0.w), o, d.z, max_dist, best);
+    if (n > 1) test_column_vertices<WANT_NORMAL>(b0, b1, b2, static_cast<int32_t>(t1.w), o, d.z, max_dist, best);
+    if (n > 2) test_column_vertices<WANT_NORMAL>(c0, c1, c2, static_cast<int32_t>(t2.w), o, d.z, max_dist, best);
+    for (uint32_t k = 3; k < n; k += 4) {
+        const uint4 more = m.cell_lists[p + 1 + (k - 3) / 4];
+        test_column_triangle<WANT_NORMAL>(m, more.x, o, d.z, max_dist, best);
+        if (k + 1 < n) test_column_triangle<WANT_NORMAL>(m, more.y, o, d.z, max_dist, best);
+        if (k + 2 < n) test_column_triangle<WANT_NORMAL>(m, more.z, o, d.z, max_dist, best);
+        if (k + 3 < n) test_column_triangle<WANT_NORMAL>(m, more.w, o, d.z, max_dist, best);
     }
     return best;
 }
@@ -489,19 +533,33 @@ struct Builder {
     }
 };
 
+// How the cells of the column grid encode their candidates (diagnostics).
+struct GridStats {
+    int64_t cells, empty, run[3], list_cells, lists, list_words, candidates;
+};
+
 struct MeshHost {
     MeshDev dev{};
     Node* d_nodes = nullptr;
     float4* d_tris = nullptr;
-    uint32_t* d_cell_start = nullptr;
-    uint32_t* d_cell_refs = nullptr;
-    int64_t num_cell_refs = 0;
-    float4* d_tri_xy = nullptr;
-    float2* d_tri_z = nullptr;
+    uint32_t* d_cells = nullptr;
+    uint32_t* d_cell_lists = nullptr;  // read by the kernels as 16-byte words
+    uint4* d_col_tris = nullptr;
+    float4* d_col_verts = nullptr;
+    GridStats grid{};
     int32_t* d_off_grid = nullptr;  // flag raised by a column kernel for the tree kernel launched right after it
     int depth = 0;
     int64_t num_verts = 0;
 };
+
+template <class T>
+static int upload(T** dst, const std::vector<T>& src, const char* what) {
+    const size_t bytes = std::max<size_t>(src.size(), 1) * sizeof(T);
+    int rc = check_hip(hipMalloc(dst, bytes), "ilx_mesh_create: hipMalloc");
+    if (rc == ILX_OK && !src.empty())
+        rc = check_hip(hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice), what);
+    return rc;
+}
 
 }  // namespace ilx
 
@@ -605,21 +663,24 @@ extern "C" int ilx_mesh_create(const float* verts_host, int64_t num_verts, const
     // and a mesh that still does not fit gets no grid -- its z-parallel rays walk the tree).
     // A cell lists a triangle when the triangle's xy projection, grown by the same pad as its box, overlaps the cell
     // grown by the rounding slack of cell_coord: box range first, then the three edge half-planes (separating axes).
-    float g0[2] = {INFINITY, INFINITY}, g1[2] = {-INFINITY, -INFINITY};
+    float m0[2] = {INFINITY, INFINITY}, g0[2], g1[2] = {-INFINITY, -INFINITY};
     for (int t = 0; t < nt; ++t)
-        for (int a = 0; a < 2; ++a) g0[a] = std::min(g0[a], box[t].mn[a]), g1[a] = std::max(g1[a], box[t].mx[a]);
+        for (int a = 0; a < 2; ++a) m0[a] = std::min(m0[a], box[t].mn[a]), g1[a] = std::max(g1[a], box[t].mx[a]);
     std::vector<uint32_t> cell_start, cell_refs;
     int gnx = 0, gny = 0;
     float inv_cell = 0.0f;
     {
-        const double wx = std::max(double(g1[0]) - g0[0], 1e-6), wy = std::max(double(g1[1]) - g0[1], 1e-6);
-        const double span = std::max(std::max(std::fabs(double(g0[0])), std::fabs(double(g1[0]))),
-                                     std::max(std::fabs(double(g0[1])), std::fabs(double(g1[1]))));
-        double cell = std::sqrt(wx * wy / (kGridCellsPerTriangle * nt));
+        const double wx = std::max(double(g1[0]) - m0[0], 1e-6), wy = std::max(double(g1[1]) - m0[1], 1e-6);
+        const double span = std::max(std::max(std::fabs(double(m0[0])), std::fabs(double(g1[0]))),
+                                     std::max(std::fabs(double(m0[1])), std::fabs(double(g1[1])))) + std::max(wx, wy);
+        double density = kGridCellsPerTriangle;
+        if (const char* e = std::getenv("ILX_GRID_DENSITY")) density = std::atof(e);
+        double cell = std::sqrt(wx * wy / (density * nt));
         cell = std::max(cell, std::max(wx, wy) / 8192.0);
-        const int64_t max_refs = std::max<int64_t>(int64_t(64) * nt, 1 << 16);
+        const int64_t max_refs = std::min<int64_t>(std::max<int64_t>(int64_t(64) * nt, 1 << 16), kCellIndexMask - 8);
         for (int attempt = 0; attempt < 12; ++attempt, cell *= 2.0) {
             inv_cell = static_cast<float>(1.0 / cell);
+            for (int a = 0; a < 2; ++a) g0[a] = static_cast<float>(double(m0[a]) - kGridPhase / double(inv_cell));
             gnx = std::max(1, cell_coord(g1[0], g0[0], inv_cell, 1 << 20) + 1);
             gny = std::max(1, cell_coord(g1[1], g0[1], inv_cell, 1 << 20) + 1);
             if (static_cast<int64_t>(gnx) * gny > (int64_t(1) << 26)) continue;
@@ -685,38 +746,103 @@ extern "C" int ilx_mesh_create(const float* verts_host, int64_t num_verts, const
             break;
         }
     }
-    // split triangle records for the column kernel
-    std::vector<float4> tri_xy(cell_start.empty() ? 0 : 2 * static_cast<size_t>(nt));
-    std::vector<float2> tri_z(cell_start.empty() ? 0 : static_cast<size_t>(nt));
-    {
-        // the column records are stored in tile order of the cell under each triangle's centroid (tiles of T x T
-        // cells, row-major inside), so that the candidates of neighbouring rays share cache lines
+    // Column triangles (three vertex positions + face id), ordered by the tile of the cell under their centroid and
+    // by face id inside a tile: triangles that follow each other in the caller's mesh (the two halves of a quad,
+    // neighbours along a row) stay next to each other, so most cells can name their candidates as one short run.
+    // Column vertices are ordered by the tile of their own cell.
+    std::vector<uint4> col_tris(cell_start.empty() ? 0 : static_cast<size_t>(nt));
+    std::vector<float4> col_verts(cell_start.empty() ? 0 : static_cast<size_t>(num_verts));
+    std::vector<uint32_t> cells, cell_lists;
+    int ntx = 0;
+    GridStats gstats{};
+    if (!cell_start.empty()) {
         const int T = kGridTile;
-        std::vector<uint32_t> pos(tri_z.size());
-        std::iota(pos.begin(), pos.end(), 0u);
-        if (T > 0 && !tri_z.empty()) {
-            const int ntx = (gnx + T - 1) / T;
-            std::vector<uint64_t> key(tri_z.size());
-            for (size_t i = 0; i < tri_z.size(); ++i) {
-                const int t = order[i];
-                const int cx = cell_coord(cen[3 * static_cast<size_t>(t)], g0[0], inv_cell, gnx);
-                const int cy = cell_coord(cen[3 * static_cast<size_t>(t) + 1], g0[1], inv_cell, gny);
-                key[i] = (static_cast<uint64_t>(cy / T) * ntx + cx / T) * (T * T) + (cy % T) * T + cx % T;
+        ntx = (gnx + T - 1) / T;
+        const int nty = (gny + T - 1) / T;
+        auto tile_of = [&](float x, float y) {
+            const int cx = cell_coord(x, g0[0], inv_cell, gnx), cy = cell_coord(y, g0[1], inv_cell, gny);
+            return static_cast<uint64_t>(cy / T) * ntx + cx / T;
+        };
+        // vertices
+        std::vector<uint64_t> vkey(num_verts);
+        for (int64_t v = 0; v < num_verts; ++v) vkey[v] = tile_of(verts_host[3 * v], verts_host[3 * v + 1]);
+        std::vector<uint32_t> vorder(num_verts), vpos(num_verts);
+        std::iota(vorder.begin(), vorder.end(), 0u);
+        std::stable_sort(vorder.begin(), vorder.end(), [&](uint32_t a, uint32_t b) { return vkey[a] < vkey[b]; });
+        for (int64_t r = 0; r < num_verts; ++r) {
+            vpos[vorder[r]] = static_cast<uint32_t>(r);
+            const float* v = verts_host + 3 * static_cast<int64_t>(vorder[r]);
+            col_verts[r] = make_float4(v[0], v[1], v[2], 0.0f);
+        }
+        // triangles
+        std::vector<uint64_t> key(nt);
+        for (int i = 0; i < nt; ++i) {
+            const int t = order[i];
+            double c[2] = {0.0, 0.0};
+            for (int k = 0; k < 3; ++k)
+                for (int a = 0; a < 2; ++a) c[a] += verts_host[3 * static_cast<int64_t>(tris_host[3 * t + k]) + a];
+            key[i] = tile_of(static_cast<float>(c[0] / 3.0), static_cast<float>(c[1] / 3.0));
+        }
+        std::vector<uint32_t> by_key(nt), pos(nt);
+        std::iota(by_key.begin(), by_key.end(), 0u);
+        std::sort(by_key.begin(), by_key.end(), [&](uint32_t a, uint32_t b) {
+            return key[a] != key[b] ? key[a] < key[b] : order[a] < order[b];
+        });
+        for (int r = 0; r < nt; ++r) {
+            pos[by_key[r]] = static_cast<uint32_t>(r);
+            const int t = order[by_key[r]];
+            col_tris[r] = make_uint4(vpos[tris_host[3 * t]], vpos[tris_host[3 * t + 1]], vpos[tris_host[3 * t + 2]],
+                                     static_cast<uint32_t>(t));
+        }
+        // cell words; candidate lists are shared between cells with the same candidates
+        cells.assign(static_cast<size_t>(ntx) * nty * T * T, kCellEmpty);
+        cell_lists.reserve(1 << 16);
+        std::unordered_map<uint64_t, std::vector<uint32_t>> known;  // hash of a candidate list -> offsets of lists with it
+        std::vector<uint32_t> cand;
+        // cells are visited tile by tile, so the lists of a tile's cells are neighbours in memory as well
+        for (int64_t slot = 0; slot < static_cast<int64_t>(cells.size()); ++slot) {
+            {
+                const int64_t tile = slot / (T * T);
+                const int in_tile = static_cast<int>(slot % (T * T));
+                const int cx = static_cast<int>(tile % ntx) * T + in_tile % T, cy = static_cast<int>(tile / ntx) * T + in_tile / T;
+                if (cx >= gnx || cy >= gny) continue;
+                const size_t c = static_cast<size_t>(cy) * gnx + cx;
+                const uint32_t b = cell_start[c], e = cell_start[c + 1];
+                ++gstats.cells;
+                if (b == e) {
+                    ++gstats.empty;
+                    continue;
+                }
+                cand.clear();
+                for (uint32_t k = b; k < e; ++k) cand.push_back(pos[cell_refs[k]]);
+                std::sort(cand.begin(), cand.end());
+                uint32_t& word = cells[cell_slot(cx, cy, ntx)];
+                const uint32_t n = static_cast<uint32_t>(cand.size());
+                gstats.candidates += n;
+                if (n <= 3 && cand[n - 1] - cand[0] == n - 1) {
+                    word = ((n - 1) << 30) | cand[0];
+                    ++gstats.run[n - 1];
+                    continue;
+                }
+                uint64_t hsh = 1469598103934665603ull;
+                for (uint32_t v : cand) hsh = (hsh ^ v) * 1099511628211ull;
+                std::vector<uint32_t>& same = known[hsh];
+                uint32_t at = kCellEmpty;
+                for (uint32_t off : same)
+                    if (cell_lists[off] == n && std::equal(cand.begin(), cand.end(), cell_lists.begin() + off + 1)) at = off;
+                if (at == kCellEmpty) {
+                    at = static_cast<uint32_t>(cell_lists.size());  // a multiple of 4: lists are whole 16-byte words
+                    cell_lists.push_back(n);
+                    cell_lists.insert(cell_lists.end(), cand.begin(), cand.end());
+                    while (cell_lists.size() % 4 != 0) cell_lists.push_back(cand[0]);
+                    same.push_back(at);
+                    ++gstats.lists;
+                }
+                word = (3u << 30) | (at / 4);
+                ++gstats.list_cells;
             }
-            std::vector<uint32_t> by_key(tri_z.size());
-            std::iota(by_key.begin(), by_key.end(), 0u);
-            std::stable_sort(by_key.begin(), by_key.end(), [&](uint32_t a, uint32_t b) { return key[a] < key[b]; });
-            for (size_t r = 0; r < by_key.size(); ++r) pos[by_key[r]] = static_cast<uint32_t>(r);
-            for (size_t k = 0; k + 4 < cell_refs.size() + 0; ++k) cell_refs[k] = pos[cell_refs[k]];
-            for (size_t c = 0; c + 1 < cell_start.size(); ++c)
-                std::sort(cell_refs.begin() + cell_start[c], cell_refs.begin() + cell_start[c + 1]);
         }
-        for (size_t i = 0; i < tri_z.size(); ++i) {
-            const float4 a = tris[3 * i], b = tris[3 * i + 1], c = tris[3 * i + 2];  // (v0, e1x) (e1y, e1z, e2x, e2y) (e2z, id)
-            tri_xy[2 * static_cast<size_t>(pos[i])] = make_float4(a.x, a.y, a.w, b.x);
-            tri_xy[2 * static_cast<size_t>(pos[i]) + 1] = make_float4(b.z, b.w, a.z, b.y);
-            tri_z[pos[i]] = make_float2(c.x, c.y);
-        }
+        gstats.list_words = static_cast<int64_t>(cell_lists.size());
     }
 
     auto* obj = new ilx_mesh_s();
@@ -724,25 +850,11 @@ extern "C" int ilx_mesh_create(const float* verts_host, int64_t num_verts, const
     int rc = check_hip(hipMalloc(&h.d_nodes, nodes.size() * sizeof(Node)), "ilx_mesh_create: hipMalloc(nodes)");
     if (rc == ILX_OK) rc = check_hip(hipMalloc(&h.d_off_grid, sizeof(int32_t)), "ilx_mesh_create: hipMalloc(flag)");
     if (rc == ILX_OK) rc = check_hip(hipMemset(h.d_off_grid, 0, sizeof(int32_t)), "ilx_mesh_create: hipMemset(flag)");
-    if (rc == ILX_OK && !cell_start.empty()) {
-        rc = check_hip(hipMalloc(&h.d_cell_start, cell_start.size() * sizeof(uint32_t)), "ilx_mesh_create: hipMalloc(cells)");
-        if (rc == ILX_OK)
-            rc = check_hip(hipMalloc(&h.d_cell_refs, std::max<size_t>(cell_refs.size(), 1) * sizeof(uint32_t)),
-                           "ilx_mesh_create: hipMalloc(cell refs)");
-        if (rc == ILX_OK)
-            rc = check_hip(hipMemcpy(h.d_cell_start, cell_start.data(), cell_start.size() * sizeof(uint32_t),
-                                     hipMemcpyHostToDevice), "ilx_mesh_create: copy cells");
-        if (rc == ILX_OK && !cell_refs.empty())
-            rc = check_hip(hipMemcpy(h.d_cell_refs, cell_refs.data(), cell_refs.size() * sizeof(uint32_t),
-                                     hipMemcpyHostToDevice), "ilx_mesh_create: copy cell refs");
-        if (rc == ILX_OK) rc = check_hip(hipMalloc(&h.d_tri_xy, tri_xy.size() * sizeof(float4)), "ilx_mesh_create: hipMalloc(xy)");
-        if (rc == ILX_OK) rc = check_hip(hipMalloc(&h.d_tri_z, tri_z.size() * sizeof(float2)), "ilx_mesh_create: hipMalloc(z)");
-        if (rc == ILX_OK)
-            rc = check_hip(hipMemcpy(h.d_tri_xy, tri_xy.data(), tri_xy.size() * sizeof(float4), hipMemcpyHostToDevice),
-                           "ilx_mesh_create: copy xy records");
-        if (rc == ILX_OK)
-            rc = check_hip(hipMemcpy(h.d_tri_z, tri_z.data(), tri_z.size() * sizeof(float2), hipMemcpyHostToDevice),
-                           "ilx_mesh_create: copy z records");
+    if (rc == ILX_OK && !cells.empty()) {
+        rc = upload(&h.d_cells, cells, "cells");
+        if (rc == ILX_OK) rc = upload(&h.d_cell_lists, cell_lists, "cell lists");
+        if (rc == ILX_OK) rc = upload(&h.d_col_tris, col_tris, "column triangles");
+        if (rc == ILX_OK) rc = upload(&h.d_col_verts, col_verts, "column vertices");
     }
     if (rc == ILX_OK) rc = check_hip(hipMalloc(&h.d_tris, tris.size() * sizeof(float4)), "ilx_mesh_create: hipMalloc(tris)");
     if (rc == ILX_OK)
@@ -754,20 +866,19 @@ extern "C" int ilx_mesh_create(const float* verts_host, int64_t num_verts, const
     if (rc != ILX_OK) {
         if (h.d_nodes) (void)hipFree(h.d_nodes);
         if (h.d_tris) (void)hipFree(h.d_tris);
-        if (h.d_cell_start) (void)hipFree(h.d_cell_start);
-        if (h.d_cell_refs) (void)hipFree(h.d_cell_refs);
+        if (h.d_cells) (void)hipFree(h.d_cells);
+        if (h.d_cell_lists) (void)hipFree(h.d_cell_lists);
         if (h.d_off_grid) (void)hipFree(h.d_off_grid);
-        if (h.d_tri_xy) (void)hipFree(h.d_tri_xy);
-        if (h.d_tri_z) (void)hipFree(h.d_tri_z);
+        if (h.d_col_tris) (void)hipFree(h.d_col_tris);
+        if (h.d_col_verts) (void)hipFree(h.d_col_verts);
         delete obj;
         return rc;
     }
     h.dev.nodes = h.d_nodes, h.dev.tris = h.d_tris, h.dev.num_nodes = nn, h.dev.num_tris = nt;
-    h.dev.cell_start = h.d_cell_start, h.dev.cell_refs = h.d_cell_refs;
-    h.dev.tri_xy = h.d_tri_xy, h.dev.tri_z = h.d_tri_z;
+    h.dev.cells = h.d_cells, h.dev.cell_lists = reinterpret_cast<const uint4*>(h.d_cell_lists), h.dev.col_tris = h.d_col_tris, h.dev.col_verts = h.d_col_verts;
     h.dev.gx0 = g0[0], h.dev.gy0 = g0[1], h.dev.gx1 = g1[0], h.dev.gy1 = g1[1], h.dev.inv_cell = inv_cell;
-    h.dev.nx = gnx, h.dev.ny = gny;
-    h.num_cell_refs = static_cast<int64_t>(cell_refs.size());
+    h.dev.nx = gnx, h.dev.ny = gny, h.dev.ntx = ntx;
+    h.grid = gstats;
     h.depth = bld.max_depth, h.num_verts = num_verts;
     *out = obj;
     return ILX_OK;
@@ -777,11 +888,11 @@ extern "C" void ilx_mesh_destroy(ilx_mesh_t mesh) {
     if (!mesh) return;
     if (mesh->h.d_nodes) (void)hipFree(mesh->h.d_nodes);
     if (mesh->h.d_tris) (void)hipFree(mesh->h.d_tris);
-    if (mesh->h.d_cell_start) (void)hipFree(mesh->h.d_cell_start);
-    if (mesh->h.d_cell_refs) (void)hipFree(mesh->h.d_cell_refs);
+    if (mesh->h.d_cells) (void)hipFree(mesh->h.d_cells);
+    if (mesh->h.d_cell_lists) (void)hipFree(mesh->h.d_cell_lists);
     if (mesh->h.d_off_grid) (void)hipFree(mesh->h.d_off_grid);
-    if (mesh->h.d_tri_xy) (void)hipFree(mesh->h.d_tri_xy);
-    if (mesh->h.d_tri_z) (void)hipFree(mesh->h.d_tri_z);
+    if (mesh->h.d_col_tris) (void)hipFree(mesh->h.d_col_tris);
+    if (mesh->h.d_col_verts) (void)hipFree(mesh->h.d_col_verts);
     delete mesh;
 }
 
@@ -790,6 +901,15 @@ extern "C" int ilx_mesh_info(ilx_mesh_t mesh, int64_t* num_tris, int64_t* num_no
     if (num_tris) *num_tris = mesh->h.dev.num_tris;
     if (num_nodes) *num_nodes = mesh->h.dev.num_nodes;
     if (depth) *depth = mesh->h.depth;
+    return ILX_OK;
+}
+
+extern "C" int ilx_mesh_grid_stats(ilx_mesh_t mesh, int64_t out[10]) {
+    ILX_REQUIRE(mesh && out, ILX_EINVAL, "ilx_mesh_grid_stats: NULL argument");
+    const GridStats& g = mesh->h.grid;
+    const int64_t v[10] = {g.cells, g.empty, g.run[0], g.run[1], g.run[2], g.list_cells, g.lists, g.list_words, g.candidates,
+                           mesh->h.dev.nx};
+    for (int i = 0; i < 10; ++i) out[i] = v[i];
     return ILX_OK;
 }
 
@@ -812,7 +932,7 @@ extern "C" int ilx_raycast_mesh(ilx_mesh_t mesh, const float* ray_starts, const 
     ILX_REQUIRE(num_rays < (int64_t(1) << 31) * kRayBlock, ILX_ESHAPE, "ilx_raycast_mesh: too many rays");
     CastArgs a{mesh->h.dev, ray_starts, ray_directions, max_dist, ray_hits, ray_distance, ray_normal, ray_face_id, num_rays,
                nullptr, nullptr};
-    if ((hints & ILX_RAYS_Z_PARALLEL) && mesh->h.d_cell_start) {
+    if ((hints & ILX_RAYS_Z_PARALLEL) && mesh->h.d_cells) {
         // column kernel, then the tree kernel for whatever rays were not z-parallel after all (it leaves at once
         // when the column kernel raised no flag)
         a.off_grid = mesh->h.d_off_grid;
@@ -880,7 +1000,7 @@ extern "C" int ilx_raycaster_refresh(const ilx_raycaster* rc, void* stream) {
 // Column kernel + tree kernel for the rays it left out (a no-op launch when there are none), or the tree kernel alone.
 static int launch_scan(ilx_mesh_t mesh, ScanArgs a, int hints, void* stream) {
     const int64_t rays = a.n * a.r;
-    if ((hints & ILX_RAYS_Z_PARALLEL) && mesh->h.d_cell_start) {
+    if ((hints & ILX_RAYS_Z_PARALLEL) && mesh->h.d_cells) {
         a.off_grid = mesh->h.d_off_grid;
         ILX_REQUIRE(hipMemsetAsync(a.off_grid, 0, sizeof(int32_t), as_stream(stream)) == hipSuccess, ILX_EHIP,
                     "raycaster: hipMemsetAsync failed");

@@ -11,16 +11,17 @@ import torch
 
 
 def heightfield_mesh(heights: np.ndarray, horizontal_scale: float, origin=(0.0, 0.0)):
-    """Triangulate a height grid (nx, ny): vertices on the grid, two triangles per cell (same vertex / face
-    counts as the height-field tiles of the reference's terrain generator: 81 x 81 -> 12,800 faces)."""
+    """Triangulate a height grid (nx, ny): vertices on the grid, two triangles per cell, in the face order of the
+    reference's ``convert_height_field_to_mesh`` (terrains/height_field/utils.py:157-171: row by row, the two halves
+    of a cell one after the other, split along the ind0-ind3 diagonal; 81 x 81 -> 12,800 faces)."""
     nx, ny = heights.shape
     xs = origin[0] + np.arange(nx, dtype=np.float32) * np.float32(horizontal_scale)
     ys = origin[1] + np.arange(ny, dtype=np.float32) * np.float32(horizontal_scale)
     gx, gy = np.meshgrid(xs, ys, indexing="ij")
     verts = np.stack([gx, gy, heights.astype(np.float32)], axis=-1).reshape(-1, 3)
     idx = np.arange(nx * ny, dtype=np.int32).reshape(nx, ny)
-    a, b, c, d = idx[:-1, :-1].ravel(), idx[1:, :-1].ravel(), idx[:-1, 1:].ravel(), idx[1:, 1:].ravel()
-    tris = np.concatenate([np.stack([a, b, c], -1), np.stack([b, d, c], -1)]).astype(np.int32)
+    i0, i1, i2, i3 = idx[:-1, :-1].ravel(), idx[:-1, 1:].ravel(), idx[1:, :-1].ravel(), idx[1:, 1:].ravel()
+    tris = np.stack([np.stack([i0, i3, i1], -1), np.stack([i0, i2, i3], -1)], axis=1).reshape(-1, 3).astype(np.int32)
     return verts, tris
 
 

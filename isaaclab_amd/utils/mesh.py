@@ -31,6 +31,13 @@ class Mesh:
         _abi.check(_abi.mesh_info(self.handle, ctypes.byref(nt), ctypes.byref(nn), ctypes.byref(depth)), "ilx_mesh_info")
         self.num_nodes, self.depth = nn.value, depth.value
 
+    def grid_stats(self) -> dict:
+        """How the column grid behind ``RAYS_Z_PARALLEL`` casts encodes its cells (diagnostics)."""
+        out = (ctypes.c_int64 * 10)()
+        _abi.check(_abi.mesh_grid_stats(self.handle, out), "ilx_mesh_grid_stats")
+        names = ("cells", "empty", "run1", "run2", "run3", "list_cells", "lists", "list_words", "candidates", "cells_per_row")
+        return dict(zip(names, (int(v) for v in out)))
+
     def __del__(self):
         h = getattr(self, "handle", None)
         if h and _abi is not None and getattr(_abi, "lib", None) is not None:

@@ -8,6 +8,7 @@ from isaaclab_amd.utils.mesh import convert_to_mesh, raycast_mesh
 dev = torch.device("cuda:0")
 verts, tris, h = synth.rough_terrain_mesh(seed=3)
 t0 = time.time(); mesh = convert_to_mesh(verts, tris, "cuda:0"); print("build s", time.time() - t0, "nodes", mesh.num_nodes, "depth", mesh.depth)
+print("grid", mesh.grid_stats())
 g = torch.Generator().manual_seed(0)
 n_env, R = 16384, 187
 xy = torch.rand(n_env, 2, generator=g) * torch.tensor([78.0, 158.0]) + 1
@@ -36,3 +37,12 @@ pv = np.array([[-100, -100, 0], [300, -100, 0], [-100, 300, 0], [300, 300, 0]], 
 plane = convert_to_mesh(pv, np.array([[0, 1, 2], [1, 3, 2]], dtype=np.int32), "cuda:0")
 print("plane cast us", timeit(lambda: raycast_mesh(starts, dirs, plane)))
 print("plane cast (column grid) us", timeit(lambda: raycast_mesh(starts, dirs, plane, z_parallel_hint=True)))
+# the same scan pattern under random sensor yaw, as the bench has it
+yaw = torch.rand(n_env, generator=g) * 6.2832
+cs, sn = torch.cos(yaw)[:, None], torch.sin(yaw)[:, None]
+rot = torch.stack([cs * off[None, :, 0] - sn * off[None, :, 1], sn * off[None, :, 0] + cs * off[None, :, 1]], -1)
+starts_r = torch.cat([(xy[:, None, :] + rot).reshape(-1, 2), torch.full((n_env * R, 1), 20.6)], -1).to(dev).contiguous()
+print("terrain cast, random yaw (column grid) us", timeit(lambda: raycast_mesh(starts_r, dirs, mesh, z_parallel_hint=True)))
+a = raycast_mesh(starts_r, dirs, mesh, return_distance=True, return_face_id=True)
+b = raycast_mesh(starts_r, dirs, mesh, return_distance=True, return_face_id=True, z_parallel_hint=True)
+print("identical:", bool((a[1] == b[1]).all()), bool((a[3] == b[3]).all()))
