@@ -27,6 +27,9 @@ sys.path.insert(0, ROOT)
 NUM_ENVS = 16384
 TERM_EVALS_PER_ENV_STEP = 29  # 8 obs + 9 active rewards + 2 terminations + 1 command + 4 x (actuator + contact) + 1 ray cast
 HBM_PEAK_GBS = 8000.0         # MI355X HBM3E peak (spec); measured float4-copy ceiling is ~6300 GB/s
+MFMA_F32_PEAK_TFLOPS = 157.3  # dense fp32 MFMA peak (256 CUs x 256 FLOP/clk/CU x 2.4 GHz)
+# 6-32-32-32-1 MLP: multiply-adds per row x 2, rows = envs x 12 joints
+MLP_FLOP_PER_ENV = 12 * 2 * (6 * 32 + 32 * 32 + 32 * 32 + 32 * 1)
 
 # Algorithmic bytes per env per launch (each distinct input read once, each output written once; fp32 = 4 B,
 # bool = 1 B, int64 = 8 B; per-joint constants, network weights and the terrain mesh excluded).  J=12, B=17, R=187.
@@ -99,22 +102,37 @@ def time_kernels(env, state, device, reps=20):
                                              _abi.ptr(d.default_joint_pos), 0.0, None, _abi.ptr(d.joint_pos_target), env.n, 12,
                                              _abi.stream()))
 
-    out = {}
-    for name, fn in (("actuator_net_mlp", actuator), ("scene_update", scene), ("raycaster_refresh", rays), ("mdp_step", mdp),
-                     ("joint_action_process", action)):
+    # The launches of one measurement are queued behind a long-running blocker, so that they run back to back on the
+    # device: the host (Python + ctypes, ~10 us per call) would otherwise pace the short kernels and the events would
+    # time its gaps.  Measured per launch = (event span over `reps` queued launches) / reps.
+    blocker_a = torch.randn(4096, 4096, device=device)
+    blocker_out = torch.empty_like(blocker_a)
+
+    def span(fn):
         for _ in range(3):
             fn()
         torch.cuda.synchronize()
-        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
-        for a, b in evs:
-            if name == "raycaster_refresh":
-                env.scanner._is_outdated.fill_(True)  # every env is due, as once per env step
-            a.record()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for _ in range(2):
+            torch.mm(blocker_a, blocker_a, out=blocker_out)
+        a.record()
+        for _ in range(reps):
             fn()
-            b.record()
+        b.record()
         torch.cuda.synchronize()
-        ts = sorted(a.elapsed_time(b) for a, b in evs)
-        out[name] = ts[len(ts) // 2] * 1e3  # median, microseconds
+        return a.elapsed_time(b) * 1e3 / reps  # microseconds per call
+
+    def due():
+        env.scanner._is_outdated.fill_(True)  # every env is due, as once per env step
+
+    def rays_due():
+        due()
+        rays()
+
+    out = {}
+    for name, fn in (("actuator_net_mlp", actuator), ("scene_update", scene), ("mdp_step", mdp), ("joint_action_process", action)):
+        out[name] = span(fn)
+    out["raycaster_refresh"] = span(rays_due) - span(due)
     return out
 
 
@@ -210,7 +228,6 @@ def main():
         value = args.envs * world * args.steps / elapsed
         launches = {"actuator_net_mlp": 4, "scene_update": 4, "raycaster_refresh": 1, "mdp_step": 1, "joint_action_process": 1}
         dominant = max(kern, key=lambda k: kern[k] * launches[k])
-        achieved = BYTES[dominant] * args.envs / (kern[dominant] * 1e-6) / 1e9
         # HBM-side bytes per launch of that kernel from the committed counter passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
         # of this same command, corrected as stated in the file); only meaningful for the env count it was taken at
         traffic = None
@@ -221,6 +238,16 @@ def main():
                 traffic = prof["kernels"][dominant]["hbm_bytes_per_launch"]
         except (OSError, KeyError, ValueError):
             pass
+        if dominant == "actuator_net_mlp":  # the one kernel of the step that is matrix work
+            achieved = MLP_FLOP_PER_ENV * args.envs / (kern[dominant] * 1e-6) / 1e12
+            roofline = {"bound": "mfma", "kernel": dominant, "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": achieved / MFMA_F32_PEAK_TFLOPS, "traffic": traffic, "launch_us": kern[dominant],
+                        "algorithmic_flop_per_launch": MLP_FLOP_PER_ENV * args.envs}
+        else:
+            achieved = BYTES[dominant] * args.envs / (kern[dominant] * 1e-6) / 1e9
+            roofline = {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "launch_us": kern[dominant],
+                        "algorithmic_bytes_per_launch": BYTES[dominant] * args.envs}
         line = {
             "metric": "env-steps/sec (non-physics step) ANYmal-C rough", "value": value, "unit": "env-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
@@ -232,9 +259,7 @@ def main():
             "env_term_steps_per_s": value * TERM_EVALS_PER_ENV_STEP,
             "algorithmic_bytes_per_env_step": BYTES_PER_ENV_STEP,
             "step_hbm_frac": BYTES_PER_ENV_STEP * args.envs / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-            "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "launch_us": kern[dominant], "algorithmic_bytes_per_launch": BYTES[dominant] * args.envs},
+            "roofline": roofline,
             "kernels_us": {k: round(v, 2) for k, v in kern.items()},
         }
         if not args.no_cpu_baseline and world == 1:

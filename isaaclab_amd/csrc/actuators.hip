@@ -12,6 +12,7 @@
 #include "common.h"
 #include "math_dev.h"
 
+#include <algorithm>
 #include <vector>
 
 namespace ilx {
@@ -88,9 +89,11 @@ struct NetArgs {
     float* pe_hist;
     float* v_hist;
     int hist_len;  // K
-    int n_idx;
-    int idx[kMaxHist];
-    int order;  // 0 pos_vel, 1 vel_pos
+    // feature f of the network input (actuator_net.py:160-171: input_idx gather, pos_vel / vel_pos concatenation):
+    // history slot feat_slot[f] (0 = the sample of this call) of the position errors (bit f of feat_is_pos) or velocities
+    int n_feat;
+    int feat_slot[2 * kMaxHist];
+    unsigned feat_is_pos;
     float pos_scale, vel_scale, torque_scale;
     const float* effort_limit;
     const float* vel_limit;
@@ -104,74 +107,110 @@ struct NetArgs {
 
 // Reads the row's inputs, forms the network input features, and hands back the old history values.
 // feat[f] follows actuator_net.py:160-171 (input_idx gather, scaling, pos_vel / vel_pos concatenation).
-struct RowIn {
-    float pe_new0, vel;           // q_des - q, qd
-    float pe_old[kMaxHist - 1];   // previous slots 0..K-2
-    float v_old[kMaxHist - 1];
-    float feat[2 * kMaxHist];
+// H bounds the history length and the number of input indices the instance can hold.
+template <int H>
+struct RowInT {
+    float pe_new0, vel;    // q_des - q, qd
+    float vel_limit, effort_limit;
+    float pe_old[H - 1];   // previous slots 0..K-2
+    float v_old[H - 1];
+    float feat[2 * H];
+};
+using RowIn = RowInT<kMaxHist>;
+
+// Where a row (one (env, joint) pair) lives.  I = int64_t in general; the resident kernel uses uint32_t when the
+// host has checked that every index fits, which keeps 64-bit divisions and address arithmetic off the VALU.
+template <class I>
+struct RowAt {
+    I row, hbase, pidx;  // flat (env, joint) index; index of history slot 0; index of the per-joint parameters
+};
+template <class I>
+ILX_DEV RowAt<I> row_at(const NetArgs& a, I row) {
+    const I env = row / static_cast<I>(a.j);
+    const I joint = row - env * static_cast<I>(a.j);
+    return {row, env * static_cast<I>(a.hist_len) * static_cast<I>(a.j) + joint, a.per_env ? row : joint};
+}
+
+// Row inputs as they come from memory; issue_row only issues the loads (nothing consumes them), so a caller can
+// put a tile's worth of compute between issue_row and finish_row.
+template <int H>
+struct RowRawT {
+    float q_des, q, qd, vel_limit, effort_limit;
+    float pe_old[H - 1], v_old[H - 1];
+    float slot[2 * H];  // history value feeding feature f when it is not the newest sample
 };
 
-ILX_DEV void load_row(const NetArgs& a, int64_t row, bool valid, RowIn& r) {
-    const int64_t env = row / a.j;
-    const int joint = static_cast<int>(row - env * a.j);
-    const int64_t hbase = (env * a.hist_len) * a.j + joint;
-    r.pe_new0 = valid ? (a.q_des[row] - a.q[row]) : 0.0f;
-    r.vel = valid ? a.qd[row] : 0.0f;
-#pragma unroll
-    for (int k = 0; k < kMaxHist - 1; ++k) {
-        const bool on = valid && (k < a.hist_len - 1);
-        r.pe_old[k] = on ? a.pe_hist[hbase + static_cast<int64_t>(k) * a.j] : 0.0f;
-        r.v_old[k] = on ? a.v_hist[hbase + static_cast<int64_t>(k) * a.j] : 0.0f;
+template <int H, class I>
+ILX_DEV void issue_row(const NetArgs& a, const RowAt<I>& at, bool valid, RowRawT<H>& w) {
+    w.q_des = w.q = w.qd = 0.0f;
+    w.vel_limit = w.effort_limit = 1.0f;
+    if (valid) {
+        w.q_des = a.q_des[at.row], w.q = a.q[at.row], w.qd = a.qd[at.row];
+        w.vel_limit = a.vel_limit[at.pidx], w.effort_limit = a.effort_limit[at.pidx];
     }
-    float xp[kMaxHist], xv[kMaxHist];
 #pragma unroll
-    for (int m = 0; m < kMaxHist; ++m) {
-        const int id = a.idx[m];
-        float p = r.pe_new0, v = r.vel;
-#pragma unroll
-        for (int k = 0; k < kMaxHist - 1; ++k) {
-            p = (id == k + 1) ? r.pe_old[k] : p;
-            v = (id == k + 1) ? r.v_old[k] : v;
+    for (int k = 0; k < H - 1; ++k) {
+        w.pe_old[k] = w.v_old[k] = 0.0f;
+        if (valid && k < a.hist_len - 1) {
+            w.pe_old[k] = a.pe_hist[at.hbase + static_cast<I>(k * a.j)];
+            w.v_old[k] = a.v_hist[at.hbase + static_cast<I>(k * a.j)];
         }
-        xp[m] = p * a.pos_scale;
-        xv[m] = v * a.vel_scale;
     }
+    // which history slot feeds feature f is the same for all rows (resolved on the host): one more (cached) read
 #pragma unroll
-    for (int f = 0; f < 2 * kMaxHist; ++f) {
+    for (int f = 0; f < 2 * H; ++f) {
+        w.slot[f] = 0.0f;
+        if (f < a.n_feat && a.feat_slot[f] > 0 && valid)
+            w.slot[f] = (((a.feat_is_pos >> f) & 1) ? a.pe_hist : a.v_hist)[at.hbase + static_cast<I>((a.feat_slot[f] - 1) * a.j)];
+    }
+}
+
+template <int H>
+ILX_DEV void finish_row(const NetArgs& a, const RowRawT<H>& w, RowInT<H>& r) {
+    r.pe_new0 = w.q_des - w.q;
+    r.vel = w.qd;
+    r.vel_limit = w.vel_limit, r.effort_limit = w.effort_limit;
+#pragma unroll
+    for (int k = 0; k < H - 1; ++k) r.pe_old[k] = w.pe_old[k], r.v_old[k] = w.v_old[k];
+#pragma unroll
+    for (int f = 0; f < 2 * H; ++f) {
         float val = 0.0f;
-#pragma unroll
-        for (int m = 0; m < kMaxHist; ++m) {
-            const float first = a.order == 0 ? xp[m] : xv[m];
-            const float second = a.order == 0 ? xv[m] : xp[m];
-            val = (f == m && m < a.n_idx) ? first : val;
-            val = (f == m + a.n_idx && m < a.n_idx) ? second : val;
+        if (f < a.n_feat) {
+            const bool pos = (a.feat_is_pos >> f) & 1;
+            const float v = a.feat_slot[f] > 0 ? w.slot[f] : (pos ? r.pe_new0 : r.vel);
+            val = v * (pos ? a.pos_scale : a.vel_scale);
         }
         r.feat[f] = val;
     }
 }
 
+template <int H, class I>
+ILX_DEV void load_row(const NetArgs& a, const RowAt<I>& at, bool valid, RowInT<H>& r) {
+    RowRawT<H> w;
+    issue_row(a, at, valid, w);
+    finish_row(a, w, r);
+}
+
 // actuator_net.py:150-156: roll both histories by one slot and write the newest sample into slot 0.
-ILX_DEV void store_history(const NetArgs& a, int64_t row, const RowIn& r, bool do_pos, bool do_vel) {
-    const int64_t env = row / a.j;
-    const int joint = static_cast<int>(row - env * a.j);
-    const int64_t hbase = (env * a.hist_len) * a.j + joint;
-    if (do_pos) a.pe_hist[hbase] = r.pe_new0;
-    if (do_vel) a.v_hist[hbase] = r.vel;
+template <int H, class I>
+ILX_DEV void store_history(const NetArgs& a, const RowAt<I>& at, const RowInT<H>& r, bool do_pos, bool do_vel) {
+    if (do_pos) a.pe_hist[at.hbase] = r.pe_new0;
+    if (do_vel) a.v_hist[at.hbase] = r.vel;
 #pragma unroll
-    for (int k = 0; k < kMaxHist - 1; ++k) {
+    for (int k = 0; k < H - 1; ++k) {
         if (k < a.hist_len - 1) {
-            const int64_t o = hbase + static_cast<int64_t>(k + 1) * a.j;
+            const I o = at.hbase + static_cast<I>((k + 1) * a.j);
             if (do_pos) a.pe_hist[o] = r.pe_old[k];
             if (do_vel) a.v_hist[o] = r.v_old[k];
         }
     }
 }
 
-ILX_DEV void store_torque(const NetArgs& a, int64_t row, float net_out, float vel) {
-    const int64_t pi = a.per_env ? row : (row % a.j);
+template <int H, class I>
+ILX_DEV void store_torque(const NetArgs& a, const RowAt<I>& at, float net_out, const RowInT<H>& r) {
     const float tau = net_out * a.torque_scale;  // actuator_net.py:179
-    a.computed[row] = tau;
-    a.applied[row] = dc_motor_clip(tau, vel, a.sat, a.vel_limit[pi], a.effort_limit[pi]);
+    a.computed[at.row] = tau;
+    a.applied[at.row] = dc_motor_clip(tau, r.vel, a.sat, r.vel_limit, r.effort_limit);
 }
 
 // ---- generic path ------------------------------------------------------------------------------
@@ -183,7 +222,8 @@ __global__ void __launch_bounds__(128) mlp_generic_kernel(NetArgs a) {
     const int64_t row = static_cast<int64_t>(blockIdx.x) * blockDim.x + t;
     const bool valid = row < a.rows;
     RowIn r;
-    load_row(a, valid ? row : 0, valid, r);
+    const RowAt<int64_t> at = row_at<int64_t>(a, valid ? row : 0);
+    load_row(a, at, valid, r);
 #pragma unroll
     for (int f = 0; f < 2 * kMaxHist; ++f) act[0][f][t] = r.feat[f];
     const float* p = a.net.raw;
@@ -205,8 +245,8 @@ __global__ void __launch_bounds__(128) mlp_generic_kernel(NetArgs a) {
         cur ^= 1;
     }
     if (valid) {
-        store_torque(a, row, out, r.vel);
-        store_history(a, row, r, true, true);
+        store_torque(a, at, out, r);
+        store_history(a, at, r, true, true);
     }
 }
 
@@ -247,7 +287,8 @@ __global__ void __launch_bounds__(256) mlp_mfma_kernel(NetArgs a) {
     const float* pk = a.net.packed;
 
     RowIn r;
-    load_row(a, valid ? row : 0, valid, r);
+    const RowAt<int64_t> at = row_at<int64_t>(a, valid ? row : 0);
+    load_row(a, at, valid, r);
 
     // ---- layer 0: K = in_dim, two features per MFMA (half 0 feeds the even one, half 1 the odd one)
     const float* bias = pk + a.net.ks0 * 64;
@@ -285,8 +326,108 @@ __global__ void __launch_bounds__(256) mlp_mfma_kernel(NetArgs a) {
     const float out = (half ? other + part : part + other) + wo[1024];
 
     if (valid) {
-        if (half == 0) store_torque(a, row, out, r.vel);
-        store_history(a, row, r, half == 0, half == 1);
+        if (half == 0) store_torque(a, at, out, r);
+        store_history(a, at, r, half == 0, half == 1);
+    }
+}
+
+// The same evaluation for the common depths (2 or 3 hidden layers), arranged for the latency-bound regime this
+// launch lives in (a few tiles per SIMD): every wave keeps ALL packed weights in registers (~100), walks several
+// tiles, and has the inputs of its next tile in flight while it computes the current one, so neither weight loads
+// nor the HBM round trip of the row inputs sit between MFMAs.  Two waves per SIMD: one wave's activations (VALU)
+// run under the other wave's MFMAs.  Operation order is that of mlp_mfma_kernel, so both give the same bits.
+// (Measured alternatives: weights in LDS with 3-6 waves per SIMD -- the compiler hoists the loop-invariant reads
+// back into registers and spills; one tile per wave at 6 waves per SIMD is 8-10 % slower.)
+constexpr int kResidentHist = 4;  // the resident kernel serves histories and input index lists up to this length
+
+template <int ACT, int NHID>
+__global__ void __launch_bounds__(256, 2) mlp_mfma_resident_kernel(NetArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int half = lane >> 5;
+    const int64_t tiles = (a.rows + 31) / 32;
+    const int64_t nwaves = static_cast<int64_t>(gridDim.x) * (blockDim.x >> 6);
+    int64_t tile = static_cast<int64_t>(blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (tile >= tiles) return;  // wave-uniform
+    const float* pk = a.net.packed;
+    const int ks0 = a.net.ks0;
+    float w0[kResidentHist];
+#pragma unroll
+    for (int s = 0; s < kResidentHist; ++s) w0[s] = s < ks0 ? pk[s * 64 + lane] : 0.0f;
+    const float* bias_p = pk + ks0 * 64;
+    const float* wts_p = bias_p + NHID * 1024;
+    f32x16 bias[NHID];
+    float wh[NHID > 1 ? NHID - 1 : 1][16];
+    float wo[16];
+#pragma unroll
+    for (int l = 0; l < NHID; ++l)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) bias[l][k] = bias_p[l * 1024 + k * 64 + lane];
+#pragma unroll
+    for (int l = 0; l + 1 < NHID; ++l)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) wh[l][k] = wts_p[l * 1024 + k * 64 + lane];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) wo[k] = wts_p[(NHID - 1) * 1024 + k * 64 + lane];
+    const float bo = wts_p[(NHID - 1) * 1024 + 1024];
+
+    // rows of a tile: the tile's first row is wave-uniform, so its env / joint split is scalar work and a lane only
+    // adds its offset (< 32) with a small exact division
+    const uint32_t j = static_cast<uint32_t>(a.j);
+    const float inv_j = 1.0f / static_cast<float>(j);
+    auto tile_row = [&](int64_t t) {
+        const uint32_t row0 = static_cast<uint32_t>(t) * 32u;
+        const uint32_t env0 = row0 / j, joint0 = row0 - env0 * j;
+        const uint32_t x = joint0 + (lane & 31);                      // < j + 32
+        uint32_t q = static_cast<uint32_t>(static_cast<float>(x) * inv_j);  // exact up to +-1 for x < 2^22
+        q = (q * j > x) ? q - 1 : q;
+        q = ((q + 1) * j <= x) ? q + 1 : q;
+        const uint32_t env = env0 + q, joint = x - q * j, row = row0 + (lane & 31);
+        const bool valid = row < static_cast<uint32_t>(a.rows);
+        const RowAt<uint32_t> at = {valid ? row : 0u, valid ? env * static_cast<uint32_t>(a.hist_len) * j + joint : 0u,
+                                    valid ? (a.per_env ? row : joint) : 0u};
+        return at;
+    };
+    RowInT<kResidentHist> cur;
+    RowRawT<kResidentHist> ahead;
+    RowAt<uint32_t> at = tile_row(tile), at_next = at;
+    load_row(a, at, tile * 32 + (lane & 31) < a.rows, cur);
+    for (; tile < tiles; tile += nwaves) {
+        const bool valid = tile * 32 + (lane & 31) < a.rows;
+        const bool more = tile + nwaves < tiles;
+        if (more) {  // the next tile's inputs travel while this tile computes
+            at_next = tile_row(tile + nwaves);
+            issue_row(a, at_next, (tile + nwaves) * 32 + (lane & 31) < a.rows, ahead);
+        }
+
+        f32x16 acc = bias[0];
+#pragma unroll
+        for (int s = 0; s < kResidentHist; ++s) {
+            if (s < ks0) {
+                const float bop = half ? cur.feat[2 * s + 1] : cur.feat[2 * s];
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w0[s], bop, acc, 0, 0, 0);
+            }
+        }
+        acc = activate16<ACT>(acc);
+#pragma unroll
+        for (int l = 1; l < NHID; ++l) {
+            f32x16 y = bias[l];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) y = __builtin_amdgcn_mfma_f32_32x32x2f32(wh[l - 1][k], acc[k], y, 0, 0, 0);
+            acc = activate16<ACT>(y);
+        }
+        float part = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) part = fmaf_(wo[k], acc[k], part);
+        const float other = __shfl_xor(part, 32, 64);
+        const float out = (half ? other + part : part + other) + bo;
+        RowInT<kResidentHist> upcoming = cur;
+        if (more) finish_row(a, ahead, upcoming);  // before this tile's stores: waiting for loads must not wait for them
+        if (valid) {
+            if (half == 0) store_torque(a, at, out, cur);
+            store_history(a, at, cur, half == 0, half == 1);
+        }
+        cur = upcoming;
+        at = at_next;
     }
 }
 
@@ -410,11 +551,35 @@ extern "C" int ilx_actuator_pd(int model, const float* q_des, const float* qd_de
     return ILX_OK;
 }
 
+// Compute units of the current device (queried once per device).
+static int num_cus() {
+    static int cached[64] = {0};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64) return 256;
+    if (cached[dev] == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cached[dev] = n;
+    }
+    return cached[dev];
+}
+
 template <int ACT>
 static void launch_mlp(const NetArgs& a, bool force_generic, hipStream_t s) {
     if (a.net.packed && !force_generic) {
         const int64_t tiles = (a.rows + 31) / 32;
-        hipLaunchKernelGGL(mlp_mfma_kernel<ACT>, dim3(static_cast<unsigned>((tiles + 3) / 4)), dim3(256), 0, s, a);
+        const int nhid = a.net.num_layers - 1;
+        // resident-weight kernel: two 4-wave blocks per CU, each wave walks tiles with that stride; it indexes with 32 bits
+        const unsigned resident_blocks = static_cast<unsigned>(std::min<int64_t>((tiles + 3) / 4, int64_t(2) * num_cus()));
+        const bool small = a.hist_len <= kResidentHist && a.n_feat <= 2 * kResidentHist && a.j < (1 << 20) &&
+                           a.rows * a.hist_len < (int64_t(1) << 31);
+        if (nhid == 3 && small)
+            hipLaunchKernelGGL((mlp_mfma_resident_kernel<ACT, 3>), dim3(resident_blocks), dim3(256), 0, s, a);
+        else if (nhid == 2 && small)
+            hipLaunchKernelGGL((mlp_mfma_resident_kernel<ACT, 2>), dim3(resident_blocks), dim3(256), 0, s, a);
+        else
+            hipLaunchKernelGGL(mlp_mfma_kernel<ACT>, dim3(static_cast<unsigned>((tiles + 3) / 4)), dim3(256), 0, s, a);
     } else {
         hipLaunchKernelGGL(mlp_generic_kernel<ACT>, dim3(blocks_for(a.rows, 128)), dim3(128), 0, s, a);
     }
@@ -443,13 +608,15 @@ extern "C" int ilx_actuator_net_mlp(ilx_mlp_t net, const float* q_des, const flo
     a.q_des = q_des, a.q = q, a.qd = qd;
     a.pe_hist = pos_error_history, a.v_hist = velocity_history;
     a.hist_len = history_length;
-    a.n_idx = num_input_idx;
-    for (int m = 0; m < kMaxHist; ++m) {
-        a.idx[m] = m < num_input_idx ? input_idx_host[m] : 0;
-        ILX_REQUIRE(a.idx[m] >= 0 && a.idx[m] < history_length, ILX_EINVAL,
-                    "ilx_actuator_net_mlp: input index %d outside the history (length %d)", a.idx[m], history_length);
+    a.n_feat = 2 * num_input_idx;
+    a.feat_is_pos = 0u;
+    for (int f = 0; f < 2 * kMaxHist; ++f) a.feat_slot[f] = 0;
+    for (int m = 0; m < num_input_idx; ++m) {
+        ILX_REQUIRE(input_idx_host[m] >= 0 && input_idx_host[m] < history_length, ILX_EINVAL,
+                    "ilx_actuator_net_mlp: input index %d outside the history (length %d)", input_idx_host[m], history_length);
+        a.feat_slot[m] = a.feat_slot[m + num_input_idx] = input_idx_host[m];
+        a.feat_is_pos |= 1u << (input_order == 0 ? m : m + num_input_idx);  // pos_vel: positions first
     }
-    a.order = input_order;
     a.pos_scale = pos_scale, a.vel_scale = vel_scale, a.torque_scale = torque_scale;
     a.effort_limit = effort_limit, a.vel_limit = velocity_limit, a.per_env = params_per_env, a.sat = saturation_effort;
     a.computed = computed, a.applied = applied;

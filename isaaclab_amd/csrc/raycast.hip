@@ -25,7 +25,6 @@
 
 #include <algorithm>
 #include <cmath>
-#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <numeric>
@@ -40,7 +39,8 @@ constexpr int kMaxDepth = 12;
 constexpr int kCachedNodes = 85;      // levels 0..3 of the 4-wide tree
 constexpr int kRayBlock = 256;
 constexpr int kEmptyRef = INT32_MIN;
-constexpr double kGridCellsPerTriangle = 8.0;  // column grid resolution
+constexpr double kGridCellsPerTriangle = 8.0;  // column grid resolution over the mesh's bounding rectangle (measured on the
+                                               // 2.56 M-triangle terrain: 2 -> 164 us, 4 -> 140, 8 -> 116, 16 -> 117)
 constexpr int kGridTile = 16;                  // cell words, column triangles and vertices are stored in tiles of 16 x 16 cells
 constexpr double kGridPhase = 0.5;             // the grid starts this fraction of a cell before the mesh: triangle edges
                                                // of a regular height field then run through cells, not along cell borders
@@ -673,9 +673,7 @@ extern "C" int ilx_mesh_create(const float* verts_host, int64_t num_verts, const
         const double wx = std::max(double(g1[0]) - m0[0], 1e-6), wy = std::max(double(g1[1]) - m0[1], 1e-6);
         const double span = std::max(std::max(std::fabs(double(m0[0])), std::fabs(double(g1[0]))),
                                      std::max(std::fabs(double(m0[1])), std::fabs(double(g1[1])))) + std::max(wx, wy);
-        double density = kGridCellsPerTriangle;
-        if (const char* e = std::getenv("ILX_GRID_DENSITY")) density = std::atof(e);
-        double cell = std::sqrt(wx * wy / (density * nt));
+        double cell = std::sqrt(wx * wy / (kGridCellsPerTriangle * nt));
         cell = std::max(cell, std::max(wx, wy) / 8192.0);
         const int64_t max_refs = std::min<int64_t>(std::max<int64_t>(int64_t(64) * nt, 1 << 16), kCellIndexMask - 8);
         for (int attempt = 0; attempt < 12; ++attempt, cell *= 2.0) {
