@@ -45,3 +45,13 @@ class ActuatorNetMLPCfg(DCMotorCfg):
     torque_scale: float = 1.0
     input_order: Literal["pos_vel", "vel_pos"] = "pos_vel"
     input_idx: list[int] = field(default_factory=lambda: [0, 1, 2])
+
+
+@dataclass
+class ActuatorNetLSTMCfg(DCMotorCfg):
+    """``network_file`` may be a path to a ``torch.save``'d state-dict holding the ``lstm.*`` parameters of a
+    ``torch.nn.LSTM`` and the ``<k>.weight`` / ``<k>.bias`` pairs of the Linear head after it, or ``network`` may carry them
+    directly as ``{"lstm": {"weight_ih_l0": ..., ...}, "weights": [...], "biases": [...], "activation": "softsign"}``."""
+
+    network_file: str | None = None
+    network: dict | None = None

@@ -1,9 +1,10 @@
-"""Actuator-network model on the fused HIP kernel ``ilx_actuator_net_mlp``
-(interface of ``isaaclab/actuators/actuator_net.py:102-188``).
+"""Actuator-network models on the fused HIP kernels ``ilx_actuator_net_mlp`` / ``ilx_actuator_net_lstm``
+(interface of ``isaaclab/actuators/actuator_net.py``).
 
-The reference loads an arbitrary TorchScript module; here the network is a stack of Linear layers with one
-activation (softsign / elu / tanh / relu), given as tensors.  History roll, input gather, the network and the
-DC-motor clip run in a single launch; hidden width 32 uses fp32 MFMA.
+The reference loads arbitrary TorchScript modules; here the MLP is a stack of Linear layers with one activation
+(softsign / elu / tanh / relu) and the LSTM net is a ``torch.nn.LSTM`` followed by such a stack, both given as tensors.
+History roll / recurrent state update, the network and the DC-motor clip run in a single launch; an MLP of hidden
+width 32 uses fp32 MFMA.
 """
 
 from __future__ import annotations
@@ -57,6 +58,85 @@ def load_network(cfg, device) -> tuple[list[torch.Tensor], list[torch.Tensor], s
     sd = torch.load(cfg.network_file, map_location="cpu", weights_only=True)
     keys = sorted({k.rsplit(".", 1)[0] for k in sd if k.endswith(".weight")}, key=lambda s: [int(t) if t.isdigit() else t for t in s.split(".")])
     return [sd[k + ".weight"] for k in keys], [sd[k + ".bias"] for k in keys], sd.get("activation", "softsign")
+
+
+class LstmHandle:
+    """Owns an ``ilx_lstm_t`` (device copy of the LSTM parameters in kernel order)."""
+
+    def __init__(self, params: dict[str, torch.Tensor]):
+        layers = len([k for k in params if k.startswith("weight_ih_l")])
+        if layers == 0 or len(params) != 4 * layers:
+            raise ValueError("expected weight_ih_l*, weight_hh_l*, bias_ih_l*, bias_hh_l* of a unidirectional torch.nn.LSTM")
+        p = {k: v.detach().to("cpu", torch.float32).contiguous() for k, v in params.items()}
+        self.hidden_dim = p["weight_hh_l0"].shape[1]
+        self.input_size = p["weight_ih_l0"].shape[1]
+        self.num_layers = layers
+        for l in range(layers):
+            in_l = self.input_size if l == 0 else self.hidden_dim
+            want = {"weight_ih": (4 * self.hidden_dim, in_l), "weight_hh": (4 * self.hidden_dim, self.hidden_dim),
+                    "bias_ih": (4 * self.hidden_dim,), "bias_hh": (4 * self.hidden_dim,)}
+            for nm, shape in want.items():
+                if tuple(p[f"{nm}_l{l}"].shape) != shape:
+                    raise ValueError(f"{nm}_l{l}: shape {tuple(p[f'{nm}_l{l}'].shape)}, expected {shape}")
+        arr = lambda nm: (ctypes.c_void_p * layers)(*[p[f"{nm}_l{l}"].data_ptr() for l in range(layers)])
+        self.handle = ctypes.c_void_p()
+        _abi.check(_abi.lstm_create(layers, self.input_size, self.hidden_dim, arr("weight_ih"), arr("weight_hh"), arr("bias_ih"),
+                                    arr("bias_hh"), ctypes.byref(self.handle)), "ilx_lstm_create")
+
+    def __del__(self):
+        h = getattr(self, "handle", None)
+        if h and _abi is not None and getattr(_abi, "lib", None) is not None:
+            _abi.lib.ilx_lstm_destroy(h)
+            self.handle = None
+
+
+def load_lstm_network(cfg):
+    """(lstm parameter dict, head weights, head biases, head activation) from ``cfg.network`` or a state-dict file."""
+    if getattr(cfg, "network", None) is not None:
+        net = cfg.network
+        return dict(net["lstm"]), list(net["weights"]), list(net["biases"]), net.get("activation", "softsign")
+    if not cfg.network_file:
+        raise ValueError("ActuatorNetLSTMCfg needs `network` or `network_file`")
+    sd = torch.load(cfg.network_file, map_location="cpu", weights_only=True)
+    lstm = {k.split("lstm.", 1)[1]: v for k, v in sd.items() if k.startswith("lstm.")}
+    rest = {k: v for k, v in sd.items() if not k.startswith("lstm.") and torch.is_tensor(v)}
+    keys = sorted({k.rsplit(".", 1)[0] for k in rest if k.endswith(".weight")}, key=lambda s: [int(t) if t.isdigit() else t for t in s.split(".")])
+    return lstm, [rest[k + ".weight"] for k in keys], [rest[k + ".bias"] for k in keys], sd.get("activation", "softsign")
+
+
+class ActuatorNetLSTM(DCMotor):
+    """actuator_net.py:30-99."""
+
+    def __init__(self, cfg, *args, **kwargs):
+        super().__init__(cfg, *args, **kwargs)
+        lstm, weights, biases, activation = load_lstm_network(cfg)
+        self.lstm = LstmHandle(lstm)
+        self.head = MlpHandle(weights, biases, activation)
+        rows = self._num_envs * self.num_joints
+        num_layers, hidden_dim = self.lstm.num_layers, self.lstm.hidden_dim
+        self.sea_hidden_state = torch.zeros(num_layers, rows, hidden_dim, device=self._device)
+        self.sea_cell_state = torch.zeros(num_layers, rows, hidden_dim, device=self._device)
+        layer_shape_per_env = (num_layers, self._num_envs, self.num_joints, hidden_dim)
+        self.sea_hidden_state_per_env = self.sea_hidden_state.view(layer_shape_per_env)
+        self.sea_cell_state_per_env = self.sea_cell_state.view(layer_shape_per_env)
+
+    def reset(self, env_ids: Sequence[int]):
+        self.sea_hidden_state_per_env[:, env_ids] = 0.0
+        self.sea_cell_state_per_env[:, env_ids] = 0.0
+
+    def compute(self, control_action, joint_pos, joint_vel):
+        q_des, q, qd = _abi.f32c(control_action.joint_positions), _abi.f32c(joint_pos), _abi.f32c(joint_vel)
+        n, j = q.shape
+        self._joint_vel = joint_vel
+        _abi.check(_abi.actuator_net_lstm(
+            self.lstm.handle, self.head.handle, _abi.ptr(q_des), _abi.ptr(q), _abi.ptr(qd), _abi.ptr(self.sea_hidden_state),
+            _abi.ptr(self.sea_cell_state), _abi.ptr(self.effort_limit), _abi.ptr(self.velocity_limit), 1,
+            float(self._saturation_effort), _abi.ptr(self.computed_effort), _abi.ptr(self.applied_effort), n, j, _abi.stream()),
+            "ilx_actuator_net_lstm")
+        control_action.joint_efforts = self.applied_effort
+        control_action.joint_positions = None
+        control_action.joint_velocities = None
+        return control_action
 
 
 class ActuatorNetMLP(DCMotor):

@@ -11,6 +11,7 @@
 //      - generic path: any widths <= 64, one thread per row, activations staged through LDS.
 #include "common.h"
 #include "math_dev.h"
+#include "mlp_net.h"
 
 #include <algorithm>
 #include <vector>
@@ -20,16 +21,6 @@ namespace ilx {
 // ------------------------------------------------------------------------------------------------
 // PD family
 // ------------------------------------------------------------------------------------------------
-// actuator_pd.py:223-233
-ILX_DEV float dc_motor_clip(float effort, float qd, float sat, float vel_limit, float effort_limit) {
-    const float ratio = div_(qd, vel_limit);
-    float mx = sat * (1.0f - ratio);
-    mx = fminf(fmaxf(mx, 0.0f), effort_limit);
-    float mn = sat * (-1.0f - ratio);
-    mn = fminf(fmaxf(mn, -effort_limit), 0.0f);
-    return fminf(fmaxf(effort, mn), mx);
-}
-
 template <int MODEL>
 __global__ void __launch_bounds__(256)
 actuator_pd_kernel(const float* __restrict__ q_des, const float* __restrict__ qd_des, const float* __restrict__ tau_ff,
@@ -59,27 +50,7 @@ actuator_pd_kernel(const float* __restrict__ q_des, const float* __restrict__ qd
 // ------------------------------------------------------------------------------------------------
 // MLP
 // ------------------------------------------------------------------------------------------------
-constexpr int kMaxLayers = 8;
-constexpr int kMaxWidth = 64;
 constexpr int kMaxHist = 8;
-
-template <int ACT>
-ILX_DEV float activate(float x) {
-    if (ACT == ILX_ACT_SOFTSIGN) return div_(x, 1.0f + fabsf(x));
-    if (ACT == ILX_ACT_ELU) return x > 0.0f ? x : (expf(x) - 1.0f);
-    if (ACT == ILX_ACT_TANH) return tanhf(x);
-    if (ACT == ILX_ACT_RELU) return fmaxf(x, 0.0f);
-    return x;
-}
-
-struct MlpDev {
-    int num_layers;               // linear layers
-    int dims[kMaxLayers + 1];     // in, h1, ..., out
-    int act;
-    const float* raw;             // per layer: W (out x in, row-major) then b (out)
-    const float* packed;          // MFMA operand order, or nullptr
-    int ks0;                      // k-steps of the first layer (ceil(in/2))
-};
 
 struct NetArgs {
     MlpDev net;
@@ -431,20 +402,9 @@ __global__ void __launch_bounds__(256, 2) mlp_mfma_resident_kernel(NetArgs a) {
     }
 }
 
-struct MlpHost {
-    MlpDev dev;
-    float* d_raw = nullptr;
-    float* d_packed = nullptr;
-    int device = 0;
-};
-
 }  // namespace ilx
 
 using namespace ilx;
-
-struct ilx_mlp_s {
-    MlpHost h;
-};
 
 extern "C" int ilx_mlp_create(int num_layers, const int32_t* dims, int activation, const float* const* weights_host,
                               const float* const* biases_host, ilx_mlp_t* out) {
@@ -479,6 +439,7 @@ extern "C" int ilx_mlp_create(int num_layers, const int32_t* dims, int activatio
                                      "ilx_mlp_create: hipMemcpy");
     h.dev.raw = h.d_raw;
     h.dev.packed = nullptr;
+    h.raw_floats = static_cast<int>(raw.size());
 
     bool mfma = num_layers >= 2;
     for (int l = 1; l < num_layers; ++l) mfma = mfma && dims[l] == 32;

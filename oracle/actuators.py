@@ -88,3 +88,39 @@ def actuator_net_mlp(
     computed = torques * torque_scale
     applied = dc_motor_clip(computed, qd, saturation_effort, velocity_limit, effort_limit)
     return computed, applied, pe, vh
+
+
+def lstm_cell_stack(x, hidden, cell, w_ih, w_hh, b_ih, b_hh):
+    """One time step of a multi-layer ``torch.nn.LSTM`` (the module ``ActuatorNetLSTM`` drives with a length-1 sequence,
+    actuator_net.py:86-89), written out: per layer ``gates = W_ih x + b_ih + W_hh h + b_hh``, chunks (i, f, g, o),
+    ``c' = sigmoid(f) c + sigmoid(i) tanh(g)``, ``h' = sigmoid(o) tanh(c')``; layer l + 1 takes h' of layer l.
+
+    ``x`` (R, In); ``hidden`` / ``cell`` (L, R, H).  Returns (output of the last layer (R, H), new hidden, new cell).
+    """
+    new_h, new_c = [], []
+    inp = x
+    for l in range(hidden.shape[0]):
+        gates = torch.nn.functional.linear(inp, w_ih[l], b_ih[l]) + torch.nn.functional.linear(hidden[l], w_hh[l], b_hh[l])
+        i, f, g, o = gates.chunk(4, dim=1)
+        c = torch.sigmoid(f) * cell[l] + torch.sigmoid(i) * torch.tanh(g)
+        h = torch.sigmoid(o) * torch.tanh(c)
+        new_h.append(h)
+        new_c.append(c)
+        inp = h
+    return inp, torch.stack(new_h), torch.stack(new_c)
+
+
+def actuator_net_lstm(q_des, q, qd, hidden, cell, lstm, head_weights, head_biases, head_activation, effort_limit,
+                      velocity_limit, saturation_effort):
+    """ActuatorNetLSTM.compute (actuator_net.py:76-99).
+
+    Network input per (env, joint) row = (position error, velocity); ``hidden`` / ``cell`` are the (L, N*J, H) states the
+    reference keeps on the actuator; ``lstm`` = (w_ih, w_hh, b_ih, b_hh) lists per layer; the head maps the last layer's
+    output to one torque.  Returns (computed, applied, new_hidden, new_cell).
+    """
+    n, j = q.shape
+    x = torch.stack([(q_des - q).flatten(), qd.flatten()], dim=1)
+    out, h, c = lstm_cell_stack(x, hidden, cell, *lstm)
+    computed = mlp_forward(out, head_weights, head_biases, head_activation).reshape(n, j)
+    applied = dc_motor_clip(computed, qd, saturation_effort, velocity_limit, effort_limit)
+    return computed, applied, h, c

@@ -145,6 +145,75 @@ def actuators_mlp():
     save("actuators_mlp", **out)
 
 
+class LstmNet(torch.nn.Module):
+    """Shape of the reference's LSTM actuator nets (actuator_net.py:48-54 reads ``network.lstm``): an ``nn.LSTM`` over
+    (position error, velocity) followed by a small head on the last layer's output."""
+
+    def __init__(self, hidden: int, layers: int, head: list[int], act: str):
+        super().__init__()
+        acts = {"softsign": torch.nn.Softsign, "elu": torch.nn.ELU, "tanh": torch.nn.Tanh, "relu": torch.nn.ReLU}
+        self.lstm = torch.nn.LSTM(2, hidden, layers, batch_first=True)
+        mods, d = [], hidden
+        for w in head:
+            mods += [torch.nn.Linear(d, w), acts[act]()]
+            d = w
+        mods.append(torch.nn.Linear(d, 1))
+        self.mlp = torch.nn.Sequential(*mods)
+
+    def forward(self, x: torch.Tensor, hc: tuple[torch.Tensor, torch.Tensor]):
+        out, hc2 = self.lstm(x, hc)
+        return self.mlp(out[:, -1]), hc2
+
+
+@section
+def actuators_lstm():
+    m = R.bootstrap()
+    Types = m["types"]
+    netmod = m["actuator_net"]
+    g = gen(11)
+    n, j, steps = 40, 12, 8
+    out = {}
+    for tag, hidden, layers, head, act_name in (("anydrive", 8, 2, [32], "softsign"), ("wide", 16, 3, [], "tanh")):
+        net = LstmNet(hidden, layers, head, act_name)
+        with torch.no_grad():
+            for prm in net.parameters():
+                prm.copy_(torch.randn(prm.shape, generator=g) * (0.4 if prm.dim() > 1 else 0.1))
+        buf = io.BytesIO()
+        torch.jit.save(torch.jit.script(net), buf)
+        buf.seek(0)
+        sys.modules["isaaclab.utils.assets"].read_file = lambda p, b=buf: b
+        netmod.read_file = lambda p, b=buf: b
+        # ANYmal-C ANYdrive 3 constants (isaaclab_assets/robots/anymal.py:43-51)
+        cfg = Cfg(joint_names_expr=[".*"], armature=None, friction=None, stiffness=None, damping=None,
+                  network_file="synthetic", effort_limit=80.0, velocity_limit=7.5, saturation_effort=120.0)
+        act = netmod.ActuatorNetLSTM(cfg, joint_names=_names(j), joint_ids=slice(None), num_envs=n, device="cpu",
+                                     stiffness=0.0, damping=0.0)
+        rec = dict(q_des=[], q=[], qd=[], computed=[], applied=[], hidden=[], cell=[])
+        for s in range(steps):
+            q_des = torch.randn(n, j, generator=g)
+            q = q_des + torch.randn(n, j, generator=g) * 0.3
+            qd = torch.randn(n, j, generator=g) * 4.0
+            if s == 5:
+                act.reset([1, 3])
+            ca = Types.ArticulationActions(joint_positions=q_des.clone(), joint_velocities=torch.zeros(n, j),
+                                           joint_efforts=torch.zeros(n, j), joint_indices=slice(None))
+            act.compute(ca, q.clone(), qd.clone())
+            for k, v in zip(rec, (q_des, q, qd, act.computed_effort.detach().clone(), act.applied_effort.detach().clone(),
+                                  act.sea_hidden_state.clone(), act.sea_cell_state.clone())):
+                rec[k].append(v)
+        out.update({f"{tag}_{k}": torch.stack(v) for k, v in rec.items()})
+        sd = net.lstm.state_dict()
+        for li in range(layers):
+            for nm in ("weight_ih", "weight_hh", "bias_ih", "bias_hh"):
+                out[f"{tag}_{nm}_l{li}"] = sd[f"{nm}_l{li}"].detach()
+        lin = [mod for mod in net.mlp if isinstance(mod, torch.nn.Linear)]
+        for li, mod in enumerate(lin):
+            out[f"{tag}_head_w{li}"] = mod.weight.detach()
+            out[f"{tag}_head_b{li}"] = mod.bias.detach()
+        out[f"{tag}_shape"] = torch.tensor([hidden, layers, len(lin)])
+    save("actuators_lstm", **out)
+
+
 @section
 def articulation_data():
     """Real ArticulationData on a fake physics view: derived root quantities and joint_acc."""

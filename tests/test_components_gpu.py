@@ -116,6 +116,72 @@ def test_actuator_net_mlp_anymal_shape_vs_oracle(dev):
             assert_close(act.applied_effort, app, atol=2e-5, what=f"n={n} applied step {s}")
 
 
+def _lstm_net(g, tag, act):
+    hidden, layers, nhead = (int(v) for v in g[f"{tag}_shape"])
+    lstm = {f"{nm}_l{l}": g[f"{tag}_{nm}_l{l}"] for l in range(layers) for nm in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")}
+    return dict(lstm=lstm, weights=[g[f"{tag}_head_w{i}"] for i in range(nhead)],
+                biases=[g[f"{tag}_head_b{i}"] for i in range(nhead)], activation=act)
+
+
+def test_actuator_net_lstm(dev):
+    """ActuatorNetLSTM against the reference class's fixture (8 substeps, a reset before step 5)."""
+    from isaaclab_amd.actuators import ActuatorNetLSTM, ActuatorNetLSTMCfg
+    from isaaclab_amd.utils.types import ArticulationActions
+
+    g = load_golden("actuators_lstm")
+    for tag, actname in (("anydrive", "softsign"), ("wide", "tanh")):
+        n, j = g[f"{tag}_q"].shape[1:]
+        cfg = ActuatorNetLSTMCfg(network=_lstm_net(g, tag, actname), effort_limit=80.0, velocity_limit=7.5, saturation_effort=120.0)
+        act = ActuatorNetLSTM(cfg, joint_names=_names(j), joint_ids=slice(None), num_envs=n, device=dev)
+        for s in range(g[f"{tag}_q"].shape[0]):
+            if s == 5:
+                act.reset([1, 3])
+            out = act.compute(ArticulationActions(joint_positions=g[f"{tag}_q_des"][s].to(dev)), g[f"{tag}_q"][s].to(dev),
+                              g[f"{tag}_qd"][s].to(dev))
+            # gates go through exp / tanh: states are in (-1, 1) (cell: a few units), compared at 1e-5 with a 5e-6 floor
+            assert_close(act.sea_hidden_state, g[f"{tag}_hidden"][s], atol=5e-6, what=f"{tag} hidden state step {s}")
+            assert_close(act.sea_cell_state, g[f"{tag}_cell"][s], atol=5e-6, what=f"{tag} cell state step {s}")
+            assert_close(act.computed_effort, g[f"{tag}_computed"][s], atol=2e-5, what=f"{tag} computed step {s}")
+            assert_close(act.applied_effort, g[f"{tag}_applied"][s], atol=2e-5, what=f"{tag} applied step {s}")
+            assert out.joint_positions is None and out.joint_efforts is act.applied_effort
+
+
+def test_actuator_net_lstm_anymal_shape_vs_oracle(dev):
+    """16k-env shape (196,608 rows) and a ragged row count against the oracle; hidden size not a multiple of 4 as well."""
+    from isaaclab_amd.actuators import ActuatorNetLSTM, ActuatorNetLSTMCfg
+    from isaaclab_amd.utils.types import ArticulationActions
+
+    gen = torch.Generator().manual_seed(11)
+    for n, hidden, layers, head in ((16384, 8, 2, [32]), (37, 8, 2, [32]), (53, 6, 1, [])):
+        j = 12
+        lstm = {}
+        for l in range(layers):
+            in_l = 2 if l == 0 else hidden
+            lstm[f"weight_ih_l{l}"] = torch.randn(4 * hidden, in_l, generator=gen) * 0.4
+            lstm[f"weight_hh_l{l}"] = torch.randn(4 * hidden, hidden, generator=gen) * 0.4
+            lstm[f"bias_ih_l{l}"] = torch.randn(4 * hidden, generator=gen) * 0.1
+            lstm[f"bias_hh_l{l}"] = torch.randn(4 * hidden, generator=gen) * 0.1
+        dims = [hidden] + head + [1]
+        ws = [torch.randn(dims[i + 1], dims[i], generator=gen) / dims[i] ** 0.5 for i in range(len(dims) - 1)]
+        bs = [torch.randn(dims[i + 1], generator=gen) * 0.1 for i in range(len(dims) - 1)]
+        cfg = ActuatorNetLSTMCfg(network=dict(lstm=lstm, weights=ws, biases=bs, activation="softsign"), effort_limit=80.0,
+                                 velocity_limit=7.5, saturation_effort=120.0)
+        act = ActuatorNetLSTM(cfg, joint_names=_names(j), joint_ids=slice(None), num_envs=n, device=dev)
+        params = tuple([lstm[f"{nm}_l{l}"] for l in range(layers)] for nm in ("weight_ih", "weight_hh", "bias_ih", "bias_hh"))
+        h, c = torch.zeros(layers, n * j, hidden), torch.zeros(layers, n * j, hidden)
+        lim, vl = torch.full((n, j), 80.0), torch.full((n, j), 7.5)
+        for s in range(3):
+            q_des = torch.randn(n, j, generator=gen)
+            q = q_des + torch.randn(n, j, generator=gen) * 0.3
+            qd = torch.randn(n, j, generator=gen) * 3.0
+            comp, app, h, c = OA.actuator_net_lstm(q_des, q, qd, h, c, params, ws, bs, "softsign", lim, vl, 120.0)
+            act.compute(ArticulationActions(joint_positions=q_des.to(dev)), q.to(dev), qd.to(dev))
+            assert_close(act.sea_hidden_state, h, atol=5e-6, what=f"n={n} hidden step {s}")
+            assert_close(act.sea_cell_state, c, atol=5e-6, what=f"n={n} cell step {s}")
+            assert_close(act.computed_effort, comp, atol=2e-5, what=f"n={n} computed step {s}")
+            assert_close(act.applied_effort, app, atol=2e-5, what=f"n={n} applied step {s}")
+
+
 def test_articulation_data(dev):
     from isaaclab_amd.assets.articulation_data import ArticulationData
 

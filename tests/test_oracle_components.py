@@ -50,6 +50,32 @@ def test_actuator_net_mlp():
             assert_close(app, g[f"{tag}_applied"][s], atol=1e-5, what=f"{tag} applied step {s}")
 
 
+def lstm_params(g, tag):
+    hidden, layers, nhead = (int(v) for v in g[f"{tag}_shape"])
+    lstm = tuple([g[f"{tag}_{nm}_l{l}"] for l in range(layers)] for nm in ("weight_ih", "weight_hh", "bias_ih", "bias_hh"))
+    return hidden, layers, lstm, [g[f"{tag}_head_w{i}"] for i in range(nhead)], [g[f"{tag}_head_b{i}"] for i in range(nhead)]
+
+
+def test_actuator_net_lstm():
+    g = load_golden("actuators_lstm")
+    for tag, act in (("anydrive", "softsign"), ("wide", "tanh")):
+        hidden, layers, lstm, hw, hb = lstm_params(g, tag)
+        n, j = g[f"{tag}_q"].shape[1:]
+        h, c = torch.zeros(layers, n * j, hidden), torch.zeros(layers, n * j, hidden)
+        limt, vlt = torch.full((n, j), 80.0), torch.full((n, j), 7.5)
+        for s in range(g[f"{tag}_q"].shape[0]):
+            if s == 5:  # the fixture resets envs 1 and 3 before step 5 (actuator_net.py:70-74)
+                h.view(layers, n, j, hidden)[:, [1, 3]] = 0.0
+                c.view(layers, n, j, hidden)[:, [1, 3]] = 0.0
+            comp, app, h, c = A.actuator_net_lstm(g[f"{tag}_q_des"][s], g[f"{tag}_q"][s], g[f"{tag}_qd"][s], h, c, lstm, hw, hb,
+                                                  act, limt, vlt, 120.0)
+            assert_close(h, g[f"{tag}_hidden"][s], atol=2e-6, what=f"{tag} hidden state step {s}")
+            assert_close(c, g[f"{tag}_cell"][s], atol=2e-6, what=f"{tag} cell state step {s}")
+            assert_close(comp, g[f"{tag}_computed"][s], atol=1e-5, what=f"{tag} computed step {s}")
+            assert_close(app, g[f"{tag}_applied"][s], atol=1e-5, what=f"{tag} applied step {s}")
+        assert (g[f"{tag}_applied"] != g[f"{tag}_computed"]).any()
+
+
 def test_articulation_data():
     g = load_golden("articulation_data")
     rs = AD.root_state_from_view(g["root_transforms_xyzw"], g["root_velocities"])
