@@ -47,12 +47,18 @@ BYTES = {
     # write obs 940, reward 4, step_reward 44, episode sums r+w 72, flags 5
     "mdp_step": 52 + 240 + 96 + 612 + 136 + 748 + 12 + 82 + 16 + 940 + 4 + 44 + 72 + 5,
     "joint_action_process": 48 + 2 * 48 + 48 + 48,
+    # --actuator lstm: read q_des, q, qd (3*48); read+write hidden and cell state (2 * 2 * 2 layers * 8 * 4 B * 12 joints);
+    # write computed, applied (2*48)
+    "actuator_net_lstm": 3 * 48 + 2 * 2 * 768 + 2 * 48,
 }
-BYTES_PER_ENV_STEP = (4 * (BYTES["actuator_net_mlp"] + BYTES["scene_update"]) + BYTES["raycaster_refresh"]
-                      + BYTES["mdp_step"] + BYTES["joint_action_process"])
 
 
-def build_env(device, num_envs, seed):
+def bytes_per_env_step(actuator_kernel):
+    return (4 * (BYTES[actuator_kernel] + BYTES["scene_update"]) + BYTES["raycaster_refresh"] + BYTES["mdp_step"]
+            + BYTES["joint_action_process"])
+
+
+def build_env(device, num_envs, seed, actuator="mlp"):
     from isaaclab_amd import synth
     from isaaclab_amd.envs.locomotion_step import LocomotionVelocityStep
     from isaaclab_amd.tasks import locomotion_velocity as LV
@@ -67,13 +73,13 @@ def build_env(device, num_envs, seed):
     default[idx] = torch.tensor(vals)
     state = synth.locomotion_state(num_envs, seed, num_joints=12, num_bodies=17, default_joint_pos=default,
                                    feet_ids=[13, 14, 15, 16], height_at=height_at)
-    env = LocomotionVelocityStep(num_envs, device, mesh, "anymal_c", actuator_net=dict(weights=ws, biases=bs, activation="softsign"),
-                                 seed=seed)
+    net = synth.actuator_lstm_weights() if actuator == "lstm" else dict(weights=ws, biases=bs, activation="softsign")
+    env = LocomotionVelocityStep(num_envs, device, mesh, "anymal_c", actuator_net=net, seed=seed)
     env.load_state(state)
     return env, state, (verts, tris, ws, bs, default)
 
 
-def time_kernels(env, state, device, reps=20):
+def time_kernels(env, state, device, actuator_kernel, reps=20):
     """Average duration of each kernel of the step, measured with events on the stream the kernels run on."""
     from isaaclab_amd import _abi
     from isaaclab_amd.envs import fused_mdp as FM
@@ -130,7 +136,7 @@ def time_kernels(env, state, device, reps=20):
         rays()
 
     out = {}
-    for name, fn in (("actuator_net_mlp", actuator), ("scene_update", scene), ("mdp_step", mdp), ("joint_action_process", action)):
+    for name, fn in ((actuator_kernel, actuator), ("scene_update", scene), ("mdp_step", mdp), ("joint_action_process", action)):
         out[name] = span(fn)
     out["raycaster_refresh"] = span(rays_due) - span(due)
     return out
@@ -178,6 +184,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--envs", type=int, default=NUM_ENVS, help="environments per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--actuator", choices=("mlp", "lstm"), default="mlp",
+                    help="actuator network: the headline 6-32-32-32-1 MLP, or the ANYdrive-shaped LSTM(2, 8, 2) + head "
+                         "(no CPU baseline, reported as a side measurement)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -195,7 +204,7 @@ def main():
 
     from isaaclab_amd.distributed import all_reduce_log_sums
 
-    env, state, _ = build_env(device, args.envs, seed=3000 + rank)
+    env, state, _ = build_env(device, args.envs, seed=3000 + rank, actuator=args.actuator)
     raw = state["raw_action"].to(device)
     n_log = env.mdp.log_sums.numel()
 
@@ -222,11 +231,13 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    kern = time_kernels(env, state, device)
+    act_kernel = "actuator_net_" + args.actuator
+    kern = time_kernels(env, state, device, act_kernel)
+    BYTES_PER_ENV_STEP = bytes_per_env_step(act_kernel)
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         value = args.envs * world * args.steps / elapsed
-        launches = {"actuator_net_mlp": 4, "scene_update": 4, "raycaster_refresh": 1, "mdp_step": 1, "joint_action_process": 1}
+        launches = {act_kernel: 4, "scene_update": 4, "raycaster_refresh": 1, "mdp_step": 1, "joint_action_process": 1}
         dominant = max(kern, key=lambda k: kern[k] * launches[k])
         # HBM-side bytes per launch of that kernel from the committed counter passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
         # of this same command, corrected as stated in the file); only meaningful for the env count it was taken at
@@ -255,14 +266,16 @@ def main():
             "config": {"workload": "Isaac-Velocity-Rough-Anymal-C-v0 non-physics step", "envs_per_gpu": args.envs,
                        "decimation": 4, "joints": 12, "bodies": 17, "rays": 187, "obs_dim": 235,
                        "terrain_triangles": int(env.scanner.meshes["/World/ground"].num_triangles),
-                       "actuator": "ActuatorNetMLP 6-32-32-32-1 softsign (fp32 MFMA)", "parallelism": f"env-shard x{world}"},
+                       "actuator": ("ActuatorNetMLP 6-32-32-32-1 softsign (fp32 MFMA)" if args.actuator == "mlp" else
+                                    "ActuatorNetLSTM LSTM(2, 8, 2 layers) + 8-32-1 softsign head"),
+                       "parallelism": f"env-shard x{world}"},
             "env_term_steps_per_s": value * TERM_EVALS_PER_ENV_STEP,
             "algorithmic_bytes_per_env_step": BYTES_PER_ENV_STEP,
             "step_hbm_frac": BYTES_PER_ENV_STEP * args.envs / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "roofline": roofline,
             "kernels_us": {k: round(v, 2) for k, v in kern.items()},
         }
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and args.actuator == "mlp":
             line["cpu_baseline"] = cpu_baseline(3000)
         else:
             line["cpu_baseline"] = None

@@ -146,25 +146,29 @@ int ilx_actuator_net_mlp(ilx_mlp_t net, const float* q_des, const float* q, cons
                          const float* velocity_limit, int params_per_env, float saturation_effort,
                          float* computed, float* applied, int64_t n, int j, int flags, void* stream);
 
-/* LSTM of an actuator network: what ActuatorNetLSTM reads from `network.lstm` (actuator_net.py:52-54), a
- * torch.nn.LSTM(input_size, hidden_size, num_layers, batch_first=True).  Per layer l, HOST pointers in torch's layout and
- * gate order (input, forget, cell, output): weight_ih (4H, in_l), weight_hh (4H, H), bias_ih (4H), bias_hh (4H), with
- * in_0 = input_size and in_l = H above.  num_layers <= 4, hidden_size <= 16, input_size 2..4. */
+/* Recurrent actuator network: what ActuatorNetLSTM drives (actuator_net.py:48-54,86-89), i.e. a
+ * torch.nn.LSTM(input_size, hidden_size, num_layers, batch_first=True) read from `network.lstm`, followed by the rest
+ * of the TorchScript module, here a Linear stack ("head") from hidden_size to 1 with one activation between layers.
+ * Per LSTM layer l, HOST pointers in torch's layout and gate order (input, forget, cell, output): weight_ih (4H, in_l),
+ * weight_hh (4H, H), bias_ih (4H), bias_hh (4H), with in_0 = input_size and in_l = H above.  Head: head_dims[0] = H,
+ * head_dims[head_layers] = 1, weights (dims[l+1], dims[l]) as torch.nn.Linear.  num_layers <= 4, hidden_size <= 16,
+ * input_size 2..4, head widths <= 32. */
 typedef struct ilx_lstm_s* ilx_lstm_t;
 int ilx_lstm_create(int num_layers, int input_size, int hidden_size, const float* const* weight_ih_host,
                     const float* const* weight_hh_host, const float* const* bias_ih_host,
-                    const float* const* bias_hh_host, ilx_lstm_t* out);
+                    const float* const* bias_hh_host, int head_layers, const int32_t* head_dims, int head_activation,
+                    const float* const* head_weights_host, const float* const* head_biases_host, ilx_lstm_t* out);
 void ilx_lstm_destroy(ilx_lstm_t net);
 
 /* ActuatorNetLSTM.compute — actuator_net.py:76-99.  In one launch, per (env, joint) row: network input
  * (q_des - q, qd), one time step of the LSTM on hidden_state / cell_state (num_layers, n*j, hidden_size; updated in
- * place, 16-byte aligned), `head` (a Linear stack with widths <= 32 from hidden_size to 1: the part of the TorchScript
- * module after `lstm`) on the last layer's output -> computed, applied = DC-motor clip (actuator_pd.py:223-233).
- * Resetting envs (actuator_net.py:70-74) is a plain zero fill of their state rows by the caller. */
-int ilx_actuator_net_lstm(ilx_lstm_t lstm, ilx_mlp_t head, const float* q_des, const float* q, const float* qd,
-                          float* hidden_state, float* cell_state, const float* effort_limit,
-                          const float* velocity_limit, int params_per_env, float saturation_effort, float* computed,
-                          float* applied, int64_t n, int j, void* stream);
+ * place, 16-byte aligned), the head on the last layer's output -> computed, applied = DC-motor clip
+ * (actuator_pd.py:223-233).  Resetting envs (actuator_net.py:70-74) is a plain zero fill of their state rows by the
+ * caller. */
+int ilx_actuator_net_lstm(ilx_lstm_t net, const float* q_des, const float* q, const float* qd, float* hidden_state,
+                          float* cell_state, const float* effort_limit, const float* velocity_limit,
+                          int params_per_env, float saturation_effort, float* computed, float* applied, int64_t n,
+                          int j, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Contact sensor bookkeeping — source/isaaclab/isaaclab/sensors/contact_sensor/contact_sensor.py:314-373

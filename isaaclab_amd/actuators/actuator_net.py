@@ -61,12 +61,14 @@ def load_network(cfg, device) -> tuple[list[torch.Tensor], list[torch.Tensor], s
 
 
 class LstmHandle:
-    """Owns an ``ilx_lstm_t`` (device copy of the LSTM parameters in kernel order)."""
+    """Owns an ``ilx_lstm_t``: device copy of a ``torch.nn.LSTM``'s parameters and of the Linear head after it."""
 
-    def __init__(self, params: dict[str, torch.Tensor]):
+    def __init__(self, params: dict[str, torch.Tensor], weights: list[torch.Tensor], biases: list[torch.Tensor], activation: str):
         layers = len([k for k in params if k.startswith("weight_ih_l")])
         if layers == 0 or len(params) != 4 * layers:
             raise ValueError("expected weight_ih_l*, weight_hh_l*, bias_ih_l*, bias_hh_l* of a unidirectional torch.nn.LSTM")
+        if activation not in _ACT:
+            raise ValueError(f"unsupported activation '{activation}', expected one of {sorted(_ACT)}")
         p = {k: v.detach().to("cpu", torch.float32).contiguous() for k, v in params.items()}
         self.hidden_dim = p["weight_hh_l0"].shape[1]
         self.input_size = p["weight_ih_l0"].shape[1]
@@ -78,10 +80,20 @@ class LstmHandle:
             for nm, shape in want.items():
                 if tuple(p[f"{nm}_l{l}"].shape) != shape:
                     raise ValueError(f"{nm}_l{l}: shape {tuple(p[f'{nm}_l{l}'].shape)}, expected {shape}")
+        ws = [w.detach().to("cpu", torch.float32).contiguous() for w in weights]
+        bs = [b.detach().to("cpu", torch.float32).contiguous() for b in biases]
+        dims = [self.hidden_dim] + [w.shape[0] for w in ws]
+        for i, (w, b) in enumerate(zip(ws, bs)):
+            if w.shape != (dims[i + 1], dims[i]) or b.shape != (dims[i + 1],):
+                raise ValueError(f"head layer {i}: weight {tuple(w.shape)} / bias {tuple(b.shape)} do not chain")
         arr = lambda nm: (ctypes.c_void_p * layers)(*[p[f"{nm}_l{l}"].data_ptr() for l in range(layers)])
+        n = len(ws)
         self.handle = ctypes.c_void_p()
         _abi.check(_abi.lstm_create(layers, self.input_size, self.hidden_dim, arr("weight_ih"), arr("weight_hh"), arr("bias_ih"),
-                                    arr("bias_hh"), ctypes.byref(self.handle)), "ilx_lstm_create")
+                                    arr("bias_hh"), n, (ctypes.c_int32 * (n + 1))(*dims), _ACT[activation],
+                                    (ctypes.c_void_p * n)(*[w.data_ptr() for w in ws]),
+                                    (ctypes.c_void_p * n)(*[b.data_ptr() for b in bs]), ctypes.byref(self.handle)),
+                   "ilx_lstm_create")
 
     def __del__(self):
         h = getattr(self, "handle", None)
@@ -110,10 +122,9 @@ class ActuatorNetLSTM(DCMotor):
     def __init__(self, cfg, *args, **kwargs):
         super().__init__(cfg, *args, **kwargs)
         lstm, weights, biases, activation = load_lstm_network(cfg)
-        self.lstm = LstmHandle(lstm)
-        self.head = MlpHandle(weights, biases, activation)
+        self.network = LstmHandle(lstm, weights, biases, activation)
         rows = self._num_envs * self.num_joints
-        num_layers, hidden_dim = self.lstm.num_layers, self.lstm.hidden_dim
+        num_layers, hidden_dim = self.network.num_layers, self.network.hidden_dim
         self.sea_hidden_state = torch.zeros(num_layers, rows, hidden_dim, device=self._device)
         self.sea_cell_state = torch.zeros(num_layers, rows, hidden_dim, device=self._device)
         layer_shape_per_env = (num_layers, self._num_envs, self.num_joints, hidden_dim)
@@ -129,7 +140,7 @@ class ActuatorNetLSTM(DCMotor):
         n, j = q.shape
         self._joint_vel = joint_vel
         _abi.check(_abi.actuator_net_lstm(
-            self.lstm.handle, self.head.handle, _abi.ptr(q_des), _abi.ptr(q), _abi.ptr(qd), _abi.ptr(self.sea_hidden_state),
+            self.network.handle, _abi.ptr(q_des), _abi.ptr(q), _abi.ptr(qd), _abi.ptr(self.sea_hidden_state),
             _abi.ptr(self.sea_cell_state), _abi.ptr(self.effort_limit), _abi.ptr(self.velocity_limit), 1,
             float(self._saturation_effort), _abi.ptr(self.computed_effort), _abi.ptr(self.applied_effort), n, j, _abi.stream()),
             "ilx_actuator_net_lstm")

@@ -18,7 +18,7 @@ from __future__ import annotations
 import torch
 
 from .. import _abi
-from ..actuators import ActuatorNetMLP, ActuatorNetMLPCfg, DCMotor, DCMotorCfg
+from ..actuators import ActuatorNetLSTM, ActuatorNetLSTMCfg, ActuatorNetMLP, ActuatorNetMLPCfg, DCMotor, DCMotorCfg
 from ..assets.articulation_data import ArticulationData
 from ..sensors.contact_sensor import ContactSensor, ContactSensorCfg
 from ..sensors.patterns import GridPatternCfg
@@ -56,9 +56,14 @@ class LocomotionVelocityStep:
         # actuators (one group over all joints)
         if robot == "anymal_c":
             net = actuator_net
-            cfg = ActuatorNetMLPCfg(network=net, **LV.ACTUATOR_NET, **LV.ANYMAL_ACTUATOR)
-            self.actuator = ActuatorNetMLP(cfg, joint_names=joints, joint_ids=slice(None), num_envs=n, device=dev,
-                                           stiffness=0.0, damping=0.0)
+            if "lstm" in net:  # the ANYdrive 3 model of the reference asset (anymal.py:43-51)
+                cfg = ActuatorNetLSTMCfg(network=net, **LV.ANYMAL_ACTUATOR)
+                self.actuator = ActuatorNetLSTM(cfg, joint_names=joints, joint_ids=slice(None), num_envs=n, device=dev,
+                                                stiffness=0.0, damping=0.0)
+            else:
+                cfg = ActuatorNetMLPCfg(network=net, **LV.ACTUATOR_NET, **LV.ANYMAL_ACTUATOR)
+                self.actuator = ActuatorNetMLP(cfg, joint_names=joints, joint_ids=slice(None), num_envs=n, device=dev,
+                                               stiffness=0.0, damping=0.0)
         else:
             cfg = DCMotorCfg(stiffness=LV.H1_STIFFNESS, damping=LV.H1_DAMPING, effort_limit=LV.H1_EFFORT_LIMIT,
                              velocity_limit=LV.H1_VELOCITY_LIMIT, saturation_effort=300.0)

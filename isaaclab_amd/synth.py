@@ -157,6 +157,23 @@ def actuator_mlp_weights(seed: int = 7, dims=(6, 32, 32, 32, 1)):
     return ws, bs
 
 
+def actuator_lstm_weights(seed: int = 7, hidden: int = 8, layers: int = 2, head=(32,)):
+    """Random-init LSTM actuator network of the ANYdrive shape (``torch.nn.LSTM(2, 8, 2)`` + a small head; the
+    reference's file is a remote asset): a dict for ``ActuatorNetLSTMCfg.network``."""
+    g = torch.Generator().manual_seed(seed)
+    lstm = {}
+    for l in range(layers):
+        in_l = 2 if l == 0 else hidden
+        lstm[f"weight_ih_l{l}"] = torch.randn(4 * hidden, in_l, generator=g) / hidden ** 0.5
+        lstm[f"weight_hh_l{l}"] = torch.randn(4 * hidden, hidden, generator=g) / hidden ** 0.5
+        lstm[f"bias_ih_l{l}"] = torch.randn(4 * hidden, generator=g) * 0.1
+        lstm[f"bias_hh_l{l}"] = torch.randn(4 * hidden, generator=g) * 0.1
+    dims = [hidden, *head, 1]
+    ws = [torch.randn(dims[i + 1], dims[i], generator=g) / dims[i] ** 0.5 for i in range(len(dims) - 1)]
+    bs = [torch.randn(dims[i + 1], generator=g) * 0.1 for i in range(len(dims) - 1)]
+    return dict(lstm=lstm, weights=ws, biases=bs, activation="softsign")
+
+
 # ---- manipulator kinematics for the DifferentialIK fixtures ---------------------------------------------------------
 # xArm6 revolute chain (joint origins xyz / rpy, every axis = local z), from the robot description the reference
 # ships (ROBOT/xarm/xarm6_with_gripper.urdf:79-225).  Data only; the forward kinematics below is the textbook product.
