@@ -24,6 +24,7 @@
 #include "raytri.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstring>
 #include <limits>
@@ -47,6 +48,7 @@ constexpr double kGridPhase = 0.5;             // the grid starts this fraction 
 // Cell word: 0xFFFFFFFF = empty; otherwise bits 31..30 = k and bits 29..0 = p.  k < 3: the candidates are the k + 1
 // records p .. p + k.  k = 3: a list starts at the 16-byte word cell_lists[p] = (count, r0, r1, r2), followed by
 // (r3, r4, r5, r6) ... for as long as the count says.
+constexpr int kFlagSlots = 64;  // hinted casts in flight on one mesh (on different streams) that keep their own flag
 constexpr uint32_t kCellEmpty = 0xFFFFFFFFu;
 constexpr uint32_t kCellIndexMask = 0x3FFFFFFFu;
 
@@ -288,7 +290,8 @@ struct CastArgs {
     int32_t* face;        // (n) or null
     int64_t n;
     int32_t* counters;    // (n,2) or null: nodes visited / triangles tested per ray (diagnostics)
-    int32_t* off_grid;    // column kernel: set to 1 when a ray was not z-parallel; tree kernel: null = all rays,
+    int32_t ticket;       // identifies this call among the calls that share the mesh's flag slots (never 0)
+    int32_t* off_grid;    // column kernel: set to `ticket` when a ray was not z-parallel; tree kernel: null = all rays,
                           // else only the rays the column kernel left out (and nothing at all while the flag is 0)
 };
 
@@ -306,7 +309,7 @@ ILX_DEV void write_hit(const Hit& h, f3 o, f3 d, float* hits, float* dist, float
 __global__ void __launch_bounds__(kRayBlock) raycast_kernel(CastArgs a) {
     __shared__ Node cache[kCachedNodes];
     __shared__ int32_t stack[kStackSlots * kRayBlock];
-    if (a.off_grid && *a.off_grid == 0) return;  // mop-up launch with nothing to mop up
+    if (a.off_grid && *a.off_grid != a.ticket) return;  // mop-up launch with nothing to mop up
     const int ncache = min(a.mesh.num_nodes, kCachedNodes);
     stage_nodes(a.mesh, cache, ncache);
     for (int64_t i = static_cast<int64_t>(blockIdx.x) * kRayBlock + threadIdx.x; i < a.n;
@@ -325,7 +328,7 @@ __global__ void __launch_bounds__(kRayBlock) raycast_column_kernel(CastArgs a) {
     if (i >= a.n) return;
     const f3 o = load3(a.starts + 3 * i), d = load3(a.dirs + 3 * i);
     if (!z_parallel(d)) {  // left to the tree kernel that follows
-        *a.off_grid = 1;
+        *a.off_grid = a.ticket;
         return;
     }
     const Hit h = a.normal ? trace_column<true>(a.mesh, o, d, a.max_dist) : trace_column<false>(a.mesh, o, d, a.max_dist);
@@ -351,8 +354,18 @@ struct ScanArgs {
     float height_offset;
     int64_t n;
     int r;
-    int32_t* off_grid;        // as in CastArgs
+    int32_t ticket;           // as in CastArgs
+    int32_t* off_grid;
+    // SensorBase clocks of the refreshed envs (sensor_base.py:284-293), or null: timestamp_last_update <- timestamp and
+    // is_outdated <- 0 where is_outdated was set.  Done by the launch that follows the column kernel.
+    const float* clock_now;
+    float* clock_last;
+    uint8_t* outdated;
 };
+
+// What the column kernel leaves in ray_hits_w[..., 0] of a ray it could not serve (a quiet NaN no cast produces: hits
+// are finite or +inf): the tree launch that follows picks exactly these rays up, without reading the env mask again.
+constexpr uint32_t kLeftOverBits = 0x7FC0DEADu;
 
 // Workgroups are dealt to the 8 XCDs round-robin (block b runs on XCD b % 8), each with its own L2.  This maps the
 // hardware block index to a logical one such that consecutive logical blocks -- neighbouring rays, which read the
@@ -366,10 +379,12 @@ ILX_DEV unsigned xcd_block(unsigned b, unsigned nblocks) {
 
 // World ray i = (env, ray) of the sensor; false when the env is masked out.
 // `yaw` (optional): this env's yaw-only quaternion, precomputed once per env of the block.
-ILX_DEV bool sensor_ray(const ScanArgs& a, int64_t i, f3& o, f3& d, float& pos_z, const f4* yaw = nullptr) {
+// `ignore_mask`: the caller already knows that the ray belongs to a refreshed env.
+ILX_DEV bool sensor_ray(const ScanArgs& a, int64_t i, f3& o, f3& d, float& pos_z, const f4* yaw = nullptr,
+                        bool ignore_mask = false) {
     const int64_t env = i / a.r;
     const int ray = static_cast<int>(i - env * a.r);
-    if (a.env_mask && !a.env_mask[env]) return false;
+    if (!ignore_mask && a.env_mask && !a.env_mask[env]) return false;
     f3 pos = load3(a.pos_w + a.pos_stride * env);
     const f4 q = load4u(a.quat_w + a.quat_stride * env);
     if (a.drift) {  // ray_caster.py:233-240
@@ -405,16 +420,26 @@ ILX_DEV void write_scan(const ScanArgs& a, const Hit& h, f3 o, f3 d, float pos_z
 __global__ void __launch_bounds__(kRayBlock) raycaster_update_kernel(ScanArgs a) {
     __shared__ Node cache[kCachedNodes];
     __shared__ int32_t stack[kStackSlots * kRayBlock];
-    if (a.off_grid && *a.off_grid == 0) return;  // mop-up launch with nothing to mop up
+    const bool mop_up = a.off_grid != nullptr;
+    if (mop_up && a.outdated) {  // the column kernel has read the mask: the refreshed envs record the time
+        for (int64_t e = static_cast<int64_t>(blockIdx.x) * kRayBlock + threadIdx.x; e < a.n;
+             e += static_cast<int64_t>(gridDim.x) * kRayBlock) {
+            if (a.outdated[e]) {
+                a.clock_last[e] = a.clock_now[e];
+                a.outdated[e] = 0;
+            }
+        }
+    }
+    if (mop_up && *a.off_grid != a.ticket) return;  // nothing to mop up
     const int ncache = min(a.mesh.num_nodes, kCachedNodes);
     stage_nodes(a.mesh, cache, ncache);
     const int64_t total = a.n * a.r;
     for (int64_t i = static_cast<int64_t>(blockIdx.x) * kRayBlock + threadIdx.x; i < total;
          i += static_cast<int64_t>(gridDim.x) * kRayBlock) {
+        if (mop_up && __float_as_uint(a.ray_hits_w[3 * i]) != kLeftOverBits) continue;
         f3 o, d;
         float pos_z;
-        if (!sensor_ray(a, i, o, d, pos_z)) continue;
-        if (a.off_grid && z_parallel(d)) continue;
+        if (!sensor_ray(a, i, o, d, pos_z, nullptr, mop_up)) continue;
         const Hit h = trace<false>(a.mesh, cache, ncache, stack + threadIdx.x, kRayBlock, o, d, a.max_dist);
         write_scan(a, h, o, d, pos_z, i);
     }
@@ -439,7 +464,8 @@ __global__ void __launch_bounds__(kRayBlock) raycaster_update_column_kernel(Scan
     float pos_z;
     if (!sensor_ray(a, i, o, d, pos_z, a.yaw_only ? &yaw_q[i / a.r - env0] : nullptr)) return;
     if (!z_parallel(d)) {  // left to the tree kernel that follows
-        *a.off_grid = 1;
+        *a.off_grid = a.ticket;
+        a.ray_hits_w[3 * i] = __uint_as_float(kLeftOverBits);
         return;
     }
     const Hit h = trace_column<false>(a.mesh, o, d, a.max_dist);
@@ -547,7 +573,8 @@ struct MeshHost {
     uint4* d_col_tris = nullptr;
     float4* d_col_verts = nullptr;
     GridStats grid{};
-    int32_t* d_off_grid = nullptr;  // flag raised by a column kernel for the tree kernel launched right after it
+    int32_t* d_off_grid = nullptr;  // kFlagSlots flags, one raised by a column kernel for the tree kernel launched after it
+    std::atomic<uint32_t> calls{0}; // hinted casts so far: call c uses slot c % kFlagSlots and the ticket c + 1
     int depth = 0;
     int64_t num_verts = 0;
 };
@@ -846,8 +873,8 @@ extern "C" int ilx_mesh_create(const float* verts_host, int64_t num_verts, const
     auto* obj = new ilx_mesh_s();
     MeshHost& h = obj->h;
     int rc = check_hip(hipMalloc(&h.d_nodes, nodes.size() * sizeof(Node)), "ilx_mesh_create: hipMalloc(nodes)");
-    if (rc == ILX_OK) rc = check_hip(hipMalloc(&h.d_off_grid, sizeof(int32_t)), "ilx_mesh_create: hipMalloc(flag)");
-    if (rc == ILX_OK) rc = check_hip(hipMemset(h.d_off_grid, 0, sizeof(int32_t)), "ilx_mesh_create: hipMemset(flag)");
+    if (rc == ILX_OK) rc = check_hip(hipMalloc(&h.d_off_grid, kFlagSlots * sizeof(int32_t)), "ilx_mesh_create: hipMalloc(flag)");
+    if (rc == ILX_OK) rc = check_hip(hipMemset(h.d_off_grid, 0, kFlagSlots * sizeof(int32_t)), "ilx_mesh_create: hipMemset(flag)");
     if (rc == ILX_OK && !cells.empty()) {
         rc = upload(&h.d_cells, cells, "cells");
         if (rc == ILX_OK) rc = upload(&h.d_cell_lists, cell_lists, "cell lists");
@@ -918,6 +945,14 @@ static unsigned ray_grid(int64_t rays) {
 }
 
 static int launch_scan(ilx_mesh_t mesh, ScanArgs a, int hints, void* stream);
+
+// A flag slot and a non-zero ticket for one hinted cast.  A slot is reused every kFlagSlots calls; its old value can
+// never equal the new ticket, so nothing has to be cleared between calls.
+static void take_ticket(ilx_mesh_t mesh, int32_t& ticket, int32_t*& flag) {
+    const uint32_t c = mesh->h.calls.fetch_add(1, std::memory_order_relaxed);
+    ticket = static_cast<int32_t>((c % 0x7FFFFFFEu) + 1u);
+    flag = mesh->h.d_off_grid + c % kFlagSlots;
+}
 static unsigned column_grid(int64_t rays) { return static_cast<unsigned>((rays + kRayBlock - 1) / kRayBlock); }
 
 extern "C" int ilx_raycast_mesh(ilx_mesh_t mesh, const float* ray_starts, const float* ray_directions, int64_t num_rays,
@@ -929,13 +964,11 @@ extern "C" int ilx_raycast_mesh(ilx_mesh_t mesh, const float* ray_starts, const 
     ILX_REQUIRE(ray_starts && ray_directions && ray_hits, ILX_EINVAL, "ilx_raycast_mesh: NULL operand");
     ILX_REQUIRE(num_rays < (int64_t(1) << 31) * kRayBlock, ILX_ESHAPE, "ilx_raycast_mesh: too many rays");
     CastArgs a{mesh->h.dev, ray_starts, ray_directions, max_dist, ray_hits, ray_distance, ray_normal, ray_face_id, num_rays,
-               nullptr, nullptr};
+               nullptr, 0, nullptr};
     if ((hints & ILX_RAYS_Z_PARALLEL) && mesh->h.d_cells) {
         // column kernel, then the tree kernel for whatever rays were not z-parallel after all (it leaves at once
-        // when the column kernel raised no flag)
-        a.off_grid = mesh->h.d_off_grid;
-        ILX_REQUIRE(hipMemsetAsync(a.off_grid, 0, sizeof(int32_t), as_stream(stream)) == hipSuccess, ILX_EHIP,
-                    "ilx_raycast_mesh: hipMemsetAsync failed");
+        // when the column kernel did not raise this call's flag)
+        take_ticket(mesh, a.ticket, a.off_grid);
         hipLaunchKernelGGL(raycast_column_kernel, dim3(column_grid(num_rays)), dim3(kRayBlock), 0, as_stream(stream), a);
     }
     hipLaunchKernelGGL(raycast_kernel, dim3(ray_grid(num_rays)), dim3(kRayBlock), 0, as_stream(stream), a);
@@ -949,7 +982,7 @@ extern "C" int ilx_raycast_mesh_stats(ilx_mesh_t mesh, const float* ray_starts, 
     if (num_rays <= 0) return ILX_OK;
     ILX_REQUIRE(ray_starts && ray_directions && ray_hits && counters, ILX_EINVAL, "ilx_raycast_mesh_stats: NULL operand");
     CastArgs a{mesh->h.dev, ray_starts, ray_directions, max_dist, ray_hits, nullptr, nullptr, nullptr, num_rays, counters,
-               nullptr};
+               0, nullptr};
     hipLaunchKernelGGL(raycast_kernel, dim3(ray_grid(num_rays)), dim3(kRayBlock), 0, as_stream(stream), a);
     ILX_LAUNCH_CHECK("ilx_raycast_mesh_stats");
     return ILX_OK;
@@ -965,7 +998,7 @@ extern "C" int ilx_raycaster_update(ilx_mesh_t mesh, const float* pos_w, const f
     ILX_REQUIRE(pos_w && quat_w && ray_starts_local && ray_directions_local && ray_hits_w, ILX_EINVAL,
                 "ilx_raycaster_update: NULL operand");
     ScanArgs a{mesh->h.dev, pos_w, quat_w, 3, 4, nullptr, nullptr, nullptr, ray_starts_local, ray_directions_local, env_mask,
-               attach_yaw_only, max_dist, ray_hits_w, height_scan, height_offset, n, num_rays, nullptr};
+               attach_yaw_only, max_dist, ray_hits_w, height_scan, height_offset, n, num_rays, 0, nullptr, nullptr, nullptr, nullptr};
     const int rc = launch_scan(mesh, a, hints, stream);
     if (rc != ILX_OK) return rc;
     ILX_LAUNCH_CHECK("ilx_raycaster_update");
@@ -985,25 +1018,27 @@ extern "C" int ilx_raycaster_refresh(const ilx_raycaster* rc, void* stream) {
     ILX_REQUIRE(d.pose_pos_stride >= 3 && d.pose_quat_stride >= 4, ILX_EINVAL, "ilx_raycaster_refresh: bad pose strides");
     ScanArgs a{d.mesh->h.dev, d.pose_pos, d.pose_quat, d.pose_pos_stride, d.pose_quat_stride, d.drift, d.pos_w, d.quat_w,
                d.ray_starts_local, d.ray_directions_local, d.is_outdated, d.attach_yaw_only, d.max_distance, d.ray_hits_w,
-               d.height_scan, d.height_offset, d.num_envs, d.num_rays, nullptr};
+               d.height_scan, d.height_offset, d.num_envs, d.num_rays, 0, nullptr, d.timestamp, d.timestamp_last_update,
+               d.is_outdated};
     const int status = launch_scan(d.mesh, a, d.hints, stream);
     if (status != ILX_OK) return status;
-    ILX_LAUNCH_CHECK("ilx_raycaster_refresh");
-    hipLaunchKernelGGL(sensor_refreshed_kernel, dim3(blocks_for(d.num_envs)), dim3(256), 0, as_stream(stream), d.timestamp,
-                       d.timestamp_last_update, d.is_outdated, d.num_envs);
     ILX_LAUNCH_CHECK("ilx_raycaster_refresh");
     return ILX_OK;
 }
 
-// Column kernel + tree kernel for the rays it left out (a no-op launch when there are none), or the tree kernel alone.
+// Column kernel + tree kernel for the rays it left out (that launch also advances the sensor clocks, and is otherwise a
+// no-op when there are none), or the tree kernel alone followed by the clock update.
 static int launch_scan(ilx_mesh_t mesh, ScanArgs a, int hints, void* stream) {
     const int64_t rays = a.n * a.r;
     if ((hints & ILX_RAYS_Z_PARALLEL) && mesh->h.d_cells) {
-        a.off_grid = mesh->h.d_off_grid;
-        ILX_REQUIRE(hipMemsetAsync(a.off_grid, 0, sizeof(int32_t), as_stream(stream)) == hipSuccess, ILX_EHIP,
-                    "raycaster: hipMemsetAsync failed");
+        take_ticket(mesh, a.ticket, a.off_grid);
         hipLaunchKernelGGL(raycaster_update_column_kernel, dim3(column_grid(rays)), dim3(kRayBlock), 0, as_stream(stream), a);
+        hipLaunchKernelGGL(raycaster_update_kernel, dim3(ray_grid(rays)), dim3(kRayBlock), 0, as_stream(stream), a);
+        return ILX_OK;
     }
     hipLaunchKernelGGL(raycaster_update_kernel, dim3(ray_grid(rays)), dim3(kRayBlock), 0, as_stream(stream), a);
+    if (a.outdated)
+        hipLaunchKernelGGL(sensor_refreshed_kernel, dim3(blocks_for(a.n)), dim3(256), 0, as_stream(stream), a.clock_now, a.clock_last,
+                           a.outdated, a.n);
     return ILX_OK;
 }
