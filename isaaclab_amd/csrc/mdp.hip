@@ -1,6 +1,6 @@
 // Fused MDP step: termination / reward / reset-bookkeeping / command / observation managers in ONE launch.
 //
-// A 256-thread block owns kE = 16 consecutive environments and works in three stages:
+// A kBlock = 256-thread block owns kE = 16 consecutive environments and works in three stages:
 //   STAGE   every row the active terms read (joint arrays, action, contact timers, command, root state, episode
 //           sums ...) is one contiguous chunk for 16 consecutive envs, so the block copies the chunks into LDS
 //           with fully coalesced loads, all issued back to back: one memory round trip for the whole step.  The
@@ -26,6 +26,10 @@ namespace ilx {
 
 constexpr int kMaxTerms = 32;      // per manager
 constexpr int kE = 16;             // environments per block
+constexpr int kBlock = 256;        // threads per block (measured on the ANYmal-C plan, envs x threads -> us:
+                                   // 8x256 66, 16x256 46, 32x256 56, 16x512 77, 32x512 45)
+constexpr int kWaves = kBlock / 64;
+constexpr int kEmitLanes = kBlock / kE;  // threads that write one env's observation row
 constexpr int kMaxLdsBytes = 64 * 1024;
 
 enum Need : uint32_t {
@@ -418,10 +422,10 @@ ILX_DEV void command_resample(const ilx_mdp& d, int64_t env, const float* inject
 // coalesced copy of the block's chunk of an [env][width] array into LDS
 ILX_DEV void stage_rows(float* dst, const float* src, int64_t env0, int ne, int width) {
     const float* p = src + env0 * width;
-    for (int i = threadIdx.x; i < ne * width; i += 256) dst[i] = p[i];
+    for (int i = threadIdx.x; i < ne * width; i += kBlock) dst[i] = p[i];
 }
 
-__global__ void __launch_bounds__(256) mdp_step_kernel(MdpDev m) {
+__global__ void __launch_bounds__(kBlock) mdp_step_kernel(MdpDev m) {
     extern __shared__ float S[];
     const ilx_mdp& d = m.d;
     const Layout& L = m.L;
@@ -444,14 +448,14 @@ __global__ void __launch_bounds__(256) mdp_step_kernel(MdpDev m) {
         const int32_t* src = reinterpret_cast<const int32_t*>(m.terms);
         int32_t* dst = reinterpret_cast<int32_t*>(S + L.terms);
         const int words = (NT + NR + NO) * static_cast<int>(sizeof(ilx_term) / 4);
-        for (int i = tid; i < words; i += 256) dst[i] = src[i];
+        for (int i = tid; i < words; i += kBlock) dst[i] = src[i];
         int32_t* idst = reinterpret_cast<int32_t*>(S + L.ids);
-        for (int i = tid; i < d.num_ids; i += 256) idst[i] = m.ids[i];
+        for (int i = tid; i < d.num_ids; i += kBlock) idst[i] = m.ids[i];
         uint32_t* cdst = reinterpret_cast<uint32_t*>(S + L.colterm);  // colterm and tstart are adjacent
         const int cwords = ((d.obs_dim + 3) >> 2) + NO;
         if (ph_obs)
-            for (int i = tid; i < cwords; i += 256) cdst[i] = m.cols[i];
-        for (int i = tid; i < NR + NT + 3; i += 256) S[L.logp + i] = 0.0f;
+            for (int i = tid; i < cwords; i += kBlock) cdst[i] = m.cols[i];
+        for (int i = tid; i < NR + NT + 3; i += kBlock) S[L.logp + i] = 0.0f;
     }
     stage_rows(S + L.root, d.root_state_w, env0, ne, 13);
     if (m.need & kNeedJoint) {
@@ -476,23 +480,23 @@ __global__ void __launch_bounds__(256) mdp_step_kernel(MdpDev m) {
     }
     if (d.command) stage_rows(S + L.cmd, d.command, env0, ne, CD);
     if (ph_rew || ph_reset) {  // episode sums: [term][env] in memory and in LDS
-        for (int i = tid; i < NR * kE; i += 256) {
+        for (int i = tid; i < NR * kE; i += kBlock) {
             const int term = i / kE, e = i - term * kE;
             if (e < ne) S[L.eps + i] = d.episode_sums[static_cast<int64_t>(term) * N + env0 + e];
         }
     }
     if (m.need & kNeedBodyVel) {
-        for (int i = tid; i < ne * B; i += 256) {
+        for (int i = tid; i < ne * B; i += kBlock) {
             const float* v = d.body_state_w + 13 * (env0 * B + i) + 7;
             S[L.bvx + i] = v[0], S[L.bvy + i] = v[1];
         }
     }
     if (m.need & kNeedBodyAcc) {
-        for (int i = tid; i < ne * B; i += 256) S[L.bacc + i] = norm3(load3(d.body_lin_acc_w + 3 * (env0 * B + i)));
+        for (int i = tid; i < ne * B; i += kBlock) S[L.bacc + i] = norm3(load3(d.body_lin_acc_w + 3 * (env0 * B + i)));
     }
     if (m.need & kNeedForces) {  // max over the history of |F| per (env, body): rewards.py:266 / terminations.py:157
         const int H = d.history_len;
-        for (int i = tid; i < ne * CB; i += 256) {
+        for (int i = tid; i < ne * CB; i += kBlock) {
             const int e = i / CB, b = i - e * CB;
             float mx = -__builtin_inff();
 #pragma unroll 4
@@ -558,7 +562,7 @@ __global__ void __launch_bounds__(256) mdp_step_kernel(MdpDev m) {
         // ---- rewards (reward_manager.py:128-157): this wave's share of the terms
         if (ph_rew) {
             float partial = 0.0f;
-            for (int i = wave; i < NR; i += 4) {
+            for (int i = wave; i < NR; i += kWaves) {
                 const ilx_term t = terms[NT + i];
                 if (t.weight == 0.0f) continue;  // :145-146 (episode sums and step_reward keep their values)
                 const float value = eval_reward(en, t, terminated, time_out, term_bits) * t.weight * dt;
@@ -578,7 +582,12 @@ __global__ void __launch_bounds__(256) mdp_step_kernel(MdpDev m) {
             if (d.reset_buf) d.reset_buf[env] = done;
         }
         if (ph_rew)
-            d.reward_buf[env] = ((S[L.ptotal + e] + S[L.ptotal + kE + e]) + S[L.ptotal + 2 * kE + e]) + S[L.ptotal + 3 * kE + e];
+        {
+            float total = S[L.ptotal + e];
+#pragma unroll
+            for (int w = 1; w < kWaves; ++w) total += S[L.ptotal + w * kE + e];
+            d.reward_buf[env] = total;
+        }
         reinterpret_cast<uint32_t*>(S + L.bits)[e] = term_bits;
         reinterpret_cast<uint32_t*>(S + L.bits)[kE + e] = done ? 1u : 0u;
         if (has_cmd_term) {
@@ -665,20 +674,20 @@ __global__ void __launch_bounds__(256) mdp_step_kernel(MdpDev m) {
     // ================= EMIT =================
     const uint32_t* bits = reinterpret_cast<const uint32_t*>(S + L.bits);
     if (ph_term) {
-        for (int i = tid; i < NT * kE; i += 256) {
+        for (int i = tid; i < NT * kE; i += kBlock) {
             const int term = i / kE, ee = i - term * kE;
             if (ee < ne) d.term_dones[static_cast<int64_t>(term) * N + env0 + ee] = (bits[ee] >> term) & 1u;
         }
     }
     if (ph_rew || ph_reset) {
-        for (int i = tid; i < NR * kE; i += 256) {
+        for (int i = tid; i < NR * kE; i += kBlock) {
             const int term = i / kE, ee = i - term * kE;
             if (ee >= ne) continue;
             const bool active = ph_rew && terms[NT + term].weight != 0.0f;
             if (active || (ph_reset && bits[kE + ee])) d.episode_sums[static_cast<int64_t>(term) * N + env0 + ee] = S[L.eps + i];
         }
         if (ph_rew) {
-            for (int i = tid; i < ne * NR; i += 256) {
+            for (int i = tid; i < ne * NR; i += kBlock) {
                 const int term = i % NR;
                 if (terms[NT + term].weight != 0.0f) d.step_reward[env0 * NR + i] = S[L.srew + i];
             }
@@ -691,7 +700,7 @@ __global__ void __launch_bounds__(256) mdp_step_kernel(MdpDev m) {
     // ---- observations (observation_manager.py:260-335).  The concatenated row is cut into groups of 4 columns;
     // 16 threads per env take group g, g + 16, ...; a group's noise is one Philox4x32 call.
     if (ph_obs) {
-        const int ee = tid >> 4, g = tid & 15;
+        const int ee = tid / kEmitLanes, g = tid % kEmitLanes;
         if (ee < ne) {
             const int64_t oenv = env0 + ee;
             const int O = d.obs_dim;
@@ -699,7 +708,7 @@ __global__ void __launch_bounds__(256) mdp_step_kernel(MdpDev m) {
             const uint32_t* colterm = reinterpret_cast<const uint32_t*>(S + L.colterm);
             const int32_t* tstart = reinterpret_cast<const int32_t*>(S + L.tstart);
             const ilx_term* oterms = terms + NT + NR;
-            for (int cg = g; 4 * cg < O; cg += 16) {
+            for (int cg = g; 4 * cg < O; cg += kEmitLanes) {
                 const uint32_t packed = colterm[cg];
                 int cur = static_cast<int>(packed & 255u);
                 ilx_term t = oterms[cur];
@@ -994,7 +1003,7 @@ extern "C" int ilx_mdp_step(ilx_mdp_plan_t plan, const ilx_mdp* desc, void* stre
     L.bvx = take((m.need & kNeedBodyVel) ? kE * B : 0), L.bvy = take((m.need & kNeedBodyVel) ? kE * B : 0);
     L.bacc = take((m.need & kNeedBodyAcc) ? kE * B : 0);
     L.cmd = take(kE * CD), L.root = take(kE * 13);
-    L.eps = take(kE * plan->nr), L.srew = take(kE * plan->nr), L.ptotal = take(4 * kE);
+    L.eps = take(kE * plan->nr), L.srew = take(kE * plan->nr), L.ptotal = take(kWaves * kE);
     L.derived = take(kE * kDerived), L.bits = take(2 * kE);
     L.logp = take(plan->nr + plan->nt + 3);
     L.colterm = take((plan->obs_dim + 3) / 4 + plan->no);  // one block: tstart follows the packed term indices directly
@@ -1007,7 +1016,7 @@ extern "C" int ilx_mdp_step(ilx_mdp_plan_t plan, const ilx_mdp* desc, void* stre
     m.d.terminations = m.d.rewards = m.d.observations = nullptr;
     m.d.ids = nullptr;
     const unsigned blocks = static_cast<unsigned>((d.num_envs + kE - 1) / kE);
-    hipLaunchKernelGGL(mdp_step_kernel, dim3(blocks), dim3(256), lds_bytes, as_stream(stream), m);
+    hipLaunchKernelGGL(mdp_step_kernel, dim3(blocks), dim3(kBlock), lds_bytes, as_stream(stream), m);
     ILX_LAUNCH_CHECK("ilx_mdp_step");
     return ILX_OK;
 }
