@@ -1,0 +1,121 @@
+"""C ABI error behaviour: every entry point validates its arguments on the host before touching the GPU, returns a
+negative code and leaves a message that names the function (no GPU needed: nothing here gets as far as a launch)."""
+
+import ctypes
+
+import numpy as np
+import pytest
+
+from isaaclab_amd import _abi
+
+EINVAL, ESHAPE = -1, -2
+NULL = None
+FAKE = 0x1000  # a non-NULL value for pointers that are never dereferenced on the paths below
+
+
+def fails(status, code, needle):
+    assert status == code, f"status {status}, expected {code}: {_abi.lib.ilx_last_error().decode()}"
+    msg = _abi.lib.ilx_last_error().decode()
+    assert needle in msg, msg
+
+
+def test_version_and_check_helper():
+    assert _abi.lib.ilx_version() >= 1
+    with pytest.raises(_abi.IlxError, match="ilx_math_op"):
+        _abi.check(_abi.math_op(9999, FAKE, NULL, NULL, NULL, FAKE, NULL, 4, NULL), "ilx_math_op")
+
+
+def test_math_and_articulation_arguments():
+    fails(_abi.math_op(9999, FAKE, NULL, NULL, NULL, FAKE, NULL, 4, NULL), EINVAL, "ilx_math_op")
+    fails(_abi.math_op(0, NULL, NULL, NULL, NULL, NULL, NULL, 4, NULL), EINVAL, "ilx_math_op")
+    fails(_abi.joint_acc(NULL, FAKE, FAKE, 0.005, 8, NULL), EINVAL, "ilx_joint_acc")
+    fails(_abi.root_frame_derive(NULL, 0.0, 0.0, -1.0, FAKE, FAKE, FAKE, FAKE, 4, NULL), EINVAL, "ilx_root_frame_derive")
+    fails(_abi.joint_action_process(NULL, FAKE, FAKE, NULL, 1.0, NULL, 0.0, NULL, FAKE, 4, 2, NULL), EINVAL,
+          "ilx_joint_action_process")
+
+
+def test_actuator_arguments():
+    fails(_abi.actuator_pd(7, FAKE, NULL, NULL, FAKE, FAKE, FAKE, FAKE, FAKE, NULL, 0, 0.0, FAKE, FAKE, 4, 2, NULL), EINVAL,
+          "unknown model")
+    # the DC motor needs velocity limits
+    fails(_abi.actuator_pd(1, FAKE, NULL, NULL, FAKE, FAKE, FAKE, FAKE, FAKE, NULL, 0, 0.0, FAKE, FAKE, 4, 2, NULL), EINVAL,
+          "velocity_limit")
+    w = [np.zeros((65, 6), np.float32), np.zeros((1, 65), np.float32)]
+    b = [np.zeros(65, np.float32), np.zeros(1, np.float32)]
+    arr = lambda xs: (ctypes.c_void_p * len(xs))(*[x.ctypes.data for x in xs])
+    out = ctypes.c_void_p()
+    fails(_abi.mlp_create(2, (ctypes.c_int32 * 3)(6, 65, 1), 0, arr(w), arr(b), ctypes.byref(out)), ESHAPE, "layer width 65")
+    fails(_abi.mlp_create(2, (ctypes.c_int32 * 3)(6, 32, 2), 0, arr(w), arr(b), ctypes.byref(out)), ESHAPE, "output width")
+    fails(_abi.mlp_create(1, (ctypes.c_int32 * 2)(6, 1), 99, arr(w), arr(b), ctypes.byref(out)), EINVAL, "activation")
+    fails(_abi.actuator_net_mlp(NULL, FAKE, FAKE, FAKE, FAKE, FAKE, 3, (ctypes.c_int32 * 3)(0, 1, 2), 3, 0, 1.0, 1.0, 1.0, FAKE, FAKE,
+                                1, 1.0, FAKE, FAKE, 4, 2, 0, NULL), EINVAL, "ilx_actuator_net_mlp")
+    z = [np.zeros(4, np.float32)] * 4
+    fails(_abi.lstm_create(2, 2, 17, arr(z), arr(z), arr(z), arr(z), 1, (ctypes.c_int32 * 2)(17, 1), 0, arr(z), arr(z),
+                           ctypes.byref(out)), ESHAPE, "hidden size 17")
+    fails(_abi.lstm_create(2, 2, 8, arr(z), arr(z), arr(z), arr(z), 1, (ctypes.c_int32 * 2)(6, 1), 0, arr(z), arr(z),
+                           ctypes.byref(out)), ESHAPE, "head input width")
+    fails(_abi.lstm_create(5, 2, 8, arr(z), arr(z), arr(z), arr(z), 1, (ctypes.c_int32 * 2)(8, 1), 0, arr(z), arr(z),
+                           ctypes.byref(out)), ESHAPE, "5 layers")
+    fails(_abi.actuator_net_lstm(NULL, FAKE, FAKE, FAKE, FAKE, FAKE, FAKE, FAKE, 1, 1.0, FAKE, FAKE, 4, 2, NULL), EINVAL,
+          "ilx_actuator_net_lstm")
+
+
+def test_sensor_arguments():
+    fails(_abi.contact_update(NULL, FAKE, NULL, NULL, NULL, NULL, NULL, FAKE, FAKE, FAKE, 1, 0.005, 0.0, 1.0, 4, 2, 0, NULL), EINVAL,
+          "ilx_contact_update")
+    sc = _abi.Scene()
+    sc.num_envs = -1
+    fails(_abi.scene_update(ctypes.byref(sc), NULL), EINVAL, "ilx_scene_update")
+    verts = np.zeros((3, 3), np.float32)
+    tris = np.array([[0, 1, 5]], np.int32)  # vertex 5 does not exist
+    out = ctypes.c_void_p()
+    fails(_abi.mesh_create(verts.ctypes.data, 3, tris.ctypes.data, 1, ctypes.byref(out)), EINVAL, "outside")
+    fails(_abi.mesh_create(verts.ctypes.data, 3, tris.ctypes.data, 0, ctypes.byref(out)), EINVAL, "empty mesh")
+    bad = verts.copy()
+    bad[1, 2] = np.nan
+    ok_tris = np.array([[0, 1, 2]], np.int32)
+    fails(_abi.mesh_create(bad.ctypes.data, 3, ok_tris.ctypes.data, 1, ctypes.byref(out)), EINVAL, "non-finite")
+    fails(_abi.raycast_mesh(NULL, FAKE, FAKE, 4, 1e6, FAKE, NULL, NULL, NULL, 0, NULL), EINVAL, "mesh is NULL")
+    fails(_abi.raycaster_update(NULL, FAKE, FAKE, FAKE, FAKE, NULL, 1, 1e6, FAKE, NULL, 0.0, 4, 8, 0, NULL), EINVAL, "mesh is NULL")
+    rc = _abi.RayCasterDesc()
+    fails(_abi.raycaster_refresh(ctypes.byref(rc), NULL), EINVAL, "ilx_raycaster_refresh")
+    fails(_abi.mesh_grid_stats(NULL, NULL), EINVAL, "ilx_mesh_grid_stats")
+
+
+def test_ik_arguments():
+    f = _abi.IkFrame()
+    f.ee_pos = f.ee_quat = FAKE
+    f.ee_pos_stride, f.ee_quat_stride = 13, 13
+    fails(_abi.diff_ik_compute(ctypes.byref(f), 1, 9, 1.0, 0.01, 1e-5, FAKE, 42, 7, 7, FAKE, 7, NULL, FAKE, FAKE, FAKE, 7, 4, 7, NULL),
+          EINVAL, "unknown method")
+    # a Jacobian row shorter than the joint count
+    fails(_abi.diff_ik_compute(ctypes.byref(f), 1, 3, 1.0, 0.01, 1e-5, FAKE, 42, 5, 7, FAKE, 7, NULL, FAKE, FAKE, FAKE, 7, 4, 7, NULL),
+          EINVAL, "ilx_diff_ik_compute")
+    fails(_abi.diff_ik_set_command(ctypes.byref(f), 5, 0, NULL, NULL, NULL, NULL, NULL, FAKE, FAKE, FAKE, 4, NULL), EINVAL,
+          "ilx_diff_ik_set_command")
+
+
+def test_mdp_plan_arguments():
+    from isaaclab_amd.envs import fused_mdp as FM
+
+    out = ctypes.c_void_p()
+    fails(_abi.lib.ilx_mdp_plan_create(None, ctypes.byref(out)), EINVAL, "ilx_mdp_plan_create")
+    d = FM.MdpDesc()
+    d.num_envs, d.num_ids = 8, 5000   # more index-list entries than a plan can hold
+    d.ids = (ctypes.c_int32 * 1)(0)
+    fails(_abi.lib.ilx_mdp_plan_create(ctypes.byref(d), ctypes.byref(out)), ESHAPE, "index-list entries")
+    fails(_abi.lib.ilx_mdp_step(None, ctypes.byref(d), None), EINVAL, "ilx_mdp_step")
+    # an unknown term name never reaches the library
+    with pytest.raises(KeyError):
+        FM.FusedMdp(8, "cpu", num_joints=2, num_bodies=1, num_sensor_bodies=1, history_len=1, num_rays=0, action_dim=1,
+                    command_dim=0, step_dt=0.02, max_episode_length=10, rewards=[FM.TermSpec("no_such_term", weight=1.0)],
+                    terminations=[], observations=[])
+
+
+def test_cpu_tensors_are_refused():
+    import torch
+
+    with pytest.raises(_abi.IlxError, match="no CPU fallback"):
+        _abi.ptr(torch.zeros(4))
+    with pytest.raises(_abi.IlxError, match="no CPU fallback"):
+        _abi.row_view(torch.zeros(4, 3), 3)
