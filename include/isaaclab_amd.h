@@ -239,10 +239,10 @@ int ilx_mesh_create(const float* verts_host, int64_t num_verts, const int32_t* t
 void ilx_mesh_destroy(ilx_mesh_t mesh);
 int ilx_mesh_info(ilx_mesh_t mesh, int64_t* num_tris, int64_t* num_nodes, int32_t* depth);
 /* Diagnostics of the column grid that serves ILX_RAYS_Z_PARALLEL casts (no counterpart in the reference, where the
- * structure is hidden inside wp.Mesh, ops.py:130-145).  out[0..9] = cells, empty cells, cells naming a run of 1 / 2 / 3
- * neighbouring records, cells with a candidate list, distinct lists, 32-bit words of list storage, candidates summed
- * over all cells, cells per row.  All zero when the mesh has no grid. */
-int ilx_mesh_grid_stats(ilx_mesh_t mesh, int64_t out[10]);
+ * structure is hidden inside wp.Mesh, ops.py:130-145).  out[0..11] = cells, empty cells, cells naming a run of 1 / 2 /
+ * 3 or more neighbouring records, cells with a candidate list, distinct lists, 32-bit words of list storage, candidates
+ * summed over all cells, cells per row, cells naming two / three unrelated records.  All zero when the mesh has no grid. */
+int ilx_mesh_grid_stats(ilx_mesh_t mesh, int64_t out[12]);
 
 /* raycast_mesh (ops.py:24-127) + raycast_mesh_kernel (kernels.py:13-75): closest hit per ray with
  * 0 <= t < max_dist; ray_hits (n,3) = start + t*dir, +inf on a miss; optional outputs (NULL to skip):

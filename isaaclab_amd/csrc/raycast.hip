@@ -45,12 +45,27 @@ constexpr double kGridCellsPerTriangle = 8.0;  // column grid resolution over th
 constexpr int kGridTile = 16;                  // cell words, column triangles and vertices are stored in tiles of 16 x 16 cells
 constexpr double kGridPhase = 0.5;             // the grid starts this fraction of a cell before the mesh: triangle edges
                                                // of a regular height field then run through cells, not along cell borders
-// Cell word: 0xFFFFFFFF = empty; otherwise bits 31..30 = k and bits 29..0 = p.  k < 3: the candidates are the k + 1
-// records p .. p + k.  k = 3: a list starts at the 16-byte word cell_lists[p] = (count, r0, r1, r2), followed by
-// (r3, r4, r5, r6) ... for as long as the count says.
+// Cell word (32 bits).  Triangle records are stored tile by tile, so the candidates of a cell sit in a narrow window of
+// record positions around the first record of the cell's tile (tile_base, one word per tile, read next to the cell
+// word); positions inside that window fit a few bits and a word can name up to three unrelated candidates itself:
+//   0xFFFFFFFF          empty
+//   kind 0  RUN         bits 13..0 = first record - wide window base, bits 17..14 = length - 1  (records first .. first + len - 1;
+//                       a run may contain a record that is no candidate of the cell: testing it changes nothing)
+//   kind 1  PAIR        bits 13..0 and 27..14 = two records - wide window base
+//   kind 2  TRIPLE      bits 8..0, 17..9, 26..18 = three records - narrow window base
+//   kind 3..5  FAR RUN  bits 28..0 = absolute position of the first of kind - 2 records (candidates outside the window,
+//                       e.g. one huge triangle under many tiles)
+//   kind 7  LIST        bits 28..0 = p: the 16-byte word cell_lists[p] = (count, r0, r1, r2), followed by (r3, r4, r5, r6) ...
+//                       with absolute record positions, for everything else; cells with equal candidates share a list
+// wide window base = tile_base - min(tile_base, 4096), narrow window base = tile_base - min(tile_base, 64).
 constexpr int kFlagSlots = 64;  // hinted casts in flight on one mesh (on different streams) that keep their own flag
 constexpr uint32_t kCellEmpty = 0xFFFFFFFFu;
-constexpr uint32_t kCellIndexMask = 0x3FFFFFFFu;
+constexpr uint32_t kCellIndexMask = 0x1FFFFFFFu;
+constexpr int kCellKindShift = 29;
+constexpr uint32_t kCellRun = 0, kCellPair = 1, kCellTriple = 2, kCellFar1 = 3, kCellList = 7;  // far runs: kinds 3, 4, 5
+constexpr uint32_t kMaxRun = 16;     // longest run a cell word can name
+constexpr uint32_t kLooseRun = 3;    // a candidate set spanning at most this many records is named as the whole span
+constexpr uint32_t kWideBits = 14, kWideBack = 4096, kNarrowBits = 9, kNarrowBack = 64;
 
 struct alignas(16) Node {
     float minx[4], miny[4], minz[4], maxx[4], maxy[4], maxz[4];
@@ -66,6 +81,7 @@ struct MeshDev {
     int32_t num_tris;
     // column grid over the xy footprint
     const uint32_t* cells;       // one word per cell, tile order (cell_slot)
+    const uint32_t* tile_base;   // per tile: position of its first triangle record
     const uint4* cell_lists;     // candidate lists of the cells whose candidates are not one short run
     const uint4* col_tris;       // per triangle, column order: three positions in col_verts, original face id
     const float4* col_verts;     // vertices (x, y, z, -) in tile order of their xy: neighbouring triangles share them
@@ -73,10 +89,14 @@ struct MeshDev {
     int32_t nx, ny, ntx;         // cells per axis, tiles per row
 };
 
-// Slot of cell (cx, cy) in `cells`: tiles row-major, cells row-major inside a tile.
+// Slot of cell (cx, cy) in `cells`: tiles row-major; inside a tile, blocks of 8 x 4 cells (one 128-byte line each,
+// so that a line covers a compact patch whatever direction the rays of a wavefront are lined up in), cells row-major
+// inside a block.
 __host__ __device__ inline int64_t cell_slot(int cx, int cy, int ntx) {
-    return ((static_cast<int64_t>(cy / kGridTile) * ntx + cx / kGridTile) * (kGridTile * kGridTile)) +
-           (cy % kGridTile) * kGridTile + cx % kGridTile;
+    const int tx = cx % kGridTile, ty = cy % kGridTile;
+    const int block = (ty / 4) * (kGridTile / 8) + tx / 8;
+    return ((static_cast<int64_t>(cy / kGridTile) * ntx + cx / kGridTile) * (kGridTile * kGridTile)) + block * 32 + (ty % 4) * 8 +
+           tx % 8;
 }
 
 // Cell coordinate of x along one axis.  The same expression places triangles at build time and rays at cast
@@ -243,12 +263,27 @@ ILX_DEV Hit trace_column(const MeshDev& m, f3 o, f3 d, float max_dist) {
     if (!(o.x >= m.gx0 && o.x <= m.gx1 && o.y >= m.gy0 && o.y <= m.gy1)) return best;
     const int cx = cell_coord(o.x, m.gx0, m.inv_cell, m.nx), cy = cell_coord(o.y, m.gy0, m.inv_cell, m.ny);
     const uint32_t word = m.cells[cell_slot(cx, cy, m.ntx)];
+    const uint32_t base = m.tile_base[(cy / kGridTile) * m.ntx + cx / kGridTile];
     if (word == kCellEmpty) return best;
-    const uint32_t kind = word >> 30, p = word & kCellIndexMask;
-    uint32_t n = kind + 1, p0 = p, p1 = p + 1, p2 = p + 2;
-    if (kind == 3) {
+    const uint32_t kind = word >> kCellKindShift, p = word & kCellIndexMask;
+    const bool listed = kind == kCellList;
+    const uint32_t wide = base - min(base, kWideBack), narrow = base - min(base, kNarrowBack);
+    uint32_t n, p0, p1, p2;
+    if (listed) {
         const uint4 head = m.cell_lists[p];
         n = head.x, p0 = head.y, p1 = head.z, p2 = head.w;
+    } else if (kind == kCellRun) {
+        p0 = wide + (word & ((1u << kWideBits) - 1)), p1 = p0 + 1, p2 = p0 + 2;
+        n = ((word >> kWideBits) & 15u) + 1;
+    } else if (kind == kCellPair) {
+        p0 = wide + (word & ((1u << kWideBits) - 1)), p1 = wide + ((word >> kWideBits) & ((1u << kWideBits) - 1)), p2 = p0;
+        n = 2;
+    } else if (kind == kCellTriple) {
+        p0 = narrow + (word & 511u), p1 = narrow + ((word >> kNarrowBits) & 511u), p2 = narrow + ((word >> (2 * kNarrowBits)) & 511u);
+        n = 3;
+    } else {
+        p0 = p, p1 = p + 1, p2 = p + 2;
+        n = kind - kCellFar1 + 1;
     }
     p1 = n > 1 ? p1 : p0;  // absent candidates repeat the first one: the loads below need no branch
     p2 = n > 2 ? p2 : p0;
@@ -259,12 +294,16 @@ ILX_DEV Hit trace_column(const MeshDev& m, f3 o, f3 d, float max_dist) {
     test_column_vertices<WANT_NORMAL>(a0, a1, a2, static_cast<int32_t>(t0.w), o, d.z, max_dist, best);
     if (n > 1) test_column_vertices<WANT_NORMAL>(b0, b1, b2, static_cast<int32_t>(t1.w), o, d.z, max_dist, best);
     if (n > 2) test_column_vertices<WANT_NORMAL>(c0, c1, c2, static_cast<int32_t>(t2.w), o, d.z, max_dist, best);
-    for (uint32_t k = 3; k < n; k += 4) {
-        const uint4 more = m.cell_lists[p + 1 + (k - 3) / 4];
-        test_column_triangle<WANT_NORMAL>(m, more.x, o, d.z, max_dist, best);
-        if (k + 1 < n) test_column_triangle<WANT_NORMAL>(m, more.y, o, d.z, max_dist, best);
-        if (k + 2 < n) test_column_triangle<WANT_NORMAL>(m, more.z, o, d.z, max_dist, best);
-        if (k + 3 < n) test_column_triangle<WANT_NORMAL>(m, more.w, o, d.z, max_dist, best);
+    if (listed) {
+        for (uint32_t k = 3; k < n; k += 4) {
+            const uint4 more = m.cell_lists[p + 1 + (k - 3) / 4];
+            test_column_triangle<WANT_NORMAL>(m, more.x, o, d.z, max_dist, best);
+            if (k + 1 < n) test_column_triangle<WANT_NORMAL>(m, more.y, o, d.z, max_dist, best);
+            if (k + 2 < n) test_column_triangle<WANT_NORMAL>(m, more.z, o, d.z, max_dist, best);
+            if (k + 3 < n) test_column_triangle<WANT_NORMAL>(m, more.w, o, d.z, max_dist, best);
+        }
+    } else {
+        for (uint32_t k = 3; k < n; ++k) test_column_triangle<WANT_NORMAL>(m, p0 + k, o, d.z, max_dist, best);
     }
     return best;
 }
@@ -561,7 +600,7 @@ struct Builder {
 
 // How the cells of the column grid encode their candidates (diagnostics).
 struct GridStats {
-    int64_t cells, empty, run[3], list_cells, lists, list_words, candidates;
+    int64_t cells, empty, run[3], pairs, triples, list_cells, lists, list_words, candidates;
 };
 
 struct MeshHost {
@@ -570,6 +609,7 @@ struct MeshHost {
     float4* d_tris = nullptr;
     uint32_t* d_cells = nullptr;
     uint32_t* d_cell_lists = nullptr;  // read by the kernels as 16-byte words
+    uint32_t* d_tile_base = nullptr;
     uint4* d_col_tris = nullptr;
     float4* d_col_verts = nullptr;
     GridStats grid{};
@@ -703,6 +743,7 @@ extern "C" int ilx_mesh_create(const float* verts_host, int64_t num_verts, const
         double cell = std::sqrt(wx * wy / (kGridCellsPerTriangle * nt));
         cell = std::max(cell, std::max(wx, wy) / 8192.0);
         const int64_t max_refs = std::min<int64_t>(std::max<int64_t>(int64_t(64) * nt, 1 << 16), kCellIndexMask - 8);
+        static_assert((1u << 28) <= kCellIndexMask, "a cell word must be able to name every triangle");
         for (int attempt = 0; attempt < 12; ++attempt, cell *= 2.0) {
             inv_cell = static_cast<float>(1.0 / cell);
             for (int a = 0; a < 2; ++a) g0[a] = static_cast<float>(double(m0[a]) - kGridPhase / double(inv_cell));
@@ -777,7 +818,7 @@ extern "C" int ilx_mesh_create(const float* verts_host, int64_t num_verts, const
     // Column vertices are ordered by the tile of their own cell.
     std::vector<uint4> col_tris(cell_start.empty() ? 0 : static_cast<size_t>(nt));
     std::vector<float4> col_verts(cell_start.empty() ? 0 : static_cast<size_t>(num_verts));
-    std::vector<uint32_t> cells, cell_lists;
+    std::vector<uint32_t> cells, cell_lists, tile_base;
     int ntx = 0;
     GridStats gstats{};
     if (!cell_start.empty()) {
@@ -808,10 +849,80 @@ extern "C" int ilx_mesh_create(const float* verts_host, int64_t num_verts, const
                 for (int a = 0; a < 2; ++a) c[a] += verts_host[3 * static_cast<int64_t>(tris_host[3 * t + k]) + a];
             key[i] = tile_of(static_cast<float>(c[0] / 3.0), static_cast<float>(c[1] / 3.0));
         }
+        // Order inside a tile: triangles that are candidates of the same cell should be neighbours, so that the cell can
+        // name them as a run.  Every pair of same-tile triangles that shares a small cell (2..4 candidates) is an edge,
+        // weighted by the number of such cells; edges are taken greedily by weight into vertex-disjoint paths (each
+        // triangle gets at most two neighbours, no cycles), and a tile's paths are laid out one after the other.  On a
+        // height field this keeps the two halves of a quad and one of their edge neighbours adjacent.
+        std::vector<uint32_t> rank_in_tile(nt);
+        {
+            std::vector<uint64_t> pairs;
+            pairs.reserve(static_cast<size_t>(nt) * 4);
+            for (size_t c = 0; c + 1 < cell_start.size(); ++c) {
+                const uint32_t b = cell_start[c], e = cell_start[c + 1];
+                if (e - b < 2 || e - b > 4) continue;
+                for (uint32_t x = b; x < e; ++x)
+                    for (uint32_t y = x + 1; y < e; ++y) {
+                        uint32_t p = cell_refs[x], q = cell_refs[y];
+                        if (key[p] != key[q]) continue;
+                        if (p > q) std::swap(p, q);
+                        pairs.push_back(static_cast<uint64_t>(p) << 32 | q);
+                    }
+            }
+            std::sort(pairs.begin(), pairs.end());
+            struct Edge {
+                uint32_t w, a, b;
+            };
+            std::vector<Edge> edges;
+            for (size_t i = 0; i < pairs.size();) {
+                size_t j = i;
+                while (j < pairs.size() && pairs[j] == pairs[i]) ++j;
+                edges.push_back({static_cast<uint32_t>(j - i), static_cast<uint32_t>(pairs[i] >> 32), static_cast<uint32_t>(pairs[i])});
+                i = j;
+            }
+            pairs.clear();
+            pairs.shrink_to_fit();
+            std::stable_sort(edges.begin(), edges.end(), [](const Edge& x, const Edge& y) { return x.w > y.w; });
+            std::vector<uint32_t> comp(nt), nb0(nt, UINT32_MAX), nb1(nt, UINT32_MAX);
+            std::iota(comp.begin(), comp.end(), 0u);
+            auto find = [&](uint32_t v) {
+                while (comp[v] != v) v = comp[v] = comp[comp[v]];
+                return v;
+            };
+            for (const Edge& ed : edges) {
+                if (nb1[ed.a] != UINT32_MAX || nb1[ed.b] != UINT32_MAX) continue;  // already two neighbours
+                const uint32_t ra = find(ed.a), rb = find(ed.b);
+                if (ra == rb) continue;  // would close a cycle
+                comp[ra] = rb;
+                (nb0[ed.a] == UINT32_MAX ? nb0[ed.a] : nb1[ed.a]) = ed.b;
+                (nb0[ed.b] == UINT32_MAX ? nb0[ed.b] : nb1[ed.b]) = ed.a;
+            }
+            // walk every path from its end with the lower face id; paths of a tile in the order of that id
+            std::vector<uint32_t> by_face(nt);
+            std::iota(by_face.begin(), by_face.end(), 0u);
+            std::sort(by_face.begin(), by_face.end(), [&](uint32_t a, uint32_t b) {
+                return key[a] != key[b] ? key[a] < key[b] : order[a] < order[b];
+            });
+            std::vector<uint8_t> placed(nt, 0);
+            uint32_t next = 0;
+            for (uint32_t start : by_face) {
+                if (placed[start] || nb1[start] != UINT32_MAX) continue;  // interior vertices are reached from an end
+                uint32_t prev = UINT32_MAX, v = start;
+                while (v != UINT32_MAX && !placed[v]) {
+                    placed[v] = 1;
+                    rank_in_tile[v] = next++;
+                    const uint32_t to = nb0[v] != prev ? nb0[v] : nb1[v];
+                    prev = v;
+                    v = to;
+                }
+            }
+            for (uint32_t v : by_face)  // nothing is left (paths have two ends), but never leave a triangle unplaced
+                if (!placed[v]) rank_in_tile[v] = next++;
+        }
         std::vector<uint32_t> by_key(nt), pos(nt);
         std::iota(by_key.begin(), by_key.end(), 0u);
         std::sort(by_key.begin(), by_key.end(), [&](uint32_t a, uint32_t b) {
-            return key[a] != key[b] ? key[a] < key[b] : order[a] < order[b];
+            return key[a] != key[b] ? key[a] < key[b] : rank_in_tile[a] < rank_in_tile[b];
         });
         for (int r = 0; r < nt; ++r) {
             pos[by_key[r]] = static_cast<uint32_t>(r);
@@ -819,6 +930,10 @@ extern "C" int ilx_mesh_create(const float* verts_host, int64_t num_verts, const
             col_tris[r] = make_uint4(vpos[tris_host[3 * t]], vpos[tris_host[3 * t + 1]], vpos[tris_host[3 * t + 2]],
                                      static_cast<uint32_t>(t));
         }
+        // first record of every tile (records are sorted by tile)
+        tile_base.assign(static_cast<size_t>(ntx) * nty + 1, 0u);
+        for (int i = 0; i < nt; ++i) ++tile_base[key[i] + 1];
+        for (size_t t = 1; t < tile_base.size(); ++t) tile_base[t] += tile_base[t - 1];
         // cell words; candidate lists are shared between cells with the same candidates
         cells.assign(static_cast<size_t>(ntx) * nty * T * T, kCellEmpty);
         cell_lists.reserve(1 << 16);
@@ -827,7 +942,7 @@ extern "C" int ilx_mesh_create(const float* verts_host, int64_t num_verts, const
         // cells are visited tile by tile, so the lists of a tile's cells are neighbours in memory as well
         for (int64_t slot = 0; slot < static_cast<int64_t>(cells.size()); ++slot) {
             {
-                const int64_t tile = slot / (T * T);
+                const int64_t tile = slot / (T * T);  // the same numbering as the triangles' tile key
                 const int in_tile = static_cast<int>(slot % (T * T));
                 const int cx = static_cast<int>(tile % ntx) * T + in_tile % T, cy = static_cast<int>(tile / ntx) * T + in_tile / T;
                 if (cx >= gnx || cy >= gny) continue;
@@ -844,9 +959,30 @@ extern "C" int ilx_mesh_create(const float* verts_host, int64_t num_verts, const
                 uint32_t& word = cells[cell_slot(cx, cy, ntx)];
                 const uint32_t n = static_cast<uint32_t>(cand.size());
                 gstats.candidates += n;
-                if (n <= 3 && cand[n - 1] - cand[0] == n - 1) {
-                    word = ((n - 1) << 30) | cand[0];
-                    ++gstats.run[n - 1];
+                const uint32_t span = cand[n - 1] - cand[0] + 1;
+                const uint32_t tb = tile_base[tile], wide = tb - std::min(tb, kWideBack), narrow = tb - std::min(tb, kNarrowBack);
+                auto in_window = [&](uint32_t lo, uint32_t bits) {
+                    return cand[0] >= lo && cand[n - 1] - lo < (1u << bits);
+                };
+                if ((span <= kLooseRun || (span == n && n <= kMaxRun)) && in_window(wide, kWideBits)) {
+                    word = (kCellRun << kCellKindShift) | ((span - 1) << kWideBits) | (cand[0] - wide);
+                    ++gstats.run[span <= 3 ? span - 1 : 2];
+                    continue;
+                }
+                if (span <= kLooseRun) {  // out of the window
+                    word = ((kCellFar1 + span - 1) << kCellKindShift) | cand[0];
+                    ++gstats.run[span - 1];
+                    continue;
+                }
+                if (n == 2 && in_window(wide, kWideBits)) {
+                    word = (kCellPair << kCellKindShift) | ((cand[1] - wide) << kWideBits) | (cand[0] - wide);
+                    ++gstats.pairs;
+                    continue;
+                }
+                if (n == 3 && in_window(narrow, kNarrowBits)) {
+                    word = (kCellTriple << kCellKindShift) | ((cand[2] - narrow) << (2 * kNarrowBits)) |
+                           ((cand[1] - narrow) << kNarrowBits) | (cand[0] - narrow);
+                    ++gstats.triples;
                     continue;
                 }
                 uint64_t hsh = 1469598103934665603ull;
@@ -863,7 +999,7 @@ extern "C" int ilx_mesh_create(const float* verts_host, int64_t num_verts, const
                     same.push_back(at);
                     ++gstats.lists;
                 }
-                word = (3u << 30) | (at / 4);
+                word = (kCellList << kCellKindShift) | (at / 4);
                 ++gstats.list_cells;
             }
         }
@@ -877,6 +1013,7 @@ extern "C" int ilx_mesh_create(const float* verts_host, int64_t num_verts, const
     if (rc == ILX_OK) rc = check_hip(hipMemset(h.d_off_grid, 0, kFlagSlots * sizeof(int32_t)), "ilx_mesh_create: hipMemset(flag)");
     if (rc == ILX_OK && !cells.empty()) {
         rc = upload(&h.d_cells, cells, "cells");
+        if (rc == ILX_OK) rc = upload(&h.d_tile_base, tile_base, "tile bases");
         if (rc == ILX_OK) rc = upload(&h.d_cell_lists, cell_lists, "cell lists");
         if (rc == ILX_OK) rc = upload(&h.d_col_tris, col_tris, "column triangles");
         if (rc == ILX_OK) rc = upload(&h.d_col_verts, col_verts, "column vertices");
@@ -893,6 +1030,7 @@ extern "C" int ilx_mesh_create(const float* verts_host, int64_t num_verts, const
         if (h.d_tris) (void)hipFree(h.d_tris);
         if (h.d_cells) (void)hipFree(h.d_cells);
         if (h.d_cell_lists) (void)hipFree(h.d_cell_lists);
+        if (h.d_tile_base) (void)hipFree(h.d_tile_base);
         if (h.d_off_grid) (void)hipFree(h.d_off_grid);
         if (h.d_col_tris) (void)hipFree(h.d_col_tris);
         if (h.d_col_verts) (void)hipFree(h.d_col_verts);
@@ -900,6 +1038,7 @@ extern "C" int ilx_mesh_create(const float* verts_host, int64_t num_verts, const
         return rc;
     }
     h.dev.nodes = h.d_nodes, h.dev.tris = h.d_tris, h.dev.num_nodes = nn, h.dev.num_tris = nt;
+    h.dev.tile_base = h.d_tile_base;
     h.dev.cells = h.d_cells, h.dev.cell_lists = reinterpret_cast<const uint4*>(h.d_cell_lists), h.dev.col_tris = h.d_col_tris, h.dev.col_verts = h.d_col_verts;
     h.dev.gx0 = g0[0], h.dev.gy0 = g0[1], h.dev.gx1 = g1[0], h.dev.gy1 = g1[1], h.dev.inv_cell = inv_cell;
     h.dev.nx = gnx, h.dev.ny = gny, h.dev.ntx = ntx;
@@ -915,6 +1054,7 @@ extern "C" void ilx_mesh_destroy(ilx_mesh_t mesh) {
     if (mesh->h.d_tris) (void)hipFree(mesh->h.d_tris);
     if (mesh->h.d_cells) (void)hipFree(mesh->h.d_cells);
     if (mesh->h.d_cell_lists) (void)hipFree(mesh->h.d_cell_lists);
+    if (mesh->h.d_tile_base) (void)hipFree(mesh->h.d_tile_base);
     if (mesh->h.d_off_grid) (void)hipFree(mesh->h.d_off_grid);
     if (mesh->h.d_col_tris) (void)hipFree(mesh->h.d_col_tris);
     if (mesh->h.d_col_verts) (void)hipFree(mesh->h.d_col_verts);
@@ -929,12 +1069,12 @@ extern "C" int ilx_mesh_info(ilx_mesh_t mesh, int64_t* num_tris, int64_t* num_no
     return ILX_OK;
 }
 
-extern "C" int ilx_mesh_grid_stats(ilx_mesh_t mesh, int64_t out[10]) {
+extern "C" int ilx_mesh_grid_stats(ilx_mesh_t mesh, int64_t out[12]) {
     ILX_REQUIRE(mesh && out, ILX_EINVAL, "ilx_mesh_grid_stats: NULL argument");
     const GridStats& g = mesh->h.grid;
-    const int64_t v[10] = {g.cells, g.empty, g.run[0], g.run[1], g.run[2], g.list_cells, g.lists, g.list_words, g.candidates,
-                           mesh->h.dev.nx};
-    for (int i = 0; i < 10; ++i) out[i] = v[i];
+    const int64_t v[12] = {g.cells, g.empty, g.run[0], g.run[1], g.run[2], g.list_cells, g.lists, g.list_words, g.candidates,
+                           mesh->h.dev.nx, g.pairs, g.triples};
+    for (int i = 0; i < 12; ++i) out[i] = v[i];
     return ILX_OK;
 }
 

@@ -33,9 +33,10 @@ class Mesh:
 
     def grid_stats(self) -> dict:
         """How the column grid behind ``RAYS_Z_PARALLEL`` casts encodes its cells (diagnostics)."""
-        out = (ctypes.c_int64 * 10)()
+        out = (ctypes.c_int64 * 12)()
         _abi.check(_abi.mesh_grid_stats(self.handle, out), "ilx_mesh_grid_stats")
-        names = ("cells", "empty", "run1", "run2", "run3", "list_cells", "lists", "list_words", "candidates", "cells_per_row")
+        names = ("cells", "empty", "run1", "run2", "run3", "list_cells", "lists", "list_words", "candidates", "cells_per_row",
+                 "pairs", "triples")
         return dict(zip(names, (int(v) for v in out)))
 
     def __del__(self):
