@@ -118,6 +118,23 @@ int ilx_actuator_pd(int model, const float* q_des, const float* qd_des, const fl
                     const float* velocity_limit, int params_per_env, float saturation_effort, float* computed,
                     float* applied, int64_t n, int j, void* stream);
 
+/* DelayedPDActuator.compute (actuator_pd.py:283-291) and, with a lookup table, RemotizedPDActuator.compute
+ * (:347-363), in one launch.  The three set-points are appended to their DelayBuffer rings (delay_buffer.py:158-177
+ * over circular_buffer.py:121-175: rings of shape (ring_length, n, j) with ONE write pointer for all envs; `pointer` is
+ * the slot this call writes, i.e. (previous + 1) % ring_length, starting at 0; the first push after a reset fills every
+ * slot of the env) and read back min(time_lags[env], pushes since reset) steps late; then the ideal PD law and the
+ * effort clip; then, if lookup_angles is given, the clamp to the torque limit interpolated at the joint position
+ * (utils/interpolation/linear_interpolation.py:55-88, ascending angles, held constant outside).  num_pushes (n) int64
+ * is advanced by one; time_lags (n) int32 is read.  qd_des / tau_ff may be NULL together with their rings (zeros).
+ * A reset (actuator_pd.py:262-281) is the caller's: num_pushes <- 0, new time_lags, ring rows <- 0. */
+int ilx_actuator_delayed_pd(const float* q_des, const float* qd_des, const float* tau_ff, const float* q,
+                            const float* qd, const float* stiffness, const float* damping,
+                            const float* effort_limit, int params_per_env, float* positions_ring,
+                            float* velocities_ring, float* efforts_ring, int ring_length, int pointer,
+                            int64_t* num_pushes, const int32_t* time_lags, const float* lookup_angles,
+                            const float* lookup_max_torque, int lookup_size, float* computed, float* applied,
+                            int64_t n, int j, void* stream);
+
 #define ILX_ACT_SOFTSIGN 0
 #define ILX_ACT_ELU 1
 #define ILX_ACT_TANH 2

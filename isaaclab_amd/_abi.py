@@ -83,6 +83,8 @@ root_state_pack = _sig("ilx_root_state_pack", P, P, P, c_int64, P)
 root_frame_derive = _sig("ilx_root_frame_derive", P, c_float, c_float, c_float, P, P, P, P, c_int64, P)
 joint_acc = _sig("ilx_joint_acc", P, P, P, c_float, c_int64, P)
 actuator_pd = _sig("ilx_actuator_pd", c_int, P, P, P, P, P, P, P, P, P, c_int, c_float, P, P, c_int64, c_int, P)
+actuator_delayed_pd = _sig("ilx_actuator_delayed_pd", P, P, P, P, P, P, P, P, c_int, P, P, P, c_int, c_int, P, P, P, P, c_int, P, P,
+                           c_int64, c_int, P)
 lstm_create = _sig("ilx_lstm_create", c_int, c_int, c_int, P, P, P, P, c_int, P, c_int, P, P, P)
 lib.ilx_lstm_destroy.argtypes = [P]
 lib.ilx_lstm_destroy.restype = None

@@ -34,6 +34,19 @@ class DCMotorCfg(IdealPDActuatorCfg):
 
 
 @dataclass
+class DelayedPDActuatorCfg(IdealPDActuatorCfg):
+    min_delay: int = 0
+    max_delay: int = 0
+
+
+@dataclass
+class RemotizedPDActuatorCfg(DelayedPDActuatorCfg):
+    """``joint_parameter_lookup``: rows of (joint angle, transmission ratio, maximum torque), angles ascending."""
+
+    joint_parameter_lookup: list | None = None
+
+
+@dataclass
 class ActuatorNetMLPCfg(DCMotorCfg):
     """``network_file`` may be a path to a ``torch.save``'d state-dict of Linear layers, or ``network`` may carry
     the layers directly as ``{"weights": [...], "biases": [...], "activation": "softsign"}``."""

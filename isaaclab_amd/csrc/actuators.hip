@@ -48,6 +48,85 @@ actuator_pd_kernel(const float* __restrict__ q_des, const float* __restrict__ qd
 }
 
 // ------------------------------------------------------------------------------------------------
+// Delayed / remotized PD (actuator_pd.py:236-363)
+// ------------------------------------------------------------------------------------------------
+struct DelayArgs {
+    const float* set[3];   // q_des, qd_des, tau_ff of this call (the last two may be null: zeros, nothing buffered)
+    float* ring[3];        // (len, n, j) rings of the three set-points, one write pointer for all envs
+    int len, pointer;      // slots per ring; the slot this call writes
+    int64_t* num_pushes;   // (n) pushes since the env's last reset
+    const int32_t* time_lags;  // (n)
+    const float* q;
+    const float* qd;
+    const float* kp;
+    const float* kd;
+    const float* effort_limit;
+    int per_env;
+    const float* lookup_x;  // remotized: ascending joint angles and the torque limit at each, or null
+    const float* lookup_y;
+    int lookup_n;
+    float* computed;
+    float* applied;
+    int64_t n;
+    int j, envs_per_block;
+};
+
+// utils/interpolation/linear_interpolation.py:55-88
+ILX_DEV float interpolate_held(const float* x, const float* y, int n, float q) {
+    int smaller = 0;
+    for (int i = 0; i < n; ++i) smaller += x[i] < q ? 1 : 0;
+    const int lo = smaller - 1 < 0 ? 0 : smaller - 1;
+    const int hi = smaller > n - 1 ? n - 1 : smaller;
+    const float w = hi == lo ? 0.0f : div_(q - x[lo], x[hi] - x[lo]);
+    return y[lo] + w * (y[hi] - y[lo]);
+}
+
+// A block owns whole envs (its threads read an env's push count before any of them advances it); one thread per
+// (env, joint): append the three set-points to their rings (circular_buffer.py:121-143: the first push after a reset
+// fills every slot), read them back time_lag steps late (delay_buffer.py:158-177), then the ideal PD law.
+__global__ void __launch_bounds__(256) actuator_delayed_pd_kernel(DelayArgs a) {
+    const int e_local = threadIdx.x / a.j, joint = threadIdx.x - e_local * a.j;
+    const int64_t env = static_cast<int64_t>(blockIdx.x) * a.envs_per_block + e_local;
+    const bool on = e_local < a.envs_per_block && env < a.n;
+    int64_t pushes = 0;
+    if (on) {
+        pushes = a.num_pushes[env];
+        const int64_t lag64 = a.time_lags[env] < pushes ? a.time_lags[env] : pushes;  // min(lag, pushes_after - 1)
+        int slot = (a.pointer - static_cast<int>(lag64)) % a.len;
+        slot = slot < 0 ? slot + a.len : slot;
+        const int64_t at = env * a.j + joint, plane = a.n * a.j;
+        float late[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            late[k] = 0.0f;
+            if (a.set[k]) {
+                const float v = a.set[k][at];
+                if (pushes == 0) {
+                    for (int s = 0; s < a.len; ++s) a.ring[k][s * plane + at] = v;
+                    late[k] = v;
+                } else {
+                    a.ring[k][a.pointer * plane + at] = v;
+                    late[k] = slot == a.pointer ? v : a.ring[k][slot * plane + at];
+                }
+            }
+        }
+        const int64_t pi = a.per_env ? at : joint;
+        const float pos = a.q[at];
+        const float tau = a.kp[pi] * (late[0] - pos) + a.kd[pi] * (late[1] - a.qd[at]) + late[2];  // actuator_pd.py:135-138
+        const float lim = a.effort_limit[pi];
+        float out = fminf(fmaxf(tau, -lim), lim);
+        if (a.lookup_x) {  // actuator_pd.py:354-361
+            const float cap = interpolate_held(a.lookup_x, a.lookup_y, a.lookup_n, pos);
+            out = fminf(fmaxf(out, -cap), cap);
+        }
+        a.computed[at] = tau;
+        a.applied[at] = out;
+    }
+    __syncthreads();
+    if (on && joint == 0) a.num_pushes[env] = pushes + 1;
+}
+
+// ------------------------------------------------------------------------------------------------
 // MLP
 // ------------------------------------------------------------------------------------------------
 constexpr int kMaxHist = 8;
@@ -593,5 +672,37 @@ extern "C" int ilx_actuator_net_mlp(ilx_mlp_t net, const float* q_des, const flo
         default: launch_mlp<ILX_ACT_IDENTITY>(a, generic, s); break;
     }
     ILX_LAUNCH_CHECK("ilx_actuator_net_mlp");
+    return ILX_OK;
+}
+
+extern "C" int ilx_actuator_delayed_pd(const float* q_des, const float* qd_des, const float* tau_ff, const float* q,
+                                       const float* qd, const float* stiffness, const float* damping,
+                                       const float* effort_limit, int params_per_env, float* positions_ring,
+                                       float* velocities_ring, float* efforts_ring, int ring_length, int pointer,
+                                       int64_t* num_pushes, const int32_t* time_lags, const float* lookup_angles,
+                                       const float* lookup_max_torque, int lookup_size, float* computed, float* applied,
+                                       int64_t n, int j, void* stream) {
+    ILX_REQUIRE(n >= 0 && j > 0, ILX_EINVAL, "ilx_actuator_delayed_pd: bad shape (%lld, %d)", (long long)n, j);
+    ILX_REQUIRE(j <= 256, ILX_ESHAPE, "ilx_actuator_delayed_pd: %d joints per actuator group (max 256)", j);
+    ILX_REQUIRE(q_des && q && qd && stiffness && damping && effort_limit && computed && applied && positions_ring && num_pushes &&
+                    time_lags,
+                ILX_EINVAL, "ilx_actuator_delayed_pd: NULL operand");
+    ILX_REQUIRE((qd_des == nullptr) == (velocities_ring == nullptr) && (tau_ff == nullptr) == (efforts_ring == nullptr), ILX_EINVAL,
+                "ilx_actuator_delayed_pd: a set-point and its ring must be given together");
+    ILX_REQUIRE(ring_length >= 1 && pointer >= 0 && pointer < ring_length, ILX_EINVAL,
+                "ilx_actuator_delayed_pd: pointer %d outside a ring of %d slots", pointer, ring_length);
+    ILX_REQUIRE((lookup_angles == nullptr) == (lookup_max_torque == nullptr) && (lookup_angles == nullptr || lookup_size >= 1),
+                ILX_EINVAL, "ilx_actuator_delayed_pd: the lookup table needs angles, torques and a size >= 1");
+    if (n == 0) return ILX_OK;
+    DelayArgs a;
+    a.set[0] = q_des, a.set[1] = qd_des, a.set[2] = tau_ff;
+    a.ring[0] = positions_ring, a.ring[1] = velocities_ring, a.ring[2] = efforts_ring;
+    a.len = ring_length, a.pointer = pointer, a.num_pushes = num_pushes, a.time_lags = time_lags;
+    a.q = q, a.qd = qd, a.kp = stiffness, a.kd = damping, a.effort_limit = effort_limit, a.per_env = params_per_env;
+    a.lookup_x = lookup_angles, a.lookup_y = lookup_max_torque, a.lookup_n = lookup_size;
+    a.computed = computed, a.applied = applied, a.n = n, a.j = j, a.envs_per_block = 256 / j;
+    const unsigned blocks = static_cast<unsigned>((n + a.envs_per_block - 1) / a.envs_per_block);
+    hipLaunchKernelGGL(actuator_delayed_pd_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), a);
+    ILX_LAUNCH_CHECK("ilx_actuator_delayed_pd");
     return ILX_OK;
 }

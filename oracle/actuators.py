@@ -124,3 +124,55 @@ def actuator_net_lstm(q_des, q, qd, hidden, cell, lstm, head_weights, head_biase
     computed = mlp_forward(out, head_weights, head_biases, head_activation).reshape(n, j)
     applied = dc_motor_clip(computed, qd, saturation_effort, velocity_limit, effort_limit)
     return computed, applied, h, c
+
+
+class DelayLine:
+    """DelayBuffer over a CircularBuffer (utils/buffers/delay_buffer.py:32-177, circular_buffer.py:93-175), restated:
+    a ring of ``history_length + 1`` slots shared by all envs (one write pointer), per-env push counts and time lags.
+    The first push after a reset fills every slot of that env; a read returns the entry ``min(lag, pushes - 1)`` back."""
+
+    def __init__(self, history_length: int, batch_size: int):
+        self.max_len = max(0, history_length) + 1
+        self.pointer = -1
+        self.buffer = None
+        self.num_pushes = torch.zeros(batch_size, dtype=torch.long)
+        self.time_lags = torch.zeros(batch_size, dtype=torch.int)
+
+    def reset(self, ids):
+        self.num_pushes[ids] = 0
+        if self.buffer is not None:
+            self.buffer[:, ids] = 0.0
+
+    def compute(self, data):
+        if self.buffer is None:
+            self.buffer = torch.empty((self.max_len, *data.shape), dtype=data.dtype)
+        self.pointer = (self.pointer + 1) % self.max_len
+        self.buffer[self.pointer] = data
+        fresh = self.num_pushes == 0
+        self.buffer[:, fresh] = data[fresh]
+        self.num_pushes += 1
+        valid = torch.minimum(self.time_lags.long(), self.num_pushes - 1)
+        index = torch.remainder(self.pointer - valid, self.max_len)
+        return self.buffer[index, torch.arange(data.shape[0])].clone()
+
+
+def linear_interpolation(x, y, q):
+    """utils/interpolation/linear_interpolation.py:55-88: piecewise linear through (x, y), held constant outside."""
+    q1 = q.reshape(-1)
+    smaller = torch.sum(x.unsqueeze(1) < q1.unsqueeze(0), dim=0, dtype=torch.int)
+    lo = torch.clamp(smaller - 1, min=0)
+    hi = torch.clamp(smaller, max=x.numel() - 1)
+    weight = (q1 - x[lo]) / (x[hi] - x[lo])
+    weight[hi == lo] = 0.0
+    return (y[lo] + weight * (y[hi] - y[lo])).reshape(q.shape)
+
+
+def delayed_pd(lines, q_des, qd_des, tau_ff, q, qd, stiffness, damping, effort_limit, lookup=None):
+    """DelayedPDActuator.compute (actuator_pd.py:283-291) and, with ``lookup`` = (angles, max torques),
+    RemotizedPDActuator.compute (:347-363).  ``lines`` = the three DelayLine objects (positions, velocities, efforts)."""
+    computed = pd_torque(lines[0].compute(q_des), lines[1].compute(qd_des), lines[2].compute(tau_ff), q, qd, stiffness, damping)
+    applied = clip_effort(computed, effort_limit)
+    if lookup is not None:
+        lim = linear_interpolation(lookup[0], lookup[1], q)
+        applied = torch.clamp(applied, min=-lim, max=lim)
+    return computed, applied

@@ -215,6 +215,57 @@ def actuators_lstm():
 
 
 @section
+def actuators_delayed():
+    """DelayedPDActuator and RemotizedPDActuator (actuator_pd.py:236-363) on the reference's own DelayBuffer,
+    CircularBuffer and LinearInterpolation."""
+    m = R.bootstrap()
+    Types = m["types"]
+    pd = m["actuator_pd"]
+    cb = R.load("isaaclab.utils.buffers.circular_buffer", f"{R.L}/utils/buffers/circular_buffer.py")
+    sys.modules["isaaclab.utils.buffers"] = types.ModuleType("isaaclab.utils.buffers")
+    sys.modules["isaaclab.utils.buffers"].circular_buffer = cb
+    db = R.load("isaaclab.utils.buffers.delay_buffer", f"{R.L}/utils/buffers/delay_buffer.py")
+    li = R.load("isaaclab.utils.interpolation.linear_interpolation", f"{R.L}/utils/interpolation/linear_interpolation.py")
+    pd.DelayBuffer, pd.LinearInterpolation = db.DelayBuffer, li.LinearInterpolation
+    g = gen(4101)
+    torch.manual_seed(4101)  # reset() draws the time lags from the global generator (actuator_pd.py:270-276)
+    n, j, steps = 48, 12, 9
+    base = dict(joint_names_expr=[".*"], armature=None, friction=None)
+    # Spot's knee lookup shape (isaaclab_assets/robots/spot.py): angle, transmission ratio, max torque; ascending angles
+    ang = torch.linspace(-2.79, -0.25, 12)
+    lookup = torch.stack([ang, torch.linspace(-24.8, -8.9, 12), 37.2 + 80.0 * torch.sin((ang + 2.79) * 1.1)], dim=1).tolist()
+    out = {"lookup": torch.tensor(lookup)}
+    for tag, cls, cfg in (
+        ("delayed", pd.DelayedPDActuator, Cfg(stiffness=60.0, damping=1.5, effort_limit=45.0, velocity_limit=20.0, min_delay=0,
+                                              max_delay=4, **base)),
+        ("remotized", pd.RemotizedPDActuator, Cfg(stiffness=60.0, damping=1.5, effort_limit=None, velocity_limit=None,
+                                                  min_delay=1, max_delay=3, joint_parameter_lookup=lookup, **base)),
+    ):
+        act = cls(cfg, joint_names=_names(j), joint_ids=slice(None), num_envs=n, device="cpu")
+        rec = dict(q_des=[], qd_des=[], tau_ff=[], q=[], qd=[], computed=[], applied=[], lags=[])
+        for s in range(steps):
+            q_des = torch.randn(n, j, generator=g) - (1.5 if tag == "remotized" else 0.0)
+            qd_des = torch.randn(n, j, generator=g) * 0.5
+            tau_ff = torch.randn(n, j, generator=g) * 2.0
+            q = q_des + torch.randn(n, j, generator=g) * 0.8
+            qd = torch.randn(n, j, generator=g) * 6.0
+            if s == 0:
+                act.reset(slice(None))   # as Articulation.reset does before the first step
+            if s == 5:
+                act.reset([1, 3, 8])
+            ca = Types.ArticulationActions(joint_positions=q_des.clone(), joint_velocities=qd_des.clone(),
+                                           joint_efforts=tau_ff.clone(), joint_indices=slice(None))
+            act.compute(ca, q.clone(), qd.clone())
+            for k, v in zip(rec, (q_des, qd_des, tau_ff, q, qd, act.computed_effort.clone(), act.applied_effort.clone(),
+                                  act.positions_delay_buffer.time_lags.clone())):
+                rec[k].append(v)
+        out.update({f"{tag}_{k}": torch.stack(v) for k, v in rec.items()})
+        out[f"{tag}_effort_limit"] = act.effort_limit
+        assert len(set(rec["lags"][0].tolist())) > 1
+    save("actuators_delayed", **out)
+
+
+@section
 def articulation_data():
     """Real ArticulationData on a fake physics view: derived root quantities and joint_acc."""
     m = R.bootstrap()

@@ -40,6 +40,13 @@ def test_actuator_arguments():
     # the DC motor needs velocity limits
     fails(_abi.actuator_pd(1, FAKE, NULL, NULL, FAKE, FAKE, FAKE, FAKE, FAKE, NULL, 0, 0.0, FAKE, FAKE, 4, 2, NULL), EINVAL,
           "velocity_limit")
+    # delayed PD: the write pointer must lie inside the ring; a set-point and its ring come together
+    fails(_abi.actuator_delayed_pd(FAKE, NULL, NULL, FAKE, FAKE, FAKE, FAKE, FAKE, 1, FAKE, NULL, NULL, 3, 3, FAKE, FAKE, NULL, NULL, 0,
+                                   FAKE, FAKE, 4, 2, NULL), EINVAL, "pointer 3 outside a ring of 3")
+    fails(_abi.actuator_delayed_pd(FAKE, FAKE, NULL, FAKE, FAKE, FAKE, FAKE, FAKE, 1, FAKE, NULL, NULL, 3, 0, FAKE, FAKE, NULL, NULL, 0,
+                                   FAKE, FAKE, 4, 2, NULL), EINVAL, "together")
+    fails(_abi.actuator_delayed_pd(FAKE, NULL, NULL, FAKE, FAKE, FAKE, FAKE, FAKE, 1, FAKE, NULL, NULL, 3, 0, FAKE, FAKE, NULL, NULL, 0,
+                                   FAKE, FAKE, 4, 300, NULL), ESHAPE, "300 joints")
     w = [np.zeros((65, 6), np.float32), np.zeros((1, 65), np.float32)]
     b = [np.zeros(65, np.float32), np.zeros(1, np.float32)]
     arr = lambda xs: (ctypes.c_void_p * len(xs))(*[x.ctypes.data for x in xs])

@@ -59,6 +59,40 @@ def test_pd_regex_parameters(dev):
                 joint_ids=slice(None), num_envs=4, device=dev)
 
 
+def test_delayed_and_remotized_pd(dev):
+    """DelayedPDActuator / RemotizedPDActuator against the reference classes' fixture (9 substeps, a partial reset
+    before step 5; the time lags the reference drew are installed, everything else is the class's own bookkeeping)."""
+    from isaaclab_amd.actuators import DelayedPDActuator, DelayedPDActuatorCfg, RemotizedPDActuator, RemotizedPDActuatorCfg
+    from isaaclab_amd.utils.types import ArticulationActions
+
+    g = load_golden("actuators_delayed")
+    cases = (("delayed", DelayedPDActuator, DelayedPDActuatorCfg(stiffness=60.0, damping=1.5, effort_limit=45.0, velocity_limit=20.0,
+                                                                   min_delay=0, max_delay=4)),
+             ("remotized", RemotizedPDActuator, RemotizedPDActuatorCfg(stiffness=60.0, damping=1.5, min_delay=1, max_delay=3,
+                                                                       joint_parameter_lookup=g["lookup"].tolist())))
+    for tag, cls, cfg in cases:
+        n, j = g[f"{tag}_q"].shape[1:]
+        act = cls(cfg, joint_names=_names(j), joint_ids=slice(None), num_envs=n, device=dev)
+        for s in range(g[f"{tag}_q"].shape[0]):
+            if s in (0, 5):
+                ids = slice(None) if s == 0 else [1, 3, 8]
+                act.reset(ids)
+                lags = act.positions_delay_buffer.time_lags
+                assert int(lags.min()) >= cfg.min_delay and int(lags.max()) <= cfg.max_delay
+                for b in (act.positions_delay_buffer, act.velocities_delay_buffer, act.efforts_delay_buffer):
+                    b.set_time_lag(g[f"{tag}_lags"][s][ids].to(dev), ids)   # the lags the reference drew
+            ca = ArticulationActions(joint_positions=g[f"{tag}_q_des"][s].to(dev), joint_velocities=g[f"{tag}_qd_des"][s].to(dev),
+                                     joint_efforts=g[f"{tag}_tau_ff"][s].to(dev), joint_indices=slice(None))
+            out = act.compute(ca, g[f"{tag}_q"][s].to(dev), g[f"{tag}_qd"][s].to(dev))
+            assert_exact(act.computed_effort, g[f"{tag}_computed"][s], f"{tag} computed step {s}")
+            assert_exact(act.applied_effort, g[f"{tag}_applied"][s], f"{tag} applied step {s}")
+            assert out.joint_positions is None and out.joint_efforts is act.applied_effort
+    with pytest.raises(ValueError):
+        act.positions_delay_buffer.set_time_lag(9)
+    with pytest.raises(TypeError):
+        act.positions_delay_buffer.set_time_lag(torch.zeros(n))
+
+
 @pytest.mark.parametrize("generic", [False, True])
 def test_actuator_net_mlp(dev, generic):
     from isaaclab_amd.actuators import ActuatorNetMLP, ActuatorNetMLPCfg

@@ -76,6 +76,26 @@ def test_actuator_net_lstm():
         assert (g[f"{tag}_applied"] != g[f"{tag}_computed"]).any()
 
 
+def test_delayed_and_remotized_pd():
+    g = load_golden("actuators_delayed")
+    for tag, max_delay in (("delayed", 4), ("remotized", 3)):
+        n, j = g[f"{tag}_q"].shape[1:]
+        lines = [A.DelayLine(max_delay, n) for _ in range(3)]
+        kp, kd = torch.full((n, j), 60.0), torch.full((n, j), 1.5)
+        lookup = (g["lookup"][:, 0], g["lookup"][:, 2]) if tag == "remotized" else None
+        for s in range(g[f"{tag}_q"].shape[0]):
+            if s in (0, 5):  # resets draw new lags (recorded in the fixture) and clear the rings (actuator_pd.py:262-281)
+                ids = slice(None) if s == 0 else [1, 3, 8]
+                for ln in lines:
+                    ln.time_lags[ids] = g[f"{tag}_lags"][s][ids]
+                    ln.reset(ids)
+            comp, app = A.delayed_pd(lines, g[f"{tag}_q_des"][s], g[f"{tag}_qd_des"][s], g[f"{tag}_tau_ff"][s], g[f"{tag}_q"][s],
+                                     g[f"{tag}_qd"][s], kp, kd, g[f"{tag}_effort_limit"], lookup)
+            assert_exact(comp, g[f"{tag}_computed"][s], f"{tag} computed step {s}")
+            assert_exact(app, g[f"{tag}_applied"][s], f"{tag} applied step {s}")
+        assert (g[f"{tag}_applied"] != g[f"{tag}_computed"]).float().mean() > 0.02
+
+
 def test_articulation_data():
     g = load_golden("articulation_data")
     rs = AD.root_state_from_view(g["root_transforms_xyzw"], g["root_velocities"])
