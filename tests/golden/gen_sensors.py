@@ -179,3 +179,27 @@ def ray_caster_rays():
                     f"{tag}_ray_dirs_w": ray_dirs_w, f"{tag}_pos_w": s._data.pos_w, f"{tag}_quat_w": s._data.quat_w})
     out["root_transforms_xyzw"] = root_tf
     save("ray_caster_rays", **out)
+
+
+@section
+def ray_patterns():
+    """lidar / bpearl / pinhole patterns of the reference (patterns.py:61-179) for a few configurations."""
+    mods = _load_sensor_modules()
+    pat = mods["pat"]
+    NS = types.SimpleNamespace
+    out = {}
+    for tag, cfg in (("lidar_full", NS(channels=16, vertical_fov_range=(-15.0, 15.0), horizontal_fov_range=(0.0, 360.0), horizontal_res=2.0)),
+                     ("lidar_part", NS(channels=5, vertical_fov_range=(-30.0, 10.0), horizontal_fov_range=(-60.0, 75.0), horizontal_res=7.5))):
+        s, d = pat.lidar_pattern(cfg, "cpu")
+        out[f"{tag}_starts"], out[f"{tag}_dirs"] = s, d
+    angles = [89.5, 86.6875, 83.875, 81.0625, 78.25, 75.4375, 72.625, 69.8125, 67.0, 64.1875, 61.375, 58.5625, 55.75, 52.9375,
+              50.125, 47.3125, 44.5, 41.6875, 38.875, 36.0625, 33.25, 30.4375, 27.625, 24.8125, 22, 19.1875, 16.375, 13.5625,
+              10.75, 7.9375, 5.125, 2.3125]   # the RS-Bpearl ring table (patterns_cfg.py:186-190, data)
+    s, d = pat.bpearl_pattern(NS(horizontal_fov=360.0, horizontal_res=10.0, vertical_ray_angles=angles), "cpu")
+    out["bpearl_starts"], out["bpearl_dirs"] = s, d
+    s, d = pat.bpearl_pattern(NS(horizontal_fov=90.0, horizontal_res=4.0, vertical_ray_angles=[60.0, 30.0, 5.0]), "cpu")
+    out["bpearl_small_starts"], out["bpearl_small_dirs"] = s, d
+    k = torch.tensor([[[380.0, 0.0, 32.5], [0.0, 375.0, 23.0], [0.0, 0.0, 1.0]], [[120.0, 0.0, 30.0], [0.0, 130.0, 26.0], [0.0, 0.0, 1.0]]])
+    s, d = pat.pinhole_camera_pattern(NS(width=64, height=48), k, "cpu")
+    out["pinhole_k"], out["pinhole_starts"], out["pinhole_dirs"] = k, s, d
+    save("ray_patterns", **out)

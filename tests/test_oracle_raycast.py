@@ -101,3 +101,30 @@ def test_flat_plane_known_answer():
     assert f3[0] == 0
     hs = RC.height_scan(torch.tensor([[0.3, -0.7, 0.6]]), hits[None, :1], 0.5)
     assert_close(hs, torch.tensor([[0.6 - 0.25 - 0.5]]), what="height scan")
+
+
+def test_ray_patterns_match_reference():
+    """lidar / bpearl / pinhole pattern generators (host-side set-up code) against the reference's outputs."""
+    import torch
+
+    from conftest import assert_close, assert_exact, load_golden
+    from isaaclab_amd.sensors import patterns as P
+
+    g = load_golden("ray_patterns")
+    cases = {
+        "lidar_full": P.LidarPatternCfg(channels=16, vertical_fov_range=(-15.0, 15.0), horizontal_fov_range=(0.0, 360.0), horizontal_res=2.0),
+        "lidar_part": P.LidarPatternCfg(channels=5, vertical_fov_range=(-30.0, 10.0), horizontal_fov_range=(-60.0, 75.0), horizontal_res=7.5),
+        "bpearl": P.BpearlPatternCfg(),
+        "bpearl_small": P.BpearlPatternCfg(horizontal_fov=90.0, horizontal_res=4.0, vertical_ray_angles=(60.0, 30.0, 5.0)),
+    }
+    for tag, cfg in cases.items():
+        s, d = cfg.func(cfg, "cpu")
+        assert_exact(s, g[f"{tag}_starts"], f"{tag} starts")
+        assert_close(d, g[f"{tag}_dirs"], atol=1e-6, what=f"{tag} directions")
+        assert_close(d.norm(dim=-1), torch.ones(d.shape[0]), atol=1e-6, what=f"{tag} unit length")
+    cfg = P.PinholeCameraPatternCfg(width=64, height=48)
+    s, d = P.pinhole_camera_pattern(cfg, g["pinhole_k"], "cpu")
+    assert_exact(s, g["pinhole_starts"], "pinhole starts")
+    assert_close(d, g["pinhole_dirs"], atol=1e-6, what="pinhole directions")
+    c2 = P.PinholeCameraPatternCfg.from_intrinsic_matrix([380.0, 0, 32.5, 0, 375.0, 23.0, 0, 0, 1], 64, 48)
+    assert abs(c2.horizontal_aperture - 64 * 24.0 / 380.0) < 1e-9 and abs(c2.vertical_aperture_offset - (23.0 - 24) / 375.0) < 1e-12

@@ -162,6 +162,41 @@ def test_raycaster_lazy_update_and_mask(dev):
     assert_exact(now[[1, 4]], h2.view(n, -1, 3)[[1, 4]], "reset envs are recast")
 
 
+def test_lidar_pattern_sensor(dev):
+    """A lidar pattern on a sensor attached with its full orientation (tree kernel; with the z-parallel hint forced on as
+    well: the hint must not change anything for rays that are not vertical)."""
+    from isaaclab_amd import _abi
+    from isaaclab_amd.sensors.patterns import LidarPatternCfg
+    from isaaclab_amd.sensors.ray_caster import OffsetCfg, RayCaster, RayCasterCfg
+    from isaaclab_amd.utils.mesh import convert_to_mesh
+
+    verts, tris, _ = small_mesh(n=41, size=8.0)
+    mesh = convert_to_mesh(verts.numpy(), tris.numpy(), str(dev))
+    gen = torch.Generator().manual_seed(5)
+    n = 9
+    pat = LidarPatternCfg(channels=6, vertical_fov_range=(-60.0, -5.0), horizontal_fov_range=(0.0, 360.0), horizontal_res=12.0)
+    cfg = RayCasterCfg(offset=OffsetCfg(pos=(0.1, 0.0, 0.4)), attach_yaw_only=False, pattern_cfg=pat, update_period=0.0, max_distance=30.0)
+    pos = torch.cat([torch.rand(n, 2, generator=gen) * 4.0 + 2.0, torch.full((n, 1), 1.5)], -1)
+    quat = torch.nn.functional.normalize(torch.tensor([[1.0, 0.0, 0.0, 0.0]]) + 0.2 * torch.randn(n, 4, generator=gen), dim=-1)
+    s_local, d_local = pat.func(pat, "cpu")
+    s_local = s_local + torch.tensor([0.1, 0.0, 0.4])
+    sw, dw = RC.world_rays(pos, quat, s_local, d_local, False)
+    h, _, _ = RC.raycast_brute(sw, dw, verts, tris, max_dist=30.0)
+    hit = ~torch.isinf(h[:, 0])
+    assert hit.float().mean() > 0.5 and (~hit).any()
+    for force_hint in (False, True):
+        rc = RayCaster(cfg, n, mesh, dev)
+        assert rc.num_rays == 6 * 29
+        if force_hint:
+            rc._hints = _abi.RAYS_Z_PARALLEL
+        rc.set_pose(pos.to(dev), quat.to(dev))
+        rc.update(0.005)
+        got = rc.data.ray_hits_w.cpu().view(-1, 3)
+        assert_exact(torch.isinf(got[:, 0]), ~hit, f"hit/miss pattern (hint forced: {force_hint})")
+        assert_close(got[hit], h[hit], rtol=1e-5, atol=1e-5, what=f"lidar hits (hint forced: {force_hint})")
+        assert not bool(rc._is_outdated.any())
+
+
 def test_full_size_terrain_sample(dev):
     """2.56 M-triangle rough terrain: 64 envs x 187 rays against the C oracle (BVH, and brute force on a subset)."""
     from isaaclab_amd import synth
