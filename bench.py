@@ -36,10 +36,10 @@ MLP_FLOP_PER_ENV = 12 * 2 * (6 * 32 + 32 * 32 + 32 * 32 + 32 * 1)
 BYTES = {
     # read q_des, q, qd (3*48); read+write pos-error / velocity histories (2 * 2 * 144); write computed, applied (2*48)
     "actuator_net_mlp": 3 * 48 + 4 * 144 + 2 * 48,
-    # InteractiveScene.update in one launch -- contact: read net forces 204, write net_forces_w 204, read+write
-    # history 2*612, read+write 4 timers 8*68, clock 18; joint_acc: read vel 48, read+write previous vel 96, write acc 48;
-    # scanner clock 18
-    "scene_update": 204 + 204 + 2 * 612 + 8 * 68 + 18 + 48 + 96 + 48 + 18,
+    # InteractiveScene.update in one launch -- contact: read net forces 204, write net_forces_w 204, write one history
+    # row 204 (ring) + head 8, read+write 4 timers 8*68, clock 18; joint_acc: read vel 48, read+write previous vel 96,
+    # write acc 48; scanner clock 18
+    "scene_update": 204 + 204 + 204 + 8 + 8 * 68 + 18 + 48 + 96 + 48 + 18,
     # read pose 28 + clock 9, write pose 28, ray hits 187*12, clock 5
     "raycaster_refresh": 28 + 9 + 28 + 187 * 12 + 5,
     # read root 52, joints (pos, vel, acc, torque, default) 5*48, actions 2*48, contact history 612, timers 2*68,

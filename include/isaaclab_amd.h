@@ -194,11 +194,17 @@ int ilx_actuator_net_lstm(ilx_lstm_t net, const float* q_des, const float* q, co
 
 /* advance_clock = 1: one SensorBase.update(dt) (timestamp += dt; flag sensors whose period elapsed) followed by
  * the refresh of the flagged sensors; advance_clock = 0: only SensorBase._update_outdated_buffers (refresh the
- * sensors already flagged; dt is ignored).  A refresh copies net_forces_in (n,b,3) into net_forces_w, shifts
- * the history ring (n,h,b,3; slot 0 newest; NULL when h == 0) and advances the air / contact timers (n,b; all
- * four NULL when air time is not tracked).  timestamp, timestamp_last_update (n,) float and is_outdated (n,)
- * uint8 are the SensorBase clocks. */
-int ilx_contact_update(const float* net_forces_in, float* net_forces_w, float* history, float* current_air_time,
+ * sensors already flagged; dt is ignored).  A refresh copies net_forces_in (n,b,3) into net_forces_w, pushes it
+ * into the history (n,h,b,3; NULL when h == 0) and advances the air / contact timers (n,b; all four NULL when air
+ * time is not tracked).  timestamp, timestamp_last_update (n,) float and is_outdated (n,) uint8 are the SensorBase
+ * clocks.
+ * History layout: with history_head == NULL it is the reference's (contact_sensor.py:326-328): slot 0 is the newest
+ * entry and a push moves every row one slot up.  With history_head (n,) int32 the same entries are kept as a ring per
+ * env: the entry of age k sits at slot (history_head[env] + k) % h and a push writes one row and moves the head (the
+ * terms that read the history take a maximum over it, rewards.py:266 / terminations.py:157, so they need no order;
+ * a reader that does reorders by the head).  Zero-filled heads and history are a valid initial / reset state. */
+int ilx_contact_update(const float* net_forces_in, float* net_forces_w, float* history, int32_t* history_head,
+                       float* current_air_time,
                        float* last_air_time, float* current_contact_time, float* last_contact_time,
                        float* timestamp, float* timestamp_last_update, uint8_t* is_outdated, int advance_clock,
                        float dt, float update_period, float force_threshold, int64_t n, int b, int h, void* stream);
@@ -239,6 +245,8 @@ typedef struct ilx_scene {
     float* ray_timestamp_last_update;
     uint8_t* ray_is_outdated;
     float ray_update_period;
+    /* contact sensor, ring mode of the history (see ilx_contact_update), or NULL */
+    int32_t* contact_history_head;
 } ilx_scene;
 int ilx_scene_update(const ilx_scene* scene, void* stream);
 

@@ -94,7 +94,7 @@ lib.ilx_mlp_destroy.argtypes = [P]
 lib.ilx_mlp_destroy.restype = None
 actuator_net_mlp = _sig("ilx_actuator_net_mlp", P, P, P, P, P, P, c_int, P, c_int, c_int, c_float, c_float, c_float,
                         P, P, c_int, c_float, P, P, c_int64, c_int, c_int, P)
-contact_update = _sig("ilx_contact_update", P, P, P, P, P, P, P, P, P, P, c_int, c_float, c_float, c_float, c_int64, c_int,
+contact_update = _sig("ilx_contact_update", P, P, P, P, P, P, P, P, P, P, P, c_int, c_float, c_float, c_float, c_int64, c_int,
                       c_int, P)
 mesh_create = _sig("ilx_mesh_create", P, c_int64, P, c_int64, P)
 lib.ilx_mesh_destroy.argtypes = [P]
@@ -121,7 +121,7 @@ class Scene(ctypes.Structure):
         ("contact_is_outdated", c_void_p), ("contact_update_period", c_float), ("force_threshold", c_float),
         ("num_bodies", ctypes.c_int32), ("history_length", ctypes.c_int32), ("contact_lazy", ctypes.c_int32),
         ("ray_timestamp", c_void_p), ("ray_timestamp_last_update", c_void_p), ("ray_is_outdated", c_void_p),
-        ("ray_update_period", c_float),
+        ("ray_update_period", c_float), ("contact_history_head", c_void_p),
     ]
 
 

@@ -16,6 +16,7 @@ struct ContactArgs {
     const float* in;
     float* net;
     float* hist;
+    int32_t* head;  // (n) ring mode: slot of the newest history entry per env; null: slot 0 is always the newest
     float* cur_air;
     float* last_air;
     float* cur_contact;
@@ -45,6 +46,9 @@ ILX_DEV Clock read_clock(const float* ts, const float* ts_last, const uint8_t* o
     }
     return c;
 }
+// Ring mode: the newest entry moves one slot down (mod h), so that age k sits at slot (head + k) % h.
+ILX_DEV int next_slot(int head, int h) { return (head <= 0 || head >= h ? h : head) - 1; }
+
 ILX_DEV void write_clock(float* ts, float* ts_last, uint8_t* outdated, int64_t env, const Clock& c, bool lazy) {
     ts[env] = c.ts_new;
     if (lazy) {
@@ -56,11 +60,14 @@ ILX_DEV void write_clock(float* ts, float* ts_last, uint8_t* outdated, int64_t e
 }
 
 // contact_sensor.py:324-373 for one (env, body).
-ILX_DEV void contact_body(const ContactArgs& a, int64_t env, int body, float elapsed) {
+// `slot`: ring mode, the history slot this refresh writes.
+ILX_DEV void contact_body(const ContactArgs& a, int64_t env, int body, float elapsed, int slot) {
     const int64_t eb = env * a.b + body;
     const f3 f = load3(a.in + 3 * eb);
     store3(a.net + 3 * eb, f);  // contact_sensor.py:324
-    if (a.hist) {               // contact_sensor.py:326-328
+    if (a.hist && a.head) {     // the same history as below, kept as a ring: one row written instead of h rows moved
+        store3(a.hist + 3 * ((env * a.h + slot) * a.b + body), f);
+    } else if (a.hist) {        // contact_sensor.py:326-328
         const int64_t hb = (env * a.h) * a.b + body;
         f3 old[kMaxContactHistory - 1];
 #pragma unroll
@@ -92,13 +99,16 @@ __global__ void __launch_bounds__(256) contact_update_kernel(ContactArgs a) {
     const bool active = le < a.envs_per_block && env < a.n;
 
     Clock c{0.0f, 0.0f, false};
+    int slot = 0;
     if (active) c = read_clock(a.ts, a.ts_last, a.outdated, env, a.tick, a.dt, a.period);
+    if (active && a.head) slot = next_slot(a.head[env], a.h);
     __syncthreads();
     if (active && b0 == 0) write_clock(a.ts, a.ts_last, a.outdated, env, c, false);
     if (!active || !c.refresh) return;
+    if (a.head && b0 == 0) a.head[env] = slot;
     const float elapsed = c.ts_new - c.last;  // contact_sensor.py:349
     for (int body = b0; body < a.b; body += 256) {
-        contact_body(a, env, body, elapsed);
+        contact_body(a, env, body, elapsed, slot);
         if (!wide) break;
     }
 }
@@ -132,11 +142,14 @@ __global__ void __launch_bounds__(256) scene_update_kernel(SceneArgs s) {
     const bool has_contact = a.in != nullptr;
 
     Clock c{0.0f, 0.0f, false};
+    int slot = 0;
     if (active && has_contact) c = read_clock(a.ts, a.ts_last, a.outdated, env, 1, a.dt, a.period);
+    if (active && has_contact && a.head) slot = next_slot(a.head[env], a.h);
     __syncthreads();
     if (!active) return;
     if (k0 == 0) {
         if (has_contact) write_clock(a.ts, a.ts_last, a.outdated, env, c, s.contact_lazy != 0);
+        if (has_contact && a.head && c.refresh && !s.contact_lazy) a.head[env] = slot;
         if (s.ray_ts) {
             const Clock r = read_clock(s.ray_ts, s.ray_ts_last, s.ray_outdated, env, 1, a.dt, s.ray_period);
             write_clock(s.ray_ts, s.ray_ts_last, s.ray_outdated, env, r, true);
@@ -152,7 +165,7 @@ __global__ void __launch_bounds__(256) scene_update_kernel(SceneArgs s) {
     }
     if (has_contact && c.refresh && !s.contact_lazy) {
         const float elapsed = c.ts_new - c.last;
-        for (int body = k0; body < a.b; body += s.width) contact_body(a, env, body, elapsed);
+        for (int body = k0; body < a.b; body += s.width) contact_body(a, env, body, elapsed, slot);
     }
 }
 
@@ -160,7 +173,7 @@ __global__ void __launch_bounds__(256) scene_update_kernel(SceneArgs s) {
 
 using namespace ilx;
 
-extern "C" int ilx_contact_update(const float* net_forces_in, float* net_forces_w, float* history,
+extern "C" int ilx_contact_update(const float* net_forces_in, float* net_forces_w, float* history, int32_t* history_head,
                                   float* current_air_time, float* last_air_time, float* current_contact_time,
                                   float* last_contact_time, float* timestamp, float* timestamp_last_update,
                                   uint8_t* is_outdated, int advance_clock, float dt, float update_period,
@@ -172,11 +185,12 @@ extern "C" int ilx_contact_update(const float* net_forces_in, float* net_forces_
     ILX_REQUIRE(net_forces_in && net_forces_w && timestamp && timestamp_last_update && is_outdated, ILX_EINVAL,
                 "ilx_contact_update: NULL operand");
     ILX_REQUIRE((h == 0) == (history == nullptr), ILX_EINVAL, "ilx_contact_update: history must be NULL iff h == 0");
+    ILX_REQUIRE(history || !history_head, ILX_EINVAL, "ilx_contact_update: history_head without a history");
     const int timers = (current_air_time != nullptr) + (last_air_time != nullptr) + (current_contact_time != nullptr) +
                        (last_contact_time != nullptr);
     ILX_REQUIRE(timers == 0 || timers == 4, ILX_EINVAL, "ilx_contact_update: pass all four timers or none");
     if (n == 0) return ILX_OK;
-    ContactArgs a{net_forces_in, net_forces_w, history, current_air_time, last_air_time, current_contact_time,
+    ContactArgs a{net_forces_in, net_forces_w, history, history_head, current_air_time, last_air_time, current_contact_time,
                   last_contact_time, timestamp, timestamp_last_update, is_outdated, dt, update_period, force_threshold,
                   advance_clock, n, b, h, b > 256 ? 1 : 256 / b};
     const unsigned blocks = static_cast<unsigned>((n + a.envs_per_block - 1) / a.envs_per_block);
@@ -213,7 +227,8 @@ extern "C" int ilx_scene_update(const ilx_scene* scene, void* stream) {
         const int timers = (d.current_air_time != nullptr) + (d.last_air_time != nullptr) +
                            (d.current_contact_time != nullptr) + (d.last_contact_time != nullptr);
         ILX_REQUIRE(timers == 0 || timers == 4, ILX_EINVAL, "ilx_scene_update: pass all four timers or none");
-        a.in = d.net_forces_in, a.net = d.net_forces_w, a.hist = d.net_forces_w_history;
+        ILX_REQUIRE(d.net_forces_w_history || !d.contact_history_head, ILX_EINVAL, "ilx_scene_update: history head without a history");
+        a.in = d.net_forces_in, a.net = d.net_forces_w, a.hist = d.net_forces_w_history, a.head = d.contact_history_head;
         a.cur_air = d.current_air_time, a.last_air = d.last_air_time, a.cur_contact = d.current_contact_time;
         a.last_contact = d.last_contact_time;
         a.ts = d.contact_timestamp, a.ts_last = d.contact_timestamp_last_update, a.outdated = d.contact_is_outdated;

@@ -98,7 +98,9 @@ def bind_env(mdp: FM.FusedMdp, env, asset, contact, ray, command):
         if acc is not None:
             b["body_lin_acc_w"] = acc
     if contact is not None:
-        c = _entity(env, contact).data
+        ent = _entity(env, contact)
+        # the kernels take a maximum over the history and need no order: bind the sensor's own (ring) storage
+        c = ent.raw_data if hasattr(ent, "raw_data") else ent.data
         b["net_forces_w_history"] = c.net_forces_w_history
         if c.current_air_time is not None:
             b.update(current_air_time=c.current_air_time, last_air_time=c.last_air_time,

@@ -59,6 +59,7 @@ class InteractiveScene:
             cd, h, t = c._data, c.cfg.history_length, c.cfg.track_air_time
             sc.net_forces_in, sc.net_forces_w = _abi.ptr(c._forces_in), _abi.ptr(cd.net_forces_w)
             sc.net_forces_w_history = _abi.ptr(cd.net_forces_w_history) if h > 0 else None
+            sc.contact_history_head = None if c._history_head is None else c._history_head.data_ptr()
             if t:
                 sc.current_air_time, sc.last_air_time = _abi.ptr(cd.current_air_time), _abi.ptr(cd.last_air_time)
                 sc.current_contact_time, sc.last_contact_time = _abi.ptr(cd.current_contact_time), _abi.ptr(cd.last_contact_time)

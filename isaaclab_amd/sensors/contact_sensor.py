@@ -8,6 +8,7 @@ timers and the per-sensor update clocks of ``SensorBase``.
 
 from __future__ import annotations
 
+import copy
 from collections.abc import Sequence
 from dataclasses import dataclass, field
 
@@ -60,6 +61,9 @@ class ContactSensor:
         self._timestamp_last_update = torch.zeros(n, device=self._device)
         self._data = ContactSensorData()
         self._data.net_forces_w = torch.zeros(n, b, 3, device=self._device)
+        # The history is stored as a ring per env (entry of age k at slot (head + k) % h): a refresh writes one row
+        # instead of moving h.  `data.net_forces_w_history` hands out the reference's newest-first order.
+        self._history_head = torch.zeros(n, dtype=torch.int32, device=self._device) if h > 1 else None
         if h > 0:
             self._data.net_forces_w_history = torch.zeros(n, h, b, 3, device=self._device)
         else:
@@ -91,7 +95,30 @@ class ContactSensor:
     @property
     def data(self) -> ContactSensorData:
         self._update_outdated_buffers()
+        if self._history_head is None:
+            return self._data
+        d = copy.copy(self._data)
+        d.net_forces_w_history = self.ordered_history()
+        return d
+
+    @property
+    def raw_data(self) -> ContactSensorData:
+        """The buffers as the kernels keep them (history as a ring, see ``history_head``), refreshed like ``data``."""
+        self._update_outdated_buffers()
         return self._data
+
+    @property
+    def history_head(self) -> torch.Tensor | None:
+        """(n,) int32 slot of the newest history entry per env, or None when the history is stored newest-first."""
+        return self._history_head
+
+    def ordered_history(self) -> torch.Tensor:
+        """``net_forces_w_history`` in the reference's order (index 0 = newest), without touching the update clocks."""
+        if self._history_head is None:
+            return self._data.net_forces_w_history
+        h = self.cfg.history_length
+        slots = (self._history_head.long().unsqueeze(1) + torch.arange(h, device=self._device)) % h   # (n, h): age -> slot
+        return self._data.net_forces_w_history[torch.arange(self._num_envs, device=self._device).unsqueeze(1), slots]
 
     def find_bodies(self, name_keys, preserve_order: bool = False):
         """contact_sensor.py:157-167."""
@@ -134,7 +161,7 @@ class ContactSensor:
         t = self.cfg.track_air_time
         _abi.check(_abi.contact_update(
             _abi.ptr(self._forces_in), _abi.ptr(d.net_forces_w), _abi.ptr(d.net_forces_w_history) if h > 0 else None,
-            _abi.ptr(d.current_air_time) if t else None, _abi.ptr(d.last_air_time) if t else None,
+            None if self._history_head is None else self._history_head.data_ptr(), _abi.ptr(d.current_air_time) if t else None, _abi.ptr(d.last_air_time) if t else None,
             _abi.ptr(d.current_contact_time) if t else None, _abi.ptr(d.last_contact_time) if t else None,
             _abi.ptr(self._timestamp), _abi.ptr(self._timestamp_last_update), self._is_outdated.data_ptr(),
             int(advance_clock), float(dt), float(self.cfg.update_period), float(self.cfg.force_threshold), self._num_envs, self._num_bodies,

@@ -68,8 +68,10 @@ def test_actuator_arguments():
 
 
 def test_sensor_arguments():
-    fails(_abi.contact_update(NULL, FAKE, NULL, NULL, NULL, NULL, NULL, FAKE, FAKE, FAKE, 1, 0.005, 0.0, 1.0, 4, 2, 0, NULL), EINVAL,
+    fails(_abi.contact_update(NULL, FAKE, NULL, NULL, NULL, NULL, NULL, NULL, FAKE, FAKE, FAKE, 1, 0.005, 0.0, 1.0, 4, 2, 0, NULL), EINVAL,
           "ilx_contact_update")
+    fails(_abi.contact_update(FAKE, FAKE, NULL, FAKE, NULL, NULL, NULL, NULL, FAKE, FAKE, FAKE, 1, 0.005, 0.0, 1.0, 4, 2, 0, NULL), EINVAL,
+          "history_head without a history")
     sc = _abi.Scene()
     sc.num_envs = -1
     fails(_abi.scene_update(ctypes.byref(sc), NULL), EINVAL, "ilx_scene_update")

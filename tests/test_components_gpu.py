@@ -267,7 +267,7 @@ def test_contact_sensor(dev):
 def test_contact_sensor_slow_period(dev):
     g = load_golden("contact_sensor")
     for k, s in _drive_contact(dev, g, 0.02):
-        assert_exact(s._data.net_forces_w_history, g["slow_hist"][k], f"slow hist step {k}")
+        assert_exact(s.ordered_history(), g["slow_hist"][k], f"slow hist step {k}")
         assert_exact(s._data.current_air_time, g["slow_cur_air"][k], f"slow cur_air step {k}")
         assert_exact(s._data.current_contact_time, g["slow_cur_contact"][k], f"slow cur_contact step {k}")
         assert_exact(s._is_outdated, g["slow_outdated"][k], f"slow outdated step {k}")

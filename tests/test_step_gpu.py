@@ -59,7 +59,7 @@ def test_anymal_full_step_matches_oracle(dev):
         assert_exact(env.mdp.is_standing_env, oracle.cmd.is_standing_env, f"is_standing_env step {step}")
         assert_exact(env.mdp.time_left, oracle.cmd.time_left, f"time_left step {step}")
         c = env.contact._data
-        assert_exact(c.net_forces_w_history, oracle.s["net_forces_w_history"], f"contact history step {step}")
+        assert_exact(env.contact.ordered_history(), oracle.s["net_forces_w_history"], f"contact history step {step}")
         for k in ("current_air_time", "last_air_time", "current_contact_time", "last_contact_time"):
             assert_exact(getattr(c, k), oracle.s[k], f"{k} step {step}")
         assert_exact(env.actuator._joint_pos_error_history, oracle.s["pos_error_history"], f"pos error history step {step}")
