@@ -387,7 +387,10 @@ __global__ void __launch_bounds__(256) mlp_mfma_kernel(NetArgs a) {
 // nor the HBM round trip of the row inputs sit between MFMAs.  Two waves per SIMD: one wave's activations (VALU)
 // run under the other wave's MFMAs.  Operation order is that of mlp_mfma_kernel, so both give the same bits.
 // (Measured alternatives: weights in LDS with 3-6 waves per SIMD -- the compiler hoists the loop-invariant reads
-// back into registers and spills; one tile per wave at 6 waves per SIMD is 8-10 % slower.)
+// back into registers and spills; one tile per wave at 6 waves per SIMD is 8-10 % slower; two tiles per wave staggered
+// by half a layer, one MFMA then one element's activation, at one wave per SIMD: 23 us against 19 -- per tile the
+// kernel issues ~525 vector instructions besides its 35 MFMAs, about as many cycles as the MFMAs themselves, and
+// only a second wave on the SIMD hides those.)
 constexpr int kResidentHist = 4;  // the resident kernel serves histories and input index lists up to this length
 
 template <int ACT, int NHID>
@@ -437,16 +440,27 @@ __global__ void __launch_bounds__(256, 2) mlp_mfma_resident_kernel(NetArgs a) {
                                     valid ? (a.per_env ? row : joint) : 0u};
         return at;
     };
-    RowInT<kResidentHist> cur;
+    // Loop order per tile: issue the loads of the next tile, issue the STORES OF THE PREVIOUS tile, compute this tile,
+    // take in the next tile's loads.  A store keeps its data registers busy until it completes (~1-2 us); issued at the
+    // end of an iteration it would make the next iteration wait as soon as it reuses one of them, issued here it has a
+    // whole tile of MFMAs to complete under.
+    RowInT<kResidentHist> cur, done;
     RowRawT<kResidentHist> ahead;
-    RowAt<uint32_t> at = tile_row(tile), at_next = at;
+    RowAt<uint32_t> at = tile_row(tile), at_next = at, at_done = at;
+    float out_done = 0.0f;
+    bool valid_done = false;
     load_row(a, at, tile * 32 + (lane & 31) < a.rows, cur);
+    done = cur;
     for (; tile < tiles; tile += nwaves) {
         const bool valid = tile * 32 + (lane & 31) < a.rows;
         const bool more = tile + nwaves < tiles;
         if (more) {  // the next tile's inputs travel while this tile computes
             at_next = tile_row(tile + nwaves);
             issue_row(a, at_next, (tile + nwaves) * 32 + (lane & 31) < a.rows, ahead);
+        }
+        if (valid_done) {
+            if (half == 0) store_torque(a, at_done, out_done, done);
+            store_history(a, at_done, done, half == 0, half == 1);
         }
 
         f32x16 acc = bias[0];
@@ -469,15 +483,14 @@ __global__ void __launch_bounds__(256, 2) mlp_mfma_resident_kernel(NetArgs a) {
 #pragma unroll
         for (int k = 0; k < 16; ++k) part = fmaf_(wo[k], acc[k], part);
         const float other = __shfl_xor(part, 32, 64);
-        const float out = (half ? other + part : part + other) + bo;
-        RowInT<kResidentHist> upcoming = cur;
-        if (more) finish_row(a, ahead, upcoming);  // before this tile's stores: waiting for loads must not wait for them
-        if (valid) {
-            if (half == 0) store_torque(a, at, out, cur);
-            store_history(a, at, cur, half == 0, half == 1);
-        }
-        cur = upcoming;
+        out_done = (half ? other + part : part + other) + bo;
+        done = cur, at_done = at, valid_done = valid;
+        if (more) finish_row(a, ahead, cur);
         at = at_next;
+    }
+    if (valid_done) {
+        if (half == 0) store_torque(a, at_done, out_done, done);
+        store_history(a, at_done, done, half == 0, half == 1);
     }
 }
 
