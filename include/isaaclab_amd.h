@@ -188,6 +188,34 @@ int ilx_actuator_net_lstm(ilx_lstm_t net, const float* q_des, const float* q, co
                           int j, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Reset / push event terms — source/isaaclab/isaaclab/envs/mdp/events.py:610-866.  The reference passes the new state to
+ * the simulator (write_root_pose_to_sim, write_root_velocity_to_sim, write_joint_state_to_sim); these entry points write
+ * it into the state buffers.  env_ids (count) int64 lists the envs, as the reference's env_ids tensor does.  Random
+ * numbers: `u` non-NULL = one row of unit-interval draws per listed env, in the order the reference draws them
+ * (torch.rand through math.sample_uniform, math.py:1313-1331); `u` NULL = Philox keyed by (seed, draw, env id, column).
+ * Ranges are HOST arrays of 12 floats: lower bounds of x, y, z, roll, pitch, yaw, then the upper bounds.
+ * ------------------------------------------------------------------------------------------------ */
+
+/* reset_root_state_uniform (:638-680): position = default + env origin + sample, orientation = default * quat_from_euler
+ * of the sampled angles, velocity = default + sample; rows env_ids of root_state_w (n,13).  u: (count, 12) = pose draws
+ * then velocity draws.  env_origins (n,3) may be NULL. */
+int ilx_event_reset_root_state_uniform(const int64_t* env_ids, int64_t count, const float* default_root_state,
+                                       const float* env_origins, const float* pose_range_host,
+                                       const float* velocity_range_host, const float* u, uint64_t seed, uint64_t draw,
+                                       float* root_state_w, void* stream);
+/* reset_joints_by_scale (:802-832, by_scale = 1) / reset_joints_by_offset (:835-866, by_scale = 0): default joint state
+ * times / plus a sample, clamped to the soft position limits (n,j,2) and +-soft velocity limits (n,j); rows env_ids of
+ * joint_pos / joint_vel (n,j).  u: (count, 2j) = position draws then velocity draws. */
+int ilx_event_reset_joints(int by_scale, const int64_t* env_ids, int64_t count, const float* default_joint_pos,
+                           const float* default_joint_vel, const float* soft_joint_pos_limits,
+                           const float* soft_joint_vel_limits, float position_lo, float position_hi, float velocity_lo,
+                           float velocity_hi, const float* u, uint64_t seed, uint64_t draw, float* joint_pos,
+                           float* joint_vel, int j, void* stream);
+/* push_by_setting_velocity (:610-635): root velocity (columns 7..12 of root_state_w) += sample.  u: (count, 6). */
+int ilx_event_push_by_setting_velocity(const int64_t* env_ids, int64_t count, const float* velocity_range_host,
+                                       const float* u, uint64_t seed, uint64_t draw, float* root_state_w, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Contact sensor bookkeeping — source/isaaclab/isaaclab/sensors/contact_sensor/contact_sensor.py:314-373
  * plus the update timing of sensors/sensor_base.py:197-205,284-293.
  * ------------------------------------------------------------------------------------------------ */

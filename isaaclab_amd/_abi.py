@@ -108,6 +108,13 @@ joint_action_process = _sig("ilx_joint_action_process", P, P, P, P, c_float, P, 
 raycast_mesh_stats = _sig("ilx_raycast_mesh_stats", P, P, P, c_int64, c_float, P, P, P)
 
 
+c_uint64 = ctypes.c_uint64
+event_reset_root_state_uniform = _sig("ilx_event_reset_root_state_uniform", P, c_int64, P, P, P, P, P, c_uint64, c_uint64, P, P)
+event_reset_joints = _sig("ilx_event_reset_joints", c_int, P, c_int64, P, P, P, P, c_float, c_float, c_float, c_float, P, c_uint64,
+                          c_uint64, P, P, c_int, P)
+event_push_by_setting_velocity = _sig("ilx_event_push_by_setting_velocity", P, c_int64, P, P, c_uint64, c_uint64, P, P)
+
+
 class Scene(ctypes.Structure):
     """Mirror of ``ilx_scene`` (include/isaaclab_amd.h)."""
 

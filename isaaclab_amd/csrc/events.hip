@@ -1,0 +1,134 @@
+// Reset / push event terms (reference: isaaclab/envs/mdp/events.py:610-866): new root and joint states for a list of
+// envs, drawn uniformly from per-axis ranges.  The reference hands the result to the simulator
+// (write_root_pose_to_sim / write_root_velocity_to_sim / write_joint_state_to_sim); here it lands in the state buffers
+// the rest of the step reads.  The unit-interval draws are either given (u, one row per listed env: parity tests) or
+// come from Philox keyed by (seed, draw, env id, column), so a reset is reproducible whatever the launch geometry.
+#include "common.h"
+#include "math_dev.h"
+#include "philox.h"
+
+namespace ilx {
+
+struct Range6 {
+    float lo[6], hi[6];
+};
+
+struct EventRng {
+    const float* u;  // (count, width) or null
+    int width;
+    uint64_t seed, draw;
+};
+ILX_DEV float draw01(const EventRng& r, int64_t k, int64_t env, int col) {
+    return r.u ? r.u[k * r.width + col] : philox_uniform(r.seed, r.draw, static_cast<uint64_t>(env), static_cast<uint32_t>(col));
+}
+// isaaclab.utils.math.sample_uniform (math.py:1313-1331): rand * (upper - lower) + lower
+ILX_DEV float ranged(float u, float lo, float hi) { return u * (hi - lo) + lo; }
+
+// events.py:638-680, one thread per listed env.
+__global__ void __launch_bounds__(256)
+reset_root_kernel(const int64_t* __restrict__ ids, int64_t count, const float* __restrict__ def, const float* __restrict__ origins,
+                  Range6 pose, Range6 vel, EventRng rng, float* __restrict__ root) {
+    const int64_t k = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (k >= count) return;
+    const int64_t env = ids[k];
+    const float* d = def + 13 * env;
+    float rp[6], rv[6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+        rp[c] = ranged(draw01(rng, k, env, c), pose.lo[c], pose.hi[c]);
+        rv[c] = ranged(draw01(rng, k, env, 6 + c), vel.lo[c], vel.hi[c]);
+    }
+    float* out = root + 13 * env;
+    const f3 o = origins ? load3(origins + 3 * env) : f3{0.0f, 0.0f, 0.0f};
+    out[0] = d[0] + o.x + rp[0], out[1] = d[1] + o.y + rp[1], out[2] = d[2] + o.z + rp[2];  // events.py:669
+    const f4 q = quat_mul(f4{d[3], d[4], d[5], d[6]}, quat_from_euler_xyz(rp[3], rp[4], rp[5]));  // :670-671
+    out[3] = q.w, out[4] = q.x, out[5] = q.y, out[6] = q.z;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) out[7 + c] = d[7 + c] + rv[c];  // :677
+}
+
+// events.py:802-866, one thread per (listed env, joint).
+__global__ void __launch_bounds__(256)
+reset_joints_kernel(int scale, const int64_t* __restrict__ ids, int64_t count, int j, const float* __restrict__ def_pos,
+                    const float* __restrict__ def_vel, const float* __restrict__ pos_limits, const float* __restrict__ vel_limits,
+                    float pos_lo, float pos_hi, float vel_lo, float vel_hi, EventRng rng, float* __restrict__ joint_pos,
+                    float* __restrict__ joint_vel) {
+    const int64_t t = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (t >= count * j) return;
+    const int64_t k = t / j;
+    const int c = static_cast<int>(t - k * j);
+    const int64_t env = ids[k], at = env * j + c;
+    const float sp = ranged(draw01(rng, k, env, c), pos_lo, pos_hi), sv = ranged(draw01(rng, k, env, j + c), vel_lo, vel_hi);
+    float p = scale ? def_pos[at] * sp : def_pos[at] + sp;
+    float v = scale ? def_vel[at] * sv : def_vel[at] + sv;
+    p = fminf(fmaxf(p, pos_limits[2 * at]), pos_limits[2 * at + 1]);  // torch.clamp: max with the lower bound first
+    const float vl = vel_limits[at];
+    v = fminf(fmaxf(v, -vl), vl);
+    joint_pos[at] = p;
+    joint_vel[at] = v;
+}
+
+// events.py:610-635, one thread per (listed env, velocity component).
+__global__ void __launch_bounds__(256)
+push_velocity_kernel(const int64_t* __restrict__ ids, int64_t count, Range6 vel, EventRng rng, float* __restrict__ root) {
+    const int64_t t = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (t >= count * 6) return;
+    const int64_t k = t / 6;
+    const int c = static_cast<int>(t - k * 6);
+    const int64_t env = ids[k];
+    root[13 * env + 7 + c] += ranged(draw01(rng, k, env, c), vel.lo[c], vel.hi[c]);
+}
+
+static Range6 range6(const float* host12) {
+    Range6 r;
+    for (int c = 0; c < 6; ++c) r.lo[c] = host12[c], r.hi[c] = host12[6 + c];
+    return r;
+}
+
+}  // namespace ilx
+
+using namespace ilx;
+
+extern "C" int ilx_event_reset_root_state_uniform(const int64_t* env_ids, int64_t count, const float* default_root_state,
+                                                  const float* env_origins, const float* pose_range_host,
+                                                  const float* velocity_range_host, const float* u, uint64_t seed,
+                                                  uint64_t draw, float* root_state_w, void* stream) {
+    ILX_REQUIRE(count >= 0, ILX_EINVAL, "ilx_event_reset_root_state_uniform: negative env count");
+    if (count == 0) return ILX_OK;
+    ILX_REQUIRE(env_ids && default_root_state && pose_range_host && velocity_range_host && root_state_w, ILX_EINVAL,
+                "ilx_event_reset_root_state_uniform: NULL operand");
+    hipLaunchKernelGGL(reset_root_kernel, dim3(blocks_for(count)), dim3(256), 0, as_stream(stream), env_ids, count,
+                       default_root_state, env_origins, range6(pose_range_host), range6(velocity_range_host),
+                       EventRng{u, 12, seed, draw}, root_state_w);
+    ILX_LAUNCH_CHECK("ilx_event_reset_root_state_uniform");
+    return ILX_OK;
+}
+
+extern "C" int ilx_event_reset_joints(int by_scale, const int64_t* env_ids, int64_t count, const float* default_joint_pos,
+                                      const float* default_joint_vel, const float* soft_joint_pos_limits,
+                                      const float* soft_joint_vel_limits, float position_lo, float position_hi,
+                                      float velocity_lo, float velocity_hi, const float* u, uint64_t seed, uint64_t draw,
+                                      float* joint_pos, float* joint_vel, int j, void* stream) {
+    ILX_REQUIRE(count >= 0 && j > 0, ILX_EINVAL, "ilx_event_reset_joints: bad shape (%lld, %d)", (long long)count, j);
+    if (count == 0) return ILX_OK;
+    ILX_REQUIRE(env_ids && default_joint_pos && default_joint_vel && soft_joint_pos_limits && soft_joint_vel_limits && joint_pos &&
+                    joint_vel,
+                ILX_EINVAL, "ilx_event_reset_joints: NULL operand");
+    hipLaunchKernelGGL(reset_joints_kernel, dim3(blocks_for(count * j)), dim3(256), 0, as_stream(stream), by_scale, env_ids, count, j,
+                       default_joint_pos, default_joint_vel, soft_joint_pos_limits, soft_joint_vel_limits, position_lo, position_hi,
+                       velocity_lo, velocity_hi, EventRng{u, 2 * j, seed, draw}, joint_pos, joint_vel);
+    ILX_LAUNCH_CHECK("ilx_event_reset_joints");
+    return ILX_OK;
+}
+
+extern "C" int ilx_event_push_by_setting_velocity(const int64_t* env_ids, int64_t count, const float* velocity_range_host,
+                                                  const float* u, uint64_t seed, uint64_t draw, float* root_state_w,
+                                                  void* stream) {
+    ILX_REQUIRE(count >= 0, ILX_EINVAL, "ilx_event_push_by_setting_velocity: negative env count");
+    if (count == 0) return ILX_OK;
+    ILX_REQUIRE(env_ids && velocity_range_host && root_state_w, ILX_EINVAL, "ilx_event_push_by_setting_velocity: NULL operand");
+    hipLaunchKernelGGL(push_velocity_kernel, dim3(blocks_for(count * 6)), dim3(256), 0, as_stream(stream), env_ids, count,
+                       range6(velocity_range_host), EventRng{u, 6, seed, draw}, root_state_w);
+    ILX_LAUNCH_CHECK("ilx_event_push_by_setting_velocity");
+    return ILX_OK;
+}

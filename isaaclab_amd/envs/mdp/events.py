@@ -1,0 +1,91 @@
+"""Reset / push event terms on the HIP kernels ``ilx_event_*`` (interface of ``isaaclab/envs/mdp/events.py:610-866``).
+
+Same signatures as the reference: ``func(env, env_ids, <ranges>, asset_cfg)``.  The reference hands the new state to the
+simulator through ``asset.write_*_to_sim``; here it is written into the asset's state buffers
+(``data.root_state_w`` / ``joint_pos`` / ``joint_vel``), and the asset's ``write_*_to_sim`` methods are called with the
+new rows as well when it has them.  Random numbers come from Philox on the device, keyed by ``env.event_seed`` (0 when
+absent) and a per-call counter; ``_u`` injects unit-interval draws instead (parity tests).
+"""
+
+from __future__ import annotations
+
+import ctypes
+import itertools
+
+import torch
+
+from ... import _abi
+from ...managers.scene_entity_cfg import SceneEntityCfg
+
+_AXES = ("x", "y", "z", "roll", "pitch", "yaw")
+_draws = itertools.count(1)
+
+
+def _range12(d: dict):
+    lo = [float(d.get(k, (0.0, 0.0))[0]) for k in _AXES]
+    hi = [float(d.get(k, (0.0, 0.0))[1]) for k in _AXES]
+    return (ctypes.c_float * 12)(*lo, *hi)
+
+
+def _ids(env_ids, n, device) -> torch.Tensor:
+    if env_ids is None or (isinstance(env_ids, slice) and env_ids == slice(None)):
+        return torch.arange(n, dtype=torch.long, device=device)
+    return torch.as_tensor(env_ids, dtype=torch.long, device=device).contiguous()
+
+
+def _rng(env, u):
+    return (None if u is None else _abi.ptr(_abi.f32c(u)), int(getattr(env, "event_seed", 0)), next(_draws))
+
+
+def reset_root_state_uniform(env, env_ids, pose_range: dict, velocity_range: dict, asset_cfg: SceneEntityCfg = SceneEntityCfg("robot"),
+                             *, _u=None):
+    """events.py:638-680."""
+    asset = env.scene[asset_cfg.name]
+    d = asset.data
+    ids = _ids(env_ids, d.root_state_w.shape[0], d.root_state_w.device)
+    origins = getattr(env.scene, "env_origins", None)
+    up, seed, draw = _rng(env, _u)
+    _abi.check(_abi.event_reset_root_state_uniform(ids.data_ptr(), ids.numel(), _abi.ptr(d.default_root_state),
+                                                   None if origins is None else _abi.ptr(_abi.f32c(origins)), _range12(pose_range),
+                                                   _range12(velocity_range), up, seed, draw, _abi.ptr(d.root_state_w), _abi.stream()),
+               "ilx_event_reset_root_state_uniform")
+    if hasattr(asset, "write_root_pose_to_sim"):
+        asset.write_root_pose_to_sim(d.root_state_w[ids, :7], env_ids=ids)
+        asset.write_root_velocity_to_sim(d.root_state_w[ids, 7:], env_ids=ids)
+
+
+def _reset_joints(by_scale, env, env_ids, position_range, velocity_range, asset_cfg, u):
+    asset = env.scene[asset_cfg.name]
+    d = asset.data
+    n, j = d.joint_pos.shape
+    ids = _ids(env_ids, n, d.joint_pos.device)
+    up, seed, draw = _rng(env, u)
+    _abi.check(_abi.event_reset_joints(int(by_scale), ids.data_ptr(), ids.numel(), _abi.ptr(d.default_joint_pos),
+                                       _abi.ptr(d.default_joint_vel), _abi.ptr(d.soft_joint_pos_limits),
+                                       _abi.ptr(d.soft_joint_vel_limits), float(position_range[0]), float(position_range[1]),
+                                       float(velocity_range[0]), float(velocity_range[1]), up, seed, draw, _abi.ptr(d.joint_pos),
+                                       _abi.ptr(d.joint_vel), j, _abi.stream()), "ilx_event_reset_joints")
+    if hasattr(asset, "write_joint_state_to_sim"):
+        asset.write_joint_state_to_sim(d.joint_pos[ids], d.joint_vel[ids], env_ids=ids)
+
+
+def reset_joints_by_scale(env, env_ids, position_range, velocity_range, asset_cfg: SceneEntityCfg = SceneEntityCfg("robot"), *, _u=None):
+    """events.py:802-832."""
+    _reset_joints(True, env, env_ids, position_range, velocity_range, asset_cfg, _u)
+
+
+def reset_joints_by_offset(env, env_ids, position_range, velocity_range, asset_cfg: SceneEntityCfg = SceneEntityCfg("robot"), *, _u=None):
+    """events.py:835-866."""
+    _reset_joints(False, env, env_ids, position_range, velocity_range, asset_cfg, _u)
+
+
+def push_by_setting_velocity(env, env_ids, velocity_range: dict, asset_cfg: SceneEntityCfg = SceneEntityCfg("robot"), *, _u=None):
+    """events.py:610-635."""
+    asset = env.scene[asset_cfg.name]
+    d = asset.data
+    ids = _ids(env_ids, d.root_state_w.shape[0], d.root_state_w.device)
+    up, seed, draw = _rng(env, _u)
+    _abi.check(_abi.event_push_by_setting_velocity(ids.data_ptr(), ids.numel(), _range12(velocity_range), up, seed, draw,
+                                                   _abi.ptr(d.root_state_w), _abi.stream()), "ilx_event_push_by_setting_velocity")
+    if hasattr(asset, "write_root_velocity_to_sim"):
+        asset.write_root_velocity_to_sim(d.root_state_w[ids, 7:], env_ids=ids)

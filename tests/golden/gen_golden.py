@@ -189,7 +189,7 @@ def main(argv):
 
 if __name__ == "__main__":
     # sections defined in sibling modules register themselves on import
-    for extra in ("gen_terms", "gen_actuators", "gen_sensors", "gen_ik", "gen_shadow", "gen_managers"):
+    for extra in ("gen_terms", "gen_actuators", "gen_sensors", "gen_ik", "gen_shadow", "gen_managers", "gen_events"):
         if os.path.exists(os.path.join(HERE, extra + ".py")):
             mod = __import__(extra)
             for k, f in getattr(mod, "SECTIONS", {}).items():

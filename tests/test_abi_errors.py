@@ -91,6 +91,17 @@ def test_sensor_arguments():
     fails(_abi.mesh_grid_stats(NULL, NULL), EINVAL, "ilx_mesh_grid_stats")
 
 
+def test_event_arguments():
+    r = (ctypes.c_float * 12)()
+    fails(_abi.event_reset_root_state_uniform(NULL, 4, FAKE, NULL, r, r, NULL, 0, 0, FAKE, NULL), EINVAL,
+          "ilx_event_reset_root_state_uniform")
+    fails(_abi.event_reset_joints(1, FAKE, 4, FAKE, FAKE, FAKE, FAKE, 0.0, 1.0, 0.0, 1.0, NULL, 0, 0, FAKE, FAKE, 0, NULL), EINVAL,
+          "ilx_event_reset_joints")
+    fails(_abi.event_push_by_setting_velocity(FAKE, -1, r, NULL, 0, 0, FAKE, NULL), EINVAL, "ilx_event_push_by_setting_velocity")
+    # an empty env list is a no-op, as the reference's functions are for an empty env_ids tensor
+    assert _abi.event_push_by_setting_velocity(NULL, 0, r, NULL, 0, 0, NULL, NULL) == 0
+
+
 def test_ik_arguments():
     f = _abi.IkFrame()
     f.ee_pos = f.ee_quat = FAKE

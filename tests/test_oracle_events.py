@@ -1,0 +1,27 @@
+"""CPU: the oracle's event terms against outputs of the reference functions (tests/golden/gen_events.py)."""
+
+from conftest import assert_close, assert_exact, load_golden
+from oracle import events as E
+
+POSE = {"x": (-0.5, 0.5), "y": (-0.5, 0.5), "yaw": (-3.14, 3.14), "roll": (-0.2, 0.1)}
+VEL = {"x": (-0.5, 0.5), "y": (-0.5, 0.5), "z": (-0.1, 0.2), "roll": (-0.5, 0.5), "pitch": (-0.5, 0.5), "yaw": (-0.5, 0.5)}
+PUSH = {"x": (-0.5, 0.5), "y": (-0.5, 0.5), "yaw": (-1.0, 0.25)}
+JOINT = {"scale": ((0.5, 1.5), (-1.0, 2.0)), "offset": ((-0.6, 0.6), (-0.5, 0.5))}
+
+
+def test_reset_and_push_events():
+    g = load_golden("events")
+    ids = g["env_ids"]
+    pose, vel = E.reset_root_state_uniform(g["default_root_state"][ids], g["env_origins"][ids], POSE, VEL, g["root_u_pose"], g["root_u_vel"])
+    assert_exact(pose[:, :3], g["root_pose"][:, :3], "root position")
+    assert_close(pose[:, 3:], g["root_pose"][:, 3:], atol=1e-6, what="root orientation")
+    assert_exact(vel, g["root_vel"], "root velocity")
+    for tag, (pr, vr) in JOINT.items():
+        pos, jv = E.reset_joints(g["default_joint_pos"][ids], g["default_joint_vel"][ids], g["soft_joint_pos_limits"][ids],
+                                 g["soft_joint_vel_limits"][ids], pr, vr, g[f"{tag}_u_pos"], g[f"{tag}_u_vel"], tag == "scale")
+        assert_exact(pos, g[f"{tag}_joint_pos"], f"{tag} joint positions")
+        assert_exact(jv, g[f"{tag}_joint_vel"], f"{tag} joint velocities")
+        assert (jv.abs() == g["soft_joint_vel_limits"][ids]).any(), "some joint velocities are clamped"
+    lim = g["soft_joint_pos_limits"][ids]
+    assert ((pos == lim[..., 0]) | (pos == lim[..., 1])).any(), "some joint positions are clamped (offset case)"
+    assert_exact(E.push_by_setting_velocity(g["root_vel_w"][ids], PUSH, g["push_u"]), g["push_vel"], "pushed velocity")
