@@ -202,17 +202,21 @@ def main():
 
         dist.init_process_group("nccl", device_id=device)
 
-    from isaaclab_amd.distributed import all_reduce_log_sums
+    from isaaclab_amd.distributed import OverlappedLogReducer
 
     env, state, _ = build_env(device, args.envs, seed=3000 + rank, actuator=args.actuator)
     raw = state["raw_action"].to(device)
     n_log = env.mdp.log_sums.numel()
 
+    # episode statistics of the done envs: the only cross-rank exchange of the path, one all-reduce per step, started
+    # after the step and completed beside the next two (nothing in the step consumes it)
+    reducer = OverlappedLogReducer(n_log, device)
+
     def one_step():
-        env.mdp.log_sums.zero_()
+        buf, _ = reducer.begin_step()
+        env.mdp.bind(log_sums=buf)
         env.step(raw)
-        if dist is not None:  # episode statistics of the done envs: the only cross-rank exchange of the path
-            all_reduce_log_sums(env.mdp.log_sums)
+        reducer.end_step()
 
     for _ in range(args.warmup):
         one_step()
@@ -222,6 +226,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         one_step()
+    reducer.finish()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()

@@ -37,6 +37,62 @@ def all_reduce_log_sums(log_sums: torch.Tensor, group=None) -> torch.Tensor:
     return log_sums
 
 
+class OverlappedLogReducer:
+    """The same all-reduce, taken off the step's critical path.
+
+    A 17-float all-reduce is pure latency (tens of microseconds over xGMI), a tenth of an env step; nothing in the step
+    needs its result, so it runs beside the next steps.  Two statistics vectors alternate: step k accumulates into
+    ``buffer(k)``, its all-reduce is started asynchronously right after the step, and the totals are read when the
+    buffer comes round again, two steps later (``begin_step`` waits for that all-reduce first: a stream wait on RCCL,
+    a host wait on gloo).  With no process group (single GPU) the totals are the local sums, with the same delay.
+
+        red = OverlappedLogReducer(n, device)
+        for k in ...:
+            buf, totals = red.begin_step()   # totals: global statistics of step k - 2 (None before), or skip them
+            mdp.bind(log_sums=buf); env.step(...)
+            red.end_step()
+        red.finish()
+    """
+
+    def __init__(self, numel: int, device, group=None):
+        import torch.distributed as dist
+
+        self._dist = dist if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1 else None
+        self._group = group
+        self._bufs = [torch.zeros(numel, device=device), torch.zeros(numel, device=device)]
+        self._works = [None, None]
+        self._filled = [False, False]
+        self._k = 0
+
+    def begin_step(self, want_totals: bool = False):
+        i = self._k & 1
+        if self._works[i] is not None:
+            self._works[i].wait()
+            self._works[i] = None
+        totals = self._bufs[i].clone() if want_totals and self._filled[i] else None
+        self._bufs[i].zero_()
+        return self._bufs[i], totals
+
+    def end_step(self):
+        i = self._k & 1
+        if self._dist is not None:
+            self._works[i] = self._dist.all_reduce(self._bufs[i], op=self._dist.ReduceOp.SUM, group=self._group, async_op=True)
+        self._filled[i] = True
+        self._k += 1
+
+    def finish(self) -> list[torch.Tensor]:
+        """Wait for the all-reduces still in flight; returns the totals not handed out yet, oldest first."""
+        out = []
+        for i in ((self._k & 1), (self._k + 1) & 1):
+            if self._works[i] is not None:
+                self._works[i].wait()
+                self._works[i] = None
+            if self._filled[i]:
+                out.append(self._bufs[i].clone())
+                self._filled[i] = False
+        return out
+
+
 def episode_log(log_sums: torch.Tensor, reward_names: Sequence[str], termination_names: Sequence[str],
                 max_episode_length_s: float, metric_names: Sequence[str] = ("error_vel_xy", "error_vel_yaw"),
                 command_name: str = "base_velocity") -> dict:

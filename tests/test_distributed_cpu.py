@@ -111,3 +111,52 @@ def test_two_rank_statistics_equal_single_process(tmp_path):
     log = episode_log(r0, REWARDS, TERMS, MAX_LEN * STEP_DT)
     assert log["num_resets"] == int(single[-1]) and log["Episode_Termination/time_out"] >= 2
     assert abs(log["Episode_Reward/track_lin_vel_xy_exp"] - float(single[0]) / float(single[-1]) / (MAX_LEN * STEP_DT)) < 1e-6
+
+
+def _overlap_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    from isaaclab_amd.distributed import OverlappedLogReducer
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        red = OverlappedLogReducer(5, "cpu")
+        got = []
+        for k in range(5):
+            buf, totals = red.begin_step(want_totals=True)
+            if totals is not None:
+                got.append(totals)
+            buf += torch.arange(5.0) * (k + 1) + rank      # what the fused kernel would accumulate in step k
+            red.end_step()
+        got += red.finish()
+        torch.save(torch.stack(got), os.path.join(out_dir, f"overlap{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_overlapped_reducer_matches_blocking_all_reduce(tmp_path):
+    """Two ranks, five steps: the overlapped reducer hands out every step's global sums, in order, two steps late."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_overlap_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = (torch.load(tmp_path / f"overlap{r}.pt") for r in range(2))
+    assert torch.equal(r0, r1)
+    want = torch.stack([2 * torch.arange(5.0) * (k + 1) + 1.0 for k in range(5)])   # rank 0 adds 0, rank 1 adds 1
+    assert torch.equal(r0, want)
+
+
+def test_overlapped_reducer_single_process():
+    from isaaclab_amd.distributed import OverlappedLogReducer
+
+    red = OverlappedLogReducer(3, "cpu")
+    seen = []
+    for k in range(4):
+        buf, totals = red.begin_step(want_totals=True)
+        if totals is not None:
+            seen.append(totals)
+        buf += float(k + 1)
+        red.end_step()
+    seen += red.finish()
+    assert [float(t[0]) for t in seen] == [1.0, 2.0, 3.0, 4.0]
