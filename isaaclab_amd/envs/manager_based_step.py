@@ -53,6 +53,12 @@ class _Asset:
     def set_joint_position_target(self, target, joint_ids=None):
         self.data.joint_pos_target[:, joint_ids if joint_ids is not None else slice(None)] = target
 
+    def set_joint_velocity_target(self, target, joint_ids=None):
+        self.data.joint_vel_target[:, joint_ids if joint_ids is not None else slice(None)] = target
+
+    def set_joint_effort_target(self, target, joint_ids=None):
+        self.data.joint_effort_target[:, joint_ids if joint_ids is not None else slice(None)] = target
+
 
 class ManagerBasedStep:
     """Shared sequence; subclasses provide the action term and the actuator groups."""

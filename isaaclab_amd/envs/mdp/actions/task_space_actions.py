@@ -41,6 +41,10 @@ class DifferentialInverseKinematicsActionCfg:
     clip: dict | None = None
     controller: DifferentialIKControllerCfg = field(default_factory=DifferentialIKControllerCfg)
     debug_vis: bool = False
+    class_type: type = None
+
+    def __post_init__(self):
+        self.class_type = self.class_type or DifferentialInverseKinematicsAction
 
 
 class DifferentialInverseKinematicsAction:

@@ -1,0 +1,5 @@
+"""Command terms with the reference's module layout (``isaaclab/envs/mdp/commands``)."""
+
+from .commands_cfg import UniformPoseCommandCfg, UniformVelocityCommandCfg  # noqa: F401
+from .pose_command import UniformPoseCommand  # noqa: F401
+from .velocity_command import UniformVelocityCommand  # noqa: F401

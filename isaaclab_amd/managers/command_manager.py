@@ -1,0 +1,131 @@
+"""``CommandTerm`` / ``CommandManager`` (interface of ``isaaclab/managers/command_manager.py``).
+
+A command term keeps the reference's buffers (``time_left``, ``command_counter``, ``metrics``, the command tensor) and
+its ``compute(dt)`` / ``reset(env_ids)`` are each one launch of the fused MDP kernel restricted to its COMMAND or
+RESET phase; the concrete terms are in :mod:`isaaclab_amd.envs.mdp.commands`.
+"""
+
+from __future__ import annotations
+
+from collections.abc import Sequence
+from dataclasses import dataclass
+
+import torch
+
+from ..envs import fused_mdp as FM
+
+
+@dataclass
+class CommandTermCfg:
+    """manager_term_cfg.py (CommandTermCfg)."""
+
+    class_type: type = None
+    resampling_time_range: tuple[float, float] = (0.0, 0.0)
+    debug_vis: bool = False
+
+
+class CommandTerm:
+    """command_manager.py:27-222 without the debug visualisation.
+
+    Subclasses describe themselves to the kernel through :meth:`_kernel_cfg` (kind, ranges, flags) and bind the
+    asset tensors the kernel reads in :meth:`_bind_state`.  Random draws come from the kernel's counter-based generator
+    (seed ``cfg``-independent, one stream per env and call); ``_samples`` / ``_reset_samples`` may hold an (N, 7) tensor
+    of the values to use instead -- column 0 the resampling time, 1.. the term's draws in the reference's order -- which
+    is how the tests replay the reference's draws.
+    """
+
+    metric_names: tuple[str, str] = ("metric0", "metric1")
+
+    def __init__(self, cfg: CommandTermCfg, env):
+        self.cfg, self._env = cfg, env
+        self.num_envs, self.device = env.num_envs, torch.device(env.device)
+        k = self._kernel_cfg()
+        self._mdp = FM.FusedMdp(self.num_envs, self.device, num_joints=k.pop("num_joints", 1), num_bodies=k.pop("num_bodies", 1),
+                                command_dim=k.pop("command_dim"), step_dt=env.step_dt, command=k, seed=getattr(env, "seed", 0) or 0)
+        m = self._mdp
+        self.time_left, self.command_counter = m.time_left, m.command_counter
+        self.metrics = {self.metric_names[0]: m.command_metrics[0], self.metric_names[1]: m.command_metrics[1]}
+        self._samples = self._reset_samples = None
+
+    def _kernel_cfg(self) -> dict:
+        raise NotImplementedError
+
+    def _bind_state(self):
+        raise NotImplementedError
+
+    @property
+    def command(self) -> torch.Tensor:
+        raise NotImplementedError
+
+    def reset(self, env_ids: Sequence[int] | None = None) -> dict[str, float]:
+        """command_manager.py:120-149: log the mean metrics of the reset envs, zero them, zero the counter, resample."""
+        m = self._mdp
+        m.terminated.zero_()
+        m.time_outs.zero_()
+        if env_ids is None or (isinstance(env_ids, slice) and env_ids == slice(None)):
+            m.time_outs.fill_(True)
+            count = self.num_envs
+        else:
+            ids = torch.as_tensor(env_ids, device=self.device, dtype=torch.long) if not isinstance(env_ids, slice) else env_ids
+            m.time_outs[ids] = True
+            count = int(m.time_outs.sum())
+        extras = {name: float("nan") for name in self.metrics}
+        if count == 0:
+            return extras  # torch.mean over nothing, as in the reference
+        self._bind_state()
+        m.bind(reset_command_samples=self._reset_samples)
+        m.log_sums.zero_()
+        m.step(FM.PHASE_RESET)
+        sums = m.log_sums[:2].tolist()
+        return {name: sums[i] / count for i, name in enumerate(self.metrics)}
+
+    def compute(self, dt: float):
+        """command_manager.py:151-166: metrics, ``time_left -= dt``, resample where it ran out, post-process."""
+        m = self._mdp
+        m.desc.step_dt = dt
+        self._bind_state()
+        m.bind(command_samples=self._samples)
+        m.step(FM.PHASE_COMMAND)
+
+
+class CommandManager:
+    """command_manager.py:225-423: the terms of a cfg object (or dict), in declaration order."""
+
+    def __init__(self, cfg, env):
+        self.cfg, self._env = cfg, env
+        self._terms: dict[str, CommandTerm] = {}
+        items = cfg.items() if isinstance(cfg, dict) else vars(cfg).items()
+        for name, term_cfg in items:
+            if term_cfg is None:
+                continue
+            if not isinstance(term_cfg, CommandTermCfg):
+                raise TypeError(f"Configuration for the term '{name}' is not of type CommandTermCfg. Received: '{type(term_cfg)}'.")
+            term = term_cfg.class_type(term_cfg, env)
+            if not isinstance(term, CommandTerm):
+                raise TypeError(f"Returned object for the term '{name}' is not of type CommandType.")
+            self._terms[name] = term
+
+    def __str__(self) -> str:
+        return f"<CommandManager> contains {len(self._terms)} active terms: " + ", ".join(
+            f"{name} ({type(term).__name__})" for name, term in self._terms.items())
+
+    @property
+    def active_terms(self) -> list[str]:
+        return list(self._terms.keys())
+
+    def reset(self, env_ids: Sequence[int] | None = None) -> dict[str, float]:
+        extras = {}
+        for name, term in self._terms.items():
+            for metric_name, value in term.reset(env_ids=env_ids).items():
+                extras[f"Metrics/{name}/{metric_name}"] = value
+        return extras
+
+    def compute(self, dt: float):
+        for term in self._terms.values():
+            term.compute(dt)
+
+    def get_command(self, name: str) -> torch.Tensor:
+        return self._terms[name].command
+
+    def get_term(self, name: str) -> CommandTerm:
+        return self._terms[name]

@@ -1,0 +1,194 @@
+"""GPU: ActionManager / joint action terms and CommandManager / command terms through their reference-shaped classes,
+against the fixtures recorded from the reference's classes."""
+
+import math
+from types import SimpleNamespace as NS
+
+import pytest
+import torch
+
+from conftest import assert_close, assert_exact, load_golden
+
+pytestmark = pytest.mark.gpu
+
+JOINTS = ["LF_HAA", "LH_HAA", "RF_HAA", "RH_HAA", "LF_HFE", "LH_HFE", "RF_HFE", "RH_HFE", "LF_KFE", "LH_KFE", "RF_KFE", "RH_KFE"]
+
+
+def _asset(g, tag, dev):
+    from isaaclab_amd.assets.articulation_data import ArticulationData
+    from isaaclab_amd.envs.manager_based_step import _Asset
+
+    n = g[f"{tag}_joint_pos"].shape[0]
+    data = ArticulationData(n, len(JOINTS), 1, dev, joint_names=JOINTS, body_names=["base"])
+    data.default_joint_pos[:] = g[f"{tag}_default_joint_pos"].to(dev)
+    data.default_joint_vel[:] = g[f"{tag}_default_joint_vel"].to(dev)
+    data.joint_pos = g[f"{tag}_joint_pos"].to(dev).contiguous()
+    return _Asset(data), n
+
+
+def _run_actions(dev, tag, cfg, term_names):
+    from isaaclab_amd.managers import ActionManager
+
+    g = load_golden("actions")
+    asset, n = _asset(g, tag, dev)
+    env = NS(num_envs=n, device=dev, scene={"robot": asset})
+    mgr = ActionManager(cfg, env)
+    assert mgr.active_terms == term_names
+    assert mgr.total_action_dim == g[f"{tag}_raw"].shape[2]
+    for k in range(g[f"{tag}_raw"].shape[0]):
+        mgr.process_action(g[f"{tag}_raw"][k].to(dev))
+        mgr.apply_action()
+        assert_exact(mgr.action, g[f"{tag}_action"][k], f"{tag} action {k}")
+        assert_exact(mgr.prev_action, g[f"{tag}_prev_action"][k], f"{tag} prev_action {k}")
+        for name in term_names:
+            # one multiply-add per element: the reference rounds the product first, the kernel may contract it
+            assert_close(mgr.get_term(name).processed_actions, g[f"{tag}_processed_{name}"][k], rtol=1e-6, atol=1e-7,
+                         what=f"{tag} processed {name} {k}")
+        assert_close(asset.data.joint_pos_target, g[f"{tag}_pos_target"][k], rtol=1e-6, atol=1e-7, what=f"{tag} pos target {k}")
+        assert_close(asset.data.joint_vel_target, g[f"{tag}_vel_target"][k], rtol=1e-6, atol=1e-7, what=f"{tag} vel target {k}")
+        assert_close(asset.data.joint_effort_target, g[f"{tag}_effort_target"][k], rtol=1e-6, atol=1e-7, what=f"{tag} effort target {k}")
+    assert mgr.reset(g[f"{tag}_reset_ids"].to(dev)) == {}
+    assert_exact(mgr.action, g[f"{tag}_reset_action"], f"{tag} reset action")
+    assert_exact(mgr.prev_action, g[f"{tag}_reset_prev_action"], f"{tag} reset prev_action")
+    for name in term_names:
+        assert_exact(mgr.get_term(name).raw_actions, g[f"{tag}_reset_raw_{name}"], f"{tag} reset raw {name}")
+    return mgr
+
+
+def test_joint_position_action_manager(dev):
+    from isaaclab_amd.envs.mdp.actions import JointPositionActionCfg
+
+    mgr = _run_actions(dev, "anymal", NS(joint_pos=JointPositionActionCfg(joint_names=[".*"], scale=0.5)), ["joint_pos"])
+    assert mgr.get_term("joint_pos")._joint_ids == slice(None)
+    with pytest.raises(ValueError, match="Invalid action shape, expected: 12, received: 11"):
+        mgr.process_action(torch.zeros(96, 11, device=dev))
+
+
+def test_two_action_terms(dev):
+    from isaaclab_amd.envs.mdp.actions import JointEffortActionCfg, RelativeJointPositionActionCfg
+
+    cfg = dict(legs=JointEffortActionCfg(joint_names=[".*_HAA", ".*_KFE"], scale={".*_HAA": 2.0, ".*_KFE": -3.0},
+                                         offset={".*_KFE": 0.25}, clip={".*_HAA": (-1.0, 1.5)}),
+               hips=RelativeJointPositionActionCfg(joint_names=[".*_HFE"], scale=0.25), unused=None)
+    _run_actions(dev, "split", cfg, ["legs", "hips"])
+
+
+def test_ordered_velocity_action(dev):
+    from isaaclab_amd.envs.mdp.actions import JointVelocityActionCfg
+
+    mgr = _run_actions(dev, "ordered", NS(vel=JointVelocityActionCfg(joint_names=["RH_KFE", "LF_HAA", "RF_HFE"], preserve_order=True,
+                                                                   scale=1.5)), ["vel"])
+    assert mgr.get_term("vel")._joint_ids == [11, 0, 6]
+
+
+def test_action_manager_rejects_foreign_cfg(dev):
+    from isaaclab_amd.managers import ActionManager
+
+    with pytest.raises(TypeError, match="is not of type ActionTermCfg"):
+        ActionManager(dict(bad=3.0), NS(num_envs=4, device=dev, scene={}))
+
+
+def test_velocity_command_term(dev):
+    from isaaclab_amd.envs.mdp.commands import UniformVelocityCommandCfg
+    from isaaclab_amd.managers import CommandManager
+    from isaaclab_amd.tasks import locomotion_velocity as LV
+    from oracle import mathx as M
+
+    g = load_golden("velocity_command")
+    for tag in ("rough", "mixed"):
+        lo, hi, stand, head, stiff = g[f"{tag}_cfg"].tolist()
+        p = lambda key: g[f"{tag}_pre_{key}"]  # noqa: E731
+        n = p("time_left").shape[0]
+        yaw = p("heading_w")
+        quat = torch.stack([torch.cos(yaw / 2), torch.zeros(n), torch.zeros(n), torch.sin(yaw / 2)], -1)
+        rs = torch.cat([torch.zeros(n, 3), quat, M.quat_rotate(quat, p("root_lin_vel_b")), M.quat_rotate(quat, p("root_ang_vel_b"))], -1)
+        robot = NS(data=NS(root_state_w=rs.to(dev).contiguous()))
+        R = UniformVelocityCommandCfg.Ranges
+        cfg = UniformVelocityCommandCfg(resampling_time_range=(lo, hi), rel_standing_envs=stand, rel_heading_envs=head,
+                                        heading_command=True, heading_control_stiffness=stiff,
+                                        ranges=R(lin_vel_x=(-1.0, 1.0), lin_vel_y=(-1.0, 1.0), ang_vel_z=(-1.0, 1.0),
+                                                 heading=(-math.pi, math.pi)))
+        env = NS(num_envs=n, device=dev, step_dt=LV.STEP_DT, scene={"robot": robot})
+        mgr = CommandManager(NS(base_velocity=cfg, nothing=None), env)
+        assert mgr.active_terms == ["base_velocity"]
+        term = mgr.get_term("base_velocity")
+        term.vel_command_b.copy_(p("vel_command_b"))
+        term.heading_target.copy_(p("heading_target"))
+        term.is_heading_env.copy_(p("is_heading_env"))
+        term.is_standing_env.copy_(p("is_standing_env"))
+        term.time_left.copy_(p("time_left"))
+        term.command_counter.copy_(p("command_counter"))
+        term.metrics["error_vel_xy"].copy_(p("metric_xy"))
+        term.metrics["error_vel_yaw"].copy_(p("metric_yaw"))
+        for k in range(g[f"{tag}_samples"].shape[0]):
+            term._samples = g[f"{tag}_samples"][k].to(dev).contiguous()
+            mgr.compute(LV.STEP_DT)
+            assert_exact(term.time_left, g[f"{tag}_time_left"][k], f"{tag} time_left step {k}")
+            assert_exact(term.command_counter, g[f"{tag}_command_counter"][k], f"{tag} counter step {k}")
+            assert_exact(term.is_standing_env, g[f"{tag}_is_standing_env"][k], f"{tag} is_standing_env step {k}")
+            assert_exact(term.heading_target, g[f"{tag}_heading_target"][k], f"{tag} heading_target step {k}")
+            assert_close(mgr.get_command("base_velocity"), g[f"{tag}_vel_command_b"][k], atol=2e-5, what=f"{tag} command step {k}")
+            assert_close(term.metrics["error_vel_xy"], g[f"{tag}_metric_xy"][k], atol=1e-6, what=f"{tag} metric xy step {k}")
+            assert_close(term.metrics["error_vel_yaw"], g[f"{tag}_metric_yaw"][k], atol=1e-6, what=f"{tag} metric yaw step {k}")
+        ids = g[f"{tag}_reset_ids"]
+        term._reset_samples = g[f"{tag}_reset_samples"].to(dev).contiguous()
+        extras = mgr.reset(ids.to(dev))
+        want = g[f"{tag}_reset_extras"].tolist()
+        assert extras["Metrics/base_velocity/error_vel_xy"] == pytest.approx(want[0], rel=1e-5, abs=1e-6)
+        assert extras["Metrics/base_velocity/error_vel_yaw"] == pytest.approx(want[1], rel=1e-5, abs=1e-6)
+        assert_exact(term.command_counter, g[f"{tag}_reset_command_counter"], f"{tag} reset counter")
+        assert_exact(term.time_left, g[f"{tag}_reset_time_left"], f"{tag} reset time_left")
+        assert_exact(term.command.cpu()[ids], g[f"{tag}_reset_vel_command_b"][ids], f"{tag} reset command")
+        assert (term.metrics["error_vel_xy"].cpu()[ids] == 0).all()
+
+
+def test_velocity_command_needs_heading_range(dev):
+    from isaaclab_amd.envs.mdp.commands import UniformVelocityCommand, UniformVelocityCommandCfg
+
+    cfg = UniformVelocityCommandCfg(resampling_time_range=(1.0, 2.0), heading_command=True)
+    with pytest.raises(ValueError, match="ranges.heading"):
+        UniformVelocityCommand(cfg, NS(num_envs=4, device=dev, step_dt=0.02, scene={"robot": NS(data=None)}))
+
+
+def test_pose_command_term(dev):
+    from isaaclab_amd.envs.mdp.commands import UniformPoseCommandCfg
+    from isaaclab_amd.managers import CommandManager
+
+    g = load_golden("pose_command")
+    for tag in ("reach", "unique"):
+        v = g[f"{tag}_cfg"].tolist()
+        n = g[f"{tag}_pre_time_left"].shape[0]
+        bodies = [f"link{i}" for i in range(8)] + ["ee", "finger_l", "finger_r"]
+        robot = NS(data=NS(root_state_w=g[f"{tag}_root_state_w"].to(dev).contiguous(), body_state_w=g[f"{tag}_body_state_w"].to(dev).contiguous()),
+                   num_bodies=len(bodies), find_bodies=lambda name: ([bodies.index(name)], [name]))
+        R = UniformPoseCommandCfg.Ranges
+        cfg = UniformPoseCommandCfg(resampling_time_range=(v[0], v[1]), body_name="ee", make_quat_unique=bool(v[14]),
+                                    ranges=R(pos_x=(v[2], v[3]), pos_y=(v[4], v[5]), pos_z=(v[6], v[7]), roll=(v[8], v[9]),
+                                             pitch=(v[10], v[11]), yaw=(v[12], v[13])))
+        mgr = CommandManager(dict(ee_pose=cfg), NS(num_envs=n, device=dev, step_dt=1 / 30, scene={"robot": robot}))
+        term = mgr.get_term("ee_pose")
+        assert term.body_idx == 8
+        assert_exact(term.command[:, 3], torch.ones(n), "identity orientation before the first resampling")
+        term.pose_command_b.copy_(g[f"{tag}_pre_pose_command_b"])
+        term.time_left.copy_(g[f"{tag}_pre_time_left"])
+        term.command_counter.copy_(g[f"{tag}_pre_command_counter"])
+        for k in range(3):
+            term._samples = g[f"{tag}_samples"][k].to(dev).contiguous()
+            mgr.compute(1 / 30)
+            assert_exact(term.time_left, g[f"{tag}_time_left"][k], f"{tag} time_left step {k}")
+            assert_exact(term.command_counter, g[f"{tag}_command_counter"][k], f"{tag} counter step {k}")
+            assert_close(mgr.get_command("ee_pose"), g[f"{tag}_pose_command_b"][k], atol=1e-6, what=f"{tag} command step {k}")
+            assert_close(term.metrics["position_error"], g[f"{tag}_position_error"][k], atol=1e-6, what=f"{tag} position error {k}")
+            assert_close(term.metrics["orientation_error"], g[f"{tag}_orientation_error"][k], atol=3e-6, what=f"{tag} orientation error {k}")
+        # the world-frame command of the last step's metrics belongs to the command before that step's resampling;
+        # check the property against the envs that kept their command
+        kept = ~g[f"{tag}_resampled"][2]
+        assert_close(term.pose_command_w.cpu()[kept], g[f"{tag}_pose_command_w"][2][kept], atol=2e-6, what=f"{tag} pose_command_w")
+        ids = g[f"{tag}_reset_ids"]
+        term._reset_samples = g[f"{tag}_reset_samples"].to(dev).contiguous()
+        extras = mgr.reset(ids.tolist())
+        want = g[f"{tag}_reset_extras"].tolist()
+        assert extras["Metrics/ee_pose/position_error"] == pytest.approx(want[0], rel=1e-5, abs=1e-6)
+        assert extras["Metrics/ee_pose/orientation_error"] == pytest.approx(want[1], rel=1e-5, abs=1e-6)
+        assert_exact(term.time_left, g[f"{tag}_reset_time_left"], f"{tag} reset time_left")
+        assert_close(term.command, g[f"{tag}_reset_pose_command_b"], atol=1e-6, what=f"{tag} reset command")

@@ -46,3 +46,14 @@ print("terrain cast, random yaw (column grid) us", timeit(lambda: raycast_mesh(s
 a = raycast_mesh(starts_r, dirs, mesh, return_distance=True, return_face_id=True)
 b = raycast_mesh(starts_r, dirs, mesh, return_distance=True, return_face_id=True, z_parallel_hint=True)
 print("identical:", bool((a[1] == b[1]).all()), bool((a[3] == b[3]).all()))
+# what env ordering is worth: the same rays with the envs visited in Morton order of their 2 m bin
+def morton(ix, iy):
+    key = torch.zeros_like(ix)
+    for b in range(8):
+        key |= ((ix >> b) & 1) << (2 * b) | ((iy >> b) & 1) << (2 * b + 1)
+    return key
+for bin_m in (8.0, 2.0, 0.5):
+    order = torch.argsort(morton((xy[:, 0] / bin_m).long(), (xy[:, 1] / bin_m).long()))
+    s_sorted = starts_r.view(n_env, R, 3)[order.to(dev)].reshape(-1, 3).contiguous()
+    print("terrain cast, random yaw, envs in Morton order of %.1f m bins us" % bin_m,
+          timeit(lambda: raycast_mesh(s_sorted, dirs, mesh, z_parallel_hint=True)))
