@@ -6,3 +6,4 @@ from .scene_entity_cfg import SceneEntityCfg  # noqa: F401
 from .termination_manager import TerminationManager  # noqa: F401
 from .action_manager import ActionManager, ActionTerm, ActionTermCfg  # noqa: F401
 from .command_manager import CommandManager, CommandTerm, CommandTermCfg  # noqa: F401
+from .event_manager import EventManager, EventTermCfg, ManagerTermBase  # noqa: F401
