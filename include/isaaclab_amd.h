@@ -215,6 +215,25 @@ int ilx_event_reset_joints(int by_scale, const int64_t* env_ids, int64_t count, 
 int ilx_event_push_by_setting_velocity(const int64_t* env_ids, int64_t count, const float* velocity_range_host,
                                        const float* u, uint64_t seed, uint64_t draw, float* root_state_w, void* stream);
 
+/* Terrain curriculum of the velocity tasks: terrain_levels_vel
+ * (source/isaaclab_tasks/isaaclab_tasks/manager_based/locomotion/velocity/mdp/curriculums.py:26-55) fused with
+ * TerrainImporter.update_env_origins (source/isaaclab/isaaclab/terrains/terrain_importer.py:307-322), for the listed envs:
+ *   distance  = |root_pos_w.xy - env_origins.xy|
+ *   move_up   = distance > half_terrain_size                     (terrain_generator.size[0] / 2)
+ *   move_down = distance < |command.xy| * max_episode_length_s * 0.5, and not move_up
+ *   level += move_up - move_down; level >= num_rows -> a random level in [0, num_rows); level < 0 -> 0
+ *   env_origins[env] = terrain_origins[level, terrain_types[env]]
+ * move_up / move_down (count bytes each, both or neither): given flags replace the first three lines, which makes the
+ * call TerrainImporter.update_env_origins alone.  random_levels (count) holds the replacement levels
+ * (torch.randint_like draws one per listed env) or is NULL: Philox keyed by (seed, draw, env).  terrain_levels /
+ * terrain_types are int64 (n); terrain_origins (num_rows, num_cols, 3); env_origins (n,3). */
+int ilx_curriculum_terrain_levels(const int64_t* env_ids, int64_t count, const float* root_state_w, const float* command,
+                                  int command_dim, float half_terrain_size, float max_episode_length_s,
+                                  const uint8_t* move_up, const uint8_t* move_down, int64_t* terrain_levels,
+                                  const int64_t* terrain_types, const float* terrain_origins, int num_rows, int num_cols,
+                                  const int64_t* random_levels, uint64_t seed, uint64_t draw, float* env_origins,
+                                  void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Contact sensor bookkeeping — source/isaaclab/isaaclab/sensors/contact_sensor/contact_sensor.py:314-373
  * plus the update timing of sensors/sensor_base.py:197-205,284-293.

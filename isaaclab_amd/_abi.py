@@ -113,6 +113,8 @@ event_reset_root_state_uniform = _sig("ilx_event_reset_root_state_uniform", P, c
 event_reset_joints = _sig("ilx_event_reset_joints", c_int, P, c_int64, P, P, P, P, c_float, c_float, c_float, c_float, P, c_uint64,
                           c_uint64, P, P, c_int, P)
 event_push_by_setting_velocity = _sig("ilx_event_push_by_setting_velocity", P, c_int64, P, P, c_uint64, c_uint64, P, P)
+curriculum_terrain_levels = _sig("ilx_curriculum_terrain_levels", P, c_int64, P, P, c_int, c_float, c_float, P, P, P, P, P, c_int, c_int,
+                                 P, c_uint64, c_uint64, P, P)
 
 
 class Scene(ctypes.Structure):

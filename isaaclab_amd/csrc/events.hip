@@ -79,6 +79,52 @@ push_velocity_kernel(const int64_t* __restrict__ ids, int64_t count, Range6 vel,
     root[13 * env + 7 + c] += ranged(draw01(rng, k, env, c), vel.lo[c], vel.hi[c]);
 }
 
+// Terrain curriculum: the term of isaaclab_tasks/manager_based/locomotion/velocity/mdp/curriculums.py:26-55 fused with
+// TerrainImporter.update_env_origins (isaaclab/terrains/terrain_importer.py:307-322), one thread per listed env.
+struct CurriculumArgs {
+    const int64_t* ids;
+    int64_t count;
+    const float* root;        // (n,13)
+    const float* command;     // (n,command_dim) or null when the move flags are given
+    int command_dim;
+    float half_size, max_episode_length_s;
+    const uint8_t* move_up;   // (count) or null: decided here from the distance walked
+    const uint8_t* move_down; // (count) or null
+    int64_t* levels;          // (n)
+    const int64_t* types;     // (n)
+    const float* terrain_origins;  // (rows, cols, 3)
+    int rows, cols;
+    const int64_t* random_levels;  // (count) or null: Philox
+    uint64_t seed, draw;
+    float* origins;           // (n,3), read (distance) then written
+};
+__global__ void __launch_bounds__(256) terrain_levels_kernel(CurriculumArgs a) {
+    const int64_t k = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (k >= a.count) return;
+    const int64_t env = a.ids[k];
+    bool up, down;
+    if (a.move_up) {
+        up = a.move_up[k] != 0, down = a.move_down[k] != 0;
+    } else {
+        const float* r = a.root + 13 * env;
+        const float* o = a.origins + 3 * env;
+        const float distance = norm2(r[0] - o[0], r[1] - o[1]);
+        const float* c = a.command + static_cast<int64_t>(a.command_dim) * env;
+        up = distance > a.half_size;
+        down = distance < norm2(c[0], c[1]) * a.max_episode_length_s * 0.5f;
+        down = down && !up;
+    }
+    int64_t level = a.levels[env] + (up ? 1 : 0) - (down ? 1 : 0);
+    if (level >= a.rows) {  // solved the last level: sent to a random one
+        level = a.random_levels ? a.random_levels[k]
+                                : static_cast<int64_t>(philox4(a.seed, a.draw, static_cast<uint64_t>(env), 0u).x % static_cast<uint32_t>(a.rows));
+    } else if (level < 0) {
+        level = 0;
+    }
+    a.levels[env] = level;
+    store3(a.origins + 3 * env, load3(a.terrain_origins + 3 * (level * a.cols + a.types[env])));
+}
+
 static Range6 range6(const float* host12) {
     Range6 r;
     for (int c = 0; c < 6; ++c) r.lo[c] = host12[c], r.hi[c] = host12[6 + c];
@@ -130,5 +176,28 @@ extern "C" int ilx_event_push_by_setting_velocity(const int64_t* env_ids, int64_
     hipLaunchKernelGGL(push_velocity_kernel, dim3(blocks_for(count * 6)), dim3(256), 0, as_stream(stream), env_ids, count,
                        range6(velocity_range_host), EventRng{u, 6, seed, draw}, root_state_w);
     ILX_LAUNCH_CHECK("ilx_event_push_by_setting_velocity");
+    return ILX_OK;
+}
+
+extern "C" int ilx_curriculum_terrain_levels(const int64_t* env_ids, int64_t count, const float* root_state_w,
+                                             const float* command, int command_dim, float half_terrain_size,
+                                             float max_episode_length_s, const uint8_t* move_up, const uint8_t* move_down,
+                                             int64_t* terrain_levels, const int64_t* terrain_types,
+                                             const float* terrain_origins, int num_rows, int num_cols,
+                                             const int64_t* random_levels, uint64_t seed, uint64_t draw, float* env_origins,
+                                             void* stream) {
+    ILX_REQUIRE(count >= 0 && num_rows > 0 && num_cols > 0, ILX_EINVAL, "ilx_curriculum_terrain_levels: bad shape (%lld envs, %d x %d)",
+                (long long)count, num_rows, num_cols);
+    if (count == 0) return ILX_OK;
+    ILX_REQUIRE(env_ids && terrain_levels && terrain_types && terrain_origins && env_origins, ILX_EINVAL,
+                "ilx_curriculum_terrain_levels: NULL operand");
+    ILX_REQUIRE((move_up != nullptr) == (move_down != nullptr), ILX_EINVAL,
+                "ilx_curriculum_terrain_levels: move_up and move_down come together");
+    ILX_REQUIRE(move_up || (root_state_w && command && command_dim >= 2), ILX_EINVAL,
+                "ilx_curriculum_terrain_levels: without move flags the root state and a command of width >= 2 are needed");
+    CurriculumArgs a{env_ids, count, root_state_w, command, command_dim, half_terrain_size, max_episode_length_s, move_up, move_down,
+                     terrain_levels, terrain_types, terrain_origins, num_rows, num_cols, random_levels, seed, draw, env_origins};
+    hipLaunchKernelGGL(terrain_levels_kernel, dim3(blocks_for(count)), dim3(256), 0, as_stream(stream), a);
+    ILX_LAUNCH_CHECK("ilx_curriculum_terrain_levels");
     return ILX_OK;
 }

@@ -139,3 +139,12 @@ def test_cpu_tensors_are_refused():
         _abi.ptr(torch.zeros(4))
     with pytest.raises(_abi.IlxError, match="no CPU fallback"):
         _abi.row_view(torch.zeros(4, 3), 3)
+
+
+def test_curriculum_arguments():
+    f = _abi.curriculum_terrain_levels
+    fails(f(FAKE, 4, FAKE, FAKE, 3, 4.0, 20.0, NULL, NULL, FAKE, FAKE, FAKE, 0, 6, NULL, 0, 1, FAKE, NULL), EINVAL, "bad shape")
+    fails(f(FAKE, 4, FAKE, FAKE, 3, 4.0, 20.0, FAKE, NULL, FAKE, FAKE, FAKE, 5, 6, NULL, 0, 1, FAKE, NULL), EINVAL, "come together")
+    fails(f(FAKE, 4, NULL, NULL, 0, 4.0, 20.0, NULL, NULL, FAKE, FAKE, FAKE, 5, 6, NULL, 0, 1, FAKE, NULL), EINVAL, "without move flags")
+    fails(f(FAKE, 4, FAKE, FAKE, 1, 4.0, 20.0, NULL, NULL, FAKE, FAKE, FAKE, 5, 6, NULL, 0, 1, FAKE, NULL), EINVAL, "width >= 2")
+    assert f(NULL, 0, NULL, NULL, 0, 4.0, 20.0, NULL, NULL, NULL, NULL, NULL, 5, 6, NULL, 0, 1, NULL, NULL) == 0  # nothing listed
