@@ -371,6 +371,45 @@ typedef struct ilx_raycaster {
 } ilx_raycaster;
 int ilx_raycaster_refresh(const ilx_raycaster* rc, void* stream);
 
+/* RayCasterCamera._update_buffers_impl (sensors/ray_caster/ray_caster_camera.py:257-318) for the cameras flagged in
+ * is_outdated (NULL = all), without temporaries:
+ *   camera pose  = view pose composed with the offset: pos_w = view_pos + quat_apply(view_quat, offset_pos),
+ *                  quat_w_world = view_quat * offset_quat (:415-430); frame += 1
+ *   world rays   = quat_apply(quat_w_world, ray_starts) + pos_w, quat_apply(quat_w_world, ray_directions) (:269-272)
+ *   cast         with max_dist 1e6 (:282) -> ray_hits_w [, normals]
+ *   distance_to_image_plane = x of quat_apply(quat_inv(quat_w_world), depth * direction) (:294-301)
+ *   distance_to_camera      = depth
+ *   depth_clipping: MAX  -> both images clipped to max_distance, NaN (a miss times a zero direction component) -> max_distance
+ *                   ZERO -> values > max_distance (and NaN) -> 0;  NONE -> left as they are (misses are inf / NaN)
+ * then, when is_outdated is given, timestamp_last_update <- timestamp and is_outdated <- 0 for those cameras
+ * (sensor_base.py:284-293).  ray_starts / ray_directions are per camera (n,r,3): intrinsics may differ between cameras
+ * (set_intrinsic_matrices, :121-140).  Any of the three images may be NULL (data type not requested). */
+enum { ILX_DEPTH_CLIP_NONE = 0, ILX_DEPTH_CLIP_MAX = 1, ILX_DEPTH_CLIP_ZERO = 2 };
+typedef struct ilx_raycaster_camera {
+    ilx_mesh_t mesh;
+    int64_t num_envs;
+    int32_t num_rays, depth_clipping;
+    float max_distance;
+    const float* view_pos;              /* strided rows: pose of the prim the camera is attached to */
+    const float* view_quat;             /* (w,x,y,z) */
+    int64_t view_pos_stride, view_quat_stride;
+    const float* offset_pos;            /* (n,3) in the view frame */
+    const float* offset_quat;           /* (n,4) in the "world" camera convention (+x forward, +z up) */
+    const float* ray_starts;            /* (n,r,3) */
+    const float* ray_directions;        /* (n,r,3) */
+    float* pos_w;                       /* CameraData.pos_w (n,3) */
+    float* quat_w_world;                /* CameraData.quat_w_world (n,4) */
+    int64_t* frame;                     /* (n) or NULL */
+    float* ray_hits_w;                  /* (n,r,3) */
+    float* distance_to_image_plane;     /* (n,r) = (n,height,width,1) or NULL */
+    float* distance_to_camera;          /* (n,r) or NULL */
+    float* normals;                     /* (n,r,3) or NULL */
+    float* timestamp;                   /* sensor clock, with is_outdated */
+    float* timestamp_last_update;
+    uint8_t* is_outdated;               /* (n) or NULL */
+} ilx_raycaster_camera;
+int ilx_raycaster_camera_refresh(const ilx_raycaster_camera* rc, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Differential inverse kinematics — source/isaaclab/isaaclab/controllers/differential_ik.py and the action term
  * source/isaaclab/isaaclab/envs/mdp/actions/task_space_actions.py

@@ -147,6 +147,21 @@ class RayCasterDesc(ctypes.Structure):
     ]
 
 
+class RayCasterCameraDesc(ctypes.Structure):
+    """Mirror of ``ilx_raycaster_camera`` (include/isaaclab_amd.h)."""
+
+    _fields_ = [
+        ("mesh", c_void_p), ("num_envs", c_int64), ("num_rays", ctypes.c_int32), ("depth_clipping", ctypes.c_int32),
+        ("max_distance", c_float), ("view_pos", c_void_p), ("view_quat", c_void_p), ("view_pos_stride", c_int64),
+        ("view_quat_stride", c_int64), ("offset_pos", c_void_p), ("offset_quat", c_void_p), ("ray_starts", c_void_p),
+        ("ray_directions", c_void_p), ("pos_w", c_void_p), ("quat_w_world", c_void_p), ("frame", c_void_p),
+        ("ray_hits_w", c_void_p), ("distance_to_image_plane", c_void_p), ("distance_to_camera", c_void_p), ("normals", c_void_p),
+        ("timestamp", c_void_p), ("timestamp_last_update", c_void_p), ("is_outdated", c_void_p),
+    ]
+
+
+DEPTH_CLIP = {"none": 0, "max": 1, "zero": 2}
+raycaster_camera_refresh = _sig("ilx_raycaster_camera_refresh", ctypes.POINTER(RayCasterCameraDesc), P)
 scene_update = _sig("ilx_scene_update", ctypes.POINTER(Scene), P)
 raycaster_refresh = _sig("ilx_raycaster_refresh", ctypes.POINTER(RayCasterDesc), P)
 

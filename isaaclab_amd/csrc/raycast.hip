@@ -511,6 +511,80 @@ __global__ void __launch_bounds__(kRayBlock) raycaster_update_column_kernel(Scan
     write_scan(a, h, o, d, pos_z, i);
 }
 
+// RayCasterCamera._update_buffers_impl (ray_caster_camera.py:257-318): one thread per (env, pixel) of the refreshed
+// cameras.  Camera pose = view pose composed with the offset (:415-430); rays carry the full orientation (:269-272);
+// the cast has no range limit (1e6, :282) because the clipping happens on the two distance images afterwards.
+struct CameraArgs {
+    MeshDev mesh;
+    const float* view_pos;   // strided rows
+    const float* view_quat;
+    int64_t pos_stride, quat_stride;
+    const float* offset_pos;   // (n,3)
+    const float* offset_quat;  // (n,4)
+    const float* ray_starts;   // (n,r,3): per camera, the intrinsics may differ
+    const float* ray_dirs;     // (n,r,3)
+    const uint8_t* env_mask;   // (n) or null
+    float* pos_w;              // (n,3)
+    float* quat_w_world;       // (n,4)
+    int64_t* frame;            // (n) or null
+    float* ray_hits_w;         // (n,r,3)
+    float* image_plane;        // (n,r) or null
+    float* to_camera;          // (n,r) or null
+    float* normals;            // (n,r,3) or null
+    float max_distance;
+    int clipping;              // ILX_DEPTH_CLIP_*
+    int64_t n;
+    int r;
+};
+
+__global__ void __launch_bounds__(kRayBlock) raycaster_camera_kernel(CameraArgs a) {
+    __shared__ Node cache[kCachedNodes];
+    __shared__ int32_t stack[kStackSlots * kRayBlock];
+    const int ncache = min(a.mesh.num_nodes, kCachedNodes);
+    stage_nodes(a.mesh, cache, ncache);
+    const int64_t total = a.n * a.r;
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * kRayBlock + threadIdx.x; i < total;
+         i += static_cast<int64_t>(gridDim.x) * kRayBlock) {
+        const int64_t env = i / a.r;
+        if (a.env_mask && !a.env_mask[env]) continue;
+        const f4 qv = load4u(a.view_quat + a.quat_stride * env);
+        const f3 pv = load3(a.view_pos + a.pos_stride * env);
+        const f3 off = quat_apply(qv, load3(a.offset_pos + 3 * env));
+        const f3 pos = {pv.x + off.x, pv.y + off.y, pv.z + off.z};
+        const f4 q = quat_mul(qv, load4u(a.offset_quat + 4 * env));
+        if (i == env * a.r) {  // first pixel of the camera
+            store3(a.pos_w + 3 * env, pos);
+            float* qo = a.quat_w_world + 4 * env;
+            qo[0] = q.w, qo[1] = q.x, qo[2] = q.y, qo[3] = q.z;
+            if (a.frame) a.frame[env] += 1;
+        }
+        f3 o = quat_apply(q, load3(a.ray_starts + 3 * i));
+        o = {o.x + pos.x, o.y + pos.y, o.z + pos.z};
+        const f3 d = quat_apply(q, load3(a.ray_dirs + 3 * i));
+        const Hit h = a.normals ? trace<true>(a.mesh, cache, ncache, stack + threadIdx.x, kRayBlock, o, d, 1.0e6f)
+                                : trace<false>(a.mesh, cache, ncache, stack + threadIdx.x, kRayBlock, o, d, 1.0e6f);
+        write_hit(h, o, d, a.ray_hits_w, nullptr, a.normals, nullptr, i);
+        const float inf = __builtin_inff();
+        const float depth = h.face >= 0 ? h.t : inf;
+        if (a.image_plane) {  // :294-308: x of the hit offset expressed in the camera frame, then the range rule
+            const f3 rel = quat_apply(quat_inv(q), f3{depth * d.x, depth * d.y, depth * d.z});
+            float v = rel.x;
+            if (a.clipping == ILX_DEPTH_CLIP_MAX) {
+                v = (v != v) ? a.max_distance : fminf(v, a.max_distance);
+            } else if (a.clipping == ILX_DEPTH_CLIP_ZERO) {
+                v = (v != v || v > a.max_distance) ? 0.0f : v;
+            }
+            a.image_plane[i] = v;
+        }
+        if (a.to_camera) {  // :312-316
+            float v = depth;
+            if (a.clipping == ILX_DEPTH_CLIP_MAX) v = fminf(v, a.max_distance);
+            else if (a.clipping == ILX_DEPTH_CLIP_ZERO) v = v > a.max_distance ? 0.0f : v;
+            a.to_camera[i] = v;
+        }
+    }
+}
+
 // sensor_base.py:284-293 after the refresh: the refreshed envs record the time and are no longer outdated.
 __global__ void __launch_bounds__(256)
 sensor_refreshed_kernel(const float* __restrict__ ts, float* __restrict__ ts_last, uint8_t* __restrict__ outdated, int64_t n) {
@@ -1180,5 +1254,31 @@ static int launch_scan(ilx_mesh_t mesh, ScanArgs a, int hints, void* stream) {
     if (a.outdated)
         hipLaunchKernelGGL(sensor_refreshed_kernel, dim3(blocks_for(a.n)), dim3(256), 0, as_stream(stream), a.clock_now, a.clock_last,
                            a.outdated, a.n);
+    return ILX_OK;
+}
+
+extern "C" int ilx_raycaster_camera_refresh(const ilx_raycaster_camera* rc, void* stream) {
+    ILX_REQUIRE(rc, ILX_EINVAL, "ilx_raycaster_camera_refresh: descriptor is NULL");
+    const ilx_raycaster_camera& d = *rc;
+    ILX_REQUIRE(d.mesh, ILX_EINVAL, "ilx_raycaster_camera_refresh: mesh is NULL");
+    ILX_REQUIRE(d.num_envs >= 0 && d.num_rays > 0, ILX_EINVAL, "ilx_raycaster_camera_refresh: bad shape (%lld, %d)",
+                (long long)d.num_envs, d.num_rays);
+    ILX_REQUIRE(d.depth_clipping >= ILX_DEPTH_CLIP_NONE && d.depth_clipping <= ILX_DEPTH_CLIP_ZERO, ILX_EINVAL,
+                "ilx_raycaster_camera_refresh: unknown depth clipping behaviour %d", d.depth_clipping);
+    if (d.num_envs == 0) return ILX_OK;
+    ILX_REQUIRE(d.view_pos && d.view_quat && d.offset_pos && d.offset_quat && d.ray_starts && d.ray_directions && d.pos_w &&
+                    d.quat_w_world && d.ray_hits_w,
+                ILX_EINVAL, "ilx_raycaster_camera_refresh: NULL operand");
+    ILX_REQUIRE(d.view_pos_stride >= 3 && d.view_quat_stride >= 4, ILX_EINVAL, "ilx_raycaster_camera_refresh: bad pose strides");
+    ILX_REQUIRE(!d.is_outdated || (d.timestamp && d.timestamp_last_update), ILX_EINVAL,
+                "ilx_raycaster_camera_refresh: is_outdated comes with the two sensor clocks");
+    CameraArgs a{d.mesh->h.dev, d.view_pos, d.view_quat, d.view_pos_stride, d.view_quat_stride, d.offset_pos, d.offset_quat,
+                 d.ray_starts, d.ray_directions, d.is_outdated, d.pos_w, d.quat_w_world, d.frame, d.ray_hits_w,
+                 d.distance_to_image_plane, d.distance_to_camera, d.normals, d.max_distance, d.depth_clipping, d.num_envs, d.num_rays};
+    hipLaunchKernelGGL(raycaster_camera_kernel, dim3(ray_grid(d.num_envs * d.num_rays)), dim3(kRayBlock), 0, as_stream(stream), a);
+    if (d.is_outdated)
+        hipLaunchKernelGGL(sensor_refreshed_kernel, dim3(blocks_for(d.num_envs)), dim3(256), 0, as_stream(stream), d.timestamp,
+                           d.timestamp_last_update, d.is_outdated, d.num_envs);
+    ILX_LAUNCH_CHECK("ilx_raycaster_camera_refresh");
     return ILX_OK;
 }

@@ -148,3 +148,14 @@ def test_curriculum_arguments():
     fails(f(FAKE, 4, NULL, NULL, 0, 4.0, 20.0, NULL, NULL, FAKE, FAKE, FAKE, 5, 6, NULL, 0, 1, FAKE, NULL), EINVAL, "without move flags")
     fails(f(FAKE, 4, FAKE, FAKE, 1, 4.0, 20.0, NULL, NULL, FAKE, FAKE, FAKE, 5, 6, NULL, 0, 1, FAKE, NULL), EINVAL, "width >= 2")
     assert f(NULL, 0, NULL, NULL, 0, 4.0, 20.0, NULL, NULL, NULL, NULL, NULL, 5, 6, NULL, 0, 1, NULL, NULL) == 0  # nothing listed
+
+
+def test_camera_arguments():
+    d = _abi.RayCasterCameraDesc(mesh=FAKE, num_envs=4, num_rays=0)
+    fails(_abi.raycaster_camera_refresh(ctypes.byref(d), NULL), EINVAL, "bad shape")
+    d = _abi.RayCasterCameraDesc(mesh=FAKE, num_envs=4, num_rays=8, depth_clipping=7)
+    fails(_abi.raycaster_camera_refresh(ctypes.byref(d), NULL), EINVAL, "depth clipping")
+    d = _abi.RayCasterCameraDesc(mesh=FAKE, num_envs=4, num_rays=8)
+    fails(_abi.raycaster_camera_refresh(ctypes.byref(d), NULL), EINVAL, "NULL operand")
+    d = _abi.RayCasterCameraDesc(mesh=NULL, num_envs=4, num_rays=8)
+    fails(_abi.raycaster_camera_refresh(ctypes.byref(d), NULL), EINVAL, "mesh is NULL")
