@@ -1,0 +1,82 @@
+/*
+ * isaaclab_amd — operational-space controller: source/isaaclab/isaaclab/controllers/operational_space.py
+ * (cfg: operational_space_cfg.py).
+ *
+ *   ilx_osc_set_command : OperationalSpaceController.set_command (:173-343) — splits the command into task-space
+ *                         targets and impedance parameters, resolves relative poses against the current end-effector
+ *                         pose, and moves gains, selection matrices and targets from the task frame to the root frame
+ *   ilx_osc_compute     : OperationalSpaceController.compute (:345-548) — pose error, task-space acceleration,
+ *                         optional inertial decoupling (joint-space mass matrix inverse, operational-space mass matrix,
+ *                         whole or split into translation / rotation), wrench control (open or closed loop), gravity
+ *                         compensation and null-space joint position control; one joint effort row per env
+ *
+ * One thread per env; the small inverses (mass matrix, 6x6 / 3x3 operational-space matrices, J J^T for the
+ * pseudo-inverse) are solved in double precision inside the kernel.
+ */
+#ifndef ISAACLAB_AMD_OSC_H
+#define ISAACLAB_AMD_OSC_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { ILX_OSC_POSE_REL = 0, ILX_OSC_POSE_ABS = 1, ILX_OSC_WRENCH_ABS = 2 };          /* cfg.target_types entries */
+enum { ILX_OSC_IMPEDANCE_FIXED = 0, ILX_OSC_IMPEDANCE_VARIABLE_KP = 1, ILX_OSC_IMPEDANCE_VARIABLE = 2 };
+#define ILX_OSC_MAX_DOF 12
+
+typedef struct ilx_osc {
+    int64_t num_envs;
+    /* configuration (operational_space_cfg.py) */
+    int32_t num_targets;
+    int32_t target_types[3];
+    int32_t impedance_mode;
+    int32_t inertial_dynamics_decoupling, partial_inertial_dynamics_decoupling, gravity_compensation;
+    int32_t nullspace_position;              /* cfg.nullspace_control == "position" */
+    float motion_control_axes_task[6];
+    float contact_wrench_control_axes_task[6];
+    float motion_damping_ratio_task[6];
+    float motion_stiffness_limits_task[2];
+    float motion_damping_ratio_limits_task[2];
+    float nullspace_p_gain, nullspace_d_gain; /* stiffness, 2 sqrt(stiffness) damping_ratio (:141-146) */
+    /* controller buffers, all caller-owned device memory with the reference's shapes */
+    float* task_space_target_task;           /* (n,target_dim) */
+    float* motion_p_gains_task;              /* (n,6,6) */
+    float* motion_d_gains_task;              /* (n,6,6) */
+    float* motion_p_gains_b;                 /* (n,6,6) */
+    float* motion_d_gains_b;                 /* (n,6,6) */
+    const float* contact_wrench_p_gains_task; /* (n,6,6) or NULL: open-loop wrench control */
+    float* contact_wrench_p_gains_b;         /* (n,6,6) or NULL */
+    float* selection_matrix_motion_b;        /* (n,6,6) */
+    float* selection_matrix_force_b;         /* (n,6,6) */
+    float* desired_ee_pose_task;             /* (n,7), written when a pose target is configured */
+    float* desired_ee_pose_b;                /* (n,7) */
+    float* desired_ee_wrench_task;           /* (n,6), written when a wrench target is configured */
+    float* desired_ee_wrench_b;              /* (n,6) */
+    float* os_mass_matrix_b;                 /* (n,6,6), written by compute under inertial decoupling */
+    float* ee_contact_wrench_b;              /* (n,6), written by compute under closed-loop wrench control */
+} ilx_osc;
+
+/* command (n,action_dim): targets in cfg.target_types order (pose_rel 6, pose_abs 7, wrench_abs 6), then 6 stiffness
+ * values (variable_kp, variable) and 6 damping ratios (variable); action_dim must equal that sum.
+ * current_ee_pose_b (n,7) is required with a pose_rel target; current_task_frame_pose_b (n,7) NULL = identity. */
+int ilx_osc_set_command(const ilx_osc* osc, const float* command, int action_dim, const float* current_ee_pose_b,
+                        const float* current_task_frame_pose_b, void* stream);
+
+/* jacobian_b (n,6,num_dof).  Needed by configuration: current_ee_pose_b (n,7) + current_ee_vel_b (n,6) with a pose
+ * target; current_ee_force_b (n,3) with closed-loop wrench control; mass_matrix (n,num_dof,num_dof) with inertial
+ * decoupling (optional for the null-space term); gravity (n,num_dof) with gravity compensation; current_joint_pos /
+ * current_joint_vel (n,num_dof) with null-space control (nullspace_joint_pos_target NULL = zeros), which also needs
+ * num_dof > 6.  has_pose_target / has_wrench_target: whether set_command has installed such a target since the last
+ * reset (the reference tests `desired_ee_pose_b is not None`).  joint_efforts (n,num_dof) is overwritten. */
+int ilx_osc_compute(const ilx_osc* osc, int has_pose_target, int has_wrench_target, const float* jacobian_b, int num_dof,
+                    const float* current_ee_pose_b, const float* current_ee_vel_b, const float* current_ee_force_b,
+                    const float* mass_matrix, const float* gravity, const float* current_joint_pos,
+                    const float* current_joint_vel, const float* nullspace_joint_pos_target, float* joint_efforts,
+                    void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
