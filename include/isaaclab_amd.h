@@ -234,6 +234,28 @@ int ilx_curriculum_terrain_levels(const int64_t* env_ids, int64_t count, const f
                                   const int64_t* random_levels, uint64_t seed, uint64_t draw, float* env_origins,
                                   void* stream);
 
+/* JointPositionToLimitsAction.process_actions (envs/mdp/actions/joint_actions_to_limits.py:107-129):
+ * processed = raw * scale [clamped to clip (n,a,2)]; with rescale_to_limits, clamped to [-1, 1] and mapped onto the soft
+ * joint position limits (n,num_joints,2) of the term's joints (joint_ids (a) device int32, NULL = the first a joints).
+ * With prev_applied_actions (n,a) the call is EMAJointPositionToLimitsAction.process_actions (:213-229):
+ * processed = clamp(alpha * processed + (1 - alpha) * prev_applied, limits), prev_applied <- processed
+ * (alpha (n,a) tensor or NULL + scalar). */
+int ilx_joint_action_to_limits(const float* raw_action, const float* scale, float scale_scalar, const float* clip,
+                               int rescale_to_limits, const float* soft_joint_pos_limits, const int32_t* joint_ids,
+                               int num_joints, const float* alpha, float alpha_scalar, float* prev_applied_actions,
+                               float* processed, int64_t n, int a, void* stream);
+/* BinaryJointAction.process_actions (envs/mdp/actions/binary_joint_actions.py:118-131): one action per env, float
+ * (n,) (negative closes) or boolean bytes (n,) (false closes); processed (n,j) = close_command (j) or open_command (j),
+ * clamped to clip (n,j,2) when given. */
+int ilx_binary_joint_action(const float* raw_action, const uint8_t* raw_action_bool, const float* open_command,
+                            const float* close_command, const float* clip, float* processed, int64_t n, int j,
+                            void* stream);
+/* NonHolonomicAction.apply_actions (envs/mdp/actions/non_holonomic_actions.py:147-155): yaw of the body from its
+ * quaternion (strided rows, w,x,y,z; euler_xyz_from_quat), joint_vel_command (n,3) = (cos yaw * v, sin yaw * v, yaw rate)
+ * from processed (n,2) = (v, yaw rate). */
+int ilx_non_holonomic_action_apply(const float* body_quat_w, int64_t body_quat_stride, const float* processed,
+                                   float* joint_vel_command, int64_t n, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Contact sensor bookkeeping — source/isaaclab/isaaclab/sensors/contact_sensor/contact_sensor.py:314-373
  * plus the update timing of sensors/sensor_base.py:197-205,284-293.

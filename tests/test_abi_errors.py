@@ -159,3 +159,13 @@ def test_camera_arguments():
     fails(_abi.raycaster_camera_refresh(ctypes.byref(d), NULL), EINVAL, "NULL operand")
     d = _abi.RayCasterCameraDesc(mesh=NULL, num_envs=4, num_rays=8)
     fails(_abi.raycaster_camera_refresh(ctypes.byref(d), NULL), EINVAL, "mesh is NULL")
+
+
+def test_action_term_arguments():
+    fails(_abi.joint_action_to_limits(FAKE, NULL, 1.0, NULL, 1, NULL, NULL, 8, NULL, 1.0, NULL, FAKE, 4, 3, NULL), EINVAL,
+          "soft_joint_pos_limits is needed")
+    fails(_abi.joint_action_to_limits(FAKE, NULL, 1.0, NULL, 0, FAKE, NULL, 8, NULL, 1.5, FAKE, FAKE, 4, 3, NULL), EINVAL,
+          "Moving average weight")
+    fails(_abi.joint_action_to_limits(FAKE, NULL, 1.0, NULL, 0, FAKE, NULL, 2, NULL, 1.0, NULL, FAKE, 4, 3, NULL), EINVAL, "bad shape")
+    fails(_abi.binary_joint_action(FAKE, FAKE, FAKE, FAKE, NULL, FAKE, 4, 2, NULL), EINVAL, "exactly one")
+    fails(_abi.non_holonomic_action_apply(FAKE, 3, FAKE, FAKE, 4, NULL), EINVAL, "quaternion stride")

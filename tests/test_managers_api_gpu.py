@@ -192,3 +192,89 @@ def test_pose_command_term(dev):
         assert extras["Metrics/ee_pose/orientation_error"] == pytest.approx(want[1], rel=1e-5, abs=1e-6)
         assert_exact(term.time_left, g[f"{tag}_reset_time_left"], f"{tag} reset time_left")
         assert_close(term.command, g[f"{tag}_reset_pose_command_b"], atol=1e-6, what=f"{tag} reset command")
+
+
+# ---- limit-scaled, moving-average, binary and non-holonomic action terms (fixture: the reference classes)
+JOINTS2 = ["base_x", "base_y", "base_yaw", "arm_1", "arm_2", "arm_3", "finger_l", "finger_r"]
+BODIES2 = ["world", "base", "arm", "hand"]
+
+
+def _asset2(g, dev):
+    from isaaclab_amd.assets.articulation_data import ArticulationData
+    from isaaclab_amd.envs.manager_based_step import _Asset
+
+    n = g["joint_pos"].shape[0]
+    data = ArticulationData(n, len(JOINTS2), len(BODIES2), dev, joint_names=JOINTS2, body_names=BODIES2)
+    data.soft_joint_pos_limits[:] = g["soft_joint_pos_limits"].to(dev)
+    data.joint_pos = g["joint_pos"].to(dev).contiguous()
+    data.body_state_w[:, :, 3:7] = g["body_quat_w"].to(dev)
+    return _Asset(data), n
+
+
+def _drive(term, g, tag, dev, boolean_step=None, tol=1e-6):
+    for k in range(g[f"{tag}_raw"].shape[0]):
+        raw = g[f"{tag}_raw"][k].to(dev)
+        if boolean_step == k:
+            raw = raw > 0.5
+        term.process_actions(raw)
+        term.apply_actions()
+        assert_close(term.processed_actions, g[f"{tag}_processed"][k], rtol=tol, atol=tol, what=f"{tag} processed {k}")
+
+
+def test_position_to_limits_actions(dev):
+    from isaaclab_amd.envs.mdp.actions import (EMAJointPositionToLimitsActionCfg, JointPositionToLimitsActionCfg)
+
+    g = load_golden("actions2")
+    asset, n = _asset2(g, dev)
+    env = NS(num_envs=n, device=dev, scene={"robot": asset})
+    cfg = JointPositionToLimitsActionCfg(joint_names=["arm_.*"], scale=0.8, rescale_to_limits=True)
+    term = cfg.class_type(cfg, env)
+    _drive(term, g, "limits_arm", dev)
+    assert_close(asset.data.joint_pos_target[:, 3:6], g["limits_arm_processed"][-1], atol=1e-6, what="targets of the arm joints")
+    cfg = JointPositionToLimitsActionCfg(joint_names=[".*"], rescale_to_limits=False, scale={"arm_.*": 0.5, "finger_.*": 2.0},
+                                         clip={"arm_.*": (-0.4, 0.6)})
+    term = cfg.class_type(cfg, env)
+    assert term._joint_ids == slice(None)
+    _drive(term, g, "limits_raw", dev)
+    cfg = EMAJointPositionToLimitsActionCfg(joint_names=["arm_.*", "finger_.*"], scale=1.0, rescale_to_limits=True,
+                                            alpha={"arm_.*": 0.3, "finger_.*": 0.9})
+    ema = cfg.class_type(cfg, env)
+    ema.reset(None)
+    assert_close(ema._prev_applied_actions, g["ema_prev_after_reset"], atol=0, what="moving average starts from the joint positions")
+    _drive(ema, g, "ema", dev, tol=2e-6)
+    cfg = EMAJointPositionToLimitsActionCfg(joint_names=[".*"], scale=1.0, rescale_to_limits=True, alpha=0.5)
+    ema_all = cfg.class_type(cfg, env)
+    _drive(ema_all, g, "ema_all", dev, tol=2e-6)
+    ema_all.reset(g["ema_reset_ids"].to(dev))
+    assert_close(ema_all._prev_applied_actions, g["ema_prev_after_partial_reset"], atol=2e-6, what="partial reset of the average")
+    assert_exact(ema_all.raw_actions, g["ema_raw_after_partial_reset"], "raw actions after the partial reset")
+    cfg = EMAJointPositionToLimitsActionCfg(joint_names=["arm_.*"], scale=1.0, rescale_to_limits=False, alpha=0.25)
+    _drive(cfg.class_type(cfg, env), g, "ema_scalar", dev, tol=2e-6)
+    with pytest.raises(ValueError, match="Moving average weight must be in the range"):
+        bad = EMAJointPositionToLimitsActionCfg(joint_names=["arm_.*"], alpha=1.5)
+        bad.class_type(bad, env)
+
+
+def test_binary_and_non_holonomic_actions(dev):
+    from isaaclab_amd.envs.mdp.actions import BinaryJointPositionActionCfg, BinaryJointVelocityActionCfg, NonHolonomicActionCfg
+
+    g = load_golden("actions2")
+    asset, n = _asset2(g, dev)
+    env = NS(num_envs=n, device=dev, scene={"robot": asset})
+    cfg = BinaryJointPositionActionCfg(joint_names=["finger_.*"], open_command_expr={"finger_.*": 0.04},
+                                       close_command_expr={"finger_l": 0.0, "finger_r": 0.005}, clip={"finger_l": (0.01, 0.03)})
+    term = cfg.class_type(cfg, env)
+    assert term.action_dim == 1
+    _drive(term, g, "binary_pos", dev, boolean_step=1, tol=0)
+    assert_exact(asset.data.joint_pos_target[:, 6:8], g["binary_pos_processed"][-1], "finger position targets")
+    cfg = BinaryJointVelocityActionCfg(joint_names=["finger_.*"], open_command_expr={"finger_.*": 1.5}, close_command_expr={"finger_.*": -1.5})
+    _drive(cfg.class_type(cfg, env), g, "binary_vel", dev, tol=0)
+    assert_exact(asset.data.joint_vel_target[:, 6:8], g["binary_vel_processed"][-1], "finger velocity targets")
+    with pytest.raises(ValueError, match="Could not resolve all joints"):
+        bad = BinaryJointPositionActionCfg(joint_names=["finger_.*"], open_command_expr={"finger_l": 0.04}, close_command_expr={"finger_.*": 0.0})
+        bad.class_type(bad, env)
+    cfg = NonHolonomicActionCfg(body_name="base", x_joint_name="base_x", y_joint_name="base_y", yaw_joint_name="base_yaw",
+                                scale=(1.2, 0.7), offset=(0.1, -0.05), clip={"base_x": (-1.0, 1.0)})
+    term = cfg.class_type(cfg, env)
+    _drive(term, g, "non_holonomic", dev, tol=1e-6)
+    assert_close(asset.data.joint_vel_target[:, :3], g["non_holonomic_vel_target"][:, :3], atol=2e-6, what="dummy base joint velocities")

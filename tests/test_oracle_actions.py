@@ -47,3 +47,42 @@ def test_wrong_width_raises():
 
     with pytest.raises(ValueError, match="Invalid action shape, expected: 12, received: 11"):
         A.manager_process(torch.zeros(2, 12), torch.zeros(2, 12), torch.zeros(2, 11), [8, 4])
+
+
+def test_limit_scaled_and_moving_average_actions():
+    g = load_golden("actions2")
+    lim = g["soft_joint_pos_limits"]
+    arm = [3, 4, 5]
+    for k in range(3):
+        assert_exact(A.to_limits(g["limits_arm_raw"][k], 0.8, None, True, lim[:, arm, 0], lim[:, arm, 1]), g["limits_arm_processed"][k],
+                     f"limits_arm {k}")
+    n = lim.shape[0]
+    scale = torch.ones(n, 8)
+    scale[:, 3:6], scale[:, 6:8] = 0.5, 2.0
+    clip = torch.tensor([[-float("inf"), float("inf")]]).repeat(n, 8, 1)
+    clip[:, 3:6] = torch.tensor([-0.4, 0.6])
+    for k in range(3):
+        assert_exact(A.to_limits(g["limits_raw_raw"][k], scale, clip, False, None, None), g["limits_raw_processed"][k], f"limits_raw {k}")
+    ids = [3, 4, 5, 6, 7]
+    alpha = torch.cat([torch.full((n, 3), 0.3), torch.full((n, 2), 0.9)], 1)
+    prev = g["joint_pos"][:, ids].clone()
+    assert_exact(prev, g["ema_prev_after_reset"], "moving average starts from the joint positions")
+    for k in range(4):
+        p = A.to_limits(g["ema_raw"][k], 1.0, None, True, lim[:, ids, 0], lim[:, ids, 1])
+        prev = A.ema_to_limits(p, alpha, prev, lim[:, ids, 0], lim[:, ids, 1])
+        assert_exact(prev, g["ema_processed"][k], f"ema {k}")
+
+
+def test_binary_and_non_holonomic_actions():
+    g = load_golden("actions2")
+    n = g["joint_pos"].shape[0]
+    open_c, close_c = torch.tensor([0.04, 0.04]), torch.tensor([0.0, 0.005])
+    clip = torch.tensor([[0.01, 0.03]]).repeat(n, 1, 1)
+    for k in range(3):
+        raw = g["binary_pos_raw"][k]
+        raw = (raw > 0.5) if k == 1 else raw      # step 1 of the fixture used boolean actions
+        assert_exact(A.binary(raw, open_c, close_c, clip), g["binary_pos_processed"][k], f"binary {k}")
+    proc = g["non_holonomic_processed"][-1]
+    want = g["non_holonomic_vel_target"][:, :3]
+    got = A.non_holonomic(g["body_quat_w"][:, 1], proc)
+    assert (got - want).abs().max() < 1e-6
