@@ -215,6 +215,31 @@ int ilx_event_reset_joints(int by_scale, const int64_t* env_ids, int64_t count, 
 int ilx_event_push_by_setting_velocity(const int64_t* env_ids, int64_t count, const float* velocity_range_host,
                                        const float* u, uint64_t seed, uint64_t draw, float* root_state_w, void* stream);
 
+/* reset_root_state_with_random_orientation (:683-732): position = default + env origin + sample (x, y, z entries of
+ * pose_range_host, laid out as for ilx_event_reset_root_state_uniform), orientation uniform on SO(3) = a normalised
+ * 4-vector of standard normal draws (utils/math.py:1251-1267), velocity = default + sample.  u (count, 9) = 3 position
+ * then 6 velocity draws and normal_draws (count, 4) are injected together, or both NULL (Philox, Box-Muller). */
+int ilx_event_reset_root_state_random_orientation(const int64_t* env_ids, int64_t count, const float* default_root_state,
+                                                  const float* env_origins, const float* pose_range_host,
+                                                  const float* velocity_range_host, const float* u,
+                                                  const float* normal_draws, uint64_t seed, uint64_t draw,
+                                                  float* root_state_w, void* stream);
+/* apply_external_force_torque (:579-607) with Articulation.set_external_force_and_torque
+ * (assets/articulation/articulation.py:778-805): uniform forces / torques for the listed envs and bodies (body_ids device
+ * int32 (num_selected_bodies) or NULL = the first num_selected_bodies bodies) written into external_force_b /
+ * external_torque_b (n,num_bodies,3).  u (2, count, num_selected_bodies, 3): force draws, then torque draws. */
+int ilx_event_apply_external_force_torque(const int64_t* env_ids, int64_t count, const int32_t* body_ids,
+                                          int num_selected_bodies, int num_bodies, float force_lo, float force_hi,
+                                          float torque_lo, float torque_hi, const float* u, uint64_t seed, uint64_t draw,
+                                          float* external_force_b, float* external_torque_b, void* stream);
+/* reset_scene_to_default (:911-933) for one articulation, rows env_ids: root_state_w <- default_root_state with the env
+ * origin added to the position, joint_pos / joint_vel <- the default joint state (no sampling, no clamping).  Either part
+ * may be left out (root_state_w NULL, or joint_pos NULL). */
+int ilx_event_reset_scene_to_default(const int64_t* env_ids, int64_t count, const float* default_root_state,
+                                     const float* env_origins, float* root_state_w, const float* default_joint_pos,
+                                     const float* default_joint_vel, float* joint_pos, float* joint_vel, int j,
+                                     void* stream);
+
 /* Terrain curriculum of the velocity tasks: terrain_levels_vel
  * (source/isaaclab_tasks/isaaclab_tasks/manager_based/locomotion/velocity/mdp/curriculums.py:26-55) fused with
  * TerrainImporter.update_env_origins (source/isaaclab/isaaclab/terrains/terrain_importer.py:307-322), for the listed envs:

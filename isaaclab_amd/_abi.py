@@ -116,6 +116,11 @@ event_reset_root_state_uniform = _sig("ilx_event_reset_root_state_uniform", P, c
 event_reset_joints = _sig("ilx_event_reset_joints", c_int, P, c_int64, P, P, P, P, c_float, c_float, c_float, c_float, P, c_uint64,
                           c_uint64, P, P, c_int, P)
 event_push_by_setting_velocity = _sig("ilx_event_push_by_setting_velocity", P, c_int64, P, P, c_uint64, c_uint64, P, P)
+event_reset_root_state_random_orientation = _sig("ilx_event_reset_root_state_random_orientation", P, c_int64, P, P, P, P, P, P, c_uint64,
+                                                 c_uint64, P, P)
+event_apply_external_force_torque = _sig("ilx_event_apply_external_force_torque", P, c_int64, P, c_int, c_int, c_float, c_float, c_float,
+                                         c_float, P, c_uint64, c_uint64, P, P, P)
+event_reset_scene_to_default = _sig("ilx_event_reset_scene_to_default", P, c_int64, P, P, P, P, P, P, P, c_int, P)
 curriculum_terrain_levels = _sig("ilx_curriculum_terrain_levels", P, c_int64, P, P, c_int, c_float, c_float, P, P, P, P, P, c_int, c_int,
                                  P, c_uint64, c_uint64, P, P)
 

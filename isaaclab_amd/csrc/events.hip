@@ -79,6 +79,86 @@ push_velocity_kernel(const int64_t* __restrict__ ids, int64_t count, Range6 vel,
     root[13 * env + 7 + c] += ranged(draw01(rng, k, env, c), vel.lo[c], vel.hi[c]);
 }
 
+// events.py:683-732: position = default + origin + sample, orientation uniform on SO(3) as a normalised 4-vector of
+// standard normal draws (math.py:1251-1267), velocity = default + sample.  One thread per listed env.
+struct NormalRng {
+    const float* z;  // (count, 4) standard normal draws, or null: Box-Muller on Philox
+    uint64_t seed, draw;
+};
+__global__ void __launch_bounds__(256)
+reset_root_random_orientation_kernel(const int64_t* __restrict__ ids, int64_t count, const float* __restrict__ def,
+                                     const float* __restrict__ origins, Range6 pose, Range6 vel, EventRng rng, NormalRng nrm,
+                                     float* __restrict__ root) {
+    const int64_t k = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (k >= count) return;
+    const int64_t env = ids[k];
+    const float* d = def + 13 * env;
+    float* out = root + 13 * env;
+    const f3 o = origins ? load3(origins + 3 * env) : f3{0.0f, 0.0f, 0.0f};
+    const float og[3] = {o.x, o.y, o.z};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) out[c] = d[c] + og[c] + ranged(draw01(rng, k, env, c), pose.lo[c], pose.hi[c]);
+    float g[4];
+    if (nrm.z) {
+        for (int c = 0; c < 4; ++c) g[c] = nrm.z[4 * k + c];
+    } else {  // two Box-Muller pairs from one Philox call
+        const u4 r = philox4(nrm.seed, nrm.draw, static_cast<uint64_t>(env), 0x40000000u);
+        const float u1 = 1.0f - u01(r.x), u2 = u01(r.y), u3 = 1.0f - u01(r.z), u4v = u01(r.w);  // (0, 1] for the logarithm
+        const float ra = sqrt_(-2.0f * logf(u1)), rb = sqrt_(-2.0f * logf(u3));
+        g[0] = ra * cosf(6.2831853f * u2), g[1] = ra * sinf(6.2831853f * u2);
+        g[2] = rb * cosf(6.2831853f * u4v), g[3] = rb * sinf(6.2831853f * u4v);
+    }
+    const float nq = fmaxf(norm4(f4{g[0], g[1], g[2], g[3]}), 1.0e-12f);  // torch.nn.functional.normalize(eps=1e-12)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) out[3 + c] = div_(g[c], nq);
+#pragma unroll
+    for (int c = 0; c < 6; ++c) out[7 + c] = d[7 + c] + ranged(draw01(rng, k, env, 3 + c), vel.lo[c], vel.hi[c]);
+}
+
+// events.py:579-607 with Articulation.set_external_force_and_torque (articulation.py:778-805): uniform forces and torques
+// into the wrench buffers of the listed (env, body) pairs.  One thread per (listed env, listed body, component).
+__global__ void __launch_bounds__(256)
+external_wrench_kernel(const int64_t* __restrict__ ids, int64_t count, const int32_t* __restrict__ body_ids, int nb, int num_bodies,
+                       float f_lo, float f_hi, float t_lo, float t_hi, const float* __restrict__ u, uint64_t seed, uint64_t draw,
+                       float* __restrict__ force, float* __restrict__ torque) {
+    const int64_t t = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    const int64_t per = static_cast<int64_t>(nb) * 3;
+    if (t >= count * per) return;
+    const int64_t k = t / per;
+    const int r = static_cast<int>(t - k * per), b = r / 3, c = r - 3 * b;
+    const int64_t env = ids[k];
+    const int body = body_ids ? body_ids[b] : b;
+    const float uf = u ? u[t] : philox_uniform(seed, draw, static_cast<uint64_t>(env), static_cast<uint32_t>(r));
+    const float ut = u ? u[count * per + t] : philox_uniform(seed, draw, static_cast<uint64_t>(env), static_cast<uint32_t>(per + r));
+    const int64_t at = (env * num_bodies + body) * 3 + c;
+    force[at] = ranged(uf, f_lo, f_hi);
+    torque[at] = ranged(ut, t_lo, t_hi);
+}
+
+// events.py:911-933 for one articulation: the default root state moved to the env origin and the default joint state,
+// copied as they are (no sampling, no clamping).  One thread per (listed env, column) over 13 root + j joint columns.
+__global__ void __launch_bounds__(256)
+scene_to_default_kernel(const int64_t* __restrict__ ids, int64_t count, int j, const float* __restrict__ def_root,
+                        const float* __restrict__ origins, float* __restrict__ root, const float* __restrict__ def_pos,
+                        const float* __restrict__ def_vel, float* __restrict__ joint_pos, float* __restrict__ joint_vel) {
+    const int64_t t = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    const int width = 13 + j;
+    if (t >= count * width) return;
+    const int64_t k = t / width;
+    const int c = static_cast<int>(t - k * width);
+    const int64_t env = ids[k];
+    if (c < 13) {
+        if (!root) return;
+        float v = def_root[13 * env + c];
+        if (c < 3 && origins) v += origins[3 * env + c];
+        root[13 * env + c] = v;
+    } else if (joint_pos) {
+        const int64_t at = env * j + (c - 13);
+        joint_pos[at] = def_pos[at];
+        joint_vel[at] = def_vel[at];
+    }
+}
+
 // Terrain curriculum: the term of isaaclab_tasks/manager_based/locomotion/velocity/mdp/curriculums.py:26-55 fused with
 // TerrainImporter.update_env_origins (isaaclab/terrains/terrain_importer.py:307-322), one thread per listed env.
 struct CurriculumArgs {
@@ -199,5 +279,57 @@ extern "C" int ilx_curriculum_terrain_levels(const int64_t* env_ids, int64_t cou
                      terrain_levels, terrain_types, terrain_origins, num_rows, num_cols, random_levels, seed, draw, env_origins};
     hipLaunchKernelGGL(terrain_levels_kernel, dim3(blocks_for(count)), dim3(256), 0, as_stream(stream), a);
     ILX_LAUNCH_CHECK("ilx_curriculum_terrain_levels");
+    return ILX_OK;
+}
+
+extern "C" int ilx_event_reset_root_state_random_orientation(const int64_t* env_ids, int64_t count, const float* default_root_state,
+                                                             const float* env_origins, const float* pose_range_host,
+                                                             const float* velocity_range_host, const float* u,
+                                                             const float* normal_draws, uint64_t seed, uint64_t draw,
+                                                             float* root_state_w, void* stream) {
+    ILX_REQUIRE(count >= 0, ILX_EINVAL, "ilx_event_reset_root_state_random_orientation: negative env count");
+    if (count == 0) return ILX_OK;
+    ILX_REQUIRE(env_ids && default_root_state && pose_range_host && velocity_range_host && root_state_w, ILX_EINVAL,
+                "ilx_event_reset_root_state_random_orientation: NULL operand");
+    ILX_REQUIRE((u != nullptr) == (normal_draws != nullptr), ILX_EINVAL,
+                "ilx_event_reset_root_state_random_orientation: uniform and normal draws are injected together");
+    hipLaunchKernelGGL(reset_root_random_orientation_kernel, dim3(blocks_for(count)), dim3(256), 0, as_stream(stream), env_ids, count,
+                       default_root_state, env_origins, range6(pose_range_host), range6(velocity_range_host),
+                       EventRng{u, 9, seed, draw}, NormalRng{normal_draws, seed, draw}, root_state_w);
+    ILX_LAUNCH_CHECK("ilx_event_reset_root_state_random_orientation");
+    return ILX_OK;
+}
+
+extern "C" int ilx_event_apply_external_force_torque(const int64_t* env_ids, int64_t count, const int32_t* body_ids,
+                                                     int num_selected_bodies, int num_bodies, float force_lo, float force_hi,
+                                                     float torque_lo, float torque_hi, const float* u, uint64_t seed,
+                                                     uint64_t draw, float* external_force_b, float* external_torque_b,
+                                                     void* stream) {
+    ILX_REQUIRE(count >= 0 && num_selected_bodies > 0 && num_selected_bodies <= num_bodies, ILX_EINVAL,
+                "ilx_event_apply_external_force_torque: bad shape (%lld envs, %d of %d bodies)", (long long)count,
+                num_selected_bodies, num_bodies);
+    if (count == 0) return ILX_OK;
+    ILX_REQUIRE(env_ids && external_force_b && external_torque_b, ILX_EINVAL, "ilx_event_apply_external_force_torque: NULL operand");
+    hipLaunchKernelGGL(external_wrench_kernel, dim3(blocks_for(count * num_selected_bodies * 3)), dim3(256), 0, as_stream(stream),
+                       env_ids, count, body_ids, num_selected_bodies, num_bodies, force_lo, force_hi, torque_lo, torque_hi, u, seed, draw,
+                       external_force_b, external_torque_b);
+    ILX_LAUNCH_CHECK("ilx_event_apply_external_force_torque");
+    return ILX_OK;
+}
+
+extern "C" int ilx_event_reset_scene_to_default(const int64_t* env_ids, int64_t count, const float* default_root_state,
+                                               const float* env_origins, float* root_state_w, const float* default_joint_pos,
+                                               const float* default_joint_vel, float* joint_pos, float* joint_vel, int j,
+                                               void* stream) {
+    ILX_REQUIRE(count >= 0 && j >= 0, ILX_EINVAL, "ilx_event_reset_scene_to_default: bad shape (%lld, %d)", (long long)count, j);
+    if (count == 0) return ILX_OK;
+    ILX_REQUIRE(env_ids && (root_state_w || joint_pos), ILX_EINVAL, "ilx_event_reset_scene_to_default: NULL operand");
+    ILX_REQUIRE(!root_state_w || default_root_state, ILX_EINVAL, "ilx_event_reset_scene_to_default: default_root_state is NULL");
+    ILX_REQUIRE(!joint_pos || (j > 0 && default_joint_pos && default_joint_vel && joint_vel), ILX_EINVAL,
+                "ilx_event_reset_scene_to_default: the joint state comes with its defaults");
+    if (!joint_pos) j = 0;
+    hipLaunchKernelGGL(scene_to_default_kernel, dim3(blocks_for(count * (13 + j))), dim3(256), 0, as_stream(stream), env_ids, count, j,
+                       default_root_state, env_origins, root_state_w, default_joint_pos, default_joint_vel, joint_pos, joint_vel);
+    ILX_LAUNCH_CHECK("ilx_event_reset_scene_to_default");
     return ILX_OK;
 }

@@ -89,3 +89,66 @@ def push_by_setting_velocity(env, env_ids, velocity_range: dict, asset_cfg: Scen
                                                    _abi.ptr(d.root_state_w), _abi.stream()), "ilx_event_push_by_setting_velocity")
     if hasattr(asset, "write_root_velocity_to_sim"):
         asset.write_root_velocity_to_sim(d.root_state_w[ids, 7:], env_ids=ids)
+
+
+def reset_root_state_with_random_orientation(env, env_ids, pose_range: dict, velocity_range: dict,
+                                             asset_cfg: SceneEntityCfg = SceneEntityCfg("robot"), *, _u=None, _z=None):
+    """events.py:683-732.  ``_u`` (count, 9) unit-interval draws (3 position, 6 velocity) and ``_z`` (count, 4) standard
+    normal draws replay the reference's; they are given together."""
+    asset = env.scene[asset_cfg.name]
+    d = asset.data
+    ids = _ids(env_ids, d.root_state_w.shape[0], d.root_state_w.device)
+    origins = getattr(env.scene, "env_origins", None)
+    up, seed, draw = _rng(env, _u)
+    _abi.check(_abi.event_reset_root_state_random_orientation(
+        ids.data_ptr(), ids.numel(), _abi.ptr(d.default_root_state), None if origins is None else _abi.ptr(_abi.f32c(origins)),
+        _range12(pose_range), _range12(velocity_range), up, None if _z is None else _abi.ptr(_abi.f32c(_z)), seed, draw,
+        _abi.ptr(d.root_state_w), _abi.stream()), "ilx_event_reset_root_state_random_orientation")
+    if hasattr(asset, "write_root_pose_to_sim"):
+        asset.write_root_pose_to_sim(d.root_state_w[ids, :7], env_ids=ids)
+        asset.write_root_velocity_to_sim(d.root_state_w[ids, 7:], env_ids=ids)
+
+
+def apply_external_force_torque(env, env_ids, force_range: tuple[float, float], torque_range: tuple[float, float],
+                                asset_cfg: SceneEntityCfg = SceneEntityCfg("robot"), *, _u=None):
+    """events.py:579-607: uniform forces / torques into the asset's external wrench buffers
+    (``data``-side ``_external_force_b`` / ``_external_torque_b`` of shape (N, bodies, 3), created on first use);
+    ``asset.has_external_wrench`` is raised as ``set_external_force_and_torque`` does.  ``_u`` (2, count, bodies, 3)."""
+    asset = env.scene[asset_cfg.name]
+    d = getattr(asset, "data", asset)
+    num_bodies = asset.num_bodies if hasattr(asset, "num_bodies") else d.body_state_w.shape[1]
+    n, dev = d.root_state_w.shape[0], d.root_state_w.device
+    ids = _ids(env_ids, n, dev)
+    for name in ("_external_force_b", "_external_torque_b"):
+        if getattr(asset, name, None) is None:
+            setattr(asset, name, torch.zeros(n, num_bodies, 3, device=dev))
+    body_ids = asset_cfg.body_ids
+    if isinstance(body_ids, list):
+        bid = torch.tensor(body_ids, dtype=torch.int32, device=dev)
+        nb, bptr = len(body_ids), bid.data_ptr()
+    else:
+        nb, bptr = num_bodies, None
+    up, seed, draw = _rng(env, _u)
+    _abi.check(_abi.event_apply_external_force_torque(ids.data_ptr(), ids.numel(), bptr, nb, num_bodies, float(force_range[0]),
+                                                      float(force_range[1]), float(torque_range[0]), float(torque_range[1]), up, seed,
+                                                      draw, _abi.ptr(asset._external_force_b), _abi.ptr(asset._external_torque_b),
+                                                      _abi.stream()), "ilx_event_apply_external_force_torque")
+    # articulation.py:778-781 tests the sampled values; a non-degenerate range always yields some non-zero entry
+    asset.has_external_wrench = any(float(v) != 0.0 for v in (*force_range, *torque_range))
+
+
+def reset_scene_to_default(env, env_ids):
+    """events.py:911-933 for the scene's articulations (rigid and deformable objects are not modelled here)."""
+    origins = getattr(env.scene, "env_origins", None)
+    for asset in env.scene.articulations.values():
+        d = getattr(asset, "data", asset)
+        ids = _ids(env_ids, d.root_state_w.shape[0], d.root_state_w.device)
+        _abi.check(_abi.event_reset_scene_to_default(ids.data_ptr(), ids.numel(), _abi.ptr(d.default_root_state),
+                                                     None if origins is None else _abi.ptr(_abi.f32c(origins)), _abi.ptr(d.root_state_w),
+                                                     _abi.ptr(d.default_joint_pos), _abi.ptr(d.default_joint_vel), _abi.ptr(d.joint_pos),
+                                                     _abi.ptr(d.joint_vel), d.joint_pos.shape[1], _abi.stream()),
+                   "ilx_event_reset_scene_to_default")
+        if hasattr(asset, "write_root_pose_to_sim"):
+            asset.write_root_pose_to_sim(d.root_state_w[ids, :7], env_ids=ids)
+            asset.write_root_velocity_to_sim(d.root_state_w[ids, 7:], env_ids=ids)
+            asset.write_joint_state_to_sim(d.joint_pos[ids], d.joint_vel[ids], env_ids=ids)

@@ -48,3 +48,25 @@ def push_by_setting_velocity(root_vel_w, velocity_range: dict, u):
     """events.py:610-635 for the selected rows."""
     vr = ranges(velocity_range)
     return root_vel_w + sample(u, vr[:, 0], vr[:, 1])
+
+
+def reset_root_state_with_random_orientation(default_root_state, env_origins, pose_range: dict, velocity_range: dict, u_pos, z, u_vel):
+    """events.py:683-732 for the selected rows; ``z`` (k,4) are the standard normal draws of ``random_orientation``
+    (math.py:1251-1267: ``normalize(randn(num, 4), eps=1e-12)``)."""
+    pr, vr = ranges(pose_range)[:3], ranges(velocity_range)
+    positions = default_root_state[:, 0:3] + env_origins + sample(u_pos, pr[:, 0], pr[:, 1])
+    orientations = torch.nn.functional.normalize(z, p=2.0, dim=-1, eps=1e-12)
+    velocities = default_root_state[:, 7:13] + sample(u_vel, vr[:, 0], vr[:, 1])
+    return torch.cat([positions, orientations], dim=-1), velocities
+
+
+def apply_external_force_torque(force_range, torque_range, u_force, u_torque):
+    """events.py:601-604."""
+    return sample(u_force, *force_range), sample(u_torque, *torque_range)
+
+
+def reset_scene_to_default(default_root_state, env_origins, default_joint_pos, default_joint_vel):
+    """events.py:922-933 for the selected rows of one articulation."""
+    root = default_root_state.clone()
+    root[:, 0:3] += env_origins
+    return root, default_joint_pos.clone(), default_joint_vel.clone()

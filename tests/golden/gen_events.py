@@ -62,6 +62,7 @@ def events():
         env_origins = origins
 
     env = types.SimpleNamespace(scene=Scene(robot=asset))
+    env.scene.num_envs = n
     cfg = types.SimpleNamespace(name="robot", joint_ids=slice(None), body_ids=slice(None))
     ids = torch.tensor([3, 0, 17, 63, 40, 41, 9], dtype=torch.long)
     out = dict(default_root_state=data.default_root_state, default_joint_pos=data.default_joint_pos,
@@ -86,4 +87,35 @@ def events():
     ev.push_by_setting_velocity(env, ids, {"x": (-0.5, 0.5), "y": (-0.5, 0.5), "yaw": (-1.0, 0.25)}, cfg)
     out["push_u"] = redraw(13, [(len(ids), 6)])[0]
     out["push_vel"] = asset.calls[0][1]
+    asset.calls.clear()
+    # reset_root_state_with_random_orientation (:683-732): rand (k,3), randn (k,4), rand (k,6) in that order
+    torch.manual_seed(14)
+    ev.reset_root_state_with_random_orientation(env, ids, {"x": (-1.0, 1.0), "z": (0.0, 0.3)}, vel_range, cfg)
+    torch.manual_seed(14)
+    out["rand_orient_u_pos"] = torch.rand(len(ids), 3)
+    out["rand_orient_z"] = torch.randn(len(ids), 4)
+    out["rand_orient_u_vel"] = torch.rand(len(ids), 6)
+    out["rand_orient_pose"], out["rand_orient_vel"] = asset.calls[0][1], asset.calls[1][1]
+    asset.calls.clear()
+    # apply_external_force_torque (:579-607) on a body subset, through a recording set_external_force_and_torque
+    nb = 5
+    asset.num_bodies = nb
+    wrench = {}
+    asset.set_external_force_and_torque = lambda f, t, env_ids=None, body_ids=None: wrench.update(f=f.clone(), t=t.clone(), env_ids=env_ids.clone(), body_ids=body_ids)
+    bcfg = types.SimpleNamespace(name="robot", joint_ids=slice(None), body_ids=[0, 3, 4])
+    torch.manual_seed(15)
+    ev.apply_external_force_torque(env, ids, (-8.0, 12.0), (-1.5, 0.5), bcfg)
+    torch.manual_seed(15)
+    out["wrench_u"] = torch.stack([torch.rand(len(ids), 3, 3), torch.rand(len(ids), 3, 3)])
+    out["wrench_force"], out["wrench_torque"] = wrench["f"], wrench["t"]
+    torch.manual_seed(16)
+    ev.apply_external_force_torque(env, None, (0.0, 2.0), (0.0, 0.0), cfg)   # env_ids None -> every env, all bodies
+    torch.manual_seed(16)
+    out["wrench_all_u"] = torch.stack([torch.rand(n, nb, 3), torch.rand(n, nb, 3)])
+    out["wrench_all_force"], out["wrench_all_torque"] = wrench["f"], wrench["t"]
+    # reset_scene_to_default (:911-933)
+    env.scene.rigid_objects, env.scene.articulations, env.scene.deformable_objects = {}, {"robot": asset}, {}
+    ev.reset_scene_to_default(env, ids)
+    out["default_pose"], out["default_vel"] = asset.calls[0][1], asset.calls[1][1]
+    out["default_joint_pos_rows"], out["default_joint_vel_rows"] = asset.calls[2][1], asset.calls[2][2]
     save("events", **out)

@@ -85,3 +85,55 @@ def test_events_device_rng(dev):
     jp = d.joint_pos.cpu()
     assert ((jp >= lim[..., 0]) & (jp <= lim[..., 1])).all()
     assert (d.joint_vel.cpu() == torch.clamp(g["default_joint_vel"], -g["soft_joint_vel_limits"], g["soft_joint_vel_limits"])).all()
+
+
+def test_random_orientation_wrench_and_default_events(dev):
+    from isaaclab_amd.envs import mdp
+    from isaaclab_amd.managers import SceneEntityCfg
+
+    g = load_golden("events")
+    ids = g["env_ids"]
+    idd = ids.to(dev)
+    n = g["default_joint_pos"].shape[0]
+    others = torch.tensor([i for i in range(n) if i not in ids.tolist()]).to(dev)
+    env, d = _env(g, dev)
+    before = d.root_state_w.clone()
+    mdp.reset_root_state_with_random_orientation(env, idd, {"x": (-1.0, 1.0), "z": (0.0, 0.3)}, VEL,
+                                                 _u=torch.cat([g["rand_orient_u_pos"], g["rand_orient_u_vel"]], -1).to(dev),
+                                                 _z=g["rand_orient_z"].to(dev))
+    rows = d.root_state_w[idd]
+    assert_exact(rows[:, :3], g["rand_orient_pose"][:, :3], "position")
+    assert_close(rows[:, 3:7], g["rand_orient_pose"][:, 3:], atol=1e-6, what="random orientation")
+    assert_exact(rows[:, 7:], g["rand_orient_vel"], "velocity")
+    assert_exact(d.root_state_w[others], before[others], "other envs untouched")
+    # generated draws: unit quaternions, different per env, reproducible for the same (seed, call)
+    mdp.reset_root_state_with_random_orientation(env, None, {}, {})
+    q = d.root_state_w[:, 3:7].cpu()
+    assert_close(q.norm(dim=-1), torch.ones(n), atol=1e-6, what="unit quaternions")
+    assert len(torch.unique(q[:, 0])) == n and float(q.mean(0).abs().max()) < 0.35
+    # external wrench on three of five bodies
+    asset = env.scene["robot"]
+    asset.num_bodies = 5
+    d.body_state_w = torch.zeros(n, 5, 13, device=dev)
+    cfg = SceneEntityCfg("robot")
+    cfg.body_ids = [0, 3, 4]
+    mdp.apply_external_force_torque(env, idd, (-8.0, 12.0), (-1.5, 0.5), cfg, _u=g["wrench_u"].to(dev))
+    assert asset.has_external_wrench
+    assert_exact(asset._external_force_b[idd][:, [0, 3, 4]], g["wrench_force"], "forces")
+    assert_exact(asset._external_torque_b[idd][:, [0, 3, 4]], g["wrench_torque"], "torques")
+    assert float(asset._external_force_b[:, [1, 2]].abs().max()) == 0 and float(asset._external_force_b[others].abs().max()) == 0
+    mdp.apply_external_force_torque(env, None, (0.0, 2.0), (0.0, 0.0), SceneEntityCfg("robot"), _u=g["wrench_all_u"].to(dev))
+    assert_exact(asset._external_force_b, g["wrench_all_force"], "forces on every body")
+    assert_exact(asset._external_torque_b, g["wrench_all_torque"], "zero torques")
+    mdp.apply_external_force_torque(env, None, (0.0, 0.0), (0.0, 0.0), SceneEntityCfg("robot"))
+    assert not asset.has_external_wrench and float(asset._external_force_b.abs().max()) == 0
+    # scene back to its defaults for the listed envs
+    env.scene.articulations = {"robot": asset}
+    d.joint_pos.fill_(9.0)
+    d.joint_vel.fill_(9.0)
+    mdp.reset_scene_to_default(env, idd)
+    assert_exact(d.root_state_w[idd][:, :7], g["default_pose"], "default pose")
+    assert_exact(d.root_state_w[idd][:, 7:], g["default_vel"], "default velocity")
+    assert_exact(d.joint_pos[idd], g["default_joint_pos_rows"], "default joint positions")
+    assert_exact(d.joint_vel[idd], g["default_joint_vel_rows"], "default joint velocities")
+    assert float((d.joint_pos[others] - 9.0).abs().max()) == 0

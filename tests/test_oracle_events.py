@@ -25,3 +25,21 @@ def test_reset_and_push_events():
     lim = g["soft_joint_pos_limits"][ids]
     assert ((pos == lim[..., 0]) | (pos == lim[..., 1])).any(), "some joint positions are clamped (offset case)"
     assert_exact(E.push_by_setting_velocity(g["root_vel_w"][ids], PUSH, g["push_u"]), g["push_vel"], "pushed velocity")
+
+
+def test_random_orientation_wrench_and_default_events():
+    g = load_golden("events")
+    ids = g["env_ids"]
+    pose, vel = E.reset_root_state_with_random_orientation(g["default_root_state"][ids], g["env_origins"][ids], {"x": (-1.0, 1.0), "z": (0.0, 0.3)},
+                                                           VEL, g["rand_orient_u_pos"], g["rand_orient_z"], g["rand_orient_u_vel"])
+    assert_exact(pose, g["rand_orient_pose"], "pose with random orientation")
+    assert_exact(vel, g["rand_orient_vel"], "velocity")
+    f, t = E.apply_external_force_torque((-8.0, 12.0), (-1.5, 0.5), g["wrench_u"][0], g["wrench_u"][1])
+    assert_exact(f, g["wrench_force"], "forces")
+    assert_exact(t, g["wrench_torque"], "torques")
+    root, q, qd = E.reset_scene_to_default(g["default_root_state"][ids], g["env_origins"][ids], g["default_joint_pos"][ids],
+                                           g["default_joint_vel"][ids])
+    assert_exact(root[:, :7], g["default_pose"], "default pose")
+    assert_exact(root[:, 7:], g["default_vel"], "default velocity")
+    assert_exact(q, g["default_joint_pos_rows"], "default joint positions")
+    assert_exact(qd, g["default_joint_vel_rows"], "default joint velocities")
