@@ -281,6 +281,47 @@ int ilx_binary_joint_action(const float* raw_action, const uint8_t* raw_action_b
 int ilx_non_holonomic_action_apply(const float* body_quat_w, int64_t body_quat_stride, const float* processed,
                                    float* joint_vel_command, int64_t n, void* stream);
 
+/* UniformPose2dCommand / TerrainBasedPose2dCommand (envs/mdp/commands/pose_2d_command.py) under CommandTerm
+ * (managers/command_manager.py:120-187).
+ *   compute(dt): metrics error_pos_2d = |pos_command_w.xy - root_pos.xy|, error_heading = |wrap(heading_command_w - heading_w)|
+ *                (:88-91); time_left -= dt; envs at <= 0 resample: time_left, command_counter += 1, a new target = env origin
+ *                + uniform (x, y) (:93-101), or one of the terrain's flat patches valid_targets[level, type, pick] (:177-185),
+ *                z += default root z; heading towards / away from the target (simple_heading, :103-119) or uniform; then
+ *                pos_command_b = quat_rotate_inverse(yaw_quat(root_quat), pos_command_w - root_pos),
+ *                heading_command_b = wrap(heading_command_w - heading_w) (:124-128).
+ *   reset(mask): for flagged envs the three metrics are added to log_sums[0..2] (+1 to log_sums[3]) and zeroed, the
+ *                counter is zeroed, and the command is resampled.
+ * Draws: samples / reset_samples (n,4) hold the VALUES to use (time_left, x offset, y offset, heading) and patch_ids /
+ * reset_patch_ids (n) the patch picks, or NULL: Philox keyed by (seed, draw, env). */
+typedef struct ilx_pose2d_command {
+    int64_t num_envs;
+    const float* root_state_w;         /* (n,13) */
+    const float* default_root_state;   /* (n,13) */
+    const float* env_origins;          /* (n,3), uniform variant */
+    const float* valid_targets;        /* (rows, cols, patches, 3) or NULL: terrain-based variant */
+    const int64_t* terrain_levels;     /* (n) */
+    const int64_t* terrain_types;      /* (n) */
+    int32_t num_terrain_cols, num_patches;
+    int32_t simple_heading;
+    float resampling_time_range[2], pos_x[2], pos_y[2], heading[2];
+    float* pos_command_w;              /* (n,3) */
+    float* heading_command_w;          /* (n) */
+    float* pos_command_b;              /* (n,3) */
+    float* heading_command_b;          /* (n) */
+    float* time_left;                  /* (n) */
+    int64_t* command_counter;          /* (n) */
+    float* error_pos;                  /* (n) metrics["error_pos"]: never updated by the reference, only logged and zeroed */
+    float* error_heading;              /* (n) */
+    float* error_pos_2d;               /* (n) */
+    const float* samples;              /* (n,4) or NULL */
+    const float* reset_samples;
+    const int64_t* patch_ids;          /* (n) or NULL */
+    const int64_t* reset_patch_ids;
+    uint64_t seed, draw;
+} ilx_pose2d_command;
+int ilx_pose2d_command_compute(const ilx_pose2d_command* cmd, float dt, void* stream);
+int ilx_pose2d_command_reset(const ilx_pose2d_command* cmd, const uint8_t* reset_mask, float* log_sums, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Contact sensor bookkeeping — source/isaaclab/isaaclab/sensors/contact_sensor/contact_sensor.py:314-373
  * plus the update timing of sensors/sensor_base.py:197-205,284-293.

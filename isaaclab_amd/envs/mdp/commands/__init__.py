@@ -3,3 +3,5 @@
 from .commands_cfg import UniformPoseCommandCfg, UniformVelocityCommandCfg  # noqa: F401
 from .pose_command import UniformPoseCommand  # noqa: F401
 from .velocity_command import UniformVelocityCommand  # noqa: F401
+from .pose_2d_command import (TerrainBasedPose2dCommand, TerrainBasedPose2dCommandCfg, UniformPose2dCommand,  # noqa: F401
+                              UniformPose2dCommandCfg)

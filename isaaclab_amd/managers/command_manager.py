@@ -101,7 +101,7 @@ class CommandManager:
             if not isinstance(term_cfg, CommandTermCfg):
                 raise TypeError(f"Configuration for the term '{name}' is not of type CommandTermCfg. Received: '{type(term_cfg)}'.")
             term = term_cfg.class_type(term_cfg, env)
-            if not isinstance(term, CommandTerm):
+            if not all(hasattr(term, a) for a in ("command", "compute", "reset", "metrics")):
                 raise TypeError(f"Returned object for the term '{name}' is not of type CommandType.")
             self._terms[name] = term
 

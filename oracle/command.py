@@ -175,3 +175,57 @@ def pose_compute(cfg: PoseCommandCfg, pose_command_b, time_left, command_counter
     new = torch.cat([samples[:, 1:4], quat], dim=-1)
     pose_command_b = torch.where(mask.unsqueeze(-1), new, pose_command_b)
     return pose_command_b, time_left, command_counter, mask
+
+
+# ---- 2-D pose command (envs/mdp/commands/pose_2d_command.py) ------------------------------------------------------
+def heading_w(root_quat):
+    """articulation_data.py:416-425."""
+    fwd = M.quat_apply(root_quat, torch.tensor([[1.0, 0.0, 0.0]]).repeat(root_quat.shape[0], 1))
+    return torch.atan2(fwd[:, 1], fwd[:, 0])
+
+
+def pose2d_compute(state: dict, root_state_w, dt: float, samples, picks=None, *, simple_heading: bool, env_origins=None,
+                   default_root_z=None, valid_targets=None, terrain_levels=None, terrain_types=None):
+    """One ``CommandTerm.compute`` (command_manager.py:151-166) of the 2-D pose command (pose_2d_command.py:88-128, 177-206).
+
+    ``state``: pos_command_w, heading_command_w, time_left, command_counter (updated in place); ``samples`` (n,4) holds the
+    drawn values (time left, x, y, heading) and ``picks`` (n) the patch indices of the terrain-based variant.
+    Returns (command (n,4), error_pos_2d, error_heading)."""
+    root_pos, root_quat = root_state_w[:, :3], root_state_w[:, 3:7]
+    hw = heading_w(root_quat)
+    err_pos = torch.norm(state["pos_command_w"][:, :2] - root_pos[:, :2], dim=1)
+    err_head = torch.abs(M.wrap_to_pi(state["heading_command_w"] - hw))
+    state["time_left"] -= dt
+    ids = (state["time_left"] <= 0.0).nonzero().flatten()
+    if len(ids) > 0:
+        pose2d_resample(state, ids, root_pos, hw, samples, picks, simple_heading=simple_heading, env_origins=env_origins,
+                        default_root_z=default_root_z, valid_targets=valid_targets, terrain_levels=terrain_levels,
+                        terrain_types=terrain_types)
+    target_vec = state["pos_command_w"] - root_pos
+    pos_b = M.quat_rotate_inverse(M.yaw_quat(root_quat), target_vec)
+    head_b = M.wrap_to_pi(state["heading_command_w"] - hw)
+    return torch.cat([pos_b, head_b.unsqueeze(1)], dim=1), err_pos, err_head
+
+
+def pose2d_resample(state, ids, root_pos, hw, samples, picks, *, simple_heading, env_origins, default_root_z, valid_targets,
+                    terrain_levels, terrain_types):
+    """command_manager.py:172-187 + pose_2d_command.py:93-122 / :177-206."""
+    state["time_left"][ids] = samples[ids, 0]
+    state["command_counter"][ids] += 1
+    if valid_targets is None:
+        pos = env_origins[ids].clone()
+        pos[:, 0] += samples[ids, 1]
+        pos[:, 1] += samples[ids, 2]
+    else:
+        pos = valid_targets[terrain_levels[ids], terrain_types[ids], picks[ids]].clone()
+    pos[:, 2] += default_root_z[ids]
+    state["pos_command_w"][ids] = pos
+    if simple_heading:
+        vec = pos - root_pos[ids]
+        direction = torch.atan2(vec[:, 1], vec[:, 0])
+        flipped = M.wrap_to_pi(direction + torch.pi)
+        to_dir = M.wrap_to_pi(direction - hw[ids]).abs()
+        to_flipped = M.wrap_to_pi(flipped - hw[ids]).abs()
+        state["heading_command_w"][ids] = torch.where(to_dir < to_flipped, direction, flipped)
+    else:
+        state["heading_command_w"][ids] = samples[ids, 3]

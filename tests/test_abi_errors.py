@@ -169,3 +169,18 @@ def test_action_term_arguments():
     fails(_abi.joint_action_to_limits(FAKE, NULL, 1.0, NULL, 0, FAKE, NULL, 2, NULL, 1.0, NULL, FAKE, 4, 3, NULL), EINVAL, "bad shape")
     fails(_abi.binary_joint_action(FAKE, FAKE, FAKE, FAKE, NULL, FAKE, 4, 2, NULL), EINVAL, "exactly one")
     fails(_abi.non_holonomic_action_apply(FAKE, 3, FAKE, FAKE, 4, NULL), EINVAL, "quaternion stride")
+
+
+def test_pose2d_command_arguments():
+    from isaaclab_amd.envs.mdp.commands.pose_2d_command import Pose2dDesc, _compute, _reset
+
+    d = Pose2dDesc(num_envs=4)
+    fails(_compute(ctypes.byref(d), 0.02, NULL), EINVAL, "NULL operand")
+    full = {name: FAKE for name in ("root_state_w", "default_root_state", "pos_command_w", "heading_command_w", "pos_command_b",
+                                    "heading_command_b", "time_left", "command_counter", "error_pos", "error_heading", "error_pos_2d")}
+    d = Pose2dDesc(num_envs=4, **full)
+    fails(_compute(ctypes.byref(d), 0.02, NULL), EINVAL, "env_origins is NULL")
+    d = Pose2dDesc(num_envs=4, valid_targets=FAKE, **full)
+    fails(_compute(ctypes.byref(d), 0.02, NULL), EINVAL, "terrain-based targets need")
+    d = Pose2dDesc(num_envs=4, env_origins=FAKE, **full)
+    fails(_reset(ctypes.byref(d), NULL, NULL, NULL), EINVAL, "reset_mask is NULL")

@@ -278,3 +278,60 @@ def test_binary_and_non_holonomic_actions(dev):
     term = cfg.class_type(cfg, env)
     _drive(term, g, "non_holonomic", dev, tol=1e-6)
     assert_close(asset.data.joint_vel_target[:, :3], g["non_holonomic_vel_target"][:, :3], atol=2e-6, what="dummy base joint velocities")
+
+
+@pytest.mark.parametrize("tag", ["uniform", "uniform_simple", "terrain", "terrain_simple"])
+def test_pose2d_command_terms(dev, tag):
+    from isaaclab_amd.envs.mdp.commands import TerrainBasedPose2dCommandCfg, UniformPose2dCommandCfg
+    from isaaclab_amd.managers import CommandManager
+
+    g = load_golden("pose2d_command")
+    n = g[f"{tag}_pre_time_left"].shape[0]
+    data = NS(root_state_w=torch.zeros(n, 13, device=dev), default_root_state=g[f"{tag}_default_root_state"].to(dev).contiguous())
+
+    class Scene(dict):
+        pass
+
+    scene = Scene(robot=NS(data=data))
+    scene.env_origins = g[f"{tag}_env_origins"].to(dev)
+    terrain = tag.startswith("terrain")
+    if terrain:
+        scene["terrain"] = NS(flat_patches={"target": g[f"{tag}_valid_targets"].to(dev)},
+                              terrain_levels=g[f"{tag}_terrain_levels"].to(dev), terrain_types=g[f"{tag}_terrain_types"].to(dev))
+    Cfg = TerrainBasedPose2dCommandCfg if terrain else UniformPose2dCommandCfg
+    cfg = Cfg(resampling_time_range=(0.03, 0.09), simple_heading="simple" in tag,
+              ranges=Cfg.Ranges(pos_x=(-3.0, 3.0), pos_y=(-2.0, 2.5), heading=(-3.0, 3.1)))
+    mgr = CommandManager(dict(pose_command=cfg), NS(num_envs=n, device=dev, step_dt=0.02, scene=scene))
+    term = mgr.get_term("pose_command")
+    for k in ("pos_command_w", "heading_command_w", "time_left", "command_counter"):
+        getattr(term, k).copy_(g[f"{tag}_pre_{k}"])
+    for k in range(g[f"{tag}_samples"].shape[0]):
+        data.root_state_w.copy_(g[f"{tag}_root_state_w"][k])
+        term._samples = g[f"{tag}_samples"][k].to(dev).contiguous()
+        term._patch_ids = g[f"{tag}_picks"][k].to(dev).contiguous()
+        mgr.compute(0.02)
+        assert_exact(term.time_left, g[f"{tag}_time_left"][k], f"{tag} time_left {k}")
+        assert_exact(term.command_counter, g[f"{tag}_command_counter"][k], f"{tag} counter {k}")
+        assert_exact(term.pos_command_w, g[f"{tag}_pos_command_w"][k], f"{tag} pos_command_w {k}")
+        assert_close(term.heading_command_w, g[f"{tag}_heading_command_w"][k], atol=2e-6, what=f"{tag} heading_command_w {k}")
+        # the base-frame target is a rotation of an O(10 m) vector: 1e-6 of that magnitude on every component
+        assert_close(mgr.get_command("pose_command"), g[f"{tag}_command"][k], atol=1e-5, what=f"{tag} command {k}")
+        assert_close(term.metrics["error_pos_2d"], g[f"{tag}_error_pos_2d"][k], atol=1e-6, what=f"{tag} error_pos_2d {k}")
+        assert_close(term.metrics["error_heading"], g[f"{tag}_error_heading"][k], atol=2e-6, what=f"{tag} error_heading {k}")
+    ids = g[f"{tag}_reset_ids"]
+    term._reset_samples = g[f"{tag}_reset_samples"].to(dev).contiguous()
+    term._reset_patch_ids = g[f"{tag}_reset_picks"].to(dev).contiguous()
+    extras = mgr.reset(ids.tolist())
+    want = g[f"{tag}_reset_extras"].tolist()
+    for i, name in enumerate(("error_pos", "error_heading", "error_pos_2d")):
+        assert extras[f"Metrics/pose_command/{name}"] == pytest.approx(want[i], rel=1e-5, abs=2e-6)
+    assert_exact(term.time_left, g[f"{tag}_reset_time_left"], f"{tag} reset time_left")
+    assert_exact(term.command_counter, g[f"{tag}_reset_command_counter"], f"{tag} reset counter")
+    assert_exact(term.pos_command_w, g[f"{tag}_reset_pos_command_w"], f"{tag} reset pos_command_w")
+    assert_close(term.heading_command_w, g[f"{tag}_reset_heading_command_w"], atol=2e-6, what=f"{tag} reset heading")
+    assert_close(term.metrics["error_pos_2d"], g[f"{tag}_reset_error_pos_2d"], atol=1e-6, what=f"{tag} reset metric")
+    # generated draws stay in range
+    term._samples = term._patch_ids = None
+    term.time_left.fill_(0.0)
+    mgr.compute(0.02)
+    assert float(term.time_left.min()) >= 0.03 and float(term.time_left.max()) <= 0.09
