@@ -96,6 +96,22 @@ int ilx_root_frame_derive(const float* root_state, float gx, float gy, float gz,
 int ilx_joint_acc(const float* joint_vel, float* previous_joint_vel, float* joint_acc, float time_elapsed,
                   int64_t count, void* stream);
 
+/* Samplers of isaaclab.utils.math (source/isaaclab/isaaclab/utils/math.py:1225-1390), out (rows, width):
+ *   UNIFORM      rand * (upper - lower) + lower            (:1313-1331)   a = lower, b = upper
+ *   LOG_UNIFORM  exp(uniform(log lower, log upper))        (:1334-1368)
+ *   TRIANGLE     triangular distribution on [lower, upper] (:1288-1310)
+ *   GAUSSIAN     mean + std * N(0, 1)                      (:1371-1390)   a = mean, b = std
+ *   RANDOM_ORIENTATION      normalised 4-vector of N(0, 1) (:1251-1267)   width 4, a / b unused
+ *   RANDOM_YAW_ORIENTATION  quat_from_euler_xyz(0, 0, 2 pi rand) (:1270-1285), width 4
+ * a / b are device tensors addressed as a[row * a_row_stride + col * a_col_stride] (0, 0 = one value; 0, 1 = per column;
+ * width, 1 = per element) or NULL (then the scalar).  u / z (rows, width; rows for the yaw case) replay given unit-interval
+ * / standard-normal draws, NULL = Philox keyed by (seed, draw, row, column). */
+enum { ILX_SAMPLE_UNIFORM = 0, ILX_SAMPLE_LOG_UNIFORM = 1, ILX_SAMPLE_TRIANGLE = 2, ILX_SAMPLE_GAUSSIAN = 3,
+       ILX_SAMPLE_RANDOM_ORIENTATION = 4, ILX_SAMPLE_RANDOM_YAW_ORIENTATION = 5 };
+int ilx_sample(int kind, const float* a, int64_t a_row_stride, int64_t a_col_stride, float a_scalar, const float* b,
+               int64_t b_row_stride, int64_t b_col_stride, float b_scalar, const float* u, const float* z, uint64_t seed,
+               uint64_t draw, float* out, int64_t rows, int width, void* stream);
+
 /* ActionManager.process_action (managers/action_manager.py:318-339) for one JointAction term
  * (envs/mdp/actions/joint_actions.py:130-139): prev_action <- action, action <- raw_action,
  * processed = raw * scale + offset, clamped to clip (n,a,2) when given.  scale / offset are (n,a) tensors or

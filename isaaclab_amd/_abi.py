@@ -78,6 +78,8 @@ def f32c(t: torch.Tensor) -> torch.Tensor:
 # ---- signatures --------------------------------------------------------------------------------
 P = c_void_p
 math_op = _sig("ilx_math_op", c_int, P, P, P, P, P, P, c_int64, P)
+sample = _sig("ilx_sample", c_int, P, c_int64, c_int64, c_float, P, c_int64, c_int64, c_float, P, P, ctypes.c_uint64, ctypes.c_uint64, P,
+              c_int64, c_int, P)
 math_range_op = _sig("ilx_math_range_op", c_int, P, P, P, c_int, P, c_int64, c_int, P)
 root_state_pack = _sig("ilx_root_state_pack", P, P, P, c_int64, P)
 root_frame_derive = _sig("ilx_root_frame_derive", P, c_float, c_float, c_float, P, P, P, P, c_int64, P)

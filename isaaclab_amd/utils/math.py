@@ -268,3 +268,92 @@ def transform_points(points, pos=None, quat=None):
     elif quat is None:
         pts = pts.clone()
     return pts if batched else pts.squeeze(0)
+
+
+# ---- samplers (math.py:1225-1390) ---------------------------------------------------------------------------------
+# The reference draws with torch.rand / torch.randn on the global generator; these draw on the device with Philox keyed
+# by (seed, call counter, row, column).  ``_u`` / ``_z`` hand in unit-interval / standard-normal draws instead.
+_sampling = {"seed": 0, "draw": 0}
+SAMPLE_UNIFORM, SAMPLE_LOG_UNIFORM, SAMPLE_TRIANGLE, SAMPLE_GAUSSIAN, SAMPLE_RANDOM_ORIENTATION, SAMPLE_RANDOM_YAW_ORIENTATION = range(6)
+
+
+def set_sampling_seed(seed: int):
+    """Seed of the device samplers (the call counter restarts)."""
+    _sampling["seed"], _sampling["draw"] = int(seed), 0
+
+
+def _operand(v, rows: int, width: int, device):
+    """(tensor pointer or None, row stride, column stride, scalar) of a sampler bound given as a float or a tensor that
+    broadcasts against (rows, width)."""
+    if not isinstance(v, torch.Tensor):
+        return None, 0, 0, float(v), None
+    t = _abi.f32c(v.to(device))
+    if t.numel() == 1:
+        return None, 0, 0, float(t), None
+    if t.dim() >= 1 and t.shape[-1] == width and t.numel() == width:
+        return _abi.ptr(t), 0, 1, 0.0, t
+    if t.numel() == rows * width:
+        return _abi.ptr(t), width, 1, 0.0, t
+    if t.numel() == rows:  # one value per row, e.g. bounds of shape (rows, 1)
+        return _abi.ptr(t), 1, 0, 0.0, t
+    raise ValueError(f"sampler bound of shape {tuple(v.shape)} does not broadcast against ({rows}, {width})")
+
+
+def _sample(kind: int, a, b, size, device, u=None, z=None) -> torch.Tensor:
+    if isinstance(size, int):
+        size = (size,)
+    size = tuple(size)
+    dev = torch.device(device)
+    if dev.type != "cuda":
+        raise _abi.IlxError("isaaclab_amd samplers draw on the GPU; there is no CPU fallback")
+    width = size[-1] if len(size) > 1 else 1
+    rows = 1
+    for s in (size[:-1] if len(size) > 1 else size):
+        rows *= s
+    out = torch.empty(size, device=dev)
+    ap, ar, ac, asc, _ka = _operand(a, rows, width, dev)
+    bp, br, bc, bsc, _kb = _operand(b, rows, width, dev)
+    _sampling["draw"] += 1
+    _abi.check(_abi.sample(kind, ap, ar, ac, asc, bp, br, bc, bsc, None if u is None else _abi.ptr(_abi.f32c(u.to(dev))),
+                           None if z is None else _abi.ptr(_abi.f32c(z.to(dev))), _sampling["seed"], _sampling["draw"], _abi.ptr(out),
+                           rows, width, _abi.stream()), "ilx_sample")
+    return out
+
+
+def sample_uniform(lower, upper, size, device, *, _u=None) -> torch.Tensor:
+    """math.py:1313-1331."""
+    return _sample(SAMPLE_UNIFORM, lower, upper, size, device, u=_u)
+
+
+def sample_log_uniform(lower, upper, size, device, *, _u=None) -> torch.Tensor:
+    """math.py:1334-1368."""
+    return _sample(SAMPLE_LOG_UNIFORM, lower, upper, size, device, u=_u)
+
+
+def sample_triangle(lower: float, upper: float, size, device, *, _u=None) -> torch.Tensor:
+    """math.py:1288-1310."""
+    return _sample(SAMPLE_TRIANGLE, lower, upper, size, device, u=_u)
+
+
+def sample_gaussian(mean, std, size, device, *, _z=None) -> torch.Tensor:
+    """math.py:1371-1390 (with tensor ``mean`` / ``std`` the reference ignores ``size`` and takes their shape)."""
+    if isinstance(mean, torch.Tensor) and mean.numel() > 1:
+        size = tuple(mean.shape)
+    return _sample(SAMPLE_GAUSSIAN, mean, std, size, device, z=_z)
+
+
+def default_orientation(num: int, device) -> torch.Tensor:
+    """math.py:1228-1248."""
+    quat = torch.zeros((num, 4), dtype=torch.float, device=device)
+    quat[..., 0] = 1.0
+    return quat
+
+
+def random_orientation(num: int, device, *, _z=None) -> torch.Tensor:
+    """math.py:1251-1267."""
+    return _sample(SAMPLE_RANDOM_ORIENTATION, 0.0, 0.0, (num, 4), device, z=_z)
+
+
+def random_yaw_orientation(num: int, device, *, _u=None) -> torch.Tensor:
+    """math.py:1270-1285."""
+    return _sample(SAMPLE_RANDOM_YAW_ORIENTATION, 0.0, 0.0, (num, 4), device, u=_u)

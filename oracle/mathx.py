@@ -381,3 +381,33 @@ def transform_points(points, pos=None, quat=None):
     if pos is not None:
         pts = pts + (pos[None, None, :] if pos.dim() == 1 else pos[:, None, :])
     return pts if batched else pts.squeeze(0)
+
+
+# ---- samplers (math.py:1225-1390), with the unit-interval / standard-normal draws as arguments ---------------------
+def sample_uniform(u, lower, upper):
+    return u * (upper - lower) + lower
+
+
+def sample_log_uniform(u, lower, upper):
+    lower, upper = torch.as_tensor(lower, dtype=torch.float32), torch.as_tensor(upper, dtype=torch.float32)
+    return torch.exp(sample_uniform(u, torch.log(lower), torch.log(upper)))
+
+
+def sample_triangle(u, lower, upper):
+    r = 2 * u - 1
+    r = torch.where(r < 0.0, -torch.sqrt(-r), torch.sqrt(r))
+    r = (r + 1.0) / 2.0
+    return (upper - lower) * r + lower
+
+
+def sample_gaussian(z, mean, std):
+    return z * std + mean
+
+
+def random_orientation(z):
+    return torch.nn.functional.normalize(z, p=2.0, dim=-1, eps=1e-12)
+
+
+def random_yaw_orientation(u):
+    zero = torch.zeros_like(u)
+    return quat_from_euler_xyz(zero, zero, 2 * torch.pi * u)

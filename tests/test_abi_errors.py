@@ -184,3 +184,9 @@ def test_pose2d_command_arguments():
     fails(_compute(ctypes.byref(d), 0.02, NULL), EINVAL, "terrain-based targets need")
     d = Pose2dDesc(num_envs=4, env_origins=FAKE, **full)
     fails(_reset(ctypes.byref(d), NULL, NULL, NULL), EINVAL, "reset_mask is NULL")
+
+
+def test_sampler_arguments():
+    fails(_abi.sample(9, NULL, 0, 0, 0.0, NULL, 0, 0, 1.0, NULL, NULL, 0, 1, FAKE, 4, 3, NULL), EINVAL, "unknown kind")
+    fails(_abi.sample(4, NULL, 0, 0, 0.0, NULL, 0, 0, 1.0, NULL, NULL, 0, 1, FAKE, 4, 3, NULL), ESHAPE, "4 wide")
+    fails(_abi.sample(0, NULL, 0, 0, 0.0, NULL, 0, 0, 1.0, NULL, NULL, 0, 1, NULL, 4, 3, NULL), EINVAL, "out is NULL")

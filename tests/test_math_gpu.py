@@ -117,3 +117,54 @@ def test_large_batch_and_leading_dims(hm, dev):
 def test_empty_input(hm, dev):
     out = hm.quat_mul(torch.zeros(0, 4, device=dev), torch.zeros(0, 4, device=dev))
     assert out.shape == (0, 4)
+
+
+def test_samplers_replay_reference_draws(dev):
+    """The device samplers fed with the draws the reference consumed (fixture from the reference functions)."""
+    from isaaclab_amd.utils import math as M
+
+    g = load_golden("sampling")
+    d = str(dev)
+    assert_exact(M.sample_uniform(-0.5, 2.0, (500, 3), d, _u=g["uniform_scalar_u"]), g["uniform_scalar"], "uniform, scalar bounds")
+    assert_exact(M.sample_uniform(g["uniform_cols_lo"], g["uniform_cols_hi"], (500, 6), d, _u=g["uniform_cols_u"]), g["uniform_cols"],
+                 "uniform, per-column bounds")
+    assert_exact(M.sample_uniform(0.1, 0.2, 500, d, _u=g["uniform_1d_u"]), g["uniform_1d"], "uniform, 1-D")
+    assert_close(M.sample_log_uniform(1e-3, 10.0, (500, 2), d, _u=g["log_uniform_u"]), g["log_uniform"], rtol=2e-6, atol=0, what="log-uniform")
+    # five roundings in a row (two of them after a square root): a last-place difference on a few elements
+    assert_close(M.sample_triangle(-2.0, 3.0, (500, 2), d, _u=g["triangle_u"]), g["triangle"], rtol=3e-7, atol=3e-7, what="triangle")
+    assert_close(M.sample_gaussian(0.5, 2.0, (500, 3), d, _z=g["gaussian_z"]), g["gaussian"], rtol=1e-6, atol=1e-6, what="gaussian")
+    assert_close(M.sample_gaussian(g["gaussian_t_mean"], g["gaussian_t_std"], (500, 3), d, _z=g["gaussian_t_z"]), g["gaussian_t"],
+                 rtol=1e-5, atol=1e-6, what="gaussian, tensor parameters")
+    assert_close(M.random_orientation(500, d, _z=g["random_orientation_z"]), g["random_orientation"], atol=1e-6, what="random orientation")
+    assert_close(M.random_yaw_orientation(500, d, _u=g["random_yaw_u"]), g["random_yaw"], atol=1e-6, what="random yaw orientation")
+    assert_exact(M.default_orientation(7, d), g["default_orientation"], "default orientation")
+
+
+def test_samplers_generate_the_right_distributions(dev):
+    """Generated (Philox) draws: ranges, moments, reproducibility per seed, fresh values per call."""
+    from isaaclab_amd.utils import math as M
+
+    d, n = str(dev), 200000
+    M.set_sampling_seed(5)
+    a = M.sample_uniform(-1.0, 3.0, (n, 2), d)
+    b = M.sample_uniform(-1.0, 3.0, (n, 2), d)
+    M.set_sampling_seed(5)
+    a2 = M.sample_uniform(-1.0, 3.0, (n, 2), d)
+    assert torch.equal(a, a2) and not torch.equal(a, b)
+    assert float(a.min()) >= -1.0 and float(a.max()) < 3.0 and abs(float(a.mean()) - 1.0) < 0.01
+    assert abs(float(a.std()) - 4.0 / 12 ** 0.5) < 0.01 and abs(float(torch.corrcoef(a.T)[0, 1])) < 0.01
+    lg = M.sample_log_uniform(1e-2, 1e2, n, d)
+    assert float(lg.min()) >= 1e-2 * (1 - 1e-6) and float(lg.max()) <= 1e2 * (1 + 1e-6) and abs(float(lg.log10().mean())) < 0.02
+    tri = M.sample_triangle(0.0, 2.0, n, d)
+    assert abs(float(tri.mean()) - 1.0) < 0.01 and float(tri.min()) >= 0.0 and float(tri.max()) <= 2.0
+    z = M.sample_gaussian(1.5, 0.5, (n, 3), d)
+    assert abs(float(z.mean()) - 1.5) < 0.01 and abs(float(z.std()) - 0.5) < 0.01
+    k = ((z - 1.5) / 0.5) ** 4
+    assert abs(float(k.mean()) - 3.0) < 0.1, "normal kurtosis"
+    q = M.random_orientation(n, d)
+    assert_close(q.norm(dim=-1), torch.ones(n), atol=1e-6, what="unit quaternions")
+    assert float(q.mean(0).abs().max()) < 0.01 and abs(float((q[:, 0] ** 2).mean()) - 0.25) < 0.01
+    y = M.random_yaw_orientation(n, d)
+    assert float(y[:, 1:3].abs().max()) == 0.0
+    yaw = 2 * torch.atan2(y[:, 3], y[:, 0])
+    assert abs(float(yaw.mean()) - torch.pi) < 0.02 and float(yaw.min()) >= 0.0
