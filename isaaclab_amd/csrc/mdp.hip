@@ -400,6 +400,26 @@ ILX_DEV void stage_rows(float* dst, const float* src, int64_t env0, int ne, int 
     for (int i = threadIdx.x; i < ne * width; i += kBlock) dst[i] = p[i];
 }
 
+// A block's chunk of an [env][width] array, taken in two steps: issue() puts every thread's loads in flight (two floats
+// per thread cover rows up to 32 wide; indices past the chunk read its last element instead of branching), commit()
+// writes them to LDS.  With all issues of the STAGE section ahead of all commits the global round trips overlap; one
+// copy loop per array instead costs a full memory latency per array.
+struct Staged {
+    float a, b;
+};
+ILX_DEV Staged issue_rows(const float* src, int64_t env0, int ne, int width) {
+    const float* p = src + env0 * width;
+    const int n = ne * width, t = threadIdx.x;
+    return {p[t < n ? t : n - 1], p[t + kBlock < n ? t + kBlock : n - 1]};
+}
+ILX_DEV void commit_rows(float* dst, Staged r, const float* src, int64_t env0, int ne, int width) {
+    const int n = ne * width, t = threadIdx.x;
+    if (t < n) dst[t] = r.a;
+    if (t + kBlock < n) dst[t + kBlock] = r.b;
+    const float* p = src + env0 * width;
+    for (int i = t + 2 * kBlock; i < n; i += kBlock) dst[i] = p[i];
+}
+
 __global__ void __launch_bounds__(kBlock) mdp_step_kernel(MdpDev m) {
     extern __shared__ float S[];
     const ilx_mdp& d = m.d;
@@ -432,28 +452,40 @@ __global__ void __launch_bounds__(kBlock) mdp_step_kernel(MdpDev m) {
             for (int i = tid; i < cwords; i += kBlock) cdst[i] = m.cols[i];
         for (int i = tid; i < NR + NT + 3; i += kBlock) S[L.logp + i] = 0.0f;
     }
-    stage_rows(S + L.root, d.root_state_w, env0, ne, 13);
-    if (m.need & kNeedJoint) {
-        stage_rows(S + L.q, d.joint_pos, env0, ne, J);
-        stage_rows(S + L.qd, d.joint_vel, env0, ne, J);
-        stage_rows(S + L.qdd, d.joint_acc, env0, ne, J);
-        stage_rows(S + L.tau_a, d.applied_torque, env0, ne, J);
-        stage_rows(S + L.tau_c, d.computed_torque, env0, ne, J);
-        stage_rows(S + L.q0, d.default_joint_pos, env0, ne, J);
-        stage_rows(S + L.qd0, d.default_joint_vel, env0, ne, J);
-        stage_rows(S + L.vlim, d.soft_joint_vel_limits, env0, ne, J);
-        stage_rows(S + L.lim, d.soft_joint_pos_limits, env0, ne, 2 * J);
+    const bool sj = m.need & kNeedJoint, sa = m.need & kNeedAction, spa = sa && d.prev_action, st = m.need & kNeedTimers,
+               sc = d.command != nullptr;
+    const Staged zero{0.0f, 0.0f};
+    const Staged r_root = issue_rows(d.root_state_w, env0, ne, 13);
+    const Staged r_q = sj ? issue_rows(d.joint_pos, env0, ne, J) : zero, r_qd = sj ? issue_rows(d.joint_vel, env0, ne, J) : zero,
+                 r_qdd = sj ? issue_rows(d.joint_acc, env0, ne, J) : zero, r_ta = sj ? issue_rows(d.applied_torque, env0, ne, J) : zero,
+                 r_tc = sj ? issue_rows(d.computed_torque, env0, ne, J) : zero, r_q0 = sj ? issue_rows(d.default_joint_pos, env0, ne, J) : zero,
+                 r_qd0 = sj ? issue_rows(d.default_joint_vel, env0, ne, J) : zero,
+                 r_vl = sj ? issue_rows(d.soft_joint_vel_limits, env0, ne, J) : zero,
+                 r_lim = sj ? issue_rows(d.soft_joint_pos_limits, env0, ne, 2 * J) : zero;
+    const Staged r_act = sa ? issue_rows(d.action, env0, ne, A) : zero, r_pact = spa ? issue_rows(d.prev_action, env0, ne, A) : zero;
+    const Staged r_air = st ? issue_rows(d.current_air_time, env0, ne, CB) : zero, r_lair = st ? issue_rows(d.last_air_time, env0, ne, CB) : zero,
+                 r_ct = st ? issue_rows(d.current_contact_time, env0, ne, CB) : zero;
+    const Staged r_cmd = sc ? issue_rows(d.command, env0, ne, CD) : zero;
+    commit_rows(S + L.root, r_root, d.root_state_w, env0, ne, 13);
+    if (sj) {
+        commit_rows(S + L.q, r_q, d.joint_pos, env0, ne, J);
+        commit_rows(S + L.qd, r_qd, d.joint_vel, env0, ne, J);
+        commit_rows(S + L.qdd, r_qdd, d.joint_acc, env0, ne, J);
+        commit_rows(S + L.tau_a, r_ta, d.applied_torque, env0, ne, J);
+        commit_rows(S + L.tau_c, r_tc, d.computed_torque, env0, ne, J);
+        commit_rows(S + L.q0, r_q0, d.default_joint_pos, env0, ne, J);
+        commit_rows(S + L.qd0, r_qd0, d.default_joint_vel, env0, ne, J);
+        commit_rows(S + L.vlim, r_vl, d.soft_joint_vel_limits, env0, ne, J);
+        commit_rows(S + L.lim, r_lim, d.soft_joint_pos_limits, env0, ne, 2 * J);
     }
-    if (m.need & kNeedAction) {
-        stage_rows(S + L.act, d.action, env0, ne, A);
-        if (d.prev_action) stage_rows(S + L.pact, d.prev_action, env0, ne, A);
+    if (sa) commit_rows(S + L.act, r_act, d.action, env0, ne, A);
+    if (spa) commit_rows(S + L.pact, r_pact, d.prev_action, env0, ne, A);
+    if (st) {
+        commit_rows(S + L.air, r_air, d.current_air_time, env0, ne, CB);
+        commit_rows(S + L.last_air, r_lair, d.last_air_time, env0, ne, CB);
+        commit_rows(S + L.contact_t, r_ct, d.current_contact_time, env0, ne, CB);
     }
-    if (m.need & kNeedTimers) {
-        stage_rows(S + L.air, d.current_air_time, env0, ne, CB);
-        stage_rows(S + L.last_air, d.last_air_time, env0, ne, CB);
-        stage_rows(S + L.contact_t, d.current_contact_time, env0, ne, CB);
-    }
-    if (d.command) stage_rows(S + L.cmd, d.command, env0, ne, CD);
+    if (sc) commit_rows(S + L.cmd, r_cmd, d.command, env0, ne, CD);
     if (ph_rew || ph_reset) {  // episode sums: [term][env] in memory and in LDS
         for (int i = tid; i < NR * kE; i += kBlock) {
             const int term = i / kE, e = i - term * kE;
@@ -691,6 +723,29 @@ __global__ void __launch_bounds__(kBlock) mdp_step_kernel(MdpDev m) {
                 if (!d.noise_u && m.any_noise) {
                     const u4 r = philox4(d.seed, d.step_index, static_cast<uint64_t>(oenv), static_cast<uint32_t>(cg));
                     u[0] = u01(r.x), u[1] = u01(r.y), u[2] = u01(r.z), u[3] = u01(r.w);
+                }
+                if (t.kind == ILX_OBS_HEIGHT_SCAN && packed == static_cast<uint32_t>(cur) * 0x01010101u && 4 * cg + 3 < O) {
+                    // Four columns of the height scan (most of a locomotion observation) with their hit heights read
+                    // back to back; through the per-column path below each load sits in its own branch of the term switch
+                    // and waits for the one before it.
+                    const float* z = d.ray_hits_w + 3 * (oenv * d.num_rays + (4 * cg - tstart[cur])) + 2;
+                    const float z0 = z[0], z1 = z[3], z2 = z[6], z3 = z[9];
+                    float un[4] = {u[0], u[1], u[2], u[3]};
+                    if ((t.flags & ILX_OBS_FLAG_NOISE) && d.noise_u) {
+                        const float* nu = d.noise_u + oenv * O + 4 * cg;
+                        un[0] = nu[0], un[1] = nu[1], un[2] = nu[2], un[3] = nu[3];
+                    }
+                    const float sensor_height = S[L.derived + kDerived * ee + 9];
+                    float v[4] = {sensor_height - z0 - t.aux, sensor_height - z1 - t.aux, sensor_height - z2 - t.aux,
+                                  sensor_height - z3 - t.aux};
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        if (t.flags & ILX_OBS_FLAG_NOISE) v[c] = v[c] + un[c] * t.p[1] + t.p[0];
+                        if (t.flags & ILX_OBS_FLAG_CLIP) v[c] = fminf(fmaxf(v[c], t.p[2]), t.p[3]);
+                        if (t.flags & ILX_OBS_FLAG_SCALE) v[c] = v[c] * t.weight;
+                        row[4 * cg + c] = v[c];
+                    }
+                    continue;
                 }
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
