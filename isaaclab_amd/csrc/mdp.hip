@@ -92,14 +92,23 @@ struct Env {
     ILX_DEV float joint_sum(const ilx_term& t, F f) const {
         const int n = jcount(t);
         float acc = 0.0f;
-        for (int k = 0; k < n; ++k) acc += f(id(t, k));
+        // four elements' reads in flight together; the additions keep their order (the sum is compared bit for bit)
+        int k = 0;
+        for (; k + 4 <= n; k += 4) {
+            const float f0 = f(id(t, k)), f1 = f(id(t, k + 1)), f2 = f(id(t, k + 2)), f3 = f(id(t, k + 3));
+            acc += f0;
+            acc += f1;
+            acc += f2;
+            acc += f3;
+        }
+        for (; k < n; ++k) acc += f(id(t, k));
         return acc;
     }
     template <typename F>
     ILX_DEV bool joint_any(const ilx_term& t, F f) const {
         const int n = jcount(t);
         bool hit = false;
-        for (int k = 0; k < n; ++k) hit = hit || f(id(t, k));
+        for (int k = 0; k < n; ++k) hit = hit | f(id(t, k));  // no short circuit: the reads do not wait for each other
         return hit;
     }
 };
@@ -131,7 +140,7 @@ ILX_DEV bool eval_termination(const Env& e, const ilx_term& t, int64_t ep_len) {
         case ILX_TERM_ILLEGAL_CONTACT: {  // :150-158
             const int n = e.bcount_sensor(t);
             bool hit = false;
-            for (int k = 0; k < n; ++k) hit = hit || (e.sbody(L.fpeak, e.id(t, k)) > t.p[0]);
+            for (int k = 0; k < n; ++k) hit = hit | (e.sbody(L.fpeak, e.id(t, k)) > t.p[0]);
             return hit;
         }
     }
@@ -439,19 +448,6 @@ __global__ void __launch_bounds__(kBlock) mdp_step_kernel(MdpDev m) {
     const int32_t* ids = reinterpret_cast<const int32_t*>(S + L.ids);
 
     // ================= STAGE =================
-    {
-        const int32_t* src = reinterpret_cast<const int32_t*>(m.terms);
-        int32_t* dst = reinterpret_cast<int32_t*>(S + L.terms);
-        const int words = (NT + NR + NO) * static_cast<int>(sizeof(ilx_term) / 4);
-        for (int i = tid; i < words; i += kBlock) dst[i] = src[i];
-        int32_t* idst = reinterpret_cast<int32_t*>(S + L.ids);
-        for (int i = tid; i < d.num_ids; i += kBlock) idst[i] = m.ids[i];
-        uint32_t* cdst = reinterpret_cast<uint32_t*>(S + L.colterm);  // colterm and tstart are adjacent
-        const int cwords = ((d.obs_dim + 3) >> 2) + NO;
-        if (ph_obs)
-            for (int i = tid; i < cwords; i += kBlock) cdst[i] = m.cols[i];
-        for (int i = tid; i < NR + NT + 3; i += kBlock) S[L.logp + i] = 0.0f;
-    }
     const bool sj = m.need & kNeedJoint, sa = m.need & kNeedAction, spa = sa && d.prev_action, st = m.need & kNeedTimers,
                sc = d.command != nullptr;
     const Staged zero{0.0f, 0.0f};
@@ -466,6 +462,20 @@ __global__ void __launch_bounds__(kBlock) mdp_step_kernel(MdpDev m) {
     const Staged r_air = st ? issue_rows(d.current_air_time, env0, ne, CB) : zero, r_lair = st ? issue_rows(d.last_air_time, env0, ne, CB) : zero,
                  r_ct = st ? issue_rows(d.current_contact_time, env0, ne, CB) : zero;
     const Staged r_cmd = sc ? issue_rows(d.command, env0, ne, CD) : zero;
+    // the term tables (cold in L2 at the start of a launch) are fetched while the row loads above are in flight
+    {
+        const int32_t* src = reinterpret_cast<const int32_t*>(m.terms);
+        int32_t* dst = reinterpret_cast<int32_t*>(S + L.terms);
+        const int words = (NT + NR + NO) * static_cast<int>(sizeof(ilx_term) / 4);
+        for (int i = tid; i < words; i += kBlock) dst[i] = src[i];
+        int32_t* idst = reinterpret_cast<int32_t*>(S + L.ids);
+        for (int i = tid; i < d.num_ids; i += kBlock) idst[i] = m.ids[i];
+        uint32_t* cdst = reinterpret_cast<uint32_t*>(S + L.colterm);  // colterm and tstart are adjacent
+        const int cwords = ((d.obs_dim + 3) >> 2) + NO;
+        if (ph_obs)
+            for (int i = tid; i < cwords; i += kBlock) cdst[i] = m.cols[i];
+        for (int i = tid; i < NR + NT + 3; i += kBlock) S[L.logp + i] = 0.0f;
+    }
     commit_rows(S + L.root, r_root, d.root_state_w, env0, ne, 13);
     if (sj) {
         commit_rows(S + L.q, r_q, d.joint_pos, env0, ne, J);
