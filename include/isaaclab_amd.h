@@ -338,6 +338,37 @@ typedef struct ilx_pose2d_command {
 int ilx_pose2d_command_compute(const ilx_pose2d_command* cmd, float dt, void* stream);
 int ilx_pose2d_command_reset(const ilx_pose2d_command* cmd, const uint8_t* reset_mask, float* log_sums, void* stream);
 
+/* NormalVelocityCommand (envs/mdp/commands/velocity_command.py:218-287) under CommandTerm (managers/command_manager.py:120-187).
+ *   compute(dt): metrics error_vel_xy += |cmd.xy - root_lin_vel_b.xy| / max_command_step, error_vel_yaw += |cmd.z -
+ *                root_ang_vel_b.z| / max_command_step (:111-121; max_command_step = resampling_time_range[1] / step_dt);
+ *                time_left -= dt; envs at <= 0 resample (:252-272): time_left, command_counter += 1, each component ~
+ *                N(mean, std) times a +-1 coin (u <= 0.5 keeps the sign), per-component zero flags (u <= zero_prob) and the
+ *                standing flag (u <= rel_standing_envs); then standing envs and flagged components are zeroed (:274-287).
+ *   reset(mask): for flagged envs the two metrics are added to log_sums[0..1] (+1 to log_sums[2]) and zeroed, the counter
+ *                is zeroed, and the command is resampled (no zeroing: that happens at the next compute).
+ * Draws: samples / reset_samples (n,11) hold, per env, time_left, the three normal VALUES (mean and std applied), the three
+ * sign coins, the three zero coins and the standing coin, in the order the reference draws them; NULL: Philox keyed by
+ * (seed, draw, env) with Box-Muller normals. */
+typedef struct ilx_normal_velocity_command {
+    int64_t num_envs;
+    const float* root_state_w;   /* (n,13) */
+    float mean_vel[3], std_vel[3], zero_prob[3];
+    float rel_standing_envs, max_command_step;
+    float resampling_time_range[2];
+    float* vel_command_b;        /* (n,3) */
+    uint8_t* is_zero_vel_env;    /* (n,3): x, y, yaw */
+    uint8_t* is_standing_env;    /* (n) */
+    float* time_left;            /* (n) */
+    int64_t* command_counter;    /* (n) */
+    float* error_vel_xy;         /* (n) */
+    float* error_vel_yaw;        /* (n) */
+    const float* samples;        /* (n,11) or NULL */
+    const float* reset_samples;
+    uint64_t seed, draw;
+} ilx_normal_velocity_command;
+int ilx_normal_velocity_command_compute(const ilx_normal_velocity_command* cmd, float dt, void* stream);
+int ilx_normal_velocity_command_reset(const ilx_normal_velocity_command* cmd, const uint8_t* reset_mask, float* log_sums, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Contact sensor bookkeeping — source/isaaclab/isaaclab/sensors/contact_sensor/contact_sensor.py:314-373
  * plus the update timing of sensors/sensor_base.py:197-205,284-293.

@@ -1,3 +1,4 @@
+// Command terms that run as their own launch.
 // 2-D pose command terms (reference: isaaclab/envs/mdp/commands/pose_2d_command.py on top of
 // isaaclab/managers/command_manager.py:151-187): a target position in the world and a heading, re-expressed every step in
 // the robot's base frame.  One thread per env does the whole CommandTerm.compute / reset for that env.
@@ -104,6 +105,98 @@ static int check_pose2d(const ilx_pose2d_command& c, const char* who) {
     return ILX_OK;
 }
 
+// NormalVelocityCommand (velocity_command.py:218-287 under command_manager.py:120-187): a base-frame velocity command drawn
+// from a normal distribution with random sign; per-component and whole-command zeroing by coin flips.
+struct NormalVelArgs {
+    ilx_normal_velocity_command c;
+    int reset;
+    float dt;
+    const uint8_t* reset_mask;
+    float* log_sums;  // reset: [sum error_vel_xy, sum error_vel_yaw, count]
+};
+
+// velocity_command.py:252-272; ``s`` is the env's row of 11 injected values or null
+ILX_DEV void normal_vel_resample(const ilx_normal_velocity_command& c, const float* s, int64_t env, uint32_t salt, float& time_left,
+                                 int64_t& counter, float* v, bool* zero, bool& standing) {
+    float g[3], coin[8];
+    if (s) {
+        time_left = s[0];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) g[k] = s[1 + k];
+#pragma unroll
+        for (int k = 0; k < 7; ++k) coin[k] = s[4 + k];
+    } else {
+        const u4 a = philox4(c.seed, c.draw, static_cast<uint64_t>(env), salt), b = philox4(c.seed, c.draw, static_cast<uint64_t>(env), salt + 1u),
+                 e = philox4(c.seed, c.draw, static_cast<uint64_t>(env), salt + 2u);
+        time_left = u01(a.x) * (c.resampling_time_range[1] - c.resampling_time_range[0]) + c.resampling_time_range[0];
+        const float u1 = 1.0f - u01(a.y), u2 = u01(a.z), u3 = 1.0f - u01(a.w), u4v = u01(b.x);  // (0, 1] for the logarithm
+        const float ra = sqrt_(-2.0f * logf(u1)), rb = sqrt_(-2.0f * logf(u3));
+        const float n0 = ra * cosf(6.2831853f * u2), n1 = ra * sinf(6.2831853f * u2), n2 = rb * cosf(6.2831853f * u4v);
+        g[0] = n0 * c.std_vel[0] + c.mean_vel[0], g[1] = n1 * c.std_vel[1] + c.mean_vel[1], g[2] = n2 * c.std_vel[2] + c.mean_vel[2];
+        coin[0] = u01(b.y), coin[1] = u01(b.z), coin[2] = u01(b.w), coin[3] = u01(e.x), coin[4] = u01(e.y), coin[5] = u01(e.z), coin[6] = u01(e.w);
+    }
+    counter += 1;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        v[k] = g[k] * (coin[k] <= 0.5f ? 1.0f : -1.0f);
+        zero[k] = coin[3 + k] <= c.zero_prob[k];
+    }
+    standing = coin[6] <= c.rel_standing_envs;
+}
+
+__global__ void __launch_bounds__(256) normal_velocity_command_kernel(NormalVelArgs a) {
+    const ilx_normal_velocity_command& c = a.c;
+    const int64_t env = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (env >= c.num_envs) return;
+    float v[3] = {c.vel_command_b[3 * env], c.vel_command_b[3 * env + 1], c.vel_command_b[3 * env + 2]};
+    bool zero[3] = {c.is_zero_vel_env[3 * env] != 0, c.is_zero_vel_env[3 * env + 1] != 0, c.is_zero_vel_env[3 * env + 2] != 0};
+    bool standing = c.is_standing_env[env] != 0;
+    float time_left = c.time_left[env];
+    int64_t counter = c.command_counter[env];
+    if (a.reset) {  // command_manager.py:120-149
+        if (!a.reset_mask[env]) return;
+        if (a.log_sums) {
+            atomicAdd(a.log_sums + 0, c.error_vel_xy[env]);
+            atomicAdd(a.log_sums + 1, c.error_vel_yaw[env]);
+            atomicAdd(a.log_sums + 2, 1.0f);
+        }
+        c.error_vel_xy[env] = c.error_vel_yaw[env] = 0.0f;
+        counter = 0;
+        normal_vel_resample(c, c.reset_samples ? c.reset_samples + 11 * env : nullptr, env, 16u, time_left, counter, v, zero, standing);
+    } else {  // command_manager.py:151-166
+        const float* rs = c.root_state_w + 13 * env;
+        const f4 q = {rs[3], rs[4], rs[5], rs[6]};
+        const f3 lin_b = quat_rotate_inverse(q, f3{rs[7], rs[8], rs[9]}), ang_b = quat_rotate_inverse(q, f3{rs[10], rs[11], rs[12]});
+        c.error_vel_xy[env] += div_(norm2(v[0] - lin_b.x, v[1] - lin_b.y), c.max_command_step);  // velocity_command.py:111-121
+        c.error_vel_yaw[env] += div_(fabsf(v[2] - ang_b.z), c.max_command_step);
+        time_left = time_left - a.dt;
+        if (time_left <= 0.0f)
+            normal_vel_resample(c, c.samples ? c.samples + 11 * env : nullptr, env, 0u, time_left, counter, v, zero, standing);
+        if (standing) v[0] = v[1] = v[2] = 0.0f;  // velocity_command.py:274-287
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            if (zero[k]) v[k] = 0.0f;
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        c.vel_command_b[3 * env + k] = v[k];
+        c.is_zero_vel_env[3 * env + k] = zero[k];
+    }
+    c.is_standing_env[env] = standing;
+    c.time_left[env] = time_left;
+    c.command_counter[env] = counter;
+}
+
+static int check_normal_vel(const ilx_normal_velocity_command& c, const char* who) {
+    ILX_REQUIRE(c.num_envs >= 0, ILX_EINVAL, "%s: negative env count", who);
+    if (c.num_envs == 0) return ILX_OK;
+    ILX_REQUIRE(c.root_state_w && c.vel_command_b && c.is_zero_vel_env && c.is_standing_env && c.time_left && c.command_counter &&
+                    c.error_vel_xy && c.error_vel_yaw,
+                ILX_EINVAL, "%s: NULL operand", who);
+    ILX_REQUIRE(c.max_command_step > 0.0f, ILX_EINVAL, "%s: max_command_step must be positive", who);
+    return ILX_OK;
+}
+
 }  // namespace ilx
 
 using namespace ilx;
@@ -126,5 +219,27 @@ extern "C" int ilx_pose2d_command_reset(const ilx_pose2d_command* cmd, const uin
     Pose2dArgs a{*cmd, 1, 0.0f, reset_mask, log_sums};
     hipLaunchKernelGGL(pose2d_command_kernel, dim3(blocks_for(cmd->num_envs)), dim3(256), 0, as_stream(stream), a);
     ILX_LAUNCH_CHECK("ilx_pose2d_command_reset");
+    return ILX_OK;
+}
+
+extern "C" int ilx_normal_velocity_command_compute(const ilx_normal_velocity_command* cmd, float dt, void* stream) {
+    ILX_REQUIRE(cmd, ILX_EINVAL, "ilx_normal_velocity_command_compute: descriptor is NULL");
+    if (const int s = check_normal_vel(*cmd, "ilx_normal_velocity_command_compute")) return s;
+    if (cmd->num_envs == 0) return ILX_OK;
+    NormalVelArgs a{*cmd, 0, dt, nullptr, nullptr};
+    hipLaunchKernelGGL(normal_velocity_command_kernel, dim3(blocks_for(cmd->num_envs)), dim3(256), 0, as_stream(stream), a);
+    ILX_LAUNCH_CHECK("ilx_normal_velocity_command_compute");
+    return ILX_OK;
+}
+
+extern "C" int ilx_normal_velocity_command_reset(const ilx_normal_velocity_command* cmd, const uint8_t* reset_mask, float* log_sums,
+                                                 void* stream) {
+    ILX_REQUIRE(cmd, ILX_EINVAL, "ilx_normal_velocity_command_reset: descriptor is NULL");
+    if (const int s = check_normal_vel(*cmd, "ilx_normal_velocity_command_reset")) return s;
+    if (cmd->num_envs == 0) return ILX_OK;
+    ILX_REQUIRE(reset_mask, ILX_EINVAL, "ilx_normal_velocity_command_reset: reset_mask is NULL");
+    NormalVelArgs a{*cmd, 1, 0.0f, reset_mask, log_sums};
+    hipLaunchKernelGGL(normal_velocity_command_kernel, dim3(blocks_for(cmd->num_envs)), dim3(256), 0, as_stream(stream), a);
+    ILX_LAUNCH_CHECK("ilx_normal_velocity_command_reset");
     return ILX_OK;
 }

@@ -2,6 +2,7 @@
 
 from __future__ import annotations
 
+import math
 from dataclasses import dataclass, field
 
 from ....managers.command_manager import CommandTermCfg
@@ -30,6 +31,38 @@ class UniformVelocityCommandCfg(CommandTermCfg):
             from .velocity_command import UniformVelocityCommand
 
             self.class_type = UniformVelocityCommand
+
+
+@dataclass
+class NormalVelocityCommandCfg(UniformVelocityCommandCfg):
+    """commands_cfg.py:99-129."""
+
+    @dataclass
+    class Ranges:
+        mean_vel: tuple[float, float, float] = (0.0, 0.0, 0.0)
+        std_vel: tuple[float, float, float] = (0.0, 0.0, 0.0)
+        zero_prob: tuple[float, float, float] = (0.0, 0.0, 0.0)
+
+    heading_command: bool = False
+    ranges: Ranges = field(default_factory=Ranges)
+
+    def __post_init__(self):
+        if self.class_type is None:
+            from .velocity_command import NormalVelocityCommand
+
+            self.class_type = NormalVelocityCommand
+
+
+@dataclass
+class NullCommandCfg(CommandTermCfg):
+    """commands_cfg.py:22-32: never resamples."""
+
+    def __post_init__(self):
+        self.resampling_time_range = (math.inf, math.inf)
+        if self.class_type is None:
+            from .null_command import NullCommand
+
+            self.class_type = NullCommand
 
 
 @dataclass

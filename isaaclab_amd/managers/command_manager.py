@@ -101,7 +101,8 @@ class CommandManager:
             if not isinstance(term_cfg, CommandTermCfg):
                 raise TypeError(f"Configuration for the term '{name}' is not of type CommandTermCfg. Received: '{type(term_cfg)}'.")
             term = term_cfg.class_type(term_cfg, env)
-            if not all(hasattr(term, a) for a in ("command", "compute", "reset", "metrics")):
+            # looked up on the class first: reading NullCommand.command raises by design
+            if not all(hasattr(type(term), a) or a in vars(term) for a in ("command", "compute", "reset", "metrics")):
                 raise TypeError(f"Returned object for the term '{name}' is not of type CommandType.")
             self._terms[name] = term
 

@@ -229,3 +229,36 @@ def pose2d_resample(state, ids, root_pos, hw, samples, picks, *, simple_heading,
         state["heading_command_w"][ids] = torch.where(to_dir < to_flipped, direction, flipped)
     else:
         state["heading_command_w"][ids] = samples[ids, 3]
+
+
+# ---- normal velocity command (envs/mdp/commands/velocity_command.py:218-287) -------------------------------------------
+def normal_velocity_compute(state: dict, root_state_w, dt: float, samples, *, zero_prob, rel_standing_envs: float,
+                            max_command_step: float):
+    """One ``CommandTerm.compute`` (command_manager.py:151-166) of NormalVelocityCommand.
+
+    ``state``: vel_command_b (n,3), is_zero (n,3) bool, is_standing (n) bool, time_left, command_counter, error_vel_xy,
+    error_vel_yaw (all updated in place).  ``samples`` (n,11): time left, the three normal values, three sign coins, three
+    zero coins, the standing coin."""
+    q = root_state_w[:, 3:7]
+    lin_b, ang_b = M.quat_rotate_inverse(q, root_state_w[:, 7:10]), M.quat_rotate_inverse(q, root_state_w[:, 10:13])
+    v = state["vel_command_b"]
+    state["error_vel_xy"] += torch.norm(v[:, :2] - lin_b[:, :2], dim=-1) / max_command_step   # velocity_command.py:111-121
+    state["error_vel_yaw"] += torch.abs(v[:, 2] - ang_b[:, 2]) / max_command_step
+    state["time_left"] -= dt
+    ids = (state["time_left"] <= 0.0).nonzero().flatten()
+    if len(ids) > 0:
+        normal_velocity_resample(state, ids, samples, zero_prob=zero_prob, rel_standing_envs=rel_standing_envs)
+    v[state["is_standing"]] = 0.0                                                                # :274-287
+    v[state["is_zero"]] = 0.0
+    return v
+
+
+def normal_velocity_resample(state, ids, samples, *, zero_prob, rel_standing_envs):
+    """command_manager.py:172-187 + velocity_command.py:252-272."""
+    state["time_left"][ids] = samples[ids, 0]
+    state["command_counter"][ids] += 1
+    one, minus = torch.tensor(1.0), torch.tensor(-1.0)
+    for k in range(3):
+        state["vel_command_b"][ids, k] = samples[ids, 1 + k] * torch.where(samples[ids, 4 + k] <= 0.5, one, minus)
+        state["is_zero"][ids, k] = samples[ids, 7 + k] <= zero_prob[k]
+    state["is_standing"][ids] = samples[ids, 10] <= rel_standing_envs

@@ -186,6 +186,17 @@ def test_pose2d_command_arguments():
     fails(_reset(ctypes.byref(d), NULL, NULL, NULL), EINVAL, "reset_mask is NULL")
 
 
+def test_normal_velocity_command_arguments():
+    from isaaclab_amd.envs.mdp.commands.velocity_command import NormalVelDesc, _normal_compute, _normal_reset
+
+    fails(_normal_compute(ctypes.byref(NormalVelDesc(num_envs=4)), 0.02, NULL), EINVAL, "NULL operand")
+    full = {name: FAKE for name in ("root_state_w", "vel_command_b", "is_zero_vel_env", "is_standing_env", "time_left", "command_counter",
+                                    "error_vel_xy", "error_vel_yaw")}
+    fails(_normal_compute(ctypes.byref(NormalVelDesc(num_envs=4, **full)), 0.02, NULL), EINVAL, "max_command_step must be positive")
+    fails(_normal_reset(ctypes.byref(NormalVelDesc(num_envs=4, max_command_step=4.5, **full)), NULL, NULL, NULL), EINVAL, "reset_mask is NULL")
+    assert _normal_compute(ctypes.byref(NormalVelDesc(num_envs=0)), 0.02, NULL) == 0
+
+
 def test_sampler_arguments():
     fails(_abi.sample(9, NULL, 0, 0, 0.0, NULL, 0, 0, 1.0, NULL, NULL, 0, 1, FAKE, 4, 3, NULL), EINVAL, "unknown kind")
     fails(_abi.sample(4, NULL, 0, 0, 0.0, NULL, 0, 0, 1.0, NULL, NULL, 0, 1, FAKE, 4, 3, NULL), ESHAPE, "4 wide")

@@ -335,3 +335,60 @@ def test_pose2d_command_terms(dev, tag):
     term.time_left.fill_(0.0)
     mgr.compute(0.02)
     assert float(term.time_left.min()) >= 0.03 and float(term.time_left.max()) <= 0.09
+
+
+def test_normal_velocity_and_null_command_terms(dev):
+    from isaaclab_amd.envs.mdp.commands import NormalVelocityCommandCfg, NullCommandCfg
+    from isaaclab_amd.managers import CommandManager
+
+    g = load_golden("normal_velocity_command")
+    n = g["pre_time_left"].shape[0]
+    data = NS(root_state_w=torch.zeros(n, 13, device=dev))
+    cfg = NormalVelocityCommandCfg(resampling_time_range=(0.03, 0.09), rel_standing_envs=0.15,
+                                   ranges=NormalVelocityCommandCfg.Ranges(mean_vel=(1.0, 0.4, 0.6), std_vel=(0.5, 0.2, 0.3),
+                                                                          zero_prob=(0.1, 0.3, 0.2)))
+    mgr = CommandManager(dict(base_velocity=cfg, nothing=NullCommandCfg()), NS(num_envs=n, device=dev, step_dt=0.02, scene={"robot": NS(data=data)}))
+    term = mgr.get_term("base_velocity")
+    term.vel_command_b.copy_(g["pre_vel_command_b"])
+    term.is_standing_env.copy_(g["pre_is_standing_env"])
+    term.is_zero_vel_x_env.copy_(g["pre_is_zero_vel_x_env"])
+    term.is_zero_vel_y_env.copy_(g["pre_is_zero_vel_y_env"])
+    term.is_zero_vel_yaw_env.copy_(g["pre_is_zero_vel_yaw_env"])
+    term.time_left.copy_(g["pre_time_left"])
+    term.command_counter.copy_(g["pre_command_counter"])
+    term.metrics["error_vel_xy"].copy_(g["pre_error_vel_xy"])
+    term.metrics["error_vel_yaw"].copy_(g["pre_error_vel_yaw"])
+
+    def check(prefix, what):
+        assert_exact(term.time_left, g[f"{prefix}time_left"], f"time_left {what}")
+        assert_exact(term.command_counter, g[f"{prefix}command_counter"], f"counter {what}")
+        assert_exact(mgr.get_command("base_velocity"), g[f"{prefix}vel_command_b"], f"command {what}")
+        assert_exact(term.is_standing_env, g[f"{prefix}is_standing_env"], f"standing flags {what}")
+        flags = torch.stack([term.is_zero_vel_x_env, term.is_zero_vel_y_env, term.is_zero_vel_yaw_env], dim=1)
+        assert_exact(flags, g[f"{prefix}is_zero"], f"zero flags {what}")
+        assert_close(term.metrics["error_vel_xy"], g[f"{prefix}error_vel_xy"], atol=1e-6, what=f"error_vel_xy {what}")
+        assert_close(term.metrics["error_vel_yaw"], g[f"{prefix}error_vel_yaw"], atol=1e-6, what=f"error_vel_yaw {what}")
+
+    for k in range(g["samples"].shape[0]):
+        data.root_state_w.copy_(g["root_state_w"][k])
+        term._samples = g["samples"][k].to(dev).contiguous()
+        mgr.compute(0.02)
+        sub = {key: g[key][k] for key in ("time_left", "command_counter", "vel_command_b", "is_standing_env", "is_zero", "error_vel_xy", "error_vel_yaw")}
+        g.update({f"step{k}_{key}": v for key, v in sub.items()})
+        check(f"step{k}_", f"step {k}")
+    term._reset_samples = g["reset_samples"].to(dev).contiguous()
+    extras = mgr.reset(g["reset_ids"].tolist())
+    want = g["reset_extras"].tolist()
+    assert extras["Metrics/base_velocity/error_vel_xy"] == pytest.approx(want[0], rel=1e-5)
+    assert extras["Metrics/base_velocity/error_vel_yaw"] == pytest.approx(want[1], rel=1e-5)
+    check("reset_", "after reset")
+    # generated draws: time left in range, the three components spread around +-mean
+    term._samples = None
+    term.time_left.fill_(0.0)
+    mgr.compute(0.02)
+    assert float(term.time_left.min()) >= 0.03 and float(term.time_left.max()) <= 0.09
+    moving = ~term.is_standing_env & ~term.is_zero_vel_x_env
+    assert abs(float(term.vel_command_b[moving, 0].abs().mean()) - 1.0) < 0.25
+    assert 0.2 < float((term.vel_command_b[moving, 0] > 0).float().mean()) < 0.8
+    with pytest.raises(RuntimeError, match="does not generate any commands"):
+        mgr.get_command("nothing")
