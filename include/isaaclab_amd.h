@@ -370,6 +370,34 @@ int ilx_normal_velocity_command_compute(const ilx_normal_velocity_command* cmd, 
 int ilx_normal_velocity_command_reset(const ilx_normal_velocity_command* cmd, const uint8_t* reset_mask, float* log_sums, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Observation modifiers — source/isaaclab/isaaclab/utils/modifiers/modifier.py, applied per term by
+ * managers/observation_manager.py:308-313 before noise, clip and scale.
+ * ------------------------------------------------------------------------------------------------ */
+#define ILX_MOD_COPY 0            /* out = in (strided copy of a column block) */
+#define ILX_MOD_SCALE 1           /* modifier.py:22-32   out = in * p0 */
+#define ILX_MOD_CLIP 2            /* modifier.py:35-46   out = clip(in, p0 if has_lo, p1 if has_hi) */
+#define ILX_MOD_BIAS 3            /* modifier.py:49-59   out = in + p0 */
+#define ILX_MOD_DIGITAL_FILTER 4  /* modifier.py:67-191  y = sum_j B[j] x[i-j] - sum_j A[j] y[i-1-j]; histories shift by one */
+#define ILX_MOD_INTEGRATOR 5      /* modifier.py:194-259 integral += (in + previous) / 2 * p0; previous = in; out = integral */
+#define ILX_MOD_MAX_TAPS 16
+typedef struct ilx_modifier {
+    const float* in;       /* (n, d), rows in_stride floats apart */
+    float* out;            /* (n, d), rows out_stride floats apart; may alias in */
+    int64_t in_stride, out_stride, n;
+    int32_t d;
+    float p0, p1;          /* multiplier / bias / lower bound / integrator dt; upper bound */
+    int32_t has_lo, has_hi;
+    int32_t na, nb;        /* digital filter: number of A and B coefficients */
+    float A[ILX_MOD_MAX_TAPS], B[ILX_MOD_MAX_TAPS];
+    float* x_n;            /* digital filter: (n, d, nb) input history, slot 0 newest; integrator: (n, d) integral */
+    float* y_n;            /* digital filter: (n, d, na) output history, slot 0 newest; integrator: (n, d) previous input */
+} ilx_modifier;
+int ilx_modifier_apply(int32_t kind, const ilx_modifier* mod, void* stream);
+/* DigitalFilter.reset / Integrator.reset (modifier.py:157-168, 232-243): zero the rows (len_a / len_b floats per env) of
+ * the two state buffers for the listed envs (env_ids NULL: the first count envs). */
+int ilx_modifier_reset(float* state_a, int64_t len_a, float* state_b, int64_t len_b, const int64_t* env_ids, int64_t count, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Contact sensor bookkeeping — source/isaaclab/isaaclab/sensors/contact_sensor/contact_sensor.py:314-373
  * plus the update timing of sensors/sensor_base.py:197-205,284-293.
  * ------------------------------------------------------------------------------------------------ */

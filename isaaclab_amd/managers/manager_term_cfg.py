@@ -32,6 +32,7 @@ class UniformNoiseCfg:
 
 @dataclass
 class ObservationTermCfg(ManagerTermBaseCfg):
+    modifiers: list | None = None   # ModifierCfg records, applied in order before noise, clip and scale
     noise: UniformNoiseCfg | None = None
     clip: tuple[float, float] | None = None
     scale: float | None = None

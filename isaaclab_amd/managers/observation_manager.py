@@ -1,11 +1,17 @@
 """``ObservationManager`` (interface of ``isaaclab/managers/observation_manager.py``) on the fused MDP kernel: a group
-is one launch that writes the concatenated, noise-corrupted, clipped and scaled row directly."""
+is one launch that writes the concatenated, noise-corrupted, clipped and scaled row directly.  A term with custom modifiers
+(observation_manager.py:308-318) leaves the fused launch raw; its modifiers, clip and scale then run on its columns of the
+row, one launch each, in the reference's order."""
 
 from __future__ import annotations
+
+import inspect
 
 import torch
 
 from ..envs.mdp import _fused as F
+from ..utils import modifiers
+from ..utils.modifiers import modifier as _mod
 from ._base import iter_terms, resolve_term
 from .manager_term_cfg import ObservationGroupCfg, ObservationTermCfg
 
@@ -24,10 +30,26 @@ class ObservationManager:
                     raise NotImplementedError("observation history buffers are not part of the fused kernel")
                 if term.noise is not None and getattr(term.noise, "operation", "add") != "add":
                     raise NotImplementedError("only additive uniform noise is compiled into the fused kernel")
+                for mod_cfg in term.modifiers or ():            # observation_manager.py:443-470
+                    if not isinstance(mod_cfg, modifiers.ModifierCfg):
+                        raise TypeError(f"Modifier configuration '{mod_cfg}' of observation term '{name}' is not of"
+                                        f" required type ModifierCfg, Received: '{type(mod_cfg)}'")
+                    if inspect.isclass(mod_cfg.func) and not issubclass(mod_cfg.func, modifiers.ModifierBase):
+                        raise TypeError(f"Modifier function '{mod_cfg.func}' for observation term '{name}'"
+                                        f" is not a subclass of 'ModifierBase'. Received: '{type(mod_cfg.func)}'.")
+                    if not callable(mod_cfg.func):
+                        raise AttributeError(f"Modifier '{mod_cfg}' of observation term '{name}' is not callable."
+                                             f" Received: {mod_cfg.func}")
+                if term.modifiers and term.noise is not None:
+                    raise NotImplementedError("noise on a term with custom modifiers is not compiled (the noise is drawn inside the fused launch)")
+                if term.modifiers and term.scale is not None and not isinstance(term.scale, (int, float)):
+                    raise NotImplementedError("a term with custom modifiers takes a scalar scale")
                 names.append(name), cfgs.append(term), specs.append(resolve_term(env, name, term))
             self._group_obs_term_names[gname], self._group_obs_term_cfgs[gname], self._group_specs[gname] = names, cfgs, specs
             self._group_cfg[gname] = gcfg
         self._plans = {}
+        self._post: dict[str, list] = {}
+        self._group_obs_class_modifiers: list[modifiers.ModifierBase] = []
         self._obs_buffer = None
 
     @property
@@ -52,13 +74,31 @@ class ObservationManager:
             if len(groups) != 1:
                 raise NotImplementedError("an observation group must read one articulation / sensor set")
             corrupt = self._flag(group, "enable_corruption", False)
-            posts = [dict(noise=(c.noise.n_min, c.noise.n_max) if (c.noise is not None and corrupt) else None, clip=c.clip,
+            posts = [dict(noise=None, clip=None, scale=None) if c.modifiers else
+                     dict(noise=(c.noise.n_min, c.noise.n_max) if (c.noise is not None and corrupt) else None, clip=c.clip,
                           scale=c.scale) for c in cfgs]
             mdp = F.make_plan(self._env, "observation", specs, posts=posts, bindings=groups[0][0])
             plan = self._plans[group] = (groups[0][0], None, specs, mdp)
+            post, col = [], 0
+            for c, spec in zip(cfgs, mdp.observations):
+                width = mdp._obs_dim(spec)
+                if c.modifiers:
+                    for mod_cfg in c.modifiers:   # class modifiers are built once with the term's shape (:449-458)
+                        if inspect.isclass(mod_cfg.func):
+                            mod_cfg.func = mod_cfg.func(cfg=mod_cfg, data_dim=(self._env.num_envs, width), device=self._env.device)
+                            self._group_obs_class_modifiers.append(mod_cfg.func)
+                    post.append((col, col + width, c))
+                col += width
+            self._post[group] = post
         return plan
 
     def reset(self, env_ids=None) -> dict[str, float]:
+        """observation_manager.py:222-236: class modifiers drop the history of the reset envs."""
+        for group in self._group_specs:
+            if any(c.modifiers for c in self._group_obs_term_cfgs[group]):
+                self._plan(group)
+        for mod in self._group_obs_class_modifiers:
+            mod.reset(env_ids=env_ids)
         return {}
 
     def compute(self) -> dict[str, torch.Tensor]:
@@ -74,4 +114,15 @@ class ObservationManager:
         bindings, _, specs, mdp = self._plan(group_name)
         mdp.bind(noise_u=noise_u)
         F.run_plan(mdp, self._env, "observation", specs, bindings)
+        for c0, c1, cfg in self._post[group_name]:
+            cols = mdp.obs[:, c0:c1]
+            obs = cols
+            for m in cfg.modifiers:
+                obs = m.func(obs, **m.params)
+            if cfg.clip:          # in place, as the reference's clip_ / mul_ (an Integrator's state is the tensor it returned)
+                _mod.apply(_mod.CLIP, obs, out=obs, p0=float(cfg.clip[0]), p1=float(cfg.clip[1]), has_lo=1, has_hi=1)
+            if cfg.scale is not None:
+                _mod.apply(_mod.SCALE, obs, out=obs, p0=float(cfg.scale))
+            if obs.data_ptr() != cols.data_ptr():
+                _mod.apply(_mod.COPY, obs, out=cols)
         return mdp.obs

@@ -197,6 +197,21 @@ def test_normal_velocity_command_arguments():
     assert _normal_compute(ctypes.byref(NormalVelDesc(num_envs=0)), 0.02, NULL) == 0
 
 
+def test_modifier_arguments():
+    from isaaclab_amd.utils.modifiers.modifier import ModifierDesc, _apply, _reset
+
+    fails(_apply(9, ctypes.byref(ModifierDesc(n=4, d=3)), NULL), EINVAL, "unknown kind")
+    fails(_apply(1, ctypes.byref(ModifierDesc(n=4, d=3)), NULL), EINVAL, "in or out is NULL")
+    fails(_apply(1, ctypes.byref(ModifierDesc(inp=FAKE, out=FAKE, n=4, d=3, in_stride=2, out_stride=3)), NULL), ESHAPE, "row strides")
+    ok = dict(inp=FAKE, out=FAKE, n=4, d=3, in_stride=3, out_stride=3)
+    fails(_apply(4, ctypes.byref(ModifierDesc(na=1, nb=17, **ok)), NULL), ESHAPE, "filter lengths")
+    fails(_apply(4, ctypes.byref(ModifierDesc(na=1, nb=2, **ok)), NULL), EINVAL, "histories")
+    fails(_apply(5, ctypes.byref(ModifierDesc(**ok)), NULL), EINVAL, "integral and previous-value")
+    assert _apply(1, ctypes.byref(ModifierDesc(n=0, d=3)), NULL) == 0
+    fails(_reset(NULL, 3, NULL, 0, NULL, 4, NULL), EINVAL, "NULL state buffer")
+    assert _reset(NULL, 0, NULL, 0, NULL, 4, NULL) == 0
+
+
 def test_sampler_arguments():
     fails(_abi.sample(9, NULL, 0, 0, 0.0, NULL, 0, 0, 1.0, NULL, NULL, 0, 1, FAKE, 4, 3, NULL), EINVAL, "unknown kind")
     fails(_abi.sample(4, NULL, 0, 0, 0.0, NULL, 0, 0, 1.0, NULL, NULL, 0, 1, FAKE, 4, 3, NULL), ESHAPE, "4 wide")
