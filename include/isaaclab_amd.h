@@ -398,6 +398,38 @@ int ilx_modifier_apply(int32_t kind, const ilx_modifier* mod, void* stream);
 int ilx_modifier_reset(float* state_a, int64_t len_a, float* state_b, int64_t len_b, const int64_t* env_ids, int64_t count, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * IMU sensor — source/isaaclab/isaaclab/sensors/imu/imu.py:142-182 with the update timing of
+ * sensors/sensor_base.py:197-205, 284-293.
+ * ------------------------------------------------------------------------------------------------ */
+
+/* advance_clock = 1: SensorBase.update(dt_clock) (timestamp += dt_clock; flag sensors whose period elapsed) followed by the
+ * refresh of the flagged sensors; advance_clock = 0: only the refresh of sensors already flagged.  A refresh computes
+ *   pos_w = p + quat_rotate(q, offset_pos), quat_w = q * offset_quat                      (q: the view's x,y,z,w as w,x,y,z)
+ *   lin_vel_w = v + w x quat_rotate(q, offset_pos - com_pos_b), ang_vel_w = w
+ *   lin_acc_w = (lin_vel_w - prev_lin_vel_w) / dt + gravity_bias, ang_acc_w = (ang_vel_w - prev_ang_vel_w) / dt
+ *   the four body-frame outputs = quat_rotate_inverse(quat_w, .), then prev_* = the world velocities. */
+typedef struct ilx_imu {
+    int64_t num_sensors;
+    const float* transforms;   /* (n,7) RigidBodyView.get_transforms(): position, quaternion x,y,z,w */
+    const float* velocities;   /* (n,6) RigidBodyView.get_velocities(): linear, angular, of the centre of mass */
+    const float* coms;         /* (n,7) RigidBodyView.get_coms(): the first three are the centre of mass in the link frame */
+    float offset_pos[3], offset_quat[4], gravity_bias[3];   /* ImuCfg.offset.pos / .rot (w,x,y,z), ImuCfg.gravity_bias */
+    float update_period;
+    float* pos_w;              /* (n,3) */
+    float* quat_w;             /* (n,4) w,x,y,z */
+    float* lin_vel_b;          /* (n,3) */
+    float* ang_vel_b;
+    float* lin_acc_b;
+    float* ang_acc_b;
+    float* prev_lin_vel_w;     /* (n,3) state of the finite difference */
+    float* prev_ang_vel_w;
+    float* timestamp;          /* (n) SensorBase clocks */
+    float* timestamp_last_update;
+    uint8_t* is_outdated;      /* (n) */
+} ilx_imu;
+int ilx_imu_update(const ilx_imu* imu, int32_t advance_clock, float dt_clock, float dt, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Contact sensor bookkeeping — source/isaaclab/isaaclab/sensors/contact_sensor/contact_sensor.py:314-373
  * plus the update timing of sensors/sensor_base.py:197-205,284-293.
  * ------------------------------------------------------------------------------------------------ */

@@ -212,6 +212,19 @@ def test_modifier_arguments():
     assert _reset(NULL, 0, NULL, 0, NULL, 4, NULL) == 0
 
 
+def test_imu_arguments():
+    from isaaclab_amd.sensors.imu import ImuDesc, _update
+
+    fails(_update(ctypes.byref(ImuDesc(num_sensors=4)), 1, 0.02, 0.02, NULL), EINVAL, "physics views' buffers")
+    views = dict(transforms=FAKE, velocities=FAKE, coms=FAKE)
+    fails(_update(ctypes.byref(ImuDesc(num_sensors=4, **views)), 1, 0.02, 0.02, NULL), EINVAL, "NULL data buffer")
+    data = {k: FAKE for k in ("pos_w", "quat_w", "lin_vel_b", "ang_vel_b", "lin_acc_b", "ang_acc_b", "prev_lin_vel_w", "prev_ang_vel_w")}
+    fails(_update(ctypes.byref(ImuDesc(num_sensors=4, **views, **data)), 1, 0.02, 0.02, NULL), EINVAL, "NULL clock buffer")
+    clocks = dict(timestamp=FAKE, timestamp_last_update=FAKE, is_outdated=FAKE)
+    fails(_update(ctypes.byref(ImuDesc(num_sensors=4, **views, **data, **clocks)), 1, 0.02, 0.0, NULL), EINVAL, "must be positive")
+    assert _update(ctypes.byref(ImuDesc(num_sensors=0)), 1, 0.02, 0.02, NULL) == 0
+
+
 def test_sampler_arguments():
     fails(_abi.sample(9, NULL, 0, 0, 0.0, NULL, 0, 0, 1.0, NULL, NULL, 0, 1, FAKE, 4, 3, NULL), EINVAL, "unknown kind")
     fails(_abi.sample(4, NULL, 0, 0, 0.0, NULL, 0, 0, 1.0, NULL, NULL, 0, 1, FAKE, 4, 3, NULL), ESHAPE, "4 wide")
