@@ -398,6 +398,31 @@ int ilx_modifier_apply(int32_t kind, const ilx_modifier* mod, void* stream);
 int ilx_modifier_reset(float* state_a, int64_t len_a, float* state_b, int64_t len_b, const int64_t* env_ids, int64_t count, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Noise — source/isaaclab/isaaclab/utils/noise/noise_model.py:20-98 (constant_noise, uniform_noise, gaussian_noise) and the
+ * per-env bias of NoiseModelWithAdditiveBias (:145-182).
+ * ------------------------------------------------------------------------------------------------ */
+#define ILX_NOISE_CONSTANT 0   /* noise = a (the bias) */
+#define ILX_NOISE_UNIFORM 1    /* noise = U[0,1) * (b - a) + a      (a = n_min, b = n_max) */
+#define ILX_NOISE_GAUSSIAN 2   /* noise = a + b * N(0,1)            (a = mean, b = std) */
+#define ILX_NOISE_ADD 0        /* out = data + noise */
+#define ILX_NOISE_SCALE 1      /* out = data * noise */
+#define ILX_NOISE_ABS 2        /* out = noise */
+typedef struct ilx_noise {
+    const float* data;        /* (rows, d), rows data_stride floats apart */
+    float* out;               /* (rows, d), rows out_stride floats apart; may alias data */
+    int64_t data_stride, out_stride, n;
+    int32_t d;
+    const int64_t* row_ids;   /* (n) rows of data / out to work on, or NULL: rows 0..n-1 */
+    float a, b, range;        /* scalar parameters; range = n_max - n_min as the caller's arithmetic rounds it */
+    const float* a_cols;      /* (d) per-column parameters or NULL (then the scalars are used) */
+    const float* b_cols;
+    const float* draws;       /* (n, d) dense U[0,1) / N(0,1) draws to use, or NULL: Philox keyed by (seed, draw, row, column) */
+    const float* row_bias;    /* (rows) added after the noise (NoiseModelWithAdditiveBias.apply), or NULL */
+    uint64_t seed, draw;
+} ilx_noise;
+int ilx_noise_apply(int32_t kind, int32_t operation, const ilx_noise* noise, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * IMU sensor — source/isaaclab/isaaclab/sensors/imu/imu.py:142-182 with the update timing of
  * sensors/sensor_base.py:197-205, 284-293.
  * ------------------------------------------------------------------------------------------------ */

@@ -5,6 +5,8 @@ from __future__ import annotations
 from dataclasses import dataclass, field
 from typing import Callable
 
+from ..utils.noise.noise_cfg import UniformNoiseCfg  # noqa: F401  (isaaclab/utils/noise/noise_cfg.py)
+
 
 @dataclass
 class ManagerTermBaseCfg:
@@ -20,14 +22,6 @@ class RewardTermCfg(ManagerTermBaseCfg):
 @dataclass
 class TerminationTermCfg(ManagerTermBaseCfg):
     time_out: bool = False
-
-
-@dataclass
-class UniformNoiseCfg:
-    """``isaaclab/utils/noise/noise_cfg.py`` (UniformNoiseCfg, operation "add")."""
-    n_min: float = -1.0
-    n_max: float = 1.0
-    operation: str = "add"
 
 
 @dataclass

@@ -13,7 +13,7 @@ from ..envs.mdp import _fused as F
 from ..utils import modifiers
 from ..utils.modifiers import modifier as _mod
 from ._base import iter_terms, resolve_term
-from .manager_term_cfg import ObservationGroupCfg, ObservationTermCfg
+from .manager_term_cfg import ObservationGroupCfg, ObservationTermCfg, UniformNoiseCfg
 
 
 class ObservationManager:
@@ -28,7 +28,8 @@ class ObservationManager:
             for name, term in iter_terms(gcfg, ObservationTermCfg):
                 if term.history_length:
                     raise NotImplementedError("observation history buffers are not part of the fused kernel")
-                if term.noise is not None and getattr(term.noise, "operation", "add") != "add":
+                if term.noise is not None and (not isinstance(term.noise, UniformNoiseCfg) or term.noise.operation != "add"
+                                               or isinstance(term.noise.n_min, torch.Tensor) or isinstance(term.noise.n_max, torch.Tensor)):
                     raise NotImplementedError("only additive uniform noise is compiled into the fused kernel")
                 for mod_cfg in term.modifiers or ():            # observation_manager.py:443-470
                     if not isinstance(mod_cfg, modifiers.ModifierCfg):

@@ -225,6 +225,16 @@ def test_imu_arguments():
     assert _update(ctypes.byref(ImuDesc(num_sensors=0)), 1, 0.02, 0.02, NULL) == 0
 
 
+def test_noise_arguments():
+    from isaaclab_amd.utils.noise.noise_model import NoiseDesc, _apply
+
+    fails(_apply(3, 0, ctypes.byref(NoiseDesc(n=4, d=3)), NULL), EINVAL, "unknown kind")
+    fails(_apply(1, 3, ctypes.byref(NoiseDesc(n=4, d=3)), NULL), EINVAL, "Unknown operation in noise")
+    fails(_apply(1, 0, ctypes.byref(NoiseDesc(n=4, d=3)), NULL), EINVAL, "data or out is NULL")
+    fails(_apply(1, 0, ctypes.byref(NoiseDesc(data=FAKE, out=FAKE, n=4, d=3, data_stride=3, out_stride=2)), NULL), ESHAPE, "row strides")
+    assert _apply(1, 0, ctypes.byref(NoiseDesc(n=0, d=3)), NULL) == 0
+
+
 def test_sampler_arguments():
     fails(_abi.sample(9, NULL, 0, 0, 0.0, NULL, 0, 0, 1.0, NULL, NULL, 0, 1, FAKE, 4, 3, NULL), EINVAL, "unknown kind")
     fails(_abi.sample(4, NULL, 0, 0, 0.0, NULL, 0, 0, 1.0, NULL, NULL, 0, 1, FAKE, 4, 3, NULL), ESHAPE, "4 wide")
