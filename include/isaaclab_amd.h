@@ -398,6 +398,30 @@ int ilx_modifier_apply(int32_t kind, const ilx_modifier* mod, void* stream);
 int ilx_modifier_reset(float* state_a, int64_t len_a, float* state_b, int64_t len_b, const int64_t* env_ids, int64_t count, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Batched ring buffers — source/isaaclab/isaaclab/utils/buffers/circular_buffer.py, delay_buffer.py (observation
+ * histories, observation_manager.py:319-327; delayed set-points).
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct ilx_circular_buffer {
+    float* buffer;         /* (max_len, n, d) */
+    int64_t* num_pushes;   /* (n) pushes since the env's last reset */
+    int32_t max_len;
+    int32_t pointer;       /* the slot of the newest entry; for an append the caller has already advanced it (:126) */
+    int64_t n;
+    int32_t d;
+} ilx_circular_buffer;
+/* CircularBuffer.append (circular_buffer.py:107-135) when data != NULL: write the slot `pointer`; envs with no push since
+ * their reset get every slot filled; num_pushes += 1.  Then, from the state after the append:
+ *   ordered_out (n, max_len*d) = CircularBuffer.buffer flattened (:78-86), oldest entry first;
+ *   delayed_out (n, d) = CircularBuffer[time_lags] (:137-166; DelayBuffer.compute, delay_buffer.py:158-177): the entry
+ *   min(time_lags[env], num_pushes[env] - 1) pushes back (time_lags NULL: the newest).
+ * Either output may be NULL.  data, ordered_out and delayed_out are rows with the given strides (in floats). */
+int ilx_circular_buffer_append(const ilx_circular_buffer* ring, const float* data, int64_t data_stride, float* ordered_out,
+                               int64_t ordered_stride, const int32_t* time_lags, float* delayed_out, int64_t delayed_stride,
+                               void* stream);
+/* CircularBuffer.reset (circular_buffer.py:92-105): num_pushes = 0 and zeroed slots for the listed envs (NULL: the first count). */
+int ilx_circular_buffer_reset(const ilx_circular_buffer* ring, const int64_t* env_ids, int64_t count, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Noise — source/isaaclab/isaaclab/utils/noise/noise_model.py:20-98 (constant_noise, uniform_noise, gaussian_noise) and the
  * per-env bias of NoiseModelWithAdditiveBias (:145-182).
  * ------------------------------------------------------------------------------------------------ */

@@ -235,6 +235,20 @@ def test_noise_arguments():
     assert _apply(1, 0, ctypes.byref(NoiseDesc(n=0, d=3)), NULL) == 0
 
 
+def test_circular_buffer_arguments():
+    from isaaclab_amd.utils.buffers.circular_buffer import RingDesc, _append, _reset
+
+    fails(_append(ctypes.byref(RingDesc(n=4, d=3, max_len=0, num_pushes=FAKE)), NULL, 0, NULL, 0, NULL, NULL, 0, NULL), EINVAL, "greater than zero")
+    fails(_append(ctypes.byref(RingDesc(n=4, d=3, max_len=2)), NULL, 0, NULL, 0, NULL, NULL, 0, NULL), EINVAL, "num_pushes is NULL")
+    fails(_append(ctypes.byref(RingDesc(n=4, d=3, max_len=2, num_pushes=FAKE)), NULL, 0, NULL, 0, NULL, NULL, 0, NULL), EINVAL, "buffer is NULL")
+    ring = dict(n=4, d=3, max_len=2, num_pushes=FAKE, buffer=FAKE)
+    fails(_append(ctypes.byref(RingDesc(pointer=2, **ring)), NULL, 0, NULL, 0, NULL, NULL, 0, NULL), EINVAL, "outside the 2 slots")
+    fails(_append(ctypes.byref(RingDesc(**ring)), FAKE, 2, NULL, 0, NULL, NULL, 0, NULL), ESHAPE, "data row stride")
+    fails(_append(ctypes.byref(RingDesc(**ring)), FAKE, 3, FAKE, 5, NULL, NULL, 0, NULL), ESHAPE, "ordered row stride")
+    fails(_reset(ctypes.byref(RingDesc(**ring)), NULL, -1, NULL), EINVAL, "negative count")
+    assert _append(ctypes.byref(RingDesc(n=0, d=3, max_len=2)), NULL, 0, NULL, 0, NULL, NULL, 0, NULL) == 0
+
+
 def test_sampler_arguments():
     fails(_abi.sample(9, NULL, 0, 0, 0.0, NULL, 0, 0, 1.0, NULL, NULL, 0, 1, FAKE, 4, 3, NULL), EINVAL, "unknown kind")
     fails(_abi.sample(4, NULL, 0, 0, 0.0, NULL, 0, 0, 1.0, NULL, NULL, 0, 1, FAKE, 4, 3, NULL), ESHAPE, "4 wide")
