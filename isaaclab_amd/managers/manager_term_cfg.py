@@ -31,6 +31,7 @@ class ObservationTermCfg(ManagerTermBaseCfg):
     clip: tuple[float, float] | None = None
     scale: float | None = None
     history_length: int = 0
+    flatten_history_dim: bool = True
 
 
 @dataclass
@@ -38,3 +39,5 @@ class ObservationGroupCfg:
     """A group is any object whose attributes (or a dict whose values) are :class:`ObservationTermCfg`."""
     concatenate_terms: bool = True
     enable_corruption: bool = False
+    history_length: int | None = None      # when set, overrides every term's history_length / flatten_history_dim
+    flatten_history_dim: bool = True

@@ -1,7 +1,8 @@
 """``ObservationManager`` (interface of ``isaaclab/managers/observation_manager.py``) on the fused MDP kernel: a group
 is one launch that writes the concatenated, noise-corrupted, clipped and scaled row directly.  A term with custom modifiers
 (observation_manager.py:308-318) leaves the fused launch raw; its modifiers, clip and scale then run on its columns of the
-row, one launch each, in the reference's order."""
+row, one launch each, in the reference's order.  A term with a history (:319-327) appends its columns to a ring and the
+ordered history goes into the term's columns of the group's final row from the same launch."""
 
 from __future__ import annotations
 
@@ -11,6 +12,7 @@ import torch
 
 from ..envs.mdp import _fused as F
 from ..utils import modifiers
+from ..utils.buffers import CircularBuffer
 from ..utils.modifiers import modifier as _mod
 from ._base import iter_terms, resolve_term
 from .manager_term_cfg import ObservationGroupCfg, ObservationTermCfg, UniformNoiseCfg
@@ -26,8 +28,11 @@ class ObservationManager:
                 continue
             names, cfgs, specs = [], [], []
             for name, term in iter_terms(gcfg, ObservationTermCfg):
-                if term.history_length:
-                    raise NotImplementedError("observation history buffers are not part of the fused kernel")
+                group_history = self._flag_of(gcfg, "history_length", None)
+                if group_history is not None:      # observation_manager.py:403-406
+                    term.history_length, term.flatten_history_dim = group_history, self._flag_of(gcfg, "flatten_history_dim", True)
+                if term.history_length > 0 and not term.flatten_history_dim:
+                    raise NotImplementedError("an observation history is handed out flattened (flatten_history_dim=True)")
                 if term.noise is not None and (not isinstance(term.noise, UniformNoiseCfg) or term.noise.operation != "add"
                                                or isinstance(term.noise.n_min, torch.Tensor) or isinstance(term.noise.n_max, torch.Tensor)):
                     raise NotImplementedError("only additive uniform noise is compiled into the fused kernel")
@@ -50,6 +55,8 @@ class ObservationManager:
             self._group_cfg[gname] = gcfg
         self._plans = {}
         self._post: dict[str, list] = {}
+        self._group_obs_term_history_buffer: dict[str, dict[str, CircularBuffer]] = {}
+        self._history_rows: dict[str, tuple] = {}
         self._group_obs_class_modifiers: list[modifiers.ModifierBase] = []
         self._obs_buffer = None
 
@@ -59,11 +66,19 @@ class ObservationManager:
 
     @property
     def group_obs_dim(self) -> dict[str, tuple[int, ...]]:
-        return {g: (self._plan(g)[3].obs_dim,) for g in self._group_specs}
+        dims = {}
+        for g in self._group_specs:
+            mdp = self._plan(g)[3]
+            rows = self._history_rows.get(g)
+            dims[g] = (mdp.obs_dim if rows is None else rows[0].shape[1],)
+        return dims
+
+    @staticmethod
+    def _flag_of(g, name, default):
+        return g.get(name, default) if isinstance(g, dict) else getattr(g, name, default)
 
     def _flag(self, group, name, default):
-        g = self._group_cfg[group]
-        return g.get(name, default) if isinstance(g, dict) else getattr(g, name, default)
+        return self._flag_of(self._group_cfg[group], name, default)
 
     def _plan(self, group):
         plan = self._plans.get(group)
@@ -91,15 +106,30 @@ class ObservationManager:
                     post.append((col, col + width, c))
                 col += width
             self._post[group] = post
+            if any(c.history_length > 0 for c in cfgs):   # observation_manager.py:412-420
+                n, dev = self._env.num_envs, self._env.device
+                rings, layout, col, out_col = {}, [], 0, 0
+                for name, c, spec in zip(self._group_obs_term_names[group], cfgs, mdp.observations):
+                    width = mdp._obs_dim(spec)
+                    out_width = width * max(c.history_length, 1)
+                    if c.history_length > 0:
+                        rings[name] = CircularBuffer(max_len=c.history_length, batch_size=n, device=dev)
+                    layout.append((name, col, col + width, out_col, out_col + out_width))
+                    col, out_col = col + width, out_col + out_width
+                self._group_obs_term_history_buffer[group] = rings
+                self._history_rows[group] = (torch.zeros(n, out_col, device=dev), layout)
         return plan
 
     def reset(self, env_ids=None) -> dict[str, float]:
         """observation_manager.py:222-236: class modifiers drop the history of the reset envs."""
         for group in self._group_specs:
-            if any(c.modifiers for c in self._group_obs_term_cfgs[group]):
+            if any(c.modifiers or c.history_length > 0 for c in self._group_obs_term_cfgs[group]):
                 self._plan(group)
         for mod in self._group_obs_class_modifiers:
             mod.reset(env_ids=env_ids)
+        for rings in self._group_obs_term_history_buffer.values():   # :227-230
+            for ring in rings.values():
+                ring.reset(batch_ids=env_ids)
         return {}
 
     def compute(self) -> dict[str, torch.Tensor]:
@@ -126,4 +156,14 @@ class ObservationManager:
                 _mod.apply(_mod.SCALE, obs, out=obs, p0=float(cfg.scale))
             if obs.data_ptr() != cols.data_ptr():
                 _mod.apply(_mod.COPY, obs, out=cols)
-        return mdp.obs
+        rows = self._history_rows.get(group_name)
+        if rows is None:
+            return mdp.obs
+        final, layout = rows
+        rings = self._group_obs_term_history_buffer[group_name]
+        for name, c0, c1, o0, o1 in layout:
+            if name in rings:
+                rings[name].append(mdp.obs[:, c0:c1], ordered_out=final[:, o0:o1])
+            else:
+                _mod.apply(_mod.COPY, mdp.obs[:, c0:c1], out=final[:, o0:o1])
+        return final
