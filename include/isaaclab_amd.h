@@ -398,6 +398,30 @@ int ilx_modifier_apply(int32_t kind, const ilx_modifier* mod, void* stream);
 int ilx_modifier_reset(float* state_a, int64_t len_a, float* state_b, int64_t len_b, const int64_t* env_ids, int64_t count, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Homogeneous poses and camera geometry — source/isaaclab/isaaclab/utils/math.py
+ * ------------------------------------------------------------------------------------------------ */
+#define ILX_POSE_MAKE 0         /* math.py:1564-1583  a (n,3) positions, b (n,3,3) rotations -> out (n,4,4) */
+#define ILX_POSE_INV 1          /* math.py:1601-1626  a (n,4,4) -> out (n,4,4) = [R^T, -R^T t; 0 1] */
+#define ILX_POSE_MUL 2          /* math.py:1629-1643  out (n,4,4) = a @ b (pose_in_A_to_pose_in_B(pose_in_A = b, pose_A_in_B = a)) */
+#define ILX_POSE_COPYSIGN 3     /* math.py:121-135    out (n) = |scalar| * sign(a) */
+#define ILX_POSE_IS_IDENTITY 4  /* math.py:728-746    a (n,3), b (n,4): *flag = 1 when any pose is not allclose to identity */
+/* a_batch / b_batch: n, or 1 when the operand is one matrix shared by all n. */
+int ilx_pose_op(int32_t op, const float* a, int64_t a_batch, const float* b, int64_t b_batch, float scalar, float* out, int32_t* flag,
+                int64_t n, void* stream);
+
+#define ILX_CAMERA_ORTHOGONALIZE 0  /* math.py:991-1079   depth (n,h,w) -> out (n,h,w) = depth / sqrt(1 + ((u-cx)/fx)^2 + ((v-cy)/fy)^2) */
+#define ILX_CAMERA_UNPROJECT 1      /* math.py:1083-1166  depth (n,h,w) -> out (n, w*h, 3), point u*h + v = K^-1 [u v 1]^T / last * depth */
+#define ILX_CAMERA_PROJECT 2        /* math.py:1170-1225  points (n,h,3) (h points per batch, w unused) -> out (n,h,3) = (x/z, y/z of K p, Z) */
+/* intrinsics (intrinsics_batch,3,3) with intrinsics_batch = n, or 1 for one calibration matrix shared by the batch. */
+int ilx_camera_op(int32_t op, const float* data, const float* intrinsics, int64_t intrinsics_batch, float* out, int64_t n, int32_t h,
+                  int32_t w, void* stream);
+
+/* sample_cylinder (math.py:1387-1420): out (n,3) = (radius cos a, radius sin a, z), a = (u0*2-1)*pi, z = u1*(h_max-h_min)+h_min.
+ * u (2,n): the unit-interval draws (angles first, then heights), or NULL: Philox keyed by (seed, draw, point). */
+int ilx_sample_cylinder(float radius, float h_min, float h_max, const float* u, uint64_t seed, uint64_t draw, float* out, int64_t n,
+                        void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Batched ring buffers — source/isaaclab/isaaclab/utils/buffers/circular_buffer.py, delay_buffer.py (observation
  * histories, observation_manager.py:319-327; delayed set-points).
  * ------------------------------------------------------------------------------------------------ */

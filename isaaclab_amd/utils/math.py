@@ -357,3 +357,10 @@ def random_orientation(num: int, device, *, _z=None) -> torch.Tensor:
 def random_yaw_orientation(num: int, device, *, _u=None) -> torch.Tensor:
     """math.py:1270-1285."""
     return _sample(SAMPLE_RANDOM_YAW_ORIENTATION, 0.0, 0.0, (num, 4), device, u=_u)
+
+
+# homogeneous poses, interpolation, camera geometry (math.py:121-135, 728-746, 991-1225, 1387-1420, 1564-1883)
+from .pose_math import (copysign, generate_random_rotation, generate_random_transformation_matrix,  # noqa: E402,F401
+                        generate_random_translation, interpolate_poses, interpolate_rotations, is_identity_pose, make_pose,
+                        orthogonalize_perspective_depth, pose_in_A_to_pose_in_B, pose_inv, project_points, quat_slerp,
+                        sample_cylinder, transform_poses_from_frame_A_to_frame_B, unmake_pose, unproject_depth)

@@ -411,3 +411,59 @@ def random_orientation(z):
 def random_yaw_orientation(u):
     zero = torch.zeros_like(u)
     return quat_from_euler_xyz(zero, zero, 2 * torch.pi * u)
+
+
+# ---- homogeneous poses and camera geometry (math.py:121-135, 991-1225, 1387-1420, 1564-1643) ------------------------------
+def copysign(mag, other):
+    return torch.full_like(other, abs(mag)) * torch.sign(other)
+
+
+def make_pose(pos, rot):
+    pose = torch.zeros(pos.shape[:-1] + (4, 4))
+    pose[..., :3, :3], pose[..., :3, 3], pose[..., 3, 3] = rot, pos, 1.0
+    return pose
+
+
+def pose_inv(pose):
+    inv = torch.zeros_like(pose)
+    rt = pose[..., :3, :3].transpose(-1, -2)
+    inv[..., :3, :3] = rt
+    inv[..., :3, 3] = torch.matmul(-rt, pose[..., :3, 3:4])[..., 0]
+    inv[..., 3, 3] = 1.0
+    return inv
+
+
+def pose_mul(pose_A_in_B, pose_in_A):
+    return torch.matmul(pose_A_in_B, pose_in_A)
+
+
+def orthogonalize_depth(depth, K):
+    """depth (N, H, W), K (N or 1, 3, 3)."""
+    n, h, w = depth.shape
+    u = torch.arange(w, dtype=torch.float32).view(1, 1, w)
+    v = torch.arange(h, dtype=torch.float32).view(1, h, 1)
+    fx, fy, cx, cy = (K[:, i, j].view(-1, 1, 1) for i, j in ((0, 0), (1, 1), (0, 2), (1, 2)))
+    return depth / torch.sqrt(1 + ((u - cx) / fx) ** 2 + ((v - cy) / fy) ** 2)
+
+
+def unproject_depth(depth, K):
+    """depth (N, H, W) orthogonal, K (N or 1, 3, 3) -> (N, W * H, 3), pixel u * H + v."""
+    n, h, w = depth.shape
+    uu, vv = torch.meshgrid(torch.arange(w, dtype=torch.float32), torch.arange(h, dtype=torch.float32), indexing="ij")
+    pix = torch.stack([uu.reshape(-1), vv.reshape(-1), torch.ones(h * w)], dim=0)[None]
+    pts = torch.matmul(torch.inverse(K.double()).float(), pix)
+    pts = pts / pts[:, -1:, :]
+    return pts.transpose(1, 2) * depth.transpose(1, 2).reshape(n, -1, 1)
+
+
+def project_points(points, K):
+    """points (N, P, 3), K (N or 1, 3, 3) -> (N, P, 3) = (u, v, Z)."""
+    p = torch.matmul(K, points.transpose(1, 2))
+    p = (p / p[:, -1:, :]).transpose(1, 2).clone()
+    p[:, :, -1] = points[:, :, -1]
+    return p
+
+
+def sample_cylinder(radius, h_range, u):
+    angles = (u[0] * 2 - 1) * torch.pi
+    return torch.stack([radius * torch.cos(angles), radius * torch.sin(angles), u[1] * (h_range[1] - h_range[0]) + h_range[0]], dim=-1)

@@ -249,6 +249,21 @@ def test_circular_buffer_arguments():
     assert _append(ctypes.byref(RingDesc(n=0, d=3, max_len=2)), NULL, 0, NULL, 0, NULL, NULL, 0, NULL) == 0
 
 
+def test_pose_and_camera_op_arguments():
+    from isaaclab_amd.utils.pose_math import _camera_op, _cylinder, _pose_op
+
+    fails(_pose_op(7, FAKE, 4, NULL, 1, 0.0, FAKE, NULL, 4, NULL), EINVAL, "unknown op")
+    fails(_pose_op(0, FAKE, 4, NULL, 4, 0.0, FAKE, NULL, 4, NULL), EINVAL, "NULL operand")
+    fails(_pose_op(1, FAKE, 4, NULL, 1, 0.0, NULL, NULL, 4, NULL), EINVAL, "NULL output")
+    fails(_pose_op(2, FAKE, 3, FAKE, 4, 0.0, FAKE, NULL, 4, NULL), ESHAPE, "neither 1 nor 4")
+    fails(_pose_op(4, FAKE, 4, FAKE, 4, 0.0, NULL, NULL, 4, NULL), EINVAL, "NULL output")
+    assert _pose_op(1, NULL, 0, NULL, 0, 0.0, NULL, NULL, 0, NULL) == 0
+    fails(_camera_op(3, FAKE, FAKE, 1, FAKE, 2, 4, 4, NULL), EINVAL, "unknown op")
+    fails(_camera_op(0, FAKE, NULL, 1, FAKE, 2, 4, 4, NULL), EINVAL, "NULL operand")
+    fails(_camera_op(1, FAKE, FAKE, 3, FAKE, 2, 4, 4, NULL), ESHAPE, "calibration matrices")
+    fails(_cylinder(1.0, 0.0, 1.0, NULL, 0, 0, NULL, 4, NULL), EINVAL, "out is NULL")
+
+
 def test_sampler_arguments():
     fails(_abi.sample(9, NULL, 0, 0, 0.0, NULL, 0, 0, 1.0, NULL, NULL, 0, 1, FAKE, 4, 3, NULL), EINVAL, "unknown kind")
     fails(_abi.sample(4, NULL, 0, 0, 0.0, NULL, 0, 0, 1.0, NULL, NULL, 0, 1, FAKE, 4, 3, NULL), ESHAPE, "4 wide")
