@@ -503,6 +503,35 @@ typedef struct ilx_imu {
 int ilx_imu_update(const ilx_imu* imu, int32_t advance_clock, float dt_clock, float dt, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * FrameTransformer sensor — source/isaaclab/isaaclab/sensors/frame_transformer/frame_transformer.py:322-385
+ * ------------------------------------------------------------------------------------------------ */
+
+/* One refresh of all envs: source pose = view row source_rows[env] (+ offset, combine_frame_transforms), target pose of
+ * frame f = view row target_rows[env * F + f] (+ offset), target in source = subtract_frame_transforms(source, target).
+ * The row indices are the reference's chain of gathers composed once:
+ *   source_rows[env]          = _per_env_indices[_source_frame_body_ids[env]]
+ *   target_rows[env * F + f]  = _per_env_indices[_target_frame_body_ids[_duplicate_frame_indices[env * F + f]]]
+ * Offsets are NULL when the reference skips them (_apply_source_frame_offset / _apply_target_frame_offset False). */
+typedef struct ilx_frame_transformer {
+    int64_t num_envs;
+    int32_t num_frames;                /* F: target frames per env */
+    const float* transforms;           /* (rows,7) RigidBodyView.get_transforms(): position, quaternion x,y,z,w */
+    const int64_t* source_rows;        /* (n) */
+    const int64_t* target_rows;        /* (n*F) */
+    const float* source_offset_pos;    /* (n,3) or NULL */
+    const float* source_offset_quat;   /* (n,4) w,x,y,z */
+    const float* target_offset_pos;    /* (n*F,3) or NULL */
+    const float* target_offset_quat;   /* (n*F,4) */
+    float* source_pos_w;               /* (n,3) */
+    float* source_quat_w;              /* (n,4) */
+    float* target_pos_w;               /* (n,F,3) */
+    float* target_quat_w;              /* (n,F,4) */
+    float* target_pos_source;          /* (n,F,3) */
+    float* target_quat_source;         /* (n,F,4) */
+} ilx_frame_transformer;
+int ilx_frame_transformer_update(const ilx_frame_transformer* sensor, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Contact sensor bookkeeping — source/isaaclab/isaaclab/sensors/contact_sensor/contact_sensor.py:314-373
  * plus the update timing of sensors/sensor_base.py:197-205,284-293.
  * ------------------------------------------------------------------------------------------------ */

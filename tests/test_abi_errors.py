@@ -264,6 +264,17 @@ def test_pose_and_camera_op_arguments():
     fails(_cylinder(1.0, 0.0, 1.0, NULL, 0, 0, NULL, 4, NULL), EINVAL, "out is NULL")
 
 
+def test_frame_transformer_arguments():
+    from isaaclab_amd.sensors.frame_transformer import FrameTransformerDesc, _update
+
+    fails(_update(ctypes.byref(FrameTransformerDesc(num_envs=4, num_frames=2)), NULL), EINVAL, "row indices are NULL")
+    rows = dict(transforms=FAKE, source_rows=FAKE, target_rows=FAKE)
+    fails(_update(ctypes.byref(FrameTransformerDesc(num_envs=4, num_frames=2, source_offset_pos=FAKE, **rows)), NULL), EINVAL,
+          "both its position and its orientation")
+    fails(_update(ctypes.byref(FrameTransformerDesc(num_envs=4, num_frames=2, **rows)), NULL), EINVAL, "NULL data buffer")
+    assert _update(ctypes.byref(FrameTransformerDesc(num_envs=4, num_frames=0)), NULL) == 0
+
+
 def test_sampler_arguments():
     fails(_abi.sample(9, NULL, 0, 0, 0.0, NULL, 0, 0, 1.0, NULL, NULL, 0, 1, FAKE, 4, 3, NULL), EINVAL, "unknown kind")
     fails(_abi.sample(4, NULL, 0, 0, 0.0, NULL, 0, 0, 1.0, NULL, NULL, 0, 1, FAKE, 4, 3, NULL), ESHAPE, "4 wide")
