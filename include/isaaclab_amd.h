@@ -219,6 +219,17 @@ int ilx_event_reset_root_state_uniform(const int64_t* env_ids, int64_t count, co
                                        const float* env_origins, const float* pose_range_host,
                                        const float* velocity_range_host, const float* u, uint64_t seed, uint64_t draw,
                                        float* root_state_w, void* stream);
+/* reset_root_state_from_terrain (:735-799): position = valid_positions[level[env], type[env], pick] + default root position
+ * (valid_positions (rows, cols, patches, 3) = terrain.flat_patches["init_pos"]), orientation = quat_from_euler_xyz of the
+ * sampled roll, pitch, yaw, velocity = default + sample.  patch_ids (count): the picks (torch.randint in the reference) or
+ * NULL: Philox.  u: (count, 9) = three angle draws then six velocity draws.  The reference adds the velocity samples to
+ * default_root_state[:, 7:13] without indexing it by env_ids, so it only runs when every env is listed and row k of the
+ * list takes the default velocity of env k; the same is done here. */
+int ilx_event_reset_root_state_from_terrain(const int64_t* env_ids, int64_t count, const float* default_root_state,
+                                            const float* valid_positions, const int64_t* terrain_levels, const int64_t* terrain_types,
+                                            int32_t num_terrain_cols, int32_t num_patches, const int64_t* patch_ids,
+                                            const float* pose_range_host, const float* velocity_range_host, const float* u,
+                                            uint64_t seed, uint64_t draw, float* root_state_w, void* stream);
 /* reset_joints_by_scale (:802-832, by_scale = 1) / reset_joints_by_offset (:835-866, by_scale = 0): default joint state
  * times / plus a sample, clamped to the soft position limits (n,j,2) and +-soft velocity limits (n,j); rows env_ids of
  * joint_pos / joint_vel (n,j).  u: (count, 2j) = position draws then velocity draws. */

@@ -114,6 +114,8 @@ raycast_mesh_stats = _sig("ilx_raycast_mesh_stats", P, P, P, c_int64, c_float, P
 
 
 c_uint64 = ctypes.c_uint64
+event_reset_root_state_from_terrain = _sig("ilx_event_reset_root_state_from_terrain", P, c_int64, P, P, P, P, c_int, c_int, P, P, P, P,
+                                          ctypes.c_uint64, ctypes.c_uint64, P, P)
 event_reset_root_state_uniform = _sig("ilx_event_reset_root_state_uniform", P, c_int64, P, P, P, P, P, c_uint64, c_uint64, P, P)
 event_reset_joints = _sig("ilx_event_reset_joints", c_int, P, c_int64, P, P, P, P, c_float, c_float, c_float, c_float, P, c_uint64,
                           c_uint64, P, P, c_int, P)

@@ -47,6 +47,39 @@ reset_root_kernel(const int64_t* __restrict__ ids, int64_t count, const float* _
     for (int c = 0; c < 6; ++c) out[7 + c] = d[7 + c] + rv[c];  // :677
 }
 
+// events.py:735-799, one thread per listed env: position = a flat patch of the env's own sub-terrain + default root
+// position, orientation from sampled euler angles, velocity = default + sample.  As in the reference the velocity takes
+// the default of row k (the position in the list), not of env_ids[k]: it reads default_root_state[:, 7:13] unindexed.
+struct TerrainPatches {
+    const float* valid_positions;  // (rows, cols, patches, 3)
+    const int64_t* levels;         // (n)
+    const int64_t* types;          // (n)
+    const int64_t* picks;          // (count) patch index per listed env, or null: Philox
+    int32_t cols, patches;
+};
+__global__ void __launch_bounds__(256)
+reset_root_from_terrain_kernel(const int64_t* __restrict__ ids, int64_t count, const float* __restrict__ def, TerrainPatches tp,
+                               Range6 pose, Range6 vel, EventRng rng, float* __restrict__ root) {
+    const int64_t k = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (k >= count) return;
+    const int64_t env = ids[k];
+    const int64_t pick = tp.picks ? tp.picks[k]
+                                  : static_cast<int64_t>(philox4(rng.seed, rng.draw, static_cast<uint64_t>(env), 0x20000000u).x %
+                                                         static_cast<uint32_t>(tp.patches));
+    const float* patch = tp.valid_positions + ((tp.levels[env] * tp.cols + tp.types[env]) * tp.patches + pick) * 3;
+    const float* d = def + 13 * env;
+    float* out = root + 13 * env;
+    out[0] = patch[0] + d[0], out[1] = patch[1] + d[1], out[2] = patch[2] + d[2];  // :779-780
+    float e[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) e[c] = ranged(draw01(rng, k, env, c), pose.lo[3 + c], pose.hi[3 + c]);  // :783-785
+    const f4 q = quat_from_euler_xyz(e[0], e[1], e[2]);                                                 // :788
+    out[3] = q.w, out[4] = q.x, out[5] = q.y, out[6] = q.z;
+    const float* dv = def + 13 * k + 7;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) out[7 + c] = dv[c] + ranged(draw01(rng, k, env, 3 + c), vel.lo[c], vel.hi[c]);  // :791-795
+}
+
 // events.py:802-866, one thread per (listed env, joint).
 __global__ void __launch_bounds__(256)
 reset_joints_kernel(int scale, const int64_t* __restrict__ ids, int64_t count, int j, const float* __restrict__ def_pos,
@@ -227,6 +260,25 @@ extern "C" int ilx_event_reset_root_state_uniform(const int64_t* env_ids, int64_
                        default_root_state, env_origins, range6(pose_range_host), range6(velocity_range_host),
                        EventRng{u, 12, seed, draw}, root_state_w);
     ILX_LAUNCH_CHECK("ilx_event_reset_root_state_uniform");
+    return ILX_OK;
+}
+
+extern "C" int ilx_event_reset_root_state_from_terrain(const int64_t* env_ids, int64_t count, const float* default_root_state,
+                                                       const float* valid_positions, const int64_t* terrain_levels,
+                                                       const int64_t* terrain_types, int32_t num_terrain_cols, int32_t num_patches,
+                                                       const int64_t* patch_ids, const float* pose_range_host,
+                                                       const float* velocity_range_host, const float* u, uint64_t seed, uint64_t draw,
+                                                       float* root_state_w, void* stream) {
+    ILX_REQUIRE(count >= 0, ILX_EINVAL, "ilx_event_reset_root_state_from_terrain: negative env count");
+    if (count == 0) return ILX_OK;
+    ILX_REQUIRE(env_ids && default_root_state && pose_range_host && velocity_range_host && root_state_w, ILX_EINVAL,
+                "ilx_event_reset_root_state_from_terrain: NULL operand");
+    ILX_REQUIRE(valid_positions && terrain_levels && terrain_types && num_terrain_cols > 0 && num_patches > 0, ILX_EINVAL,
+                "ilx_event_reset_root_state_from_terrain: the flat patches need their table, the envs' levels and types, and the table's shape");
+    hipLaunchKernelGGL(reset_root_from_terrain_kernel, dim3(blocks_for(count)), dim3(256), 0, as_stream(stream), env_ids, count,
+                       default_root_state, TerrainPatches{valid_positions, terrain_levels, terrain_types, patch_ids, num_terrain_cols, num_patches},
+                       range6(pose_range_host), range6(velocity_range_host), EventRng{u, 9, seed, draw}, root_state_w);
+    ILX_LAUNCH_CHECK("ilx_event_reset_root_state_from_terrain");
     return ILX_OK;
 }
 

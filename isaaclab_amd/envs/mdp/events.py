@@ -54,6 +54,34 @@ def reset_root_state_uniform(env, env_ids, pose_range: dict, velocity_range: dic
         asset.write_root_velocity_to_sim(d.root_state_w[ids, 7:], env_ids=ids)
 
 
+def reset_root_state_from_terrain(env, env_ids, pose_range: dict, velocity_range: dict, asset_cfg: SceneEntityCfg = SceneEntityCfg("robot"),
+                                  *, _u=None, _patch_ids=None):
+    """events.py:735-799.  ``_u`` (count, 9) / ``_patch_ids`` (count) replay given draws.  Like the reference, which adds the
+    velocity samples to the defaults of ALL envs, it only accepts the full env set."""
+    asset = env.scene[asset_cfg.name]
+    terrain = env.scene.terrain if hasattr(env.scene, "terrain") else env.scene["terrain"]
+    valid_positions = terrain.flat_patches.get("init_pos")
+    if valid_positions is None:
+        raise ValueError("The event term 'reset_root_state_from_terrain' requires valid flat patches under 'init_pos'."
+                         f" Found: {list(terrain.flat_patches.keys())}")
+    d = asset.data
+    n = d.root_state_w.shape[0]
+    ids = _ids(env_ids, n, d.root_state_w.device)
+    if ids.numel() != n:
+        raise RuntimeError(f"The size of tensor a ({n}) must match the size of tensor b ({ids.numel()}) at non-singleton dimension 0")
+    valid = _abi.f32c(valid_positions)
+    picks = None if _patch_ids is None else _patch_ids.to(device=ids.device, dtype=torch.long).contiguous()
+    up, seed, draw = _rng(env, _u)
+    _abi.check(_abi.event_reset_root_state_from_terrain(
+        ids.data_ptr(), ids.numel(), _abi.ptr(d.default_root_state), _abi.ptr(valid), terrain.terrain_levels.data_ptr(),
+        terrain.terrain_types.data_ptr(), valid.shape[1], valid.shape[2], None if picks is None else picks.data_ptr(),
+        _range12(pose_range), _range12(velocity_range), up, seed, draw, _abi.ptr(d.root_state_w), _abi.stream()),
+        "ilx_event_reset_root_state_from_terrain")
+    if hasattr(asset, "write_root_pose_to_sim"):
+        asset.write_root_pose_to_sim(d.root_state_w[ids, :7], env_ids=ids)
+        asset.write_root_velocity_to_sim(d.root_state_w[ids, 7:], env_ids=ids)
+
+
 def _reset_joints(by_scale, env, env_ids, position_range, velocity_range, asset_cfg, u):
     asset = env.scene[asset_cfg.name]
     d = asset.data

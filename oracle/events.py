@@ -70,3 +70,14 @@ def reset_scene_to_default(default_root_state, env_origins, default_joint_pos, d
     root = default_root_state.clone()
     root[:, 0:3] += env_origins
     return root, default_joint_pos.clone(), default_joint_vel.clone()
+
+
+def reset_root_state_from_terrain(default_root_state, valid_positions, levels, types, picks, pose_range: dict, velocity_range: dict, u):
+    """events.py:735-799 for the full env set: returns (pose (n,7), velocity (n,6)).  ``u`` (n,9): three angle draws, then six
+    velocity draws; ``picks`` (n): the patch chosen per env."""
+    pr, vr = ranges(pose_range), ranges(velocity_range)
+    positions = valid_positions[levels, types, picks] + default_root_state[:, :3]
+    angles = sample(u[:, :3], pr[3:, 0], pr[3:, 1])
+    orientations = M.quat_from_euler_xyz(angles[:, 0], angles[:, 1], angles[:, 2])
+    velocities = default_root_state[:, 7:13] + sample(u[:, 3:], vr[:, 0], vr[:, 1])
+    return torch.cat([positions, orientations], dim=-1), velocities

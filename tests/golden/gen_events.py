@@ -118,4 +118,26 @@ def events():
     ev.reset_scene_to_default(env, ids)
     out["default_pose"], out["default_vel"] = asset.calls[0][1], asset.calls[1][1]
     out["default_joint_pos_rows"], out["default_joint_vel_rows"] = asset.calls[2][1], asset.calls[2][2]
+    asset.calls.clear()
+    # reset_root_state_from_terrain (:735-799): randint picks, rand (n,3), rand (n,6).  It adds the velocity samples to the
+    # defaults of ALL envs, so only the full env set runs; a subset raises.
+    rows, cols, patches = 3, 4, 5
+    env.device = "cpu"
+    env.scene.terrain = types.SimpleNamespace(flat_patches={"init_pos": torch.randn(rows, cols, patches, 3, generator=g) * 6.0},
+                                              terrain_levels=torch.randint(0, rows, (n,), generator=g),
+                                              terrain_types=torch.randint(0, cols, (n,), generator=g))
+    all_ids = torch.arange(n)
+    torch.manual_seed(17)
+    ev.reset_root_state_from_terrain(env, all_ids, {"roll": (-0.2, 0.1), "yaw": (-3.14, 3.14)}, vel_range, cfg)
+    torch.manual_seed(17)
+    out["terrain_picks"] = torch.randint(0, patches, size=(n,))
+    out["terrain_u"] = torch.cat([torch.rand(n, 3), torch.rand(n, 6)], dim=1)
+    out["terrain_valid_positions"] = env.scene.terrain.flat_patches["init_pos"]
+    out["terrain_levels"], out["terrain_types"] = env.scene.terrain.terrain_levels, env.scene.terrain.terrain_types
+    out["terrain_pose"], out["terrain_vel"] = asset.calls[0][1], asset.calls[1][1]
+    try:
+        ev.reset_root_state_from_terrain(env, ids, {}, vel_range, cfg)
+        raise SystemExit("the reference accepted a subset of envs")
+    except RuntimeError as e:
+        print("subset of envs:", str(e)[:90])
     save("events", **out)

@@ -275,6 +275,15 @@ def test_frame_transformer_arguments():
     assert _update(ctypes.byref(FrameTransformerDesc(num_envs=4, num_frames=0)), NULL) == 0
 
 
+def test_reset_from_terrain_arguments():
+    r12 = (ctypes.c_float * 12)()
+    fails(_abi.event_reset_root_state_from_terrain(FAKE, 4, FAKE, NULL, FAKE, FAKE, 3, 5, NULL, r12, r12, NULL, 0, 0, FAKE, NULL), EINVAL,
+          "flat patches need their table")
+    fails(_abi.event_reset_root_state_from_terrain(FAKE, 4, NULL, FAKE, FAKE, FAKE, 3, 5, NULL, r12, r12, NULL, 0, 0, FAKE, NULL), EINVAL,
+          "NULL operand")
+    assert _abi.event_reset_root_state_from_terrain(NULL, 0, NULL, NULL, NULL, NULL, 0, 0, NULL, NULL, NULL, NULL, 0, 0, NULL, NULL) == 0
+
+
 def test_sampler_arguments():
     fails(_abi.sample(9, NULL, 0, 0, 0.0, NULL, 0, 0, 1.0, NULL, NULL, 0, 1, FAKE, 4, 3, NULL), EINVAL, "unknown kind")
     fails(_abi.sample(4, NULL, 0, 0, 0.0, NULL, 0, 0, 1.0, NULL, NULL, 0, 1, FAKE, 4, 3, NULL), ESHAPE, "4 wide")

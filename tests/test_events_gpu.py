@@ -137,3 +137,30 @@ def test_random_orientation_wrench_and_default_events(dev):
     assert_exact(d.joint_pos[idd], g["default_joint_pos_rows"], "default joint positions")
     assert_exact(d.joint_vel[idd], g["default_joint_vel_rows"], "default joint velocities")
     assert float((d.joint_pos[others] - 9.0).abs().max()) == 0
+
+
+def test_reset_root_state_from_terrain(dev):
+    from isaaclab_amd.envs import mdp
+
+    g = load_golden("events")
+    env, d = _env(g, dev)
+    n = d.root_state_w.shape[0]
+    env.scene.terrain = types.SimpleNamespace(flat_patches={"init_pos": g["terrain_valid_positions"].to(dev)},
+                                              terrain_levels=g["terrain_levels"].to(dev), terrain_types=g["terrain_types"].to(dev))
+    pose_range = {"roll": (-0.2, 0.1), "yaw": (-3.14, 3.14)}
+    mdp.reset_root_state_from_terrain(env, torch.arange(n, device=dev), pose_range, VEL, _u=g["terrain_u"].to(dev),
+                                      _patch_ids=g["terrain_picks"].to(dev))
+    assert_exact(d.root_state_w[:, :3], g["terrain_pose"][:, :3], "root position on a flat patch")
+    assert_close(d.root_state_w[:, 3:7], g["terrain_pose"][:, 3:], atol=1e-6, what="root orientation")
+    assert_exact(d.root_state_w[:, 7:], g["terrain_vel"], "root velocity")
+    # generated picks and draws: every env lands on one of the patches of its own sub-terrain
+    mdp.reset_root_state_from_terrain(env, None, pose_range, VEL)
+    own = g["terrain_valid_positions"][g["terrain_levels"], g["terrain_types"]] + g["default_root_state"][:, None, :3]
+    gap = (own - d.root_state_w[:, None, :3].cpu()).abs().amax(dim=-1).amin(dim=-1)
+    assert float(gap.max()) < 1e-5
+    # the reference adds the samples to the default velocity of ALL envs: a subset fails there, and here
+    with pytest.raises(RuntimeError, match="must match the size of tensor b"):
+        mdp.reset_root_state_from_terrain(env, g["env_ids"].to(dev), pose_range, VEL)
+    env.scene.terrain.flat_patches = {"target": None}
+    with pytest.raises(ValueError, match="requires valid flat patches under 'init_pos'"):
+        mdp.reset_root_state_from_terrain(env, None, pose_range, VEL)

@@ -43,3 +43,12 @@ def test_random_orientation_wrench_and_default_events():
     assert_exact(root[:, 7:], g["default_vel"], "default velocity")
     assert_exact(q, g["default_joint_pos_rows"], "default joint positions")
     assert_exact(qd, g["default_joint_vel_rows"], "default joint velocities")
+
+
+def test_reset_root_state_from_terrain():
+    g = load_golden("events")
+    pose, vel = E.reset_root_state_from_terrain(g["default_root_state"], g["terrain_valid_positions"], g["terrain_levels"], g["terrain_types"],
+                                                g["terrain_picks"], {"roll": (-0.2, 0.1), "yaw": (-3.14, 3.14)}, VEL, g["terrain_u"])
+    assert_exact(pose[:, :3], g["terrain_pose"][:, :3], "root position on a flat patch")
+    assert_close(pose[:, 3:], g["terrain_pose"][:, 3:], atol=1e-6, what="root orientation")
+    assert_exact(vel, g["terrain_vel"], "root velocity")
