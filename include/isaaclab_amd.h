@@ -409,6 +409,20 @@ int ilx_modifier_apply(int32_t kind, const ilx_modifier* mod, void* stream);
 int ilx_modifier_reset(float* state_a, int64_t len_a, float* state_b, int64_t len_b, const int64_t* env_ids, int64_t count, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Flat-patch search — source/isaaclab/isaaclab/terrains/utils.py:135-273 (find_flat_patches); one round of its rejection
+ * sampling is ilx_flat_patch_rays, ilx_raycast_mesh (z-parallel rays), ilx_flat_patch_check.
+ * ------------------------------------------------------------------------------------------------ */
+
+/* utils.py:236-244: for the count candidate patches (rows patch_ids of flat_patches (num_patches,3)) write the sampled
+ * centre (x, y) and build the rays: starts (count, ring_points, 3) = centre + ring (ring_points,3) at z = 100, directions -z. */
+int ilx_flat_patch_rays(const float* centre_x, const float* centre_y, const float* ring, const int64_t* patch_ids, int64_t count,
+                        int32_t ring_points, float* flat_patches, float* ray_starts, float* ray_directions, void* stream);
+/* utils.py:248-258: patch height = height of the last ring point; not_valid[k] = any height outside [z_lo, z_hi] or
+ * max - min > max_height_diff. */
+int ilx_flat_patch_check(const float* ray_hits, const int64_t* patch_ids, int64_t count, int32_t ring_points, float z_lo, float z_hi,
+                         float max_height_diff, float* flat_patches, uint8_t* not_valid, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Homogeneous poses and camera geometry — source/isaaclab/isaaclab/utils/math.py
  * ------------------------------------------------------------------------------------------------ */
 #define ILX_POSE_MAKE 0         /* math.py:1564-1583  a (n,3) positions, b (n,3,3) rotations -> out (n,4,4) */

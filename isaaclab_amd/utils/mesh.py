@@ -23,6 +23,7 @@ class Mesh:
         idx = np.ascontiguousarray(np.asarray(indices, dtype=np.int32).reshape(-1, 3))
         self.device = torch.device(device)
         self.num_vertices, self.num_triangles = pts.shape[0], idx.shape[0]
+        self.bounds_min, self.bounds_max = (pts.min(axis=0), pts.max(axis=0)) if pts.shape[0] else (np.zeros(3), np.zeros(3))
         self.handle = ctypes.c_void_p()
         with torch.cuda.device(self.device):
             _abi.check(_abi.mesh_create(pts.ctypes.data, pts.shape[0], idx.ctypes.data, idx.shape[0],

@@ -284,6 +284,15 @@ def test_reset_from_terrain_arguments():
     assert _abi.event_reset_root_state_from_terrain(NULL, 0, NULL, NULL, NULL, NULL, 0, 0, NULL, NULL, NULL, NULL, 0, 0, NULL, NULL) == 0
 
 
+def test_flat_patch_arguments():
+    from isaaclab_amd.terrains.utils import _check, _rays
+
+    fails(_rays(FAKE, FAKE, FAKE, FAKE, 4, 0, FAKE, FAKE, FAKE, NULL), EINVAL, "bad shape")
+    fails(_rays(FAKE, NULL, FAKE, FAKE, 4, 10, FAKE, FAKE, FAKE, NULL), EINVAL, "NULL operand")
+    fails(_check(NULL, FAKE, 4, 10, 0.0, 1.0, 0.1, FAKE, FAKE, NULL), EINVAL, "NULL operand")
+    assert _check(NULL, NULL, 0, 10, 0.0, 1.0, 0.1, NULL, NULL, NULL) == 0
+
+
 def test_sampler_arguments():
     fails(_abi.sample(9, NULL, 0, 0, 0.0, NULL, 0, 0, 1.0, NULL, NULL, 0, 1, FAKE, 4, 3, NULL), EINVAL, "unknown kind")
     fails(_abi.sample(4, NULL, 0, 0, 0.0, NULL, 0, 0, 1.0, NULL, NULL, 0, 1, FAKE, 4, 3, NULL), ESHAPE, "4 wide")
