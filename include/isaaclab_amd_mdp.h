@@ -95,13 +95,17 @@ enum ilx_observation_kind {
     ILX_OBS_HEIGHT_SCAN = 13,              /* :165  offset in the term's `aux` field */
     ILX_OBS_LAST_ACTION = 14,              /* :512 */
     ILX_OBS_GENERATED_COMMANDS = 15,       /* :529 */
-    ILX_OBS_KIND_COUNT = 16
+    ILX_OBS_EXTERNAL = 16,                 /* :177 body_incoming_wrench, :188 imu_orientation, :204 imu_ang_vel, :220 imu_lin_acc:
+                                              a per-env buffer kept by another component, copied as it is; `aux` = slot in
+                                              ilx_mdp.external_obs */
+    ILX_OBS_KIND_COUNT = 17
 };
 
 #define ILX_OBS_FLAG_NOISE 1
 #define ILX_OBS_FLAG_CLIP 2
 #define ILX_OBS_FLAG_SCALE 4
 #define ILX_OBS_FLAG_QUAT_UNIQUE 8
+#define ILX_MAX_EXTERNAL_OBS 4
 
 typedef struct ilx_term {
     int32_t kind;
@@ -213,6 +217,9 @@ typedef struct ilx_mdp {
     uint64_t seed;
     uint64_t step_index;
     int32_t phases;
+    /* buffers read by ILX_OBS_EXTERNAL terms: slot s is (n, external_obs_dim[s]) float32, dense */
+    const float* external_obs[ILX_MAX_EXTERNAL_OBS];
+    int32_t external_obs_dim[ILX_MAX_EXTERNAL_OBS];
 } ilx_mdp;
 
 /* Opaque prepared plan: term tables and id lists copied to the device once. */

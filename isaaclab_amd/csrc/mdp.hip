@@ -315,6 +315,7 @@ ILX_DEV int obs_dim_of(const ilx_mdp& d, const ilx_term& t) {
         case ILX_OBS_HEIGHT_SCAN: return d.num_rays;
         case ILX_OBS_LAST_ACTION: return d.action_dim;
         case ILX_OBS_GENERATED_COMMANDS: return d.command_dim;
+        case ILX_OBS_EXTERNAL: return d.external_obs_dim[static_cast<int>(t.aux)];
     }
     return 0;
 }
@@ -359,6 +360,10 @@ ILX_DEV float eval_obs(const MdpDev& m, const float* S, const int32_t* ids, int 
             return der[9] - d.ray_hits_w[3 * (env * d.num_rays + k) + 2] - t.aux;
         case ILX_OBS_LAST_ACTION: return S[L.act + e * d.action_dim + k];          // :512-521
         case ILX_OBS_GENERATED_COMMANDS: return S[L.cmd + e * d.command_dim + k];  // :529-531
+        case ILX_OBS_EXTERNAL: {  // a buffer another component keeps per env (:177-230: body wrench, IMU readings)
+            const int slot = static_cast<int>(t.aux);
+            return d.external_obs[slot][env * d.external_obs_dim[slot] + k];
+        }
     }
     return 0.0f;
 }
@@ -796,6 +801,7 @@ struct ilx_mdp_plan_s {
     bool r_contact = false, r_timers = false, r_body_state = false, r_body_vel = false, r_body_acc = false, r_joint = false,
          r_action = false, r_rays = false, r_command = false;
     bool o_joint = false, o_rays = false, o_action = false, o_command = false;
+    uint32_t o_external = 0;  // slots of the external observation buffers the plan reads
 };
 
 static int host_obs_dim(const ilx_mdp& d, const ilx_term& t) {
@@ -808,6 +814,7 @@ static int host_obs_dim(const ilx_mdp& d, const ilx_term& t) {
         case ILX_OBS_HEIGHT_SCAN: return d.num_rays;
         case ILX_OBS_LAST_ACTION: return d.action_dim;
         case ILX_OBS_GENERATED_COMMANDS: return d.command_dim;
+        case ILX_OBS_EXTERNAL: return d.external_obs_dim[static_cast<int>(t.aux)];
         default: return 3;
     }
 }
@@ -863,6 +870,12 @@ static int validate_terms(const ilx_mdp& d) {
         ILX_REQUIRE(t.kind >= 0 && t.kind < ILX_OBS_KIND_COUNT, ILX_EINVAL, "ilx_mdp: unknown observation kind %d", t.kind);
         const int rc = ids_ok(t, d.num_joints, "observation");
         if (rc != ILX_OK) return rc;
+        if (t.kind == ILX_OBS_EXTERNAL) {
+            const int slot = static_cast<int>(t.aux);
+            ILX_REQUIRE(t.aux >= 0.0f && slot < ILX_MAX_EXTERNAL_OBS && static_cast<float>(slot) == t.aux, ILX_EINVAL,
+                        "ilx_mdp: an external observation names slot %g of %d", static_cast<double>(t.aux), ILX_MAX_EXTERNAL_OBS);
+            ILX_REQUIRE(d.external_obs_dim[slot] > 0, ILX_ESHAPE, "ilx_mdp: external observation slot %d has no width", slot);
+        }
         dim += host_obs_dim(d, t);
     }
     ILX_REQUIRE(dim == d.obs_dim, ILX_ESHAPE, "ilx_mdp: observation terms add up to %d columns, obs_dim is %d", dim, d.obs_dim);
@@ -907,6 +920,7 @@ extern "C" int ilx_mdp_plan_create(const ilx_mdp* desc, ilx_mdp_plan_t* out) {
         p->o_rays |= k == ILX_OBS_HEIGHT_SCAN;
         p->o_action |= k == ILX_OBS_LAST_ACTION;
         p->o_command |= k == ILX_OBS_GENERATED_COMMANDS;
+        if (k == ILX_OBS_EXTERNAL) p->o_external |= 1u << static_cast<int>(d.observations[i].aux);
     }
     std::vector<ilx_term> all;
     all.insert(all.end(), d.terminations, d.terminations + d.num_terminations);
@@ -1003,6 +1017,9 @@ extern "C" int ilx_mdp_step(ilx_mdp_plan_t plan, const ilx_mdp* desc, void* stre
     if (d.phases & ILX_PHASE_OBSERVATION) {
         ILX_REQUIRE(!plan->o_joint || joints, ILX_EINVAL, "ilx_mdp_step: an observation term needs the joint state arrays");
         ILX_REQUIRE(!plan->o_rays || (d.ray_hits_w && d.sensor_pos_w), ILX_EINVAL, "ilx_mdp_step: height_scan needs ray_hits_w and sensor_pos_w");
+        for (int slot = 0; slot < ILX_MAX_EXTERNAL_OBS; ++slot)
+            ILX_REQUIRE(!(plan->o_external & (1u << slot)) || d.external_obs[slot], ILX_EINVAL,
+                        "ilx_mdp_step: external observation buffer %d is NULL", slot);
         ILX_REQUIRE(!plan->o_action || d.action, ILX_EINVAL, "ilx_mdp_step: last_action needs the action tensor");
         ILX_REQUIRE(!plan->o_command || d.command, ILX_EINVAL, "ilx_mdp_step: generated_commands needs the command tensor");
     }

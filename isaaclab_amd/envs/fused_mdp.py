@@ -30,7 +30,8 @@ TERM = {name: i for i, name in enumerate([
 OBS = {name: i for i, name in enumerate([
     "base_pos_z", "base_lin_vel", "base_ang_vel", "projected_gravity", "root_pos_w", "root_quat_w", "root_lin_vel_w",
     "root_ang_vel_w", "joint_pos", "joint_pos_rel", "joint_pos_limit_normalized", "joint_vel", "joint_vel_rel",
-    "height_scan", "last_action", "generated_commands"])}
+    "height_scan", "last_action", "generated_commands", "external"])}
+MAX_EXTERNAL_OBS = 4
 OBS_NOISE, OBS_CLIP, OBS_SCALE, OBS_QUAT_UNIQUE = 1, 2, 4, 8
 CMD_NONE, CMD_VELOCITY, CMD_POSE = 0, 1, 2
 PHASE_TERMINATION, PHASE_REWARD, PHASE_RESET, PHASE_COMMAND, PHASE_OBSERVATION, PHASE_ALL = 1, 2, 4, 8, 16, 31
@@ -72,6 +73,7 @@ class MdpDesc(ctypes.Structure):
         ("num_observations", c_int32), ("observations", POINTER(Term)), ("obs", c_void_p), ("noise_u", c_void_p),
         ("ids", POINTER(c_int32)), ("num_ids", c_int32),
         ("log_sums", c_void_p), ("seed", c_uint64), ("step_index", c_uint64), ("phases", c_int32),
+        ("external_obs", c_void_p * 4), ("external_obs_dim", c_int32 * 4),
     ]
 
 
@@ -130,7 +132,7 @@ class FusedMdp:
                  history_len: int = 0, num_rays: int = 0, action_dim: int = 0, command_dim: int = 3,
                  terminations=(), rewards=(), observations=(), step_dt: float = 0.02, max_episode_length: int = 1000,
                  max_episode_length_s: float | None = None, gravity=(0.0, 0.0, -1.0), command: dict | None = None,
-                 seed: int = 0):
+                 seed: int = 0, external_obs_dims=()):
         self.n, self.device = num_envs, torch.device(device)
         self.terminations, self.rewards, self.observations = list(terminations), list(rewards), list(observations)
         d = self.desc = MdpDesc()
@@ -142,6 +144,11 @@ class FusedMdp:
         d.max_episode_length_s = max_episode_length * step_dt if max_episode_length_s is None else max_episode_length_s
         d.gravity_dir = (c_float * 3)(*gravity)
         d.seed, d.step_index, d.phases = seed, 0, PHASE_ALL
+        if len(external_obs_dims) > MAX_EXTERNAL_OBS:
+            raise ValueError(f"a plan reads at most {MAX_EXTERNAL_OBS} external observation buffers, not {len(external_obs_dims)}")
+        for slot, width in enumerate(external_obs_dims):   # widths of the buffers ILX_OBS_EXTERNAL terms copy (slot = the term's aux)
+            d.external_obs_dim[slot] = int(width)
+        self._external: dict[int, torch.Tensor] = {}
         # id lists
         ids: list[int] = []
 
@@ -217,7 +224,7 @@ class FusedMdp:
         nj = d.num_joints if _norm_ids(s.ids) is None else len(_norm_ids(s.ids))
         return {"base_pos_z": 1, "root_quat_w": 4, "joint_pos": nj, "joint_pos_rel": nj, "joint_pos_limit_normalized": nj,
                 "joint_vel": nj, "joint_vel_rel": nj, "height_scan": d.num_rays, "last_action": d.action_dim,
-                "generated_commands": d.command_dim}.get(s.kind, 3)
+                "generated_commands": d.command_dim, "external": d.external_obs_dim[int(s.aux)] if s.kind == "external" else 0}.get(s.kind, 3)
 
     def _own(self, name: str, t: torch.Tensor):
         self.bind(**{name: t})
@@ -233,6 +240,15 @@ class FusedMdp:
                 raise _abi.IlxError(f"FusedMdp.bind({name}): need a contiguous GPU tensor")
             self.t[name] = t
             setattr(self.desc, name, t.data_ptr())
+
+    def bind_external(self, slot: int, t: torch.Tensor):
+        """Attach the (num_envs, width) buffer an ``external`` observation term copies."""
+        if not t.is_cuda or not t.is_contiguous() or t.dtype != torch.float32:
+            raise _abi.IlxError(f"FusedMdp.bind_external({slot}): need a contiguous float32 GPU tensor")
+        if t.numel() != self.n * self.desc.external_obs_dim[slot]:
+            raise ValueError(f"external observation {slot}: {tuple(t.shape)} is not ({self.n}, {self.desc.external_obs_dim[slot]})")
+        self._external[slot] = t
+        self.desc.external_obs[slot] = t.data_ptr()
 
     def step(self, phases: int = PHASE_ALL, step_index: int | None = None):
         self.desc.phases = phases

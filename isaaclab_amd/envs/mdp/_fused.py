@@ -31,6 +31,7 @@ class Spec:
     ray: str | None = None           # ray caster entity
     command: str | None = None       # command term name
     term_names: list | None = None   # is_terminated_term: termination terms to count
+    external: object = None          # kind "external": env -> the (num_envs, ...) tensor the term hands out as it is
 
     def bindings(self):
         return (self.asset, self.contact, self.ray, self.command)
@@ -160,7 +161,12 @@ def make_plan(env, group: str, specs, weights=None, posts=None, step_dt: float =
     asset, contact, ray, command = bindings if bindings is not None else specs[0].bindings()
     sz = sizes(env, asset, contact, ray, command)
     terms = []
+    external_dims = []
     for i, s in enumerate(specs):
+        if s.kind == "external":      # the term's slot among the plan's external buffers travels in `aux`
+            n = env.num_envs
+            s.aux = float(len(external_dims))
+            external_dims.append(s.external(env).numel() // max(n, 1))
         t = to_termspec(group, s, 1.0 if weights is None else weights[i], None if posts is None else posts[i])
         if group == "termination" and time_out_flags is not None and time_out_flags[i]:
             t.flags |= 1
@@ -178,7 +184,7 @@ def make_plan(env, group: str, specs, weights=None, posts=None, step_dt: float =
     extra[kw] = terms
     max_len = int(getattr(env, "max_episode_length", 1000))
     return FM.FusedMdp(env.num_envs, env.device, step_dt=step_dt, max_episode_length=max_len,
-                       command={"kind": "none"}, **sz, **extra)
+                       command={"kind": "none"}, external_obs_dims=external_dims, **sz, **extra)
 
 
 _PHASE = {"termination": FM.PHASE_TERMINATION, "reward": FM.PHASE_REWARD, "observation": FM.PHASE_OBSERVATION}
@@ -186,6 +192,9 @@ _PHASE = {"termination": FM.PHASE_TERMINATION, "reward": FM.PHASE_REWARD, "obser
 
 def run_plan(mdp: FM.FusedMdp, env, group: str, specs, bindings=None):
     bind_env(mdp, env, *(bindings if bindings is not None else specs[0].bindings()))
+    for s in specs:
+        if s.kind == "external":
+            mdp.bind_external(int(s.aux), _abi.f32c(s.external(env)).reshape(env.num_envs, -1))
     if group == "reward" and mdp.desc.num_terminations > 0:
         tm = env.termination_manager
         mdp.bind(terminated=tm.terminated, time_outs=tm.time_outs, term_dones=tm.term_dones_tensor())

@@ -90,3 +90,33 @@ def last_action(action_name: str | None = None):  # :512-521
 @observation_term
 def generated_commands(command_name: str):  # :529-531
     return Spec("generated_commands", asset=None, command=command_name)
+
+
+# ---- terms that hand out a buffer another component keeps (observations.py:177-230): copied into the row by the fused launch
+def _sensor(env, name):
+    sensors = getattr(env.scene, "sensors", None)
+    return sensors[name] if sensors is not None and name in sensors else env.scene[name]
+
+
+@observation_term
+def body_incoming_wrench(asset_cfg: SceneEntityCfg):  # :177-185
+    def read(env):
+        asset = env.scene[asset_cfg.name]
+        forces = asset.root_physx_view.get_link_incoming_joint_force()[:, asset_cfg.body_ids]
+        return forces.reshape(env.num_envs, -1)
+    return Spec("external", asset=None, external=read)
+
+
+@observation_term
+def imu_orientation(asset_cfg: SceneEntityCfg = SceneEntityCfg("imu")):  # :188-201
+    return Spec("external", asset=None, external=lambda env: _sensor(env, asset_cfg.name).data.quat_w)
+
+
+@observation_term
+def imu_ang_vel(asset_cfg: SceneEntityCfg = SceneEntityCfg("imu")):  # :204-217
+    return Spec("external", asset=None, external=lambda env: _sensor(env, asset_cfg.name).data.ang_vel_b)
+
+
+@observation_term
+def imu_lin_acc(asset_cfg: SceneEntityCfg = SceneEntityCfg("imu")):  # :220-231
+    return Spec("external", asset=None, external=lambda env: _sensor(env, asset_cfg.name).data.lin_acc_b)
