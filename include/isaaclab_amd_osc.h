@@ -76,6 +76,48 @@ int ilx_osc_compute(const ilx_osc* osc, int has_pose_target, int has_wrench_targ
                     const float* current_joint_vel, const float* nullspace_joint_pos_target, float* joint_efforts,
                     void* stream);
 
+/* State assembly of OperationalSpaceControllerAction (envs/mdp/actions/task_space_actions.py:568-662), one launch:
+ *   ee_pose_b_no_offset = subtract_frame_transforms(root pose, body pose of ee_body_idx)            (:597-608)
+ *   ee_pose_b           = combine_frame_transforms(ee_pose_b_no_offset, offset) when has_offset     (:610-615)
+ *   ee_vel_b            = quat_rotate_inverse(root_quat, body velocity - root velocity), linear part
+ *                         += angular x quat_rotate(ee_quat_b_no_offset, offset_pos) when has_offset  (:617-634)
+ *   ee_force_b          = quat_rotate_inverse(root_quat, ee_force_w)                                 (:636-643)
+ *   jacobian_b (n,6,dof) = R(root_quat)^-1 applied to the linear and angular rows of
+ *                         jacobians[:, jac_body_idx, :, jac_joint_ids]; with an offset the linear rows
+ *                         += -skew(offset_pos) @ angular rows, angular rows = R(offset_rot) @ angular rows  (:400-410, 576-595)
+ *   mass_matrix (n,dof,dof), gravity (n,dof), joint_pos_out / joint_vel_out (n,dof): rows / columns joint_ids of the
+ *                         articulation's tensors                                                   (:568-574, 645-649)
+ * pose_only = 1 stops after the pose (what process_actions needs, :424-425). */
+typedef struct ilx_osc_action_state {
+    int64_t num_envs;
+    int32_t num_dof, num_joints, num_bodies, ee_body_idx;
+    int32_t jac_bodies, jac_cols, jac_body_idx;   /* jacobians: (n, jac_bodies, 6, jac_cols) as root_physx_view.get_jacobians() */
+    int32_t has_offset, pose_only;
+    float offset_pos[3], offset_rot[4];           /* body_offset.pos / .rot (w,x,y,z) */
+    const int32_t* joint_ids;                     /* (dof) device: controlled joints among the articulation's joints */
+    const int32_t* jac_joint_ids;                 /* (dof) device: their Jacobian columns (+6 on a floating base) */
+    const float* root_state_w;                    /* (n,13) */
+    const float* body_state_w;                    /* (n,bodies,13) */
+    const float* jacobians;
+    const float* mass_matrices;                   /* (n,joints,joints) get_generalized_mass_matrices(), or NULL */
+    const float* gravity_forces;                  /* (n,joints) get_gravity_compensation_forces(), or NULL */
+    const float* joint_pos;                       /* (n,joints) */
+    const float* joint_vel;
+    const float* ee_force_w;                      /* (n,3) contact sensor net force on the end-effector, or NULL */
+    float* ee_pose_w;                             /* (n,7) or NULL */
+    float* ee_pose_b;                             /* (n,7) */
+    float* ee_pose_b_no_offset;                   /* (n,7) or NULL */
+    float* ee_vel_w;                              /* (n,6) or NULL */
+    float* ee_vel_b;                              /* (n,6) */
+    float* ee_force_b;                            /* (n,3) or NULL */
+    float* jacobian_b;                            /* (n,6,dof) */
+    float* mass_matrix;                           /* (n,dof,dof) */
+    float* gravity;                               /* (n,dof) */
+    float* joint_pos_out;                         /* (n,dof) */
+    float* joint_vel_out;
+} ilx_osc_action_state;
+int ilx_osc_action_state_update(const ilx_osc_action_state* state, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,4 +1,5 @@
-from .task_space_actions import DifferentialInverseKinematicsAction, DifferentialInverseKinematicsActionCfg, OffsetCfg  # noqa: F401
+from .task_space_actions import (DifferentialInverseKinematicsAction, DifferentialInverseKinematicsActionCfg, OffsetCfg,  # noqa: F401
+                                 OperationalSpaceControllerAction, OperationalSpaceControllerActionCfg)
 from .joint_actions import (JointAction, JointActionCfg, JointEffortAction, JointEffortActionCfg, JointPositionAction,  # noqa: F401
                             JointPositionActionCfg, JointVelocityAction, JointVelocityActionCfg, RelativeJointPositionAction,
                             RelativeJointPositionActionCfg)

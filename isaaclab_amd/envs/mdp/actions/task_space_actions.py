@@ -153,3 +153,273 @@ class DifferentialInverseKinematicsAction:
 
     def reset(self, env_ids: Sequence[int] | None = None) -> None:
         self._raw_actions[env_ids] = 0.0
+
+
+# ---- operational-space control (task_space_actions.py:232-700) ---------------------------------------------------------
+class OscActionStateDesc(ctypes.Structure):
+    """Mirror of ``ilx_osc_action_state`` (include/isaaclab_amd_osc.h)."""
+
+    _fields_ = [
+        ("num_envs", ctypes.c_int64), ("num_dof", ctypes.c_int32), ("num_joints", ctypes.c_int32), ("num_bodies", ctypes.c_int32),
+        ("ee_body_idx", ctypes.c_int32), ("jac_bodies", ctypes.c_int32), ("jac_cols", ctypes.c_int32), ("jac_body_idx", ctypes.c_int32),
+        ("has_offset", ctypes.c_int32), ("pose_only", ctypes.c_int32), ("offset_pos", ctypes.c_float * 3), ("offset_rot", ctypes.c_float * 4),
+        ("joint_ids", ctypes.c_void_p), ("jac_joint_ids", ctypes.c_void_p), ("root_state_w", ctypes.c_void_p),
+        ("body_state_w", ctypes.c_void_p), ("jacobians", ctypes.c_void_p), ("mass_matrices", ctypes.c_void_p),
+        ("gravity_forces", ctypes.c_void_p), ("joint_pos", ctypes.c_void_p), ("joint_vel", ctypes.c_void_p), ("ee_force_w", ctypes.c_void_p),
+        ("ee_pose_w", ctypes.c_void_p), ("ee_pose_b", ctypes.c_void_p), ("ee_pose_b_no_offset", ctypes.c_void_p),
+        ("ee_vel_w", ctypes.c_void_p), ("ee_vel_b", ctypes.c_void_p), ("ee_force_b", ctypes.c_void_p), ("jacobian_b", ctypes.c_void_p),
+        ("mass_matrix", ctypes.c_void_p), ("gravity", ctypes.c_void_p), ("joint_pos_out", ctypes.c_void_p), ("joint_vel_out", ctypes.c_void_p),
+    ]
+
+
+_osc_state = _abi._sig("ilx_osc_action_state_update", ctypes.POINTER(OscActionStateDesc), _abi.P)
+
+
+@dataclass
+class OperationalSpaceControllerActionCfg:
+    """actions_cfg.py (OperationalSpaceControllerActionCfg)."""
+
+    asset_name: str = "robot"
+    joint_names: list[str] = field(default_factory=lambda: [".*"])
+    body_name: str = ""
+    body_offset: OffsetCfg | None = None
+    task_frame_rel_path: str | None = None
+    controller_cfg: object = None
+    position_scale: float = 1.0
+    orientation_scale: float = 1.0
+    wrench_scale: float = 1.0
+    stiffness_scale: float = 1.0
+    damping_ratio_scale: float = 1.0
+    nullspace_joint_pos_target: str = "none"
+    debug_vis: bool = False
+    class_type: type = None
+
+    def __post_init__(self):
+        self.class_type = self.class_type or OperationalSpaceControllerAction
+
+
+class OperationalSpaceControllerAction:
+    """task_space_actions.py:232-700.  ``process_actions`` is three launches (end-effector pose, action scaling and clamping,
+    controller command) and ``apply_actions`` two (state assembly, controller).
+
+    The asset is duck-typed as for the IK term, plus ``root_physx_view.get_generalized_mass_matrices()`` /
+    ``get_gravity_compensation_forces()`` and ``set_joint_effort_target``.  What the reference creates on the USD stage is
+    handed in instead: ``contact_sensor`` (a sensor on the end-effector body, for closed-loop wrench control) and
+    ``task_frame_transformer`` (a FrameTransformer whose first target is the task frame), both optional.
+    """
+
+    def __init__(self, cfg: OperationalSpaceControllerActionCfg, env, contact_sensor=None, task_frame_transformer=None):
+        from ....controllers.operational_space import OperationalSpaceController
+
+        self.cfg, self._env = cfg, env
+        self._asset = env.scene[cfg.asset_name]
+        self.num_envs, self.device = env.num_envs, torch.device(env.device)
+        a, dev, n = self._asset, self.device, self.num_envs
+        self._sim_dt = env.sim.get_physics_dt() if hasattr(env, "sim") else getattr(env, "physics_dt", 0.0)
+        self._joint_ids, self._joint_names = a.find_joints(cfg.joint_names)
+        self._num_DoF = len(self._joint_ids)
+        body_ids, body_names = a.find_bodies(cfg.body_name)
+        if len(body_ids) != 1:
+            raise ValueError(f"Expected one match for the ee body name: {cfg.body_name}. Found {len(body_ids)}: {body_names}.")
+        self._ee_body_idx, self._ee_body_name = body_ids[0], body_names[0]
+        if a.is_fixed_base:  # :266-274
+            self._jacobi_ee_body_idx, self._jacobi_joint_idx = self._ee_body_idx - 1, list(self._joint_ids)
+        else:
+            self._jacobi_ee_body_idx, self._jacobi_joint_idx = self._ee_body_idx, [i + 6 for i in self._joint_ids]
+        self._joint_ids_dev = torch.tensor(list(self._joint_ids), dtype=torch.int32, device=dev)
+        self._jacobi_cols_dev = torch.tensor(self._jacobi_joint_idx, dtype=torch.int32, device=dev)
+        if self._num_DoF == a.num_joints:
+            self._joint_ids = slice(None)
+        if cfg.body_offset is not None:
+            self._offset_pos = torch.tensor(cfg.body_offset.pos, device=dev).repeat(n, 1)
+            self._offset_rot = torch.tensor(cfg.body_offset.rot, device=dev).repeat(n, 1)
+        else:
+            self._offset_pos, self._offset_rot = None, None
+        ctrl = cfg.controller_cfg
+        self._contact_sensor = None
+        if "wrench_abs" in ctrl.target_types and ctrl.contact_wrench_stiffness_task is not None:   # :296-305
+            if contact_sensor is None:
+                raise ValueError("closed-loop wrench control (contact_wrench_stiffness_task) needs the end-effector's contact sensor")
+            self._contact_sensor = contact_sensor
+        self._task_frame_transformer = None
+        self._task_frame_pose_b = None
+        if cfg.task_frame_rel_path is not None:                                                    # :307-331
+            if task_frame_transformer is None:
+                raise ValueError("task_frame_rel_path is set: the FrameTransformer that tracks the task frame must be handed in")
+            self._task_frame_transformer = task_frame_transformer
+            self._task_frame_pose_b = torch.zeros(n, 7, device=dev)
+        self._osc = OperationalSpaceController(cfg=ctrl, num_envs=n, device=dev)
+        dof, dim = self._num_DoF, self.action_dim
+        self._raw_actions = torch.zeros(n, dim, device=dev)
+        self._processed_actions = torch.zeros_like(self._raw_actions)
+        self._jacobian_b = torch.zeros(n, 6, dof, device=dev)
+        self._mass_matrix = torch.zeros(n, dof, dof, device=dev)
+        self._gravity = torch.zeros(n, dof, device=dev)
+        self._ee_pose_w, self._ee_pose_b = torch.zeros(n, 7, device=dev), torch.zeros(n, 7, device=dev)
+        self._ee_pose_b_no_offset = torch.zeros(n, 7, device=dev)
+        self._ee_vel_w, self._ee_vel_b = torch.zeros(n, 6, device=dev), torch.zeros(n, 6, device=dev)
+        self._ee_force_w, self._ee_force_b = torch.zeros(n, 3, device=dev), torch.zeros(n, 3, device=dev)
+        self._joint_pos, self._joint_vel = torch.zeros(n, dof, device=dev), torch.zeros(n, dof, device=dev)
+        self._joint_efforts = torch.zeros(n, dof, device=dev)
+        self._position_scale = torch.tensor(cfg.position_scale, device=dev)
+        self._orientation_scale = torch.tensor(cfg.orientation_scale, device=dev)
+        self._wrench_scale = torch.tensor(cfg.wrench_scale, device=dev)
+        self._stiffness_scale = torch.tensor(cfg.stiffness_scale, device=dev)
+        self._damping_ratio_scale = torch.tensor(cfg.damping_ratio_scale, device=dev)
+        self._pose_abs_idx = self._pose_rel_idx = self._wrench_abs_idx = self._stiffness_idx = self._damping_ratio_idx = None
+        self._resolve_command_indexes()
+        # the per-column scale and clamp of _preprocess_actions (:664-700) as tables for one launch
+        scale = torch.ones(dim)
+        clip = torch.tensor([[-float("inf"), float("inf")]]).repeat(dim, 1)
+        if self._pose_abs_idx is not None:
+            i = self._pose_abs_idx
+            scale[i:i + 3], scale[i + 3:i + 7] = cfg.position_scale, cfg.orientation_scale
+        if self._pose_rel_idx is not None:
+            i = self._pose_rel_idx
+            scale[i:i + 3], scale[i + 3:i + 6] = cfg.position_scale, cfg.orientation_scale
+        if self._wrench_abs_idx is not None:
+            scale[self._wrench_abs_idx:self._wrench_abs_idx + 6] = cfg.wrench_scale
+        if self._stiffness_idx is not None:
+            i = self._stiffness_idx
+            scale[i:i + 6] = cfg.stiffness_scale
+            clip[i:i + 6] = torch.tensor([float(v) for v in ctrl.motion_stiffness_limits_task])
+        if self._damping_ratio_idx is not None:
+            i = self._damping_ratio_idx
+            scale[i:i + 6] = cfg.damping_ratio_scale
+            clip[i:i + 6] = torch.tensor([float(v) for v in ctrl.motion_damping_ratio_limits_task])
+        self._scale_table = scale.to(dev).unsqueeze(0).repeat(n, 1).contiguous()
+        self._clip_table = clip.to(dev).unsqueeze(0).repeat(n, 1, 1).contiguous()
+        self._nullspace_joint_pos_target = None
+        self._resolve_nullspace_joint_pos_targets()
+
+    # -- properties (:384-410)
+    @property
+    def action_dim(self) -> int:
+        return self._osc.action_dim
+
+    @property
+    def raw_actions(self) -> torch.Tensor:
+        return self._raw_actions
+
+    @property
+    def processed_actions(self) -> torch.Tensor:
+        return self._processed_actions
+
+    @property
+    def jacobian_w(self) -> torch.Tensor:
+        return self._asset.root_physx_view.get_jacobians()[:, self._jacobi_ee_body_idx, :, self._jacobi_joint_idx]
+
+    @property
+    def jacobian_b(self) -> torch.Tensor:
+        """The end-effector body's Jacobian in the root frame, without the offset correction (:403-410)."""
+        out = torch.zeros_like(self._jacobian_b)
+        self._state(False, jacobian_out=out, with_offset=False)
+        return out
+
+    # -- operations
+    def _state(self, pose_only: bool, jacobian_out=None, with_offset: bool = True):
+        a, d, c = self._asset, self._asset.data, self.cfg
+        desc = OscActionStateDesc(num_envs=self.num_envs, num_dof=self._num_DoF, num_joints=a.num_joints, num_bodies=d.body_state_w.shape[1],
+                                  ee_body_idx=self._ee_body_idx, has_offset=int(c.body_offset is not None and with_offset), pose_only=int(pose_only),
+                                  root_state_w=_abi.ptr(d.root_state_w), body_state_w=_abi.ptr(d.body_state_w),
+                                  ee_pose_w=_abi.ptr(self._ee_pose_w), ee_pose_b=_abi.ptr(self._ee_pose_b),
+                                  ee_pose_b_no_offset=_abi.ptr(self._ee_pose_b_no_offset))
+        if c.body_offset is not None:
+            desc.offset_pos, desc.offset_rot = (ctypes.c_float * 3)(*c.body_offset.pos), (ctypes.c_float * 4)(*c.body_offset.rot)
+        else:
+            desc.offset_rot = (ctypes.c_float * 4)(1.0, 0.0, 0.0, 0.0)
+        keep = []
+        if not pose_only:
+            view = a.root_physx_view
+            jac = _abi.f32c(view.get_jacobians())
+            mass, grav = _abi.f32c(view.get_generalized_mass_matrices()), _abi.f32c(view.get_gravity_compensation_forces())
+            keep += [jac, mass, grav]
+            desc.jac_bodies, desc.jac_cols, desc.jac_body_idx = jac.shape[1], jac.shape[3], self._jacobi_ee_body_idx
+            desc.joint_ids, desc.jac_joint_ids = self._joint_ids_dev.data_ptr(), self._jacobi_cols_dev.data_ptr()
+            desc.jacobians, desc.mass_matrices, desc.gravity_forces = _abi.ptr(jac), _abi.ptr(mass), _abi.ptr(grav)
+            desc.joint_pos, desc.joint_vel = _abi.ptr(d.joint_pos), _abi.ptr(d.joint_vel)
+            if self._contact_sensor is not None:   # :636-643
+                self._contact_sensor.update(self._sim_dt)
+                self._ee_force_w = _abi.f32c(self._contact_sensor.data.net_forces_w[:, 0, :])
+                desc.ee_force_w, desc.ee_force_b = _abi.ptr(self._ee_force_w), _abi.ptr(self._ee_force_b)
+            desc.ee_vel_w, desc.ee_vel_b = _abi.ptr(self._ee_vel_w), _abi.ptr(self._ee_vel_b)
+            desc.jacobian_b = _abi.ptr(self._jacobian_b if jacobian_out is None else jacobian_out)
+            desc.mass_matrix, desc.gravity = _abi.ptr(self._mass_matrix), _abi.ptr(self._gravity)
+            desc.joint_pos_out, desc.joint_vel_out = _abi.ptr(self._joint_pos), _abi.ptr(self._joint_vel)
+        _abi.check(_osc_state(ctypes.byref(desc), _abi.stream()), "ilx_osc_action_state_update")
+
+    def process_actions(self, actions: torch.Tensor):
+        """:416-438."""
+        self._state(True)
+        self._compute_task_frame_pose()
+        raw = _abi.f32c(actions)
+        _abi.check(_abi.joint_action_process(_abi.ptr(raw), _abi.ptr(self._raw_actions), None, _abi.ptr(self._scale_table), 1.0, None, 0.0,
+                                             _abi.ptr(self._clip_table), _abi.ptr(self._processed_actions), self.num_envs, self.action_dim,
+                                             _abi.stream()), "ilx_joint_action_process")
+        self._osc.set_command(command=self._processed_actions, current_ee_pose_b=self._ee_pose_b,
+                              current_task_frame_pose_b=self._task_frame_pose_b)
+
+    def apply_actions(self):
+        """:440-462."""
+        self._state(False)
+        self._joint_efforts[:] = self._osc.compute(
+            jacobian_b=self._jacobian_b, current_ee_pose_b=self._ee_pose_b, current_ee_vel_b=self._ee_vel_b,
+            current_ee_force_b=self._ee_force_b, mass_matrix=self._mass_matrix, gravity=self._gravity,
+            current_joint_pos=self._joint_pos, current_joint_vel=self._joint_vel,
+            nullspace_joint_pos_target=self._nullspace_joint_pos_target)
+        self._asset.set_joint_effort_target(self._joint_efforts, joint_ids=self._joint_ids)
+
+    def reset(self, env_ids: Sequence[int] | None = None) -> None:
+        """:464-474."""
+        self._raw_actions[env_ids if env_ids is not None else slice(None)] = 0.0
+        if self._contact_sensor is not None:
+            self._contact_sensor.reset(env_ids)
+        if self._task_frame_transformer is not None:
+            self._task_frame_transformer.reset(env_ids)
+
+    # -- helpers
+    def _resolve_command_indexes(self):
+        """:504-537."""
+        ctrl, cmd_idx = self.cfg.controller_cfg, 0
+        for target_type in ctrl.target_types:
+            if target_type == "pose_abs":
+                self._pose_abs_idx, cmd_idx = cmd_idx, cmd_idx + 7
+            elif target_type == "pose_rel":
+                self._pose_rel_idx, cmd_idx = cmd_idx, cmd_idx + 6
+            elif target_type == "wrench_abs":
+                self._wrench_abs_idx, cmd_idx = cmd_idx, cmd_idx + 6
+            else:
+                raise ValueError("Undefined target_type for OSC within OperationalSpaceControllerAction.")
+        if ctrl.impedance_mode in ("variable_kp", "variable"):
+            self._stiffness_idx, cmd_idx = cmd_idx, cmd_idx + 6
+            if ctrl.impedance_mode == "variable":
+                self._damping_ratio_idx, cmd_idx = cmd_idx, cmd_idx + 6
+        if self.action_dim != cmd_idx:
+            raise ValueError("Not all command indexes have been resolved.")
+
+    def _resolve_nullspace_joint_pos_targets(self):
+        """:539-566."""
+        target, control = self.cfg.nullspace_joint_pos_target, self.cfg.controller_cfg.nullspace_control
+        if target != "none" and control != "position":
+            raise ValueError("Nullspace joint targets can only be set when null space control is set to 'position'.")
+        if target == "none" and control == "position":
+            raise ValueError("Nullspace joint targets must be set when null space control is set to 'position'.")
+        if target in ("zero", "none"):
+            self._nullspace_joint_pos_target = None
+        elif target == "center":
+            self._nullspace_joint_pos_target = torch.mean(self._asset.data.soft_joint_pos_limits[:, self._joint_ids, :], dim=-1)
+        elif target == "default":
+            self._nullspace_joint_pos_target = self._asset.data.default_joint_pos[:, self._joint_ids]
+        else:
+            raise ValueError("Invalid value for nullspace joint pos targets.")
+
+    def _compute_task_frame_pose(self):
+        """:651-662."""
+        if self._task_frame_transformer is not None and self._task_frame_pose_b is not None:
+            from ....utils import math as math_utils
+
+            self._task_frame_transformer.update(self._sim_dt)
+            d, t = self._asset.data, self._task_frame_transformer.data
+            pos, quat = math_utils.subtract_frame_transforms(d.root_state_w[:, :3].contiguous(), d.root_state_w[:, 3:7].contiguous(),
+                                                             t.target_pos_w[:, 0, :].contiguous(), t.target_quat_w[:, 0, :].contiguous())
+            self._task_frame_pose_b[:, :3], self._task_frame_pose_b[:, 3:] = pos, quat

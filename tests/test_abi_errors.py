@@ -293,6 +293,17 @@ def test_flat_patch_arguments():
     assert _check(NULL, NULL, 0, 10, 0.0, 1.0, 0.1, NULL, NULL, NULL) == 0
 
 
+def test_osc_action_state_arguments():
+    from isaaclab_amd.envs.mdp.actions.task_space_actions import OscActionStateDesc, _osc_state
+
+    fails(_osc_state(ctypes.byref(OscActionStateDesc(num_envs=4)), NULL), EINVAL, "root / body state or ee_pose_b is NULL")
+    pose = dict(num_envs=4, root_state_w=FAKE, body_state_w=FAKE, ee_pose_b=FAKE, num_bodies=5)
+    fails(_osc_state(ctypes.byref(OscActionStateDesc(ee_body_idx=5, **pose)), NULL), EINVAL, "outside the 5 bodies")
+    fails(_osc_state(ctypes.byref(OscActionStateDesc(ee_body_idx=4, num_dof=13, **pose)), NULL), ESHAPE, "controlled joints outside")
+    fails(_osc_state(ctypes.byref(OscActionStateDesc(ee_body_idx=4, num_dof=7, **pose)), NULL), EINVAL, "index lists are NULL")
+    assert _osc_state(ctypes.byref(OscActionStateDesc(num_envs=0)), NULL) == 0
+
+
 def test_sampler_arguments():
     fails(_abi.sample(9, NULL, 0, 0, 0.0, NULL, 0, 0, 1.0, NULL, NULL, 0, 1, FAKE, 4, 3, NULL), EINVAL, "unknown kind")
     fails(_abi.sample(4, NULL, 0, 0, 0.0, NULL, 0, 0, 1.0, NULL, NULL, 0, 1, FAKE, 4, 3, NULL), ESHAPE, "4 wide")
