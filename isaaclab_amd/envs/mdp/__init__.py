@@ -7,4 +7,4 @@ from .events import (apply_external_force_torque, push_by_setting_velocity, rese
                      reset_joints_by_scale, reset_root_state_from_terrain, reset_root_state_uniform,
                      reset_root_state_with_random_orientation,
                      reset_scene_to_default)
-from .curriculums import terrain_levels_vel  # noqa: F401
+from .curriculums import modify_reward_weight, terrain_levels_vel  # noqa: F401

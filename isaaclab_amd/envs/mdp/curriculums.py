@@ -38,6 +38,16 @@ def terrain_levels_vel(env, env_ids: Sequence[int], asset_cfg: SceneEntityCfg = 
     return torch.mean(terrain.terrain_levels.float())
 
 
+def modify_reward_weight(env, env_ids: Sequence[int], term_name: str, weight: float, num_steps: int):
+    """``isaaclab/envs/mdp/curriculums.py:20-36``: after ``num_steps`` common steps the reward term gets a new weight (the
+    fused reward plan is rebuilt once, when the weight really changes)."""
+    if env.common_step_counter > num_steps:
+        term_cfg = env.reward_manager.get_term_cfg(term_name)
+        if term_cfg.weight != weight:
+            term_cfg.weight = weight
+            env.reward_manager.set_term_cfg(term_name, term_cfg)
+
+
 @dataclass
 class CurriculumTermCfg(ManagerTermBaseCfg):
     """manager_term_cfg.py:127-137."""

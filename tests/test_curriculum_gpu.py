@@ -6,7 +6,7 @@ from types import SimpleNamespace as NS
 import pytest
 import torch
 
-from conftest import assert_exact, load_golden
+from conftest import assert_close, assert_exact, load_golden
 
 pytestmark = pytest.mark.gpu
 
@@ -92,3 +92,37 @@ def test_grid_origins(dev):
         t.update_env_origins(None, torch.ones(num, dtype=torch.bool), torch.zeros(num, dtype=torch.bool))  # no-op without sub-terrains
     with pytest.raises(ValueError, match="Environment spacing must be specified"):
         TerrainImporter(TerrainImporterCfg(num_envs=4), dev).configure_env_origins(None)
+
+
+def test_modify_reward_weight(dev):
+    """curriculums.py:20-36 on the fused reward manager: the new weight applies from the step after ``num_steps``."""
+    import math
+
+    from isaaclab_amd.envs import mdp
+    from isaaclab_amd.managers import RewardManager, RewardTermCfg as RewTerm
+    from test_terms_gpu import make_env
+
+    g = load_golden("managers_anymal")
+    steps = g["reward"].shape[0]
+    s0 = {k: v[0] for k, v in g.items() if v.shape[:1] == (steps,)}
+    env = make_env(s0, dev)
+    rm = RewardManager(dict(lin_vel_z_l2=RewTerm(mdp.lin_vel_z_l2, {}, -2.0), ang_vel_xy_l2=RewTerm(mdp.ang_vel_xy_l2, {}, -0.05)), env)
+    env.reward_manager = rm
+    before = rm.compute(dt=0.02).clone()
+    parts = rm._step_reward.clone()
+    env.common_step_counter = 10
+    mdp.modify_reward_weight(env, None, "lin_vel_z_l2", -4.0, num_steps=10)       # not yet: the counter must exceed num_steps
+    assert rm.get_term_cfg("lin_vel_z_l2").weight == -2.0
+    env.common_step_counter = 11
+    plans = rm._plans
+    mdp.modify_reward_weight(env, None, "lin_vel_z_l2", -4.0, num_steps=10)
+    assert rm.get_term_cfg("lin_vel_z_l2").weight == -4.0
+    after = rm.compute(dt=0.02)
+    assert_close(after, before + parts[:, 0] * 0.02, rtol=1e-5, atol=1e-6, what="reward with the doubled weight")
+    assert rm._plans is not plans                                                  # rebuilt once for the new weight
+    kept = rm._plans                                                               # same weight again: the plan is kept
+    mdp.modify_reward_weight(env, None, "lin_vel_z_l2", -4.0, num_steps=10)
+    assert rm._plans is kept
+    with pytest.raises(ValueError, match="not found"):
+        mdp.modify_reward_weight(env, None, "nothing", 1.0, num_steps=0)
+    assert math.isfinite(float(after.sum()))
