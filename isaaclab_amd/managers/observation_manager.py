@@ -1,7 +1,7 @@
 """``ObservationManager`` (interface of ``isaaclab/managers/observation_manager.py``) on the fused MDP kernel: a group
 is one launch that writes the concatenated, noise-corrupted, clipped and scaled row directly.  A term with custom modifiers
-(observation_manager.py:308-318) leaves the fused launch raw; its modifiers, clip and scale then run on its columns of the
-row, one launch each, in the reference's order.  A term with a history (:319-327) appends its columns to a ring and the
+(observation_manager.py:308-318), or with a noise other than additive uniform noise with scalar bounds, leaves the fused
+launch raw; its modifiers, noise, clip and scale then run on its columns of the row, one launch each, in the reference's order.  A term with a history (:319-327) appends its columns to a ring and the
 ordered history goes into the term's columns of the group's final row from the same launch."""
 
 from __future__ import annotations
@@ -33,9 +33,8 @@ class ObservationManager:
                     term.history_length, term.flatten_history_dim = group_history, self._flag_of(gcfg, "flatten_history_dim", True)
                 if term.history_length > 0 and not term.flatten_history_dim:
                     raise NotImplementedError("an observation history is handed out flattened (flatten_history_dim=True)")
-                if term.noise is not None and (not isinstance(term.noise, UniformNoiseCfg) or term.noise.operation != "add"
-                                               or isinstance(term.noise.n_min, torch.Tensor) or isinstance(term.noise.n_max, torch.Tensor)):
-                    raise NotImplementedError("only additive uniform noise is compiled into the fused kernel")
+                if term.noise is not None and not callable(getattr(term.noise, "func", None)):
+                    raise TypeError(f"Noise configuration of observation term '{name}' has no callable 'func': {term.noise}")
                 for mod_cfg in term.modifiers or ():            # observation_manager.py:443-470
                     if not isinstance(mod_cfg, modifiers.ModifierCfg):
                         raise TypeError(f"Modifier configuration '{mod_cfg}' of observation term '{name}' is not of"
@@ -46,10 +45,8 @@ class ObservationManager:
                     if not callable(mod_cfg.func):
                         raise AttributeError(f"Modifier '{mod_cfg}' of observation term '{name}' is not callable."
                                              f" Received: {mod_cfg.func}")
-                if term.modifiers and term.noise is not None:
-                    raise NotImplementedError("noise on a term with custom modifiers is not compiled (the noise is drawn inside the fused launch)")
-                if term.modifiers and term.scale is not None and not isinstance(term.scale, (int, float)):
-                    raise NotImplementedError("a term with custom modifiers takes a scalar scale")
+                if self._needs_post(term) and term.scale is not None and not isinstance(term.scale, (int, float)):
+                    raise NotImplementedError("a term with custom modifiers or a noise outside the fused launch takes a scalar scale")
                 names.append(name), cfgs.append(term), specs.append(resolve_term(env, name, term))
             self._group_obs_term_names[gname], self._group_obs_term_cfgs[gname], self._group_specs[gname] = names, cfgs, specs
             self._group_cfg[gname] = gcfg
@@ -58,6 +55,7 @@ class ObservationManager:
         self._group_obs_term_history_buffer: dict[str, dict[str, CircularBuffer]] = {}
         self._history_rows: dict[str, tuple] = {}
         self._group_obs_class_modifiers: list[modifiers.ModifierBase] = []
+        self._post_noise_draws: dict[str, torch.Tensor] = {}   # "group/term" -> draws to replay (no counterpart in the reference)
         self._obs_buffer = None
 
     @property
@@ -72,6 +70,16 @@ class ObservationManager:
             rows = self._history_rows.get(g)
             dims[g] = (mdp.obs_dim if rows is None else rows[0].shape[1],)
         return dims
+
+    @staticmethod
+    def _fused_noise(noise) -> bool:
+        """Additive uniform noise with scalar bounds is drawn inside the fused launch; every other noise runs after it."""
+        return (isinstance(noise, UniformNoiseCfg) and noise.operation == "add" and not isinstance(noise.n_min, torch.Tensor)
+                and not isinstance(noise.n_max, torch.Tensor))
+
+    @classmethod
+    def _needs_post(cls, term) -> bool:
+        return bool(term.modifiers) or (term.noise is not None and not cls._fused_noise(term.noise))
 
     @staticmethod
     def _flag_of(g, name, default):
@@ -90,20 +98,20 @@ class ObservationManager:
             if len(groups) != 1:
                 raise NotImplementedError("an observation group must read one articulation / sensor set")
             corrupt = self._flag(group, "enable_corruption", False)
-            posts = [dict(noise=None, clip=None, scale=None) if c.modifiers else
+            posts = [dict(noise=None, clip=None, scale=None) if self._needs_post(c) else
                      dict(noise=(c.noise.n_min, c.noise.n_max) if (c.noise is not None and corrupt) else None, clip=c.clip,
                           scale=c.scale) for c in cfgs]
             mdp = F.make_plan(self._env, "observation", specs, posts=posts, bindings=groups[0][0])
             plan = self._plans[group] = (groups[0][0], None, specs, mdp)
             post, col = [], 0
-            for c, spec in zip(cfgs, mdp.observations):
+            for name, c, spec in zip(self._group_obs_term_names[group], cfgs, mdp.observations):
                 width = mdp._obs_dim(spec)
-                if c.modifiers:
-                    for mod_cfg in c.modifiers:   # class modifiers are built once with the term's shape (:449-458)
+                if self._needs_post(c):
+                    for mod_cfg in c.modifiers or ():   # class modifiers are built once with the term's shape (:449-458)
                         if inspect.isclass(mod_cfg.func):
                             mod_cfg.func = mod_cfg.func(cfg=mod_cfg, data_dim=(self._env.num_envs, width), device=self._env.device)
                             self._group_obs_class_modifiers.append(mod_cfg.func)
-                    post.append((col, col + width, c))
+                    post.append((col, col + width, c, name if corrupt else None))
                 col += width
             self._post[group] = post
             if any(c.history_length > 0 for c in cfgs):   # observation_manager.py:412-420
@@ -145,11 +153,14 @@ class ObservationManager:
         bindings, _, specs, mdp = self._plan(group_name)
         mdp.bind(noise_u=noise_u)
         F.run_plan(mdp, self._env, "observation", specs, bindings)
-        for c0, c1, cfg in self._post[group_name]:
+        for c0, c1, cfg, noisy in self._post[group_name]:
             cols = mdp.obs[:, c0:c1]
             obs = cols
-            for m in cfg.modifiers:
+            for m in cfg.modifiers or ():
                 obs = m.func(obs, **m.params)
+            if cfg.noise is not None and noisy is not None:      # :313-314, only in groups with enable_corruption (:398-400)
+                draws = self._post_noise_draws.get(f"{group_name}/{noisy}")
+                obs = cfg.noise.func(obs, cfg.noise) if draws is None else cfg.noise.func(obs, cfg.noise, draws)
             if cfg.clip:          # in place, as the reference's clip_ / mul_ (an Integrator's state is the tensor it returned)
                 _mod.apply(_mod.CLIP, obs, out=obs, p0=float(cfg.clip[0]), p1=float(cfg.clip[1]), has_lo=1, has_hi=1)
             if cfg.scale is not None:

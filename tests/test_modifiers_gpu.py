@@ -108,3 +108,43 @@ def test_observation_manager_applies_modifiers(dev):
         ObservationManager(dict(policy=dict(t=ObsTerm(mdp.base_lin_vel, {}, modifiers=[dict(func=M.scale)]))), env)
     with pytest.raises(TypeError, match="not a subclass of 'ModifierBase'"):
         ObservationManager(dict(policy=dict(t=ObsTerm(mdp.base_lin_vel, {}, modifiers=[M.ModifierCfg(func=dict)]))), env)
+
+
+def test_observation_manager_noise_outside_the_fused_launch(dev):
+    """Gaussian noise, multiplicative noise and noise behind modifiers (observation_manager.py:310-318) against the noise
+    restatement with the same draws; without ``enable_corruption`` the noise is dropped (:398-400)."""
+    from isaaclab_amd.envs import mdp
+    from isaaclab_amd.managers import ObservationManager, ObservationTermCfg as ObsTerm
+    from isaaclab_amd.utils import modifiers as M
+    from isaaclab_amd.utils import noise as N
+    from oracle import noise as O
+    from test_terms_gpu import make_env
+
+    g = load_golden("managers_anymal")
+    steps = g["reward"].shape[0]
+    s0 = {k: v[0] for k, v in g.items() if v.shape[:1] == (steps,)}
+    n = s0["joint_pos"].shape[0]
+    env = make_env(s0, dev)
+
+    def terms():
+        return dict(base_lin_vel=ObsTerm(mdp.base_lin_vel, {}, noise=N.UniformNoiseCfg(0.8, 1.2, operation="scale")),
+                    joint_pos=ObsTerm(mdp.joint_pos_rel, {}, modifiers=[M.ModifierCfg(func=M.bias, params=dict(value=0.1))],
+                                      noise=N.UniformNoiseCfg(-0.05, 0.05), scale=2.0),
+                    joint_vel=ObsTerm(mdp.joint_vel_rel, {}, noise=N.GaussianNoiseCfg(mean=0.01, std=0.3), clip=(-1.0, 1.0)))
+    plain = dict(base_lin_vel=ObsTerm(mdp.base_lin_vel, {}), joint_pos=ObsTerm(mdp.joint_pos_rel, {}), joint_vel=ObsTerm(mdp.joint_vel_rel, {}))
+    om = ObservationManager(dict(plain=plain, noisy=dict(enable_corruption=True, **terms()), quiet=dict(**terms())), env)
+    gen = torch.Generator().manual_seed(3)
+    draws = dict(base_lin_vel=torch.rand(n, 3, generator=gen), joint_pos=torch.rand(n, 12, generator=gen), joint_vel=torch.randn(n, 12, generator=gen))
+    om._post_noise_draws = {f"noisy/{k}": v.to(dev) for k, v in draws.items()}
+    raw = om.compute_group("plain").cpu()
+    lin, pos, vel = raw[:, :3], raw[:, 3:15], raw[:, 15:]
+    want = torch.cat([O.uniform(lin, 0.8, 1.2, "scale", draws["base_lin_vel"]),
+                      O.uniform(pos + 0.1, -0.05, 0.05, "add", draws["joint_pos"]) * 2.0,
+                      O.gaussian(vel, 0.01, 0.3, "add", draws["joint_vel"]).clip(-1.0, 1.0)], dim=1)
+    assert_close(om.compute_group("noisy"), want, rtol=1e-6, atol=1e-6, what="noise behind the fused launch")
+    want_quiet = torch.cat([lin, (pos + 0.1) * 2.0, vel.clip(-1.0, 1.0)], dim=1)
+    assert_close(om.compute_group("quiet"), want_quiet, rtol=1e-6, atol=1e-6, what="group without corruption")
+    # generated draws: the noise is really there and differs from call to call
+    om._post_noise_draws = {}
+    a, b = om.compute_group("noisy").clone(), om.compute_group("noisy").clone()
+    assert not torch.equal(a, b) and float((a[:, :3] - b[:, :3]).abs().max()) < 0.5 * float(lin.abs().max()) + 1e-6
