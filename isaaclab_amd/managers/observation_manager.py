@@ -31,8 +31,9 @@ class ObservationManager:
                 group_history = self._flag_of(gcfg, "history_length", None)
                 if group_history is not None:      # observation_manager.py:403-406
                     term.history_length, term.flatten_history_dim = group_history, self._flag_of(gcfg, "flatten_history_dim", True)
-                if term.history_length > 0 and not term.flatten_history_dim:
-                    raise NotImplementedError("an observation history is handed out flattened (flatten_history_dim=True)")
+                if term.history_length > 0 and not term.flatten_history_dim and self._flag_of(gcfg, "concatenate_terms", True):
+                    # the reference concatenates (N, H, d) blocks along d, which only works for equal H: not supported here
+                    raise NotImplementedError("un-flattened observation histories need a group with concatenate_terms=False")
                 if term.noise is not None and not callable(getattr(term.noise, "func", None)):
                     raise TypeError(f"Noise configuration of observation term '{name}' has no callable 'func': {term.noise}")
                 for mod_cfg in term.modifiers or ():            # observation_manager.py:443-470
@@ -68,7 +69,10 @@ class ObservationManager:
         for g in self._group_specs:
             mdp = self._plan(g)[3]
             rows = self._history_rows.get(g)
-            dims[g] = (mdp.obs_dim if rows is None else rows[0].shape[1],)
+            if self._flag(g, "concatenate_terms", True):
+                dims[g] = (mdp.obs_dim if rows is None else rows[0].shape[1],)
+            else:   # observation_manager.py:100-101: the terms' own shapes
+                dims[g] = [tuple(t.shape[1:]) for t in self._split(g, mdp.obs if rows is None else rows[0]).values()]
         return dims
 
     @staticmethod
@@ -92,8 +96,6 @@ class ObservationManager:
         plan = self._plans.get(group)
         if plan is None:
             specs, cfgs = self._group_specs[group], self._group_obs_term_cfgs[group]
-            if not self._flag(group, "concatenate_terms", True):
-                raise NotImplementedError("groups with concatenate_terms=False are not compiled into the fused kernel")
             groups = F.group_specs(specs)
             if len(groups) != 1:
                 raise NotImplementedError("an observation group must read one articulation / sensor set")
@@ -128,6 +130,19 @@ class ObservationManager:
                 self._history_rows[group] = (torch.zeros(n, out_col, device=dev), layout)
         return plan
 
+    def _split(self, group: str, row: torch.Tensor) -> dict[str, torch.Tensor]:
+        """The terms of a group with ``concatenate_terms=False`` as views of the group's row (observation_manager.py:332-335);
+        a history that is not flattened comes out as (num_envs, history_length, width)."""
+        mdp = self._plans[group][3]
+        out, col = {}, 0
+        for name, c, spec in zip(self._group_obs_term_names[group], self._group_obs_term_cfgs[group], mdp.observations):
+            width = mdp._obs_dim(spec)
+            span = width * max(c.history_length, 1)
+            block = row[:, col:col + span]
+            out[name] = block.unflatten(1, (c.history_length, width)) if (c.history_length > 0 and not c.flatten_history_dim) else block
+            col += span
+        return out
+
     def reset(self, env_ids=None) -> dict[str, float]:
         """observation_manager.py:222-236: class modifiers drop the history of the reset envs."""
         for group in self._group_specs:
@@ -145,7 +160,7 @@ class ObservationManager:
         self._obs_buffer = {g: self.compute_group(g) for g in self._group_specs}
         return self._obs_buffer
 
-    def compute_group(self, group_name: str, noise_u: torch.Tensor | None = None) -> torch.Tensor:
+    def compute_group(self, group_name: str, noise_u: torch.Tensor | None = None) -> torch.Tensor | dict[str, torch.Tensor]:
         """observation_manager.py:260-335.  ``noise_u`` (no counterpart in the reference) injects the U[0,1) draws."""
         if group_name not in self._group_specs:
             raise ValueError(f"Unable to find the group '{group_name}' in the observation manager."
@@ -168,8 +183,9 @@ class ObservationManager:
             if obs.data_ptr() != cols.data_ptr():
                 _mod.apply(_mod.COPY, obs, out=cols)
         rows = self._history_rows.get(group_name)
+        split = not self._flag(group_name, "concatenate_terms", True)
         if rows is None:
-            return mdp.obs
+            return self._split(group_name, mdp.obs) if split else mdp.obs
         final, layout = rows
         rings = self._group_obs_term_history_buffer[group_name]
         for name, c0, c1, o0, o1 in layout:
@@ -177,4 +193,4 @@ class ObservationManager:
                 rings[name].append(mdp.obs[:, c0:c1], ordered_out=final[:, o0:o1])
             else:
                 _mod.apply(_mod.COPY, mdp.obs[:, c0:c1], out=final[:, o0:o1])
-        return final
+        return self._split(group_name, final) if split else final

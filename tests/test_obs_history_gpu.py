@@ -48,5 +48,38 @@ def test_observation_manager_history():
             ring.append(x)
         want = torch.cat([ring.hist.reshape(n, -1) for ring in w], dim=1)
         assert_exact(om.compute_group("whole"), want, f"group history, step {step}")
-    with pytest.raises(NotImplementedError, match="flatten_history_dim"):
+
+
+def test_groups_without_concatenation():
+    """observation_manager.py:332-335: ``concatenate_terms=False`` hands out the terms one by one; a history that is not
+    flattened keeps its (num_envs, history_length, width) shape."""
+    from isaaclab_amd.envs import mdp
+    from isaaclab_amd.managers import ObservationManager, ObservationTermCfg as ObsTerm
+    from oracle import buffers as O
+    from test_terms_gpu import make_env
+
+    dev = torch.device("cuda:0")
+    g = load_golden("managers_anymal")
+    steps = g["reward"].shape[0]
+    s0 = {k: v[0] for k, v in g.items() if v.shape[:1] == (steps,)}
+    n = s0["joint_pos"].shape[0]
+    env = make_env(s0, dev)
+    plain = dict(base_lin_vel=ObsTerm(mdp.base_lin_vel, {}), joint_vel=ObsTerm(mdp.joint_vel_rel, {}, scale=0.5))
+    split = dict(base_lin_vel=ObsTerm(mdp.base_lin_vel, {}, history_length=3, flatten_history_dim=False),
+                 joint_vel=ObsTerm(mdp.joint_vel_rel, {}, scale=0.5), concatenate_terms=False)
+    om = ObservationManager(dict(plain=plain, split=split, split_plain=dict(concatenate_terms=False, **plain)), env)
+    assert om.group_obs_dim["split"] == [(3, 3), (12,)] and om.group_obs_dim["split_plain"] == [(3,), (12,)]
+    ring = O.Ring(3, n, 3)
+    for step in range(3):
+        s = {k: v[step] for k, v in g.items() if v.shape[:1] == (steps,)}
+        env.scene["robot"].data = make_env(s, dev).scene["robot"].data
+        raw = om.compute_group("plain").cpu()
+        ring.append(raw[:, :3])
+        got = om.compute_group("split")
+        assert list(got) == ["base_lin_vel", "joint_vel"]
+        assert_exact(got["base_lin_vel"], ring.hist, f"un-flattened history, step {step}")
+        assert_exact(got["joint_vel"], raw[:, 3:], f"plain term beside it, step {step}")
+        got = om.compute_group("split_plain")
+        assert_exact(got["base_lin_vel"], raw[:, :3], "term of a split group")
+    with pytest.raises(NotImplementedError, match="concatenate_terms=False"):
         ObservationManager(dict(p=dict(t=ObsTerm(mdp.base_lin_vel, {}, history_length=2, flatten_history_dim=False))), env)
