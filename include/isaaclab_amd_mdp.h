@@ -161,8 +161,8 @@ typedef struct ilx_mdp {
     const float* ray_hits_w;                 /* (n,r,3) */
     const float* sensor_pos_w;               /* (n,3) */
     /* action manager */
-    const float* action;                     /* (n,a) */
-    const float* prev_action;
+    float* action;                           /* (n,a); the RESET phase zeroes the rows of done envs (action_manager.py:309-311) */
+    float* prev_action;
     /* episode bookkeeping */
     int64_t* episode_length_buf;             /* (n) */
     int64_t max_episode_length;

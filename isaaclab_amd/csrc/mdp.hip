@@ -637,6 +637,14 @@ __global__ void __launch_bounds__(kBlock) mdp_step_kernel(MdpDev m) {
                 command_resample(d, env, d.reset_command_samples, 16u, cs);
                 cmd_dirty = true;
             }
+            // action_manager.py:309-311: the action history of a done env restarts at zero (the observations of this
+            // launch already see it; the rewards above used the step's own actions)
+            for (int k = 0; k < d.action_dim; ++k) {
+                if (d.action) d.action[env * d.action_dim + k] = 0.0f;
+                if (d.prev_action) d.prev_action[env * d.action_dim + k] = 0.0f;
+                if (sa) S[L.act + e * d.action_dim + k] = 0.0f;
+                if (spa) S[L.pact + e * d.action_dim + k] = 0.0f;
+            }
             ep_len = 0;  // manager_based_rl_env.py:391
         }
         if (d.episode_length_buf && (ph_term || (ph_reset && done))) d.episode_length_buf[env] = ep_len;

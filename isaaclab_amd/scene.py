@@ -11,7 +11,7 @@ from __future__ import annotations
 import ctypes
 
 from . import _abi
-from .assets.articulation_data import ArticulationData
+from .assets.articulation_data import ArticulationData  # noqa: F401  (the type of the entries of `articulations`, or of their `.data`)
 from .sensors.contact_sensor import ContactSensor
 from .sensors.ray_caster import RayCaster
 
@@ -48,7 +48,7 @@ class InteractiveScene:
         force = not self.lazy_sensor_update
         sc = _abi.Scene(num_envs=self.num_envs, dt=float(dt))
         if arts:
-            d = arts[0]
+            d = getattr(arts[0], "data", arts[0])   # an Articulation or its ArticulationData
             d._sim_timestamp += dt                                   # articulation_data.py:77-82
             sc.joint_vel, sc.previous_joint_vel = _abi.ptr(d.joint_vel), _abi.ptr(d._previous_joint_vel)
             sc.joint_acc, sc.num_joints = _abi.ptr(d._joint_acc), d._j

@@ -89,6 +89,9 @@ class AnymalRoughOracle:
         reward_log = MG.reward_reset(self.episode_sums, dones, MAX_LEN * STEP_DT)
         term_log = MG.termination_reset_counts(term_dones, dones)
         cmd_log = C.velocity_reset(self.cmd_cfg, self.cmd, dones, reset_command_samples)
+        # action_manager.py:309-311: the action history of the done envs restarts at zero
+        s["action"] = torch.where(dones[:, None], torch.zeros_like(s["action"]), s["action"])
+        s["prev_action"] = torch.where(dones[:, None], torch.zeros_like(s["prev_action"]), s["prev_action"])
         s["episode_length_buf"] = torch.where(dones, torch.zeros((), dtype=torch.long), s["episode_length_buf"])
         # command, observations (:232-238)
         C.velocity_compute(self.cmd_cfg, self.cmd, STEP_DT, STEP_DT, lin_b, ang_b, heading, command_samples)

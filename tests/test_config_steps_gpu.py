@@ -62,6 +62,9 @@ def test_cartpole_step(dev):
         ref_reward = MG.reward_compute(vals, [1.0, -2.0, -1.0, -0.01, -0.005], CP.STEP_DT, sums, step_reward)
         MG.reward_reset(sums, dones, CP.MAX_EPISODE_LENGTH * CP.STEP_DT)
         ep = torch.where(dones, torch.zeros_like(ep), ep)
+        # action_manager.py:309-311: the action history of the done envs restarts at zero
+        action = torch.where(dones[:, None], torch.zeros_like(action), action)
+        prev_action = torch.where(dones[:, None], torch.zeros_like(prev_action), prev_action)
         ref_obs = torch.cat([q, qd], -1)   # defaults are zero
         assert_exact(terminated, term, f"terminated step {step}")
         assert_exact(time_outs, trunc, f"time_outs step {step}")
@@ -183,6 +186,8 @@ def test_reach_step(dev, arm_action):
                                                                              RE.STEP_DT, samples)
         cmd_state["cmd"] = cmd
         ep = torch.where(dones, torch.zeros_like(ep), ep)
+        action = torch.where(dones[:, None], torch.zeros_like(action), action)            # action_manager.py:309-311
+        prev_action = torch.where(dones[:, None], torch.zeros_like(prev_action), prev_action)
         parts = [(T.joint_pos_rel(q, default), (-0.01, 0.01)), (T.joint_vel_rel(qd, torch.zeros(n, 9)), (-0.01, 0.01)), (cmd, None),
                  (action, None)]
         cols, col = [], 0
