@@ -446,6 +446,10 @@ int ilx_camera_op(int32_t op, const float* data, const float* intrinsics, int64_
 int ilx_sample_cylinder(float radius, float h_min, float h_max, const float* u, uint64_t seed, uint64_t draw, float* out, int64_t n,
                         void* stream);
 
+/* LinearInterpolation.compute (utils/interpolation/linear_interpolation.py:55-88): piecewise-linear function through the
+ * samples (x ascending, num_samples of them), held constant outside them; out[i] = f(q[i]). */
+int ilx_linear_interpolation(const float* x, const float* y, int32_t num_samples, const float* q, float* out, int64_t count, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Batched ring buffers — source/isaaclab/isaaclab/utils/buffers/circular_buffer.py, delay_buffer.py (observation
  * histories, observation_manager.py:319-327; delayed set-points).

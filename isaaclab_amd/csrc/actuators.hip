@@ -81,6 +81,13 @@ ILX_DEV float interpolate_held(const float* x, const float* y, int n, float q) {
     return y[lo] + w * (y[hi] - y[lo]);
 }
 
+// LinearInterpolation.compute (linear_interpolation.py:55-88) for arbitrary query points, one thread per point.
+__global__ void __launch_bounds__(256) linear_interpolation_kernel(const float* x, const float* y, int n, const float* q, float* out,
+                                                                   int64_t count) {
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i < count) out[i] = interpolate_held(x, y, n, q[i]);
+}
+
 // A block owns whole envs (its threads read an env's push count before any of them advances it); one thread per
 // (env, joint): append the three set-points to their rings (circular_buffer.py:121-143: the first push after a reset
 // fills every slot), read them back time_lag steps late (delay_buffer.py:158-177), then the ideal PD law.
@@ -717,5 +724,16 @@ extern "C" int ilx_actuator_delayed_pd(const float* q_des, const float* qd_des, 
     const unsigned blocks = static_cast<unsigned>((n + a.envs_per_block - 1) / a.envs_per_block);
     hipLaunchKernelGGL(actuator_delayed_pd_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), a);
     ILX_LAUNCH_CHECK("ilx_actuator_delayed_pd");
+    return ILX_OK;
+}
+
+extern "C" int ilx_linear_interpolation(const float* x, const float* y, int32_t num_samples, const float* q, float* out, int64_t count,
+                                        void* stream) {
+    ILX_REQUIRE(num_samples >= 1, ILX_EINVAL, "Input tensor x is empty!");
+    ILX_REQUIRE(count >= 0, ILX_EINVAL, "ilx_linear_interpolation: negative count");
+    if (count == 0) return ILX_OK;
+    ILX_REQUIRE(x && y && q && out, ILX_EINVAL, "ilx_linear_interpolation: NULL operand");
+    hipLaunchKernelGGL(linear_interpolation_kernel, dim3(blocks_for(count)), dim3(256), 0, as_stream(stream), x, y, num_samples, q, out, count);
+    ILX_LAUNCH_CHECK("ilx_linear_interpolation");
     return ILX_OK;
 }
