@@ -125,19 +125,12 @@ class DirectRLEnv:
         return self.obs_buf, self.reward_buf, self.reset_terminated, self.reset_time_outs, self.extras
 
     def _write_data_to_sim(self):
-        for a in getattr(self.scene, "articulations", {}).values():
-            if hasattr(a, "write_data_to_sim"):
-                a.write_data_to_sim()
+        self.scene.write_data_to_sim()
 
     # -- hooks (direct_rl_env.py:556-640)
     def _reset_idx(self, env_ids: Sequence[int]):
         """direct_rl_env.py:556-580; a task extends it (state writes, its own buffers)."""
-        for a in getattr(self.scene, "articulations", {}).values():
-            if hasattr(a, "reset"):
-                a.reset(env_ids)
-        for s in getattr(self.scene, "sensors", {}).values():
-            if hasattr(s, "reset"):
-                s.reset(env_ids)
+        self.scene.reset(env_ids)
         if self.event_manager is not None and "reset" in self.event_manager.available_modes:
             self.event_manager.apply(mode="reset", env_ids=env_ids, global_env_step_count=self._sim_step_counter // self.cfg.decimation)
         if self._action_noise_model is not None:

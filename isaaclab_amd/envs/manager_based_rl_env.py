@@ -134,15 +134,9 @@ class ManagerBasedRLEnv:
         return self.obs_buf, self.reward_buf, self.reset_terminated, self.reset_time_outs, self.extras
 
     # -- helpers
-    def _entities(self):
-        arts = getattr(self.scene, "articulations", {})
-        return list(arts.values())
-
     def _write_data_to_sim(self):
         """interactive_scene.py:470-482."""
-        for a in self._entities():
-            if hasattr(a, "write_data_to_sim"):
-                a.write_data_to_sim()
+        self.scene.write_data_to_sim()
 
     def _write_and_update(self):
         """manager_based_rl_env.py:211-214 / manager_based_env.py:284-286: what follows a reset."""
@@ -151,12 +145,7 @@ class ManagerBasedRLEnv:
     def _reset_idx(self, env_ids):
         """manager_based_rl_env.py:315-372."""
         self.curriculum_manager.compute(env_ids=env_ids)
-        for a in self._entities():                       # scene.reset(env_ids), interactive_scene.py:440-468
-            if hasattr(a, "reset"):
-                a.reset(env_ids)
-        for s in getattr(self.scene, "sensors", {}).values():
-            if hasattr(s, "reset"):
-                s.reset(env_ids)
+        self.scene.reset(env_ids)
         if "reset" in self.event_manager.available_modes:
             self.event_manager.apply(mode="reset", env_ids=env_ids, global_env_step_count=self._sim_step_counter // self.cfg.decimation)
         log = self.extras["log"] = dict()

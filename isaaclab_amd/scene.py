@@ -34,6 +34,21 @@ class InteractiveScene:
     def keys(self) -> list[str]:
         return list(self.articulations) + list(self.sensors)
 
+    def reset(self, env_ids=None) -> None:
+        """interactive_scene.py:440-468: every asset and sensor resets the given envs."""
+        for a in self.articulations.values():
+            if hasattr(a, "reset"):
+                a.reset(env_ids)
+        for s in self.sensors.values():
+            if hasattr(s, "reset"):
+                s.reset(env_ids)
+
+    def write_data_to_sim(self) -> None:
+        """interactive_scene.py:470-482: the assets push their buffers (actuator models run here)."""
+        for a in self.articulations.values():
+            if hasattr(a, "write_data_to_sim"):
+                a.write_data_to_sim()
+
     def update(self, dt: float) -> None:
         arts = list(self.articulations.values())
         contacts = [s for s in self.sensors.values() if isinstance(s, ContactSensor)]
