@@ -2,3 +2,4 @@
 
 from .articulation import Articulation  # noqa: F401
 from .articulation_data import ArticulationData  # noqa: F401
+from .rigid_object import RigidObject, RigidObjectData  # noqa: F401
