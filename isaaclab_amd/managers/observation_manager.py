@@ -13,6 +13,7 @@ import torch
 from ..envs.mdp import _fused as F
 from ..utils import modifiers
 from ..utils.buffers import CircularBuffer
+from ..utils.noise import ConstantNoiseCfg, constant_noise
 from ..utils.modifiers import modifier as _mod
 from ._base import iter_terms, resolve_term
 from .manager_term_cfg import ObservationGroupCfg, ObservationTermCfg, UniformNoiseCfg
@@ -46,8 +47,6 @@ class ObservationManager:
                     if not callable(mod_cfg.func):
                         raise AttributeError(f"Modifier '{mod_cfg}' of observation term '{name}' is not callable."
                                              f" Received: {mod_cfg.func}")
-                if self._needs_post(term) and term.scale is not None and not isinstance(term.scale, (int, float)):
-                    raise NotImplementedError("a term with custom modifiers or a noise outside the fused launch takes a scalar scale")
                 names.append(name), cfgs.append(term), specs.append(resolve_term(env, name, term))
             self._group_obs_term_names[gname], self._group_obs_term_cfgs[gname], self._group_specs[gname] = names, cfgs, specs
             self._group_cfg[gname] = gcfg
@@ -83,7 +82,9 @@ class ObservationManager:
 
     @classmethod
     def _needs_post(cls, term) -> bool:
-        return bool(term.modifiers) or (term.noise is not None and not cls._fused_noise(term.noise))
+        # a per-column scale (observation_manager.py:424-440) is applied after the fused launch as well
+        return (bool(term.modifiers) or (term.noise is not None and not cls._fused_noise(term.noise))
+                or (term.scale is not None and not isinstance(term.scale, (int, float))))
 
     @staticmethod
     def _flag_of(g, name, default):
@@ -178,8 +179,13 @@ class ObservationManager:
                 obs = cfg.noise.func(obs, cfg.noise) if draws is None else cfg.noise.func(obs, cfg.noise, draws)
             if cfg.clip:          # in place, as the reference's clip_ / mul_ (an Integrator's state is the tensor it returned)
                 _mod.apply(_mod.CLIP, obs, out=obs, p0=float(cfg.clip[0]), p1=float(cfg.clip[1]), has_lo=1, has_hi=1)
-            if cfg.scale is not None:
+            if cfg.scale is not None and isinstance(cfg.scale, (int, float)):
                 _mod.apply(_mod.SCALE, obs, out=obs, p0=float(cfg.scale))
+            elif cfg.scale is not None:   # one factor per column
+                factors = torch.as_tensor(cfg.scale, dtype=torch.float32, device=obs.device)
+                if factors.numel() != c1 - c0:
+                    raise ValueError(f"Term scale must have as many entries as the term has columns: expected {c1 - c0} but received: {factors.numel()}.")
+                obs = constant_noise(obs, ConstantNoiseCfg(bias=factors, operation="scale"))
             if obs.data_ptr() != cols.data_ptr():
                 _mod.apply(_mod.COPY, obs, out=cols)
         rows = self._history_rows.get(group_name)

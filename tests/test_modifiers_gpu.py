@@ -148,3 +148,23 @@ def test_observation_manager_noise_outside_the_fused_launch(dev):
     om._post_noise_draws = {}
     a, b = om.compute_group("noisy").clone(), om.compute_group("noisy").clone()
     assert not torch.equal(a, b) and float((a[:, :3] - b[:, :3]).abs().max()) < 0.5 * float(lin.abs().max()) + 1e-6
+
+
+def test_observation_manager_per_column_scale(dev):
+    """observation_manager.py:424-440, 317-318: a tuple scale multiplies column by column."""
+    from isaaclab_amd.envs import mdp
+    from isaaclab_amd.managers import ObservationManager, ObservationTermCfg as ObsTerm
+    from test_terms_gpu import make_env
+
+    g = load_golden("managers_anymal")
+    steps = g["reward"].shape[0]
+    s0 = {k: v[0] for k, v in g.items() if v.shape[:1] == (steps,)}
+    env = make_env(s0, dev)
+    om = ObservationManager(dict(plain=dict(v=ObsTerm(mdp.base_lin_vel, {}), q=ObsTerm(mdp.joint_pos_rel, {})),
+                                 scaled=dict(v=ObsTerm(mdp.base_lin_vel, {}, clip=(-0.5, 0.5), scale=(2.0, -1.0, 0.5)), q=ObsTerm(mdp.joint_pos_rel, {}, scale=3.0))), env)
+    raw = om.compute_group("plain").cpu()
+    want = torch.cat([raw[:, :3].clip(-0.5, 0.5) * torch.tensor([2.0, -1.0, 0.5]), raw[:, 3:] * 3.0], dim=1)
+    assert_close(om.compute_group("scaled"), want, rtol=1e-6, atol=1e-6, what="per-column scale")
+    bad = ObservationManager(dict(p=dict(v=ObsTerm(mdp.base_lin_vel, {}, scale=(1.0, 2.0)))), env)
+    with pytest.raises(ValueError, match="as many entries as the term has columns"):
+        bad.compute_group("p")
