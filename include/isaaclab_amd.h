@@ -641,6 +641,19 @@ int ilx_mesh_info(ilx_mesh_t mesh, int64_t* num_tris, int64_t* num_nodes, int32_
  * 3 or more neighbouring records, cells with a candidate list, distinct lists, 32-bit words of list storage, candidates
  * summed over all cells, cells per row, cells naming two / three unrelated records.  All zero when the mesh has no grid. */
 int ilx_mesh_grid_stats(ilx_mesh_t mesh, int64_t out[12]);
+/* Diagnostics of the height-field patches found in the mesh (no counterpart in the reference).  A patch is a run of
+ * faces in the vertex / face order of convert_height_field_to_mesh (terrains/height_field/utils.py:119-173); the sensor
+ * refresh serves ILX_RAYS_Z_PARALLEL rays over its regular cells from the height grid alone.  out[0..3] = patches,
+ * faces inside patches, cells inside patches, cells whose rays take the height-grid path. */
+int ilx_mesh_lattice_stats(ilx_mesh_t mesh, int64_t out[4]);
+/* Diagnostics: with enable != 0 the sensor refreshes that follow count the rays they serve from the height grid in a
+ * device counter owned by the mesh, starting from zero (enable == 0 stops the counting); served (or NULL) receives
+ * the count before the call.  The
+ * call synchronises the device when it reads the counter; it is for tests, not for the step path. */
+int ilx_mesh_lattice_counter(ilx_mesh_t mesh, int enable, int64_t* served);
+/* The same four numbers for host arrays, computed on the host alone (no device is touched, nothing is kept). */
+int ilx_mesh_lattice_probe(const float* verts_host, int64_t num_verts, const int32_t* tris_host, int64_t num_tris,
+                           int64_t out[4]);
 
 /* raycast_mesh (ops.py:24-127) + raycast_mesh_kernel (kernels.py:13-75): closest hit per ray with
  * 0 <= t < max_dist; ray_hits (n,3) = start + t*dir, +inf on a miss; optional outputs (NULL to skip):

@@ -103,6 +103,9 @@ lib.ilx_mesh_destroy.argtypes = [P]
 lib.ilx_mesh_destroy.restype = None
 mesh_info = _sig("ilx_mesh_info", P, P, P, P)
 mesh_grid_stats = _sig("ilx_mesh_grid_stats", P, P)
+mesh_lattice_stats = _sig("ilx_mesh_lattice_stats", P, P)
+mesh_lattice_counter = _sig("ilx_mesh_lattice_counter", P, c_int, P)
+mesh_lattice_probe = _sig("ilx_mesh_lattice_probe", P, c_int64, P, c_int64, P)
 RAYS_Z_PARALLEL = 1
 raycast_mesh = _sig("ilx_raycast_mesh", P, P, P, c_int64, c_float, P, P, P, P, c_int, P)
 raycaster_update = _sig("ilx_raycaster_update", P, P, P, P, P, P, c_int, c_float, P, P, c_float, c_int64, c_int, c_int, P)

@@ -21,6 +21,7 @@
 // ILX_RAYS_Z_PARALLEL and gets the column kernel (no LDS, full occupancy); rays that turn out not to be z-parallel
 // are left to a tree-walk launch that follows, so the hint only affects speed, never results.
 #include "common.h"
+#include "lattice.h"
 #include "raytri.h"
 
 #include <algorithm>
@@ -87,6 +88,13 @@ struct MeshDev {
     const float4* col_verts;     // vertices (x, y, z, -) in tile order of their xy: neighbouring triangles share them
     float gx0, gy0, gx1, gy1, inv_cell;
     int32_t nx, ny, ntx;         // cells per axis, tiles per row
+    // height-field patches (lattice.h), or num_patches == 0
+    const LatticePatch* patches;
+    const float* lat_z;
+    const float* lat_lines;
+    const uint32_t* lat_mask;
+    int32_t num_patches;
+    unsigned long long* lat_served;  // diagnostics: rays served from the height grid are counted here (null: not counted)
 };
 
 // Slot of cell (cx, cy) in `cells`: tiles row-major; inside a tile, blocks of 8 x 4 cells (one 128-byte line each,
@@ -511,6 +519,280 @@ __global__ void __launch_bounds__(kRayBlock) raycaster_update_column_kernel(Scan
     write_scan(a, h, o, d, pos_z, i);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Sensor refresh over height-field patches (lattice.h): one wavefront per env at a time.
+//
+// An env's scan pattern covers a patch of a couple of metres, i.e. a few hundred lattice vertices.  The wavefront
+// finds the bounding rectangle of its ray starts, copies the z values, the lattice lines and the simple-cell bits
+// under it into LDS with row-contiguous loads, and every ray then intersects the two faces of its cell out of LDS.
+// Per env this reads about 25 x 25 floats of mesh data instead of ~190 cell words, ~400 index records and ~1000
+// vertices scattered over partly used 128-byte lines.  Rays that are not strictly inside a simple cell, envs whose
+// rectangle is not inside one patch or exceeds the window, and meshes without patches use the general structures.
+// ------------------------------------------------------------------------------------------------
+constexpr int kLatWin = 32;         // lattice lines per axis that an env's staged window can hold
+constexpr int kLatMaskWords = 2;    // 31 cells starting anywhere inside a 32-bit word touch at most two words
+constexpr int kLatEnvs = 8;         // envs per workgroup = wavefronts per workgroup
+constexpr int kLatKeep = 3;         // rays per lane whose pattern entry stays in registers (patterns up to 192 rays)
+constexpr int kLatMaxRays = 1024;   // longest scan pattern served per env; longer ones use the per-ray kernels
+constexpr float kLatMargin = 1.0f / 32768.0f;   // of the cell width; the barycentric slack is 1e-6 of a face
+constexpr float kLatDiagonal = 1.0f / 1024.0f;  // of the cell area: closer to the diagonal than this, both faces are tested
+
+// Per env, prepared by one lane of the prologue: the scalar work (mask, drift, yaw angle -> quaternion with atan2, sin,
+// cos, the patch search) would otherwise be repeated as whole wavefront instruction streams, and the window of the
+// height grid is known before the env's wavefront starts, so its loads are the first thing that wavefront issues.
+struct LatEnv {
+    f3 pos;                 // sensor position (+ drift)
+    f4 rot;                 // yaw part of the sensor orientation
+    int due;                // the env is refreshed by this launch
+    int sel;                // patch under the env's rays, or -1
+    int i_lo, j_lo, wi, wj; // staged window: lines i_lo .. i_lo + wi - 1 (x), j_lo .. j_lo + wj - 1 (y)
+    // the fields of the patch that the wavefront needs
+    float x0, y0, inv_dx, inv_dy;
+    int32_t nx, ny, mask_stride, face_base;
+    uint32_t z_off, line_off, mask_off;
+};
+
+// What one wavefront keeps in LDS for its env.
+struct LatStage {
+    float z[kLatWin * kLatWin];
+    float lines[2 * kLatWin];  // x lines, then y lines
+    uint32_t mask[kLatWin * kLatMaskWords];
+};
+
+ILX_DEV float wave_min(float v) {
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) v = fminf(v, __shfl_xor(v, m));
+    return v;
+}
+ILX_DEV float wave_max(float v) {
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) v = fmaxf(v, __shfl_xor(v, m));
+    return v;
+}
+
+// The staged lattice cell that the index estimate names for coordinate x (line l[k] is line lo_abs + k of the patch):
+// true when x lies strictly inside that cell c = [lo, hi] by the margin.  On an evenly spaced lattice the estimate
+// is the cell for every such x; where it is not (uneven lines, the window's edge, NaN) the ray is not served here.
+ILX_DEV bool lattice_cell(const float* l, int n, float x, float x0, float inv, int lo_abs, int& c, float& lo, float& hi) {
+    c = max(0, min(lattice_guess(x, x0, inv) - lo_abs, n - 2));
+    lo = l[c], hi = l[c + 1];
+    const float m = (hi - lo) * kLatMargin;
+    return (x - lo) > m && (hi - x) > m;
+}
+
+// Yaw-only sensors (ray_caster.py:243-247: starts rotated by the yaw, directions as they are).  One workgroup takes
+// kLatEnvs consecutive envs, one wavefront each:
+//   phase 0  every lane fetches its pattern entries; wavefront 0 reduces the pattern's xy bounding box
+//   phase 1  lanes 0..7 of wavefront 0 prepare one env each (LatEnv): pose, clocks, yaw quaternion, the rectangle the
+//            rotated pattern covers, the patch that holds it, the window of lattice lines
+//   phase 2  after the one barrier, every wavefront copies its env's window into LDS and intersects its rays there
+// Rays that are not strictly inside a simple cell use the column grid (or are left to the tree launch that follows).
+__global__ void __launch_bounds__(64 * kLatEnvs) raycaster_update_lattice_kernel(ScanArgs a) {
+    __shared__ LatStage stage_s[kLatEnvs];
+    __shared__ LatEnv env_s[kLatEnvs];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t env0 = static_cast<int64_t>(xcd_block(blockIdx.x, gridDim.x)) * kLatEnvs;
+    const float inf = __builtin_inff();
+
+    // phase 0: pattern entries of the lane (local start, z of the direction, is the direction z-parallel)
+    f3 kl[kLatKeep];
+    float kdz[kLatKeep];
+    uint32_t zpar = 0;
+#pragma unroll
+    for (int r = 0; r < kLatKeep; ++r) {
+        kl[r] = {0.0f, 0.0f, 0.0f}, kdz[r] = 0.0f;
+        const int ray = lane + 64 * r;
+        if (ray < a.r) {
+            kl[r] = load3(a.ray_starts + 3 * ray);
+            const f3 d = load3(a.ray_dirs + 3 * ray);
+            kdz[r] = d.z;
+            if (z_parallel(d)) zpar |= 1u << r;
+        }
+    }
+    if (wave == 0) {
+        float bx0 = inf, bx1 = -inf, by0 = inf, by1 = -inf;  // xy box of the z-parallel pattern entries
+#pragma unroll
+        for (int r = 0; r < kLatKeep; ++r)
+            if ((zpar >> r) & 1u) {
+                bx0 = fminf(bx0, kl[r].x), bx1 = fmaxf(bx1, kl[r].x);
+                by0 = fminf(by0, kl[r].y), by1 = fmaxf(by1, kl[r].y);
+            }
+        for (int ray = lane + 64 * kLatKeep; ray < a.r; ray += 64) {
+            const f3 l = load3(a.ray_starts + 3 * ray), d = load3(a.ray_dirs + 3 * ray);
+            if (z_parallel(d)) {
+                bx0 = fminf(bx0, l.x), bx1 = fmaxf(bx1, l.x);
+                by0 = fminf(by0, l.y), by1 = fmaxf(by1, l.y);
+            }
+        }
+        bx0 = wave_min(bx0), bx1 = wave_max(bx1), by0 = wave_min(by0), by1 = wave_max(by1);
+
+        // phase 1
+        if (lane < kLatEnvs) {
+            const int64_t env = env0 + lane;
+            LatEnv le{};
+            le.sel = -1;
+            if (env < a.n && (!a.env_mask || a.env_mask[env])) {
+                le.due = 1;
+                le.pos = load3(a.pos_w + a.pos_stride * env);
+                const f4 q = load4u(a.quat_w + a.quat_stride * env);
+                if (a.drift) {  // ray_caster.py:233-240
+                    const f3 dr = load3(a.drift + 3 * env);
+                    le.pos = {le.pos.x + dr.x, le.pos.y + dr.y, le.pos.z + dr.z};
+                }
+                if (a.pos_out) {
+                    store3(a.pos_out + 3 * env, le.pos);
+                    float* qo = a.quat_out + 4 * env;
+                    qo[0] = q.w, qo[1] = q.x, qo[2] = q.y, qo[3] = q.z;
+                }
+                if (a.outdated) {  // sensor_base.py:284-293: the refreshed env records the time
+                    a.clock_last[env] = a.clock_now[env];
+                    a.outdated[env] = 0;
+                }
+                le.rot = yaw_quat(q);
+                if (bx0 <= bx1) {
+                    // The rotation is about z: every ray start lies in the rotated box of the pattern, up to rounding.
+                    // The rectangle only decides which lines are staged -- a ray outside them is simply not served from
+                    // LDS -- so a small pad for the rounding is enough.
+                    float mnx = inf, mxx = -inf, mny = inf, mxy = -inf;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const f3 o = quat_apply(le.rot, f3{(c & 1) ? bx1 : bx0, (c & 2) ? by1 : by0, 0.0f});
+                        mnx = fminf(mnx, o.x), mxx = fmaxf(mxx, o.x), mny = fminf(mny, o.y), mxy = fmaxf(mxy, o.y);
+                    }
+                    const float pad = 1.0e-5f * ((mxx - mnx) + (mxy - mny)) + 4.0e-7f * (fabsf(le.pos.x) + fabsf(le.pos.y));
+                    mnx = mnx + le.pos.x - pad, mxx = mxx + le.pos.x + pad;
+                    mny = mny + le.pos.y - pad, mxy = mxy + le.pos.y + pad;
+                    // the patch whose extent holds the rectangle (any such patch will do: where patches overlap, the
+                    // cells are not simple)
+                    for (int p = 0; p < a.mesh.num_patches; ++p) {
+                        const float4 ext = *reinterpret_cast<const float4*>(&a.mesh.patches[p].x0);  // x0, y0, x1, y1
+                        if (mnx >= ext.x && mxx <= ext.z && mny >= ext.y && mxy <= ext.w) {
+                            le.sel = p;
+                            break;
+                        }
+                    }
+                    if (le.sel >= 0) {
+                        const LatticePatch P = a.mesh.patches[le.sel];
+                        const int gx0 = lattice_guess(mnx, P.x0, P.inv_dx), gx1 = lattice_guess(mxx, P.x0, P.inv_dx);
+                        const int gy0 = lattice_guess(mny, P.y0, P.inv_dy), gy1 = lattice_guess(mxy, P.y0, P.inv_dy);
+                        le.i_lo = max(0, min(gx0 - 1, P.nx - 2));
+                        le.j_lo = max(0, min(gy0 - 1, P.ny - 2));
+                        le.wi = min(P.nx - 1, max(gx1 + 2, le.i_lo + 1)) - le.i_lo + 1;
+                        le.wj = min(P.ny - 1, max(gy1 + 2, le.j_lo + 1)) - le.j_lo + 1;
+                        if (le.wi > kLatWin || le.wj > kLatWin) le.sel = -1;
+                        le.x0 = P.x0, le.y0 = P.y0, le.inv_dx = P.inv_dx, le.inv_dy = P.inv_dy;
+                        le.nx = P.nx, le.ny = P.ny, le.mask_stride = P.mask_stride, le.face_base = P.face_base;
+                        le.z_off = P.z_off, le.line_off = P.line_off, le.mask_off = P.mask_off;
+                    }
+                }
+            }
+            env_s[lane] = le;
+        }
+    }
+    __syncthreads();
+
+    // phase 2
+    const LatEnv& E = env_s[wave];
+    if (!E.due) return;
+    LatStage& st = stage_s[wave];
+    const int64_t env = env0 + wave;
+    const int sel = E.sel, i_lo = E.i_lo, j_lo = E.j_lo, wi = E.wi, wj = E.wj;
+    const int w0 = j_lo >> 5;
+    if (sel >= 0) {
+        // a wavefront load takes two window rows (lanes 0-31 and 32-63): row-contiguous runs of the height grid, no
+        // index arithmetic, and the LDS address of load k is 64 k + lane
+        const int half = lane >> 5, col = lane & 31;
+        const uint32_t ny = static_cast<uint32_t>(E.ny);
+        const float* zg = a.mesh.lat_z + E.z_off + (static_cast<uint32_t>(i_lo) + half) * ny + j_lo + col;
+#pragma unroll
+        for (int k0 = 0; k0 < kLatWin / 2; k0 += 8) {
+            if (2 * k0 >= wi) break;
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int row = 2 * (k0 + k) + half;
+                v[k] = (row < wi && col < wj) ? zg[static_cast<uint32_t>(2 * (k0 + k)) * ny] : 0.0f;
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) st.z[64 * (k0 + k) + lane] = v[k];
+        }
+        {   // lattice lines: x lines by lanes 0-31, y lines by lanes 32-63
+            const uint32_t at = E.line_off + (half ? static_cast<uint32_t>(E.nx + j_lo) : static_cast<uint32_t>(i_lo)) + col;
+            st.lines[lane] = col < (half ? wj : wi) ? a.mesh.lat_lines[at] : 0.0f;
+        }
+        if (lane < (wi - 1) * kLatMaskWords) {
+            const int row = lane / kLatMaskWords, w = lane - row * kLatMaskWords;
+            st.mask[lane] = (w0 + w < E.mask_stride)
+                                ? a.mesh.lat_mask[E.mask_off + static_cast<uint32_t>(i_lo + row) * E.mask_stride + w0 + w]
+                                : 0u;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+
+    const f3 pos = E.pos;
+    const f4 rot = E.rot;
+    float* const hits_env = a.ray_hits_w + 3 * (env * a.r);
+    float* const height_env = a.height ? a.height + env * a.r : nullptr;
+    // World start of a pattern entry: the arithmetic of sensor_ray with the per-env part hoisted.
+    auto world_start = [&](f3 l) {
+        const f3 o = quat_apply(rot, l);
+        return f3{o.x + pos.x, o.y + pos.y, o.z + pos.z};
+    };
+    // A ray strictly inside a simple cell is served from LDS.  Its side of the cell diagonal picks the face (operands
+    // selected, one intersection test); near the diagonal the other face is tested as well.
+    auto serve = [&](f3 o, float dz, int ray) -> bool {
+        int ci, cj;
+        float xlo, xhi, ylo, yhi;
+        const bool in_x = lattice_cell(st.lines, wi, o.x, E.x0, E.inv_dx, i_lo, ci, xlo, xhi);
+        const bool in_y = lattice_cell(st.lines + kLatWin, wj, o.y, E.y0, E.inv_dy, j_lo, cj, ylo, yhi);
+        const int jabs = j_lo + cj;
+        const uint32_t word = st.mask[ci * kLatMaskWords + ((jabs >> 5) - w0)];
+        if (!(in_x && in_y && ((word >> (jabs & 31)) & 1u))) return false;
+        const float* zc = st.z + ci * kLatWin + cj;
+        const f3 v00 = {xlo, ylo, zc[0]}, v01 = {xlo, yhi, zc[1]}, v10 = {xhi, ylo, zc[kLatWin]}, v11 = {xhi, yhi, zc[kLatWin + 1]};
+        const float wx = xhi - xlo, wy = yhi - ylo;
+        const float side = (o.y - ylo) * wx - (o.x - xlo) * wy;  // > 0: the half that holds v01
+        const bool upper = side > 0.0f;
+        const int32_t face = E.face_base + 2 * ((i_lo + ci) * (E.ny - 1) + jabs);
+        Hit h{inf, -1, {0.0f, 0.0f, 0.0f}};
+        // faces (ind0, ind3, ind1) and (ind0, ind2, ind3)
+        test_column_vertices<false>(v00, upper ? v11 : v10, upper ? v01 : v11, upper ? face : face + 1, o, dz, a.max_dist, h);
+        if (fabsf(side) <= wx * wy * kLatDiagonal)
+            test_column_vertices<false>(v00, upper ? v10 : v11, upper ? v11 : v01, upper ? face + 1 : face, o, dz, a.max_dist, h);
+        const bool ok = h.face >= 0;
+        const float hz = o.z + h.t * dz;  // kernels.py:69: start + t * dir; x and y are exact for a z-parallel ray
+        store3(hits_env + 3 * ray, ok ? f3{o.x, o.y, hz} : f3{inf, inf, inf});
+        if (height_env) height_env[ray] = pos.z - (ok ? hz : inf) - a.height_offset;
+        if (a.mesh.lat_served) atomicAdd(a.mesh.lat_served, 1ull);
+        return true;
+    };
+    uint32_t pending = 0;  // one bit per round of the ray loop: rays left to the general structures
+#pragma unroll
+    for (int r = 0; r < kLatKeep; ++r) {
+        const int ray = lane + 64 * r;
+        if (ray < a.r && !(sel >= 0 && ((zpar >> r) & 1u) && serve(world_start(kl[r]), kdz[r], ray))) pending |= 1u << r;
+    }
+    for (int ray = lane + 64 * kLatKeep, round = kLatKeep; ray < a.r; ray += 64, ++round) {
+        const f3 d = load3(a.ray_dirs + 3 * ray);
+        if (!(sel >= 0 && z_parallel(d) && serve(world_start(load3(a.ray_starts + 3 * ray)), d.z, ray))) pending |= 1u << round;
+    }
+    static_assert(kLatMaxRays <= 32 * 64, "one pending bit per round of the ray loop");
+    for (int ray = lane, round = 0; ray < a.r && (pending >> round) != 0u; ray += 64, ++round) {
+        if (!((pending >> round) & 1u)) continue;
+        const f3 o = world_start(load3(a.ray_starts + 3 * ray)), d = load3(a.ray_dirs + 3 * ray);
+        const int64_t i = env * a.r + ray;
+        if (!z_parallel(d) || !a.mesh.cells) {  // left to the tree kernel that follows
+            *a.off_grid = a.ticket;
+            a.ray_hits_w[3 * i] = __uint_as_float(kLeftOverBits);
+            continue;
+        }
+        const Hit h = trace_column<false>(a.mesh, o, d, a.max_dist);
+        write_scan(a, h, o, d, pos.z, i);
+    }
+}
+
 // RayCasterCamera._update_buffers_impl (ray_caster_camera.py:257-318): one thread per (env, pixel) of the refreshed
 // cameras.  Camera pose = view pose composed with the offset (:415-430); rays carry the full orientation (:269-272);
 // the cast has no range limit (1e6, :282) because the clipping happens on the two distance images afterwards.
@@ -597,16 +879,6 @@ sensor_refreshed_kernel(const float* __restrict__ ts, float* __restrict__ ts_las
 // ------------------------------------------------------------------------------------------------
 // host-side build
 // ------------------------------------------------------------------------------------------------
-struct Box {
-    float mn[3], mx[3];
-    void reset() {
-        for (int k = 0; k < 3; ++k) mn[k] = std::numeric_limits<float>::infinity(), mx[k] = -mn[k];
-    }
-    void grow(const Box& o) {
-        for (int k = 0; k < 3; ++k) mn[k] = std::min(mn[k], o.mn[k]), mx[k] = std::max(mx[k], o.mx[k]);
-    }
-};
-
 struct TmpNode {
     Box box[4];
     int32_t ref[4];   // >= 0: index into tmp nodes; leaf encoding otherwise
@@ -687,6 +959,12 @@ struct MeshHost {
     uint4* d_col_tris = nullptr;
     float4* d_col_verts = nullptr;
     GridStats grid{};
+    LatticePatch* d_patches = nullptr;
+    float* d_lat_z = nullptr;
+    float* d_lat_lines = nullptr;
+    uint32_t* d_lat_mask = nullptr;
+    int64_t lat_cells = 0, lat_simple = 0, lat_faces = 0;
+    unsigned long long* d_lat_served = nullptr;
     int32_t* d_off_grid = nullptr;  // kFlagSlots flags, one raised by a column kernel for the tree kernel launched after it
     std::atomic<uint32_t> calls{0}; // hinted casts so far: call c uses slot c % kFlagSlots and the ticket c + 1
     int depth = 0;
@@ -700,6 +978,32 @@ static int upload(T** dst, const std::vector<T>& src, const char* what) {
     if (rc == ILX_OK && !src.empty())
         rc = check_hip(hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice), what);
     return rc;
+}
+
+// Per-triangle boxes, inflated (the intersection formula may accept points a few ulps outside the exact triangle),
+// and box centres.  False when a vertex coordinate is not finite.
+static bool padded_boxes(const float* verts_host, const int32_t* tris_host, int nt, std::vector<Box>& box, std::vector<float>& cen) {
+    box.resize(nt);
+    cen.resize(3 * static_cast<size_t>(nt));
+    for (int t = 0; t < nt; ++t) {
+        Box b;
+        b.reset();
+        for (int k = 0; k < 3; ++k) {
+            const float* v = verts_host + 3 * static_cast<int64_t>(tris_host[3 * t + k]);
+            for (int a = 0; a < 3; ++a) {
+                if (!std::isfinite(v[a])) return false;
+                b.mn[a] = std::min(b.mn[a], v[a]), b.mx[a] = std::max(b.mx[a], v[a]);
+            }
+        }
+        for (int a = 0; a < 3; ++a) {
+            cen[3 * static_cast<size_t>(t) + a] = 0.5f * (b.mn[a] + b.mx[a]);
+            const float ext = b.mx[a] - b.mn[a];
+            const float pad = 1.0e-4f * std::max(ext, 1.0e-3f) + 4.0e-6f * std::max(std::fabs(b.mn[a]), std::fabs(b.mx[a]));
+            b.mn[a] -= pad, b.mx[a] += pad;
+        }
+        box[t] = b;
+    }
+    return true;
 }
 
 }  // namespace ilx
@@ -724,27 +1028,9 @@ extern "C" int ilx_mesh_create(const float* verts_host, int64_t num_verts, const
                     "ilx_mesh_create: triangle index %d outside [0, %lld)", tris_host[i], (long long)num_verts);
 
     // per-triangle boxes (inflated) and centroids
-    std::vector<Box> box(nt);
-    std::vector<float> cen(3 * static_cast<size_t>(nt));
-    for (int t = 0; t < nt; ++t) {
-        Box b;
-        b.reset();
-        for (int k = 0; k < 3; ++k) {
-            const float* v = verts_host + 3 * static_cast<int64_t>(tris_host[3 * t + k]);
-            for (int a = 0; a < 3; ++a) {
-                ILX_REQUIRE(std::isfinite(v[a]), ILX_EINVAL, "ilx_mesh_create: non-finite vertex coordinate");
-                b.mn[a] = std::min(b.mn[a], v[a]), b.mx[a] = std::max(b.mx[a], v[a]);
-            }
-        }
-        for (int a = 0; a < 3; ++a) {
-            cen[3 * t + a] = 0.5f * (b.mn[a] + b.mx[a]);
-            // inflate: the intersection formula may accept points a few ulps outside the exact triangle
-            const float ext = b.mx[a] - b.mn[a];
-            const float pad = 1.0e-4f * std::max(ext, 1.0e-3f) + 4.0e-6f * std::max(std::fabs(b.mn[a]), std::fabs(b.mx[a]));
-            b.mn[a] -= pad, b.mx[a] += pad;
-        }
-        box[t] = b;
-    }
+    std::vector<Box> box;
+    std::vector<float> cen;
+    if (!padded_boxes(verts_host, tris_host, nt, box, cen)) return fail(ILX_EINVAL, "ilx_mesh_create: non-finite vertex coordinate");
     std::vector<int> order(nt);
     std::iota(order.begin(), order.end(), 0);
     Builder bld{box, cen, order};
@@ -1080,6 +1366,11 @@ extern "C" int ilx_mesh_create(const float* verts_host, int64_t num_verts, const
         gstats.list_words = static_cast<int64_t>(cell_lists.size());
     }
 
+    // height-field patches (lattice.h); `box` still holds the padded triangle boxes
+    LatticeBuild lat;
+    detect_lattices(verts_host, num_verts, tris_host, nt, box, lat);
+    if (lat.z.size() >= (size_t(1) << 31)) lat = LatticeBuild{};  // 32-bit offsets in the kernels
+
     auto* obj = new ilx_mesh_s();
     MeshHost& h = obj->h;
     int rc = check_hip(hipMalloc(&h.d_nodes, nodes.size() * sizeof(Node)), "ilx_mesh_create: hipMalloc(nodes)");
@@ -1091,6 +1382,12 @@ extern "C" int ilx_mesh_create(const float* verts_host, int64_t num_verts, const
         if (rc == ILX_OK) rc = upload(&h.d_cell_lists, cell_lists, "cell lists");
         if (rc == ILX_OK) rc = upload(&h.d_col_tris, col_tris, "column triangles");
         if (rc == ILX_OK) rc = upload(&h.d_col_verts, col_verts, "column vertices");
+    }
+    if (rc == ILX_OK && !lat.patches.empty()) {
+        rc = upload(&h.d_patches, lat.patches, "lattice patches");
+        if (rc == ILX_OK) rc = upload(&h.d_lat_z, lat.z, "lattice heights");
+        if (rc == ILX_OK) rc = upload(&h.d_lat_lines, lat.lines, "lattice lines");
+        if (rc == ILX_OK) rc = upload(&h.d_lat_mask, lat.mask, "lattice cell bits");
     }
     if (rc == ILX_OK) rc = check_hip(hipMalloc(&h.d_tris, tris.size() * sizeof(float4)), "ilx_mesh_create: hipMalloc(tris)");
     if (rc == ILX_OK)
@@ -1108,6 +1405,10 @@ extern "C" int ilx_mesh_create(const float* verts_host, int64_t num_verts, const
         if (h.d_off_grid) (void)hipFree(h.d_off_grid);
         if (h.d_col_tris) (void)hipFree(h.d_col_tris);
         if (h.d_col_verts) (void)hipFree(h.d_col_verts);
+        if (h.d_patches) (void)hipFree(h.d_patches);
+        if (h.d_lat_z) (void)hipFree(h.d_lat_z);
+        if (h.d_lat_lines) (void)hipFree(h.d_lat_lines);
+        if (h.d_lat_mask) (void)hipFree(h.d_lat_mask);
         delete obj;
         return rc;
     }
@@ -1116,6 +1417,9 @@ extern "C" int ilx_mesh_create(const float* verts_host, int64_t num_verts, const
     h.dev.cells = h.d_cells, h.dev.cell_lists = reinterpret_cast<const uint4*>(h.d_cell_lists), h.dev.col_tris = h.d_col_tris, h.dev.col_verts = h.d_col_verts;
     h.dev.gx0 = g0[0], h.dev.gy0 = g0[1], h.dev.gx1 = g1[0], h.dev.gy1 = g1[1], h.dev.inv_cell = inv_cell;
     h.dev.nx = gnx, h.dev.ny = gny, h.dev.ntx = ntx;
+    h.dev.patches = h.d_patches, h.dev.lat_z = h.d_lat_z, h.dev.lat_lines = h.d_lat_lines, h.dev.lat_mask = h.d_lat_mask;
+    h.dev.num_patches = h.d_patches ? static_cast<int32_t>(lat.patches.size()) : 0;
+    h.lat_cells = lat.cells, h.lat_simple = lat.simple, h.lat_faces = lat.faces;
     h.grid = gstats;
     h.depth = bld.max_depth, h.num_verts = num_verts;
     *out = obj;
@@ -1132,6 +1436,11 @@ extern "C" void ilx_mesh_destroy(ilx_mesh_t mesh) {
     if (mesh->h.d_off_grid) (void)hipFree(mesh->h.d_off_grid);
     if (mesh->h.d_col_tris) (void)hipFree(mesh->h.d_col_tris);
     if (mesh->h.d_col_verts) (void)hipFree(mesh->h.d_col_verts);
+    if (mesh->h.d_patches) (void)hipFree(mesh->h.d_patches);
+    if (mesh->h.d_lat_z) (void)hipFree(mesh->h.d_lat_z);
+    if (mesh->h.d_lat_lines) (void)hipFree(mesh->h.d_lat_lines);
+    if (mesh->h.d_lat_mask) (void)hipFree(mesh->h.d_lat_mask);
+    if (mesh->h.d_lat_served) (void)hipFree(mesh->h.d_lat_served);
     delete mesh;
 }
 
@@ -1149,6 +1458,51 @@ extern "C" int ilx_mesh_grid_stats(ilx_mesh_t mesh, int64_t out[12]) {
     const int64_t v[12] = {g.cells, g.empty, g.run[0], g.run[1], g.run[2], g.list_cells, g.lists, g.list_words, g.candidates,
                            mesh->h.dev.nx, g.pairs, g.triples};
     for (int i = 0; i < 12; ++i) out[i] = v[i];
+    return ILX_OK;
+}
+
+extern "C" int ilx_mesh_lattice_probe(const float* verts_host, int64_t num_verts, const int32_t* tris_host, int64_t num_tris,
+                                      int64_t out[4]) {
+    ILX_REQUIRE(verts_host && tris_host && out, ILX_EINVAL, "ilx_mesh_lattice_probe: NULL argument");
+    ILX_REQUIRE(num_verts > 0 && num_tris > 0 && num_tris < (1 << 28), ILX_EINVAL, "ilx_mesh_lattice_probe: bad mesh size");
+    for (int64_t i = 0; i < 3 * num_tris; ++i)
+        ILX_REQUIRE(tris_host[i] >= 0 && tris_host[i] < num_verts, ILX_EINVAL,
+                    "ilx_mesh_lattice_probe: triangle index %d outside [0, %lld)", tris_host[i], (long long)num_verts);
+    std::vector<Box> box;
+    std::vector<float> cen;
+    ILX_REQUIRE(padded_boxes(verts_host, tris_host, static_cast<int>(num_tris), box, cen), ILX_EINVAL,
+                "ilx_mesh_lattice_probe: non-finite vertex coordinate");
+    LatticeBuild lat;
+    detect_lattices(verts_host, num_verts, tris_host, static_cast<int>(num_tris), box, lat);
+    out[0] = static_cast<int64_t>(lat.patches.size()), out[1] = lat.faces, out[2] = lat.cells, out[3] = lat.simple;
+    return ILX_OK;
+}
+
+extern "C" int ilx_mesh_lattice_stats(ilx_mesh_t mesh, int64_t out[4]) {
+    ILX_REQUIRE(mesh && out, ILX_EINVAL, "ilx_mesh_lattice_stats: NULL argument");
+    out[0] = mesh->h.dev.num_patches, out[1] = mesh->h.lat_faces, out[2] = mesh->h.lat_cells, out[3] = mesh->h.lat_simple;
+    return ILX_OK;
+}
+
+extern "C" int ilx_mesh_lattice_counter(ilx_mesh_t mesh, int enable, int64_t* served) {
+    ILX_REQUIRE(mesh, ILX_EINVAL, "ilx_mesh_lattice_counter: mesh is NULL");
+    MeshHost& h = mesh->h;
+    if (served) {
+        *served = 0;
+        if (h.d_lat_served) {
+            unsigned long long v = 0;
+            const int rc = check_hip(hipMemcpy(&v, h.d_lat_served, sizeof(v), hipMemcpyDeviceToHost), "ilx_mesh_lattice_counter: read");
+            if (rc != ILX_OK) return rc;
+            *served = static_cast<int64_t>(v);
+        }
+    }
+    if (enable) {  // (re)start the count
+        int rc = ILX_OK;
+        if (!h.d_lat_served) rc = check_hip(hipMalloc(&h.d_lat_served, sizeof(unsigned long long)), "ilx_mesh_lattice_counter: hipMalloc");
+        if (rc == ILX_OK) rc = check_hip(hipMemset(h.d_lat_served, 0, sizeof(unsigned long long)), "ilx_mesh_lattice_counter: clear");
+        if (rc != ILX_OK) return rc;
+    }
+    h.dev.lat_served = enable ? h.d_lat_served : nullptr;
     return ILX_OK;
 }
 
@@ -1244,6 +1598,16 @@ extern "C" int ilx_raycaster_refresh(const ilx_raycaster* rc, void* stream) {
 // no-op when there are none), or the tree kernel alone followed by the clock update.
 static int launch_scan(ilx_mesh_t mesh, ScanArgs a, int hints, void* stream) {
     const int64_t rays = a.n * a.r;
+    if ((hints & ILX_RAYS_Z_PARALLEL) && a.yaw_only && mesh->h.dev.num_patches > 0 && a.r <= kLatMaxRays && a.n < (int64_t(1) << 31)) {
+        // the height-field patches, one wavefront per env; the launch also advances the sensor clocks, so the tree launch
+        // behind it only looks at the flag (a small grid: it has work only when rays broke the hint)
+        take_ticket(mesh, a.ticket, a.off_grid);
+        hipLaunchKernelGGL(raycaster_update_lattice_kernel, dim3(static_cast<unsigned>((a.n + kLatEnvs - 1) / kLatEnvs)),
+                           dim3(64 * kLatEnvs), 0, as_stream(stream), a);
+        a.outdated = nullptr;
+        hipLaunchKernelGGL(raycaster_update_kernel, dim3(std::min(ray_grid(rays), 256u)), dim3(kRayBlock), 0, as_stream(stream), a);
+        return ILX_OK;
+    }
     if ((hints & ILX_RAYS_Z_PARALLEL) && mesh->h.d_cells) {
         take_ticket(mesh, a.ticket, a.off_grid);
         hipLaunchKernelGGL(raycaster_update_column_kernel, dim3(column_grid(rays)), dim3(kRayBlock), 0, as_stream(stream), a);

@@ -40,11 +40,34 @@ class Mesh:
                  "pairs", "triples")
         return dict(zip(names, (int(v) for v in out)))
 
+    def lattice_stats(self) -> dict:
+        """Height-field patches recognised in the mesh and how many of their cells serve z-parallel sensor rays from
+        the height grid alone (diagnostics)."""
+        out = (ctypes.c_int64 * 4)()
+        _abi.check(_abi.mesh_lattice_stats(self.handle, out), "ilx_mesh_lattice_stats")
+        return dict(zip(("patches", "faces", "cells", "simple_cells"), (int(v) for v in out)))
+
+    def lattice_counter(self, enable: bool = True) -> int:
+        """Switch the count of height-grid-served sensor rays on or off and return the count so far (diagnostics;
+        synchronises the device)."""
+        served = ctypes.c_int64()
+        _abi.check(_abi.mesh_lattice_counter(self.handle, int(enable), ctypes.byref(served)), "ilx_mesh_lattice_counter")
+        return served.value
+
     def __del__(self):
         h = getattr(self, "handle", None)
         if h and _abi is not None and getattr(_abi, "lib", None) is not None:
             _abi.lib.ilx_mesh_destroy(h)
             self.handle = None
+
+
+def lattice_probe(points, indices) -> dict:
+    """``Mesh.lattice_stats`` for host arrays, computed on the host alone (no device needed)."""
+    pts = np.ascontiguousarray(np.asarray(points, dtype=np.float32).reshape(-1, 3))
+    idx = np.ascontiguousarray(np.asarray(indices, dtype=np.int32).reshape(-1, 3))
+    out = (ctypes.c_int64 * 4)()
+    _abi.check(_abi.mesh_lattice_probe(pts.ctypes.data, pts.shape[0], idx.ctypes.data, idx.shape[0], out), "ilx_mesh_lattice_probe")
+    return dict(zip(("patches", "faces", "cells", "simple_cells"), (int(v) for v in out)))
 
 
 def convert_to_mesh(points: np.ndarray, indices: np.ndarray, device: str) -> Mesh:
