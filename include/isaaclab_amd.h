@@ -661,7 +661,12 @@ int ilx_mesh_lattice_probe(const float* verts_host, int64_t num_verts, const int
  * Ties in t go to the lowest face index.
  * hints: bit mask of ilx_ray_hint; a hint changes which kernel runs, never the result. */
 enum ilx_ray_hint {
-    ILX_RAYS_Z_PARALLEL = 1 /* the caller expects every direction to be (0, 0, +-z), e.g. a height-scan pattern */
+    ILX_RAYS_Z_PARALLEL = 1, /* the caller expects every direction to be (0, 0, +-z), e.g. a height-scan pattern */
+    /* With ILX_RAYS_Z_PARALLEL, for the sensor entry points with attach_yaw_only (world directions = the pattern's
+     * directions, ray_caster.py:247): a PROMISE that the caller has checked every pattern direction to be (0, 0, +-z).
+     * The launch that would pick up other rays is then not queued; a ray that breaks the promise is left with a NaN in
+     * ray_hits_w[..., 0] instead of a result. */
+    ILX_RAYS_Z_PARALLEL_CHECKED = 2
 };
 int ilx_raycast_mesh(ilx_mesh_t mesh, const float* ray_starts, const float* ray_directions, int64_t num_rays,
                      float max_dist, float* ray_hits, float* ray_distance, float* ray_normal, int32_t* ray_face_id,

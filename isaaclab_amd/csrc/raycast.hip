@@ -29,6 +29,7 @@
 #include <cmath>
 #include <cstring>
 #include <limits>
+#include <mutex>
 #include <numeric>
 #include <unordered_map>
 #include <vector>
@@ -520,7 +521,7 @@ __global__ void __launch_bounds__(kRayBlock) raycaster_update_column_kernel(Scan
 }
 
 // ------------------------------------------------------------------------------------------------
-// Sensor refresh over height-field patches (lattice.h): one wavefront per env at a time.
+// Sensor refresh over height-field patches (lattice.h): a preparation launch, then one wavefront per env.
 //
 // An env's scan pattern covers a patch of a couple of metres, i.e. a few hundred lattice vertices.  The wavefront
 // finds the bounding rectangle of its ray starts, copies the z values, the lattice lines and the simple-cell bits
@@ -531,26 +532,27 @@ __global__ void __launch_bounds__(kRayBlock) raycaster_update_column_kernel(Scan
 // ------------------------------------------------------------------------------------------------
 constexpr int kLatWin = 32;         // lattice lines per axis that an env's staged window can hold
 constexpr int kLatMaskWords = 2;    // 31 cells starting anywhere inside a 32-bit word touch at most two words
-constexpr int kLatEnvs = 8;         // envs per workgroup = wavefronts per workgroup
+constexpr int kLatWaves = 4;        // wavefronts (= envs) per workgroup of the cast
 constexpr int kLatKeep = 3;         // rays per lane whose pattern entry stays in registers (patterns up to 192 rays)
 constexpr int kLatMaxRays = 1024;   // longest scan pattern served per env; longer ones use the per-ray kernels
 constexpr float kLatMargin = 1.0f / 32768.0f;   // of the cell width; the barycentric slack is 1e-6 of a face
-constexpr float kLatDiagonal = 1.0f / 1024.0f;  // of the cell area: closer to the diagonal than this, both faces are tested
+constexpr float kLatDiagonal = 1.0f / 16384.0f; // of the cell area: closer to the diagonal than this, both faces are tested
+constexpr int kLatNotDue = -2;      // LatEnvRec::sel of an env that this refresh leaves alone
 
-// Per env, prepared by one lane of the prologue: the scalar work (mask, drift, yaw angle -> quaternion with atan2, sin,
-// cos, the patch search) would otherwise be repeated as whole wavefront instruction streams, and the window of the
-// height grid is known before the env's wavefront starts, so its loads are the first thing that wavefront issues.
-struct LatEnv {
-    f3 pos;                 // sensor position (+ drift)
-    f4 rot;                 // yaw part of the sensor orientation
-    int due;                // the env is refreshed by this launch
-    int sel;                // patch under the env's rays, or -1
-    int i_lo, j_lo, wi, wj; // staged window: lines i_lo .. i_lo + wi - 1 (x), j_lo .. j_lo + wj - 1 (y)
-    // the fields of the patch that the wavefront needs
-    float x0, y0, inv_dx, inv_dy;
+// Per env, written by the preparation launch and read (as scalars) by the env's wavefront in the cast launch.  The
+// scalar work of an env -- mask, drift, clocks, yaw angle -> quaternion (atan2, sin, cos), the patch search, the window
+// of lattice lines -- is done once by one thread there, instead of as whole wavefront instruction streams here, and the
+// wavefront's first instructions can already be the loads of its window.
+struct alignas(16) LatEnvRec {
+    float px, py, pz;        // sensor position (+ drift)
+    float rw, rx, ry, rz;    // yaw part of the sensor orientation
+    int32_t sel;             // patch under the env's rays, -1: none, kLatNotDue: env not refreshed
+    int32_t i_lo, j_lo, wi, wj;  // staged window: lines i_lo .. i_lo + wi - 1 (x), j_lo .. j_lo + wj - 1 (y)
+    float x0, y0, inv_dx, inv_dy;            // the fields of the patch that the cast needs
     int32_t nx, ny, mask_stride, face_base;
-    uint32_t z_off, line_off, mask_off;
+    uint32_t z_off, line_off, mask_off, pad;
 };
+static_assert(sizeof(LatEnvRec) == 96, "six 16-byte words");
 
 // What one wavefront keeps in LDS for its env.
 struct LatStage {
@@ -570,6 +572,101 @@ ILX_DEV float wave_max(float v) {
     return v;
 }
 
+// Preparation launch of the height-field refresh: one thread per env (yaw-only sensors, ray_caster.py:243-247).
+//   pos_w / quat_w of RayCasterData, the sensor clocks (sensor_base.py:284-293), the yaw quaternion, the rectangle
+//   that the rotated scan pattern covers, the patch that holds it and the window of lattice lines -> LatEnvRec.
+// The pattern's xy box is reduced by every workgroup for itself (a few loads per thread).
+__global__ void __launch_bounds__(256) raycaster_prepare_kernel(ScanArgs a, LatEnvRec* __restrict__ recs, float4* __restrict__ pattern) {
+    __shared__ float box_s[4][4];
+    const float inf = __builtin_inff();
+    float bx0 = inf, bx1 = -inf, by0 = inf, by1 = -inf;  // xy box of the z-parallel pattern entries
+    for (int ray = threadIdx.x; ray < a.r; ray += 256) {
+        const f3 l = load3(a.ray_starts + 3 * ray), d = load3(a.ray_dirs + 3 * ray);
+        const bool zp = z_parallel(d);
+        if (zp) {
+            bx0 = fminf(bx0, l.x), bx1 = fmaxf(bx1, l.x);
+            by0 = fminf(by0, l.y), by1 = fmaxf(by1, l.y);
+        }
+        // the pattern as the cast wants it: one 16-byte word per ray, local start and z of the direction -- NaN when
+        // the direction is not z-parallel (such a ray never takes the height-grid path)
+        if (blockIdx.x == 0) pattern[ray] = make_float4(l.x, l.y, l.z, zp ? d.z : __builtin_nanf(""));
+    }
+    bx0 = wave_min(bx0), bx1 = wave_max(bx1), by0 = wave_min(by0), by1 = wave_max(by1);
+    if ((threadIdx.x & 63) == 0) {
+        float* b = box_s[threadIdx.x >> 6];
+        b[0] = bx0, b[1] = bx1, b[2] = by0, b[3] = by1;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        bx0 = fminf(bx0, box_s[w][0]), bx1 = fmaxf(bx1, box_s[w][1]);
+        by0 = fminf(by0, box_s[w][2]), by1 = fmaxf(by1, box_s[w][3]);
+    }
+    const int64_t env = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+    if (env >= a.n) return;
+    LatEnvRec le{};
+    le.sel = kLatNotDue;
+    if (!a.env_mask || a.env_mask[env]) {
+        le.sel = -1;
+        f3 pos = load3(a.pos_w + a.pos_stride * env);
+        const f4 q = load4u(a.quat_w + a.quat_stride * env);
+        if (a.drift) {  // ray_caster.py:233-240
+            const f3 dr = load3(a.drift + 3 * env);
+            pos = {pos.x + dr.x, pos.y + dr.y, pos.z + dr.z};
+        }
+        if (a.pos_out) {
+            store3(a.pos_out + 3 * env, pos);
+            float* qo = a.quat_out + 4 * env;
+            qo[0] = q.w, qo[1] = q.x, qo[2] = q.y, qo[3] = q.z;
+        }
+        if (a.outdated) {  // the refreshed env records the time
+            a.clock_last[env] = a.clock_now[env];
+            a.outdated[env] = 0;
+        }
+        const f4 rot = yaw_quat(q);
+        le.px = pos.x, le.py = pos.y, le.pz = pos.z;
+        le.rw = rot.w, le.rx = rot.x, le.ry = rot.y, le.rz = rot.z;
+        if (bx0 <= bx1) {
+            // The rotation is about z: every ray start lies in the rotated box of the pattern, up to rounding.  The
+            // rectangle only decides which lines are staged -- a ray outside them is simply not served from LDS -- so a
+            // small pad for the rounding is enough.
+            float mnx = inf, mxx = -inf, mny = inf, mxy = -inf;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const f3 o = quat_apply(rot, f3{(c & 1) ? bx1 : bx0, (c & 2) ? by1 : by0, 0.0f});
+                mnx = fminf(mnx, o.x), mxx = fmaxf(mxx, o.x), mny = fminf(mny, o.y), mxy = fmaxf(mxy, o.y);
+            }
+            const float pad = 1.0e-5f * ((mxx - mnx) + (mxy - mny)) + 4.0e-7f * (fabsf(pos.x) + fabsf(pos.y));
+            mnx = mnx + pos.x - pad, mxx = mxx + pos.x + pad;
+            mny = mny + pos.y - pad, mxy = mxy + pos.y + pad;
+            // the patch whose extent holds the rectangle (any such patch will do: where patches overlap, the cells are
+            // not simple)
+            int sel = -1;
+            for (int p = 0; p < a.mesh.num_patches; ++p) {
+                const float4 ext = *reinterpret_cast<const float4*>(&a.mesh.patches[p].x0);  // x0, y0, x1, y1
+                if (mnx >= ext.x && mxx <= ext.z && mny >= ext.y && mxy <= ext.w) {
+                    sel = p;
+                    break;
+                }
+            }
+            if (sel >= 0) {
+                const LatticePatch P = a.mesh.patches[sel];
+                const int gx0 = lattice_guess(mnx, P.x0, P.inv_dx), gx1 = lattice_guess(mxx, P.x0, P.inv_dx);
+                const int gy0 = lattice_guess(mny, P.y0, P.inv_dy), gy1 = lattice_guess(mxy, P.y0, P.inv_dy);
+                le.i_lo = max(0, min(gx0 - 1, P.nx - 2));
+                le.j_lo = max(0, min(gy0 - 1, P.ny - 2));
+                le.wi = min(P.nx - 1, max(gx1 + 2, le.i_lo + 1)) - le.i_lo + 1;
+                le.wj = min(P.ny - 1, max(gy1 + 2, le.j_lo + 1)) - le.j_lo + 1;
+                if (le.wi <= kLatWin && le.wj <= kLatWin) le.sel = sel;
+                le.x0 = P.x0, le.y0 = P.y0, le.inv_dx = P.inv_dx, le.inv_dy = P.inv_dy;
+                le.nx = P.nx, le.ny = P.ny, le.mask_stride = P.mask_stride, le.face_base = P.face_base;
+                le.z_off = P.z_off, le.line_off = P.line_off, le.mask_off = P.mask_off;
+            }
+        }
+    }
+    recs[env] = le;
+}
+
 // The staged lattice cell that the index estimate names for coordinate x (line l[k] is line lo_abs + k of the patch):
 // true when x lies strictly inside that cell c = [lo, hi] by the margin.  On an evenly spaced lattice the estimate
 // is the cell for every such x; where it is not (uneven lines, the window's edge, NaN) the ray is not served here.
@@ -580,123 +677,29 @@ ILX_DEV bool lattice_cell(const float* l, int n, float x, float x0, float inv, i
     return (x - lo) > m && (hi - x) > m;
 }
 
-// Yaw-only sensors (ray_caster.py:243-247: starts rotated by the yaw, directions as they are).  One workgroup takes
-// kLatEnvs consecutive envs, one wavefront each:
-//   phase 0  every lane fetches its pattern entries; wavefront 0 reduces the pattern's xy bounding box
-//   phase 1  lanes 0..7 of wavefront 0 prepare one env each (LatEnv): pose, clocks, yaw quaternion, the rectangle the
-//            rotated pattern covers, the patch that holds it, the window of lattice lines
-//   phase 2  after the one barrier, every wavefront copies its env's window into LDS and intersects its rays there
-// Rays that are not strictly inside a simple cell use the column grid (or are left to the tree launch that follows).
-__global__ void __launch_bounds__(64 * kLatEnvs) raycaster_update_lattice_kernel(ScanArgs a) {
-    __shared__ LatStage stage_s[kLatEnvs];
-    __shared__ LatEnv env_s[kLatEnvs];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t env0 = static_cast<int64_t>(xcd_block(blockIdx.x, gridDim.x)) * kLatEnvs;
+// Cast launch of the height-field refresh: one wavefront per env, no barrier.  The wavefront reads its env's record
+// (uniform: scalar registers), copies the window of the height grid into LDS and intersects its rays there; a
+// wavefront's own LDS traffic is ordered.  Rays that are not strictly inside a simple cell use the column grid (or
+// are left to the tree launch that follows).
+__global__ void __launch_bounds__(64 * kLatWaves) raycaster_update_lattice_kernel(ScanArgs a, const LatEnvRec* __restrict__ recs,
+                                                                                   const float4* __restrict__ pattern) {
+    __shared__ LatStage stage_s[kLatWaves];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const float inf = __builtin_inff();
+    const int64_t env = static_cast<int64_t>(xcd_block(blockIdx.x, gridDim.x)) * kLatWaves + wave;
+    if (env >= a.n) return;
+    const LatEnvRec E = recs[env];
 
-    // phase 0: pattern entries of the lane (local start, z of the direction, is the direction z-parallel)
-    f3 kl[kLatKeep];
-    float kdz[kLatKeep];
-    uint32_t zpar = 0;
+    // pattern entries of the lane: local start, z of the direction (NaN: not z-parallel)
+    float4 kp[kLatKeep];
 #pragma unroll
     for (int r = 0; r < kLatKeep; ++r) {
-        kl[r] = {0.0f, 0.0f, 0.0f}, kdz[r] = 0.0f;
         const int ray = lane + 64 * r;
-        if (ray < a.r) {
-            kl[r] = load3(a.ray_starts + 3 * ray);
-            const f3 d = load3(a.ray_dirs + 3 * ray);
-            kdz[r] = d.z;
-            if (z_parallel(d)) zpar |= 1u << r;
-        }
+        kp[r] = ray < a.r ? pattern[ray] : make_float4(0.0f, 0.0f, 0.0f, __builtin_nanf(""));
     }
-    if (wave == 0) {
-        float bx0 = inf, bx1 = -inf, by0 = inf, by1 = -inf;  // xy box of the z-parallel pattern entries
-#pragma unroll
-        for (int r = 0; r < kLatKeep; ++r)
-            if ((zpar >> r) & 1u) {
-                bx0 = fminf(bx0, kl[r].x), bx1 = fmaxf(bx1, kl[r].x);
-                by0 = fminf(by0, kl[r].y), by1 = fmaxf(by1, kl[r].y);
-            }
-        for (int ray = lane + 64 * kLatKeep; ray < a.r; ray += 64) {
-            const f3 l = load3(a.ray_starts + 3 * ray), d = load3(a.ray_dirs + 3 * ray);
-            if (z_parallel(d)) {
-                bx0 = fminf(bx0, l.x), bx1 = fmaxf(bx1, l.x);
-                by0 = fminf(by0, l.y), by1 = fmaxf(by1, l.y);
-            }
-        }
-        bx0 = wave_min(bx0), bx1 = wave_max(bx1), by0 = wave_min(by0), by1 = wave_max(by1);
-
-        // phase 1
-        if (lane < kLatEnvs) {
-            const int64_t env = env0 + lane;
-            LatEnv le{};
-            le.sel = -1;
-            if (env < a.n && (!a.env_mask || a.env_mask[env])) {
-                le.due = 1;
-                le.pos = load3(a.pos_w + a.pos_stride * env);
-                const f4 q = load4u(a.quat_w + a.quat_stride * env);
-                if (a.drift) {  // ray_caster.py:233-240
-                    const f3 dr = load3(a.drift + 3 * env);
-                    le.pos = {le.pos.x + dr.x, le.pos.y + dr.y, le.pos.z + dr.z};
-                }
-                if (a.pos_out) {
-                    store3(a.pos_out + 3 * env, le.pos);
-                    float* qo = a.quat_out + 4 * env;
-                    qo[0] = q.w, qo[1] = q.x, qo[2] = q.y, qo[3] = q.z;
-                }
-                if (a.outdated) {  // sensor_base.py:284-293: the refreshed env records the time
-                    a.clock_last[env] = a.clock_now[env];
-                    a.outdated[env] = 0;
-                }
-                le.rot = yaw_quat(q);
-                if (bx0 <= bx1) {
-                    // The rotation is about z: every ray start lies in the rotated box of the pattern, up to rounding.
-                    // The rectangle only decides which lines are staged -- a ray outside them is simply not served from
-                    // LDS -- so a small pad for the rounding is enough.
-                    float mnx = inf, mxx = -inf, mny = inf, mxy = -inf;
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        const f3 o = quat_apply(le.rot, f3{(c & 1) ? bx1 : bx0, (c & 2) ? by1 : by0, 0.0f});
-                        mnx = fminf(mnx, o.x), mxx = fmaxf(mxx, o.x), mny = fminf(mny, o.y), mxy = fmaxf(mxy, o.y);
-                    }
-                    const float pad = 1.0e-5f * ((mxx - mnx) + (mxy - mny)) + 4.0e-7f * (fabsf(le.pos.x) + fabsf(le.pos.y));
-                    mnx = mnx + le.pos.x - pad, mxx = mxx + le.pos.x + pad;
-                    mny = mny + le.pos.y - pad, mxy = mxy + le.pos.y + pad;
-                    // the patch whose extent holds the rectangle (any such patch will do: where patches overlap, the
-                    // cells are not simple)
-                    for (int p = 0; p < a.mesh.num_patches; ++p) {
-                        const float4 ext = *reinterpret_cast<const float4*>(&a.mesh.patches[p].x0);  // x0, y0, x1, y1
-                        if (mnx >= ext.x && mxx <= ext.z && mny >= ext.y && mxy <= ext.w) {
-                            le.sel = p;
-                            break;
-                        }
-                    }
-                    if (le.sel >= 0) {
-                        const LatticePatch P = a.mesh.patches[le.sel];
-                        const int gx0 = lattice_guess(mnx, P.x0, P.inv_dx), gx1 = lattice_guess(mxx, P.x0, P.inv_dx);
-                        const int gy0 = lattice_guess(mny, P.y0, P.inv_dy), gy1 = lattice_guess(mxy, P.y0, P.inv_dy);
-                        le.i_lo = max(0, min(gx0 - 1, P.nx - 2));
-                        le.j_lo = max(0, min(gy0 - 1, P.ny - 2));
-                        le.wi = min(P.nx - 1, max(gx1 + 2, le.i_lo + 1)) - le.i_lo + 1;
-                        le.wj = min(P.ny - 1, max(gy1 + 2, le.j_lo + 1)) - le.j_lo + 1;
-                        if (le.wi > kLatWin || le.wj > kLatWin) le.sel = -1;
-                        le.x0 = P.x0, le.y0 = P.y0, le.inv_dx = P.inv_dx, le.inv_dy = P.inv_dy;
-                        le.nx = P.nx, le.ny = P.ny, le.mask_stride = P.mask_stride, le.face_base = P.face_base;
-                        le.z_off = P.z_off, le.line_off = P.line_off, le.mask_off = P.mask_off;
-                    }
-                }
-            }
-            env_s[lane] = le;
-        }
-    }
-    __syncthreads();
-
-    // phase 2
-    const LatEnv& E = env_s[wave];
-    if (!E.due) return;
-    LatStage& st = stage_s[wave];
-    const int64_t env = env0 + wave;
     const int sel = E.sel, i_lo = E.i_lo, j_lo = E.j_lo, wi = E.wi, wj = E.wj;
+    if (sel == kLatNotDue) return;
+    LatStage& st = stage_s[wave];
     const int w0 = j_lo >> 5;
     if (sel >= 0) {
         // a wavefront load takes two window rows (lanes 0-31 and 32-63): row-contiguous runs of the height grid, no
@@ -731,17 +734,24 @@ __global__ void __launch_bounds__(64 * kLatEnvs) raycaster_update_lattice_kernel
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     }
 
-    const f3 pos = E.pos;
-    const f4 rot = E.rot;
+    const f3 pos = {E.px, E.py, E.pz};
+    const f4 rot = {E.rw, E.rx, E.ry, E.rz};
     float* const hits_env = a.ray_hits_w + 3 * (env * a.r);
     float* const height_env = a.height ? a.height + env * a.r : nullptr;
-    // World start of a pattern entry: the arithmetic of sensor_ray with the per-env part hoisted.
+    // World start of a pattern entry: quat_apply(rot, l) + pos (ray_caster.py:245-246) for a yaw quaternion.  rot.x and
+    // rot.y are exact zeros (yaw_quat builds (cos, 0, 0, sin) and divides by the norm), so the products with them in
+    // quat_apply's two cross products are exact zeros and drop out; what is left is the same sequence of roundings:
+    //   t = 2 (u x l) = (-(z ly) 2, (z lx) 2, 0),  u x t = (-(z ty), z tx, 0),  o = l + w t + u x t
     auto world_start = [&](f3 l) {
-        const f3 o = quat_apply(rot, l);
-        return f3{o.x + pos.x, o.y + pos.y, o.z + pos.z};
+        const float tx = -(rot.z * l.y) * 2.0f, ty = (rot.z * l.x) * 2.0f;
+        return f3{(l.x + rot.w * tx + -(rot.z * ty)) + pos.x, (l.y + rot.w * ty + rot.z * tx) + pos.y, l.z + pos.z};
     };
-    // A ray strictly inside a simple cell is served from LDS.  Its side of the cell diagonal picks the face (operands
-    // selected, one intersection test); near the diagonal the other face is tested as well.
+    // A ray strictly inside a simple cell is served from LDS.  Its side of the cell diagonal picks the face.  Away from
+    // the diagonal the ray is inside that face by margins (of the cell: kLatMargin from the borders, kLatDiagonal from
+    // the diagonal) dozens of times the barycentric slack and the rounding of the test, so the inside test of
+    // ray_triangle_z_inside is known to pass and that of the other face to fail: only the distance t is evaluated,
+    // with the operations of ray_triangle_z_inside / ray_triangle_z_distance that feed it.  Near the diagonal both
+    // faces go through the full test.
     auto serve = [&](f3 o, float dz, int ray) -> bool {
         int ci, cj;
         float xlo, xhi, ylo, yhi;
@@ -749,20 +759,34 @@ __global__ void __launch_bounds__(64 * kLatEnvs) raycaster_update_lattice_kernel
         const bool in_y = lattice_cell(st.lines + kLatWin, wj, o.y, E.y0, E.inv_dy, j_lo, cj, ylo, yhi);
         const int jabs = j_lo + cj;
         const uint32_t word = st.mask[ci * kLatMaskWords + ((jabs >> 5) - w0)];
-        if (!(in_x && in_y && ((word >> (jabs & 31)) & 1u))) return false;
+        if (!(in_x && in_y && ((word >> (jabs & 31)) & 1u) && dz != 0.0f)) return false;
         const float* zc = st.z + ci * kLatWin + cj;
-        const f3 v00 = {xlo, ylo, zc[0]}, v01 = {xlo, yhi, zc[1]}, v10 = {xhi, ylo, zc[kLatWin]}, v11 = {xhi, yhi, zc[kLatWin + 1]};
+        const float z00 = zc[0], z01 = zc[1], z10 = zc[kLatWin], z11 = zc[kLatWin + 1];
         const float wx = xhi - xlo, wy = yhi - ylo;
-        const float side = (o.y - ylo) * wx - (o.x - xlo) * wy;  // > 0: the half that holds v01
+        const float sx = o.x - xlo, sy = o.y - ylo, sz = o.z - z00;  // ray start relative to v0 = v00
+        const float side = sy * wx - sx * wy;  // > 0: the half that holds v01, face (ind0, ind3, ind1); else (ind0, ind2, ind3)
         const bool upper = side > 0.0f;
-        const int32_t face = E.face_base + 2 * ((i_lo + ci) * (E.ny - 1) + jabs);
-        Hit h{inf, -1, {0.0f, 0.0f, 0.0f}};
-        // faces (ind0, ind3, ind1) and (ind0, ind2, ind3)
-        test_column_vertices<false>(v00, upper ? v11 : v10, upper ? v01 : v11, upper ? face : face + 1, o, dz, a.max_dist, h);
-        if (fabsf(side) <= wx * wy * kLatDiagonal)
-            test_column_vertices<false>(v00, upper ? v10 : v11, upper ? v11 : v01, upper ? face + 1 : face, o, dz, a.max_dist, h);
-        const bool ok = h.face >= 0;
-        const float hz = o.z + h.t * dz;  // kernels.py:69: start + t * dir; x and y are exact for a z-parallel ray
+        float t;
+        bool ok;
+        if (fabsf(side) > wx * wy * kLatDiagonal) {
+            // v1 - v0 and v2 - v0 of the face: (v11, v01) or (v10, v11)
+            const float e1x = wx, e1y = upper ? wy : ylo - ylo, e1z = (upper ? z11 : z10) - z00;
+            const float e2x = upper ? xlo - xlo : wx, e2y = wy, e2z = (upper ? z01 : z11) - z00;
+            const float px = -(dz * e2y), py = dz * e2x;
+            const float inv = div_(1.0f, e1x * px + e1y * py);
+            const float qz = fmaf_(sx, e1y, -(sy * e1x));
+            const float qx = fmaf_(sy, e1z, -(sz * e1y)), qy = fmaf_(sz, e1x, -(sx * e1z));
+            t = ((e2x * qx + e2y * qy) + e2z * qz) * inv;
+            ok = t >= 0.0f && t < a.max_dist;
+        } else {
+            const f3 v00 = {xlo, ylo, z00}, v01 = {xlo, yhi, z01}, v10 = {xhi, ylo, z10}, v11 = {xhi, yhi, z11};
+            const int32_t face = E.face_base + 2 * ((i_lo + ci) * (E.ny - 1) + jabs);
+            Hit h{inf, -1, {0.0f, 0.0f, 0.0f}};
+            test_column_vertices<false>(v00, v11, v01, face, o, dz, a.max_dist, h);
+            test_column_vertices<false>(v00, v10, v11, face + 1, o, dz, a.max_dist, h);
+            t = h.t, ok = h.face >= 0;
+        }
+        const float hz = o.z + t * dz;  // kernels.py:69: start + t * dir; x and y are exact for a z-parallel ray
         store3(hits_env + 3 * ray, ok ? f3{o.x, o.y, hz} : f3{inf, inf, inf});
         if (height_env) height_env[ray] = pos.z - (ok ? hz : inf) - a.height_offset;
         if (a.mesh.lat_served) atomicAdd(a.mesh.lat_served, 1ull);
@@ -772,16 +796,19 @@ __global__ void __launch_bounds__(64 * kLatEnvs) raycaster_update_lattice_kernel
 #pragma unroll
     for (int r = 0; r < kLatKeep; ++r) {
         const int ray = lane + 64 * r;
-        if (ray < a.r && !(sel >= 0 && ((zpar >> r) & 1u) && serve(world_start(kl[r]), kdz[r], ray))) pending |= 1u << r;
+        const bool zp = kp[r].w == kp[r].w;
+        if (ray < a.r && !(sel >= 0 && zp && serve(world_start(f3{kp[r].x, kp[r].y, kp[r].z}), kp[r].w, ray))) pending |= 1u << r;
     }
     for (int ray = lane + 64 * kLatKeep, round = kLatKeep; ray < a.r; ray += 64, ++round) {
-        const f3 d = load3(a.ray_dirs + 3 * ray);
-        if (!(sel >= 0 && z_parallel(d) && serve(world_start(load3(a.ray_starts + 3 * ray)), d.z, ray))) pending |= 1u << round;
+        const float4 e = pattern[ray];
+        if (!(sel >= 0 && e.w == e.w && serve(world_start(f3{e.x, e.y, e.z}), e.w, ray))) pending |= 1u << round;
     }
     static_assert(kLatMaxRays <= 32 * 64, "one pending bit per round of the ray loop");
     for (int ray = lane, round = 0; ray < a.r && (pending >> round) != 0u; ray += 64, ++round) {
         if (!((pending >> round) & 1u)) continue;
-        const f3 o = world_start(load3(a.ray_starts + 3 * ray)), d = load3(a.ray_dirs + 3 * ray);
+        const f3 l = load3(a.ray_starts + 3 * ray), d = load3(a.ray_dirs + 3 * ray);
+        f3 o = quat_apply(rot, l);  // as sensor_ray
+        o = {o.x + pos.x, o.y + pos.y, o.z + pos.z};
         const int64_t i = env * a.r + ray;
         if (!z_parallel(d) || !a.mesh.cells) {  // left to the tree kernel that follows
             *a.off_grid = a.ticket;
@@ -965,6 +992,12 @@ struct MeshHost {
     uint32_t* d_lat_mask = nullptr;
     int64_t lat_cells = 0, lat_simple = 0, lat_faces = 0;
     unsigned long long* d_lat_served = nullptr;
+    // Workspace (scan pattern + env records) between the launches of the height-field refresh: one buffer per stream (launches on one stream
+    // are ordered, so they can share it), grown on demand; outgrown buffers are kept until the mesh is destroyed because
+    // work that uses them may still be queued.
+    std::mutex ws_lock;
+    std::unordered_map<void*, std::pair<void*, size_t>> ws_by_stream;
+    std::vector<void*> ws_retired;
     int32_t* d_off_grid = nullptr;  // kFlagSlots flags, one raised by a column kernel for the tree kernel launched after it
     std::atomic<uint32_t> calls{0}; // hinted casts so far: call c uses slot c % kFlagSlots and the ticket c + 1
     int depth = 0;
@@ -1441,6 +1474,8 @@ extern "C" void ilx_mesh_destroy(ilx_mesh_t mesh) {
     if (mesh->h.d_lat_lines) (void)hipFree(mesh->h.d_lat_lines);
     if (mesh->h.d_lat_mask) (void)hipFree(mesh->h.d_lat_mask);
     if (mesh->h.d_lat_served) (void)hipFree(mesh->h.d_lat_served);
+    for (auto& kv : mesh->h.ws_by_stream) (void)hipFree(kv.second.first);
+    for (void* p : mesh->h.ws_retired) (void)hipFree(p);
     delete mesh;
 }
 
@@ -1513,6 +1548,46 @@ static unsigned ray_grid(int64_t rays) {
 }
 
 static int launch_scan(ilx_mesh_t mesh, ScanArgs a, int hints, void* stream);
+
+// Bytes between the two launches of the height-field refresh: the scan pattern (16 bytes per ray, padded to whole env
+// records), then one record per env.
+static size_t lattice_workspace_bytes(int64_t n, int r) {
+    const size_t pat = (static_cast<size_t>(r) * sizeof(float4) + sizeof(LatEnvRec) - 1) / sizeof(LatEnvRec) * sizeof(LatEnvRec);
+    return pat + static_cast<size_t>(n) * sizeof(LatEnvRec);
+}
+
+// The three launches of the height-field refresh on a workspace of lattice_workspace_bytes(a.n, a.r): preparation (one
+// thread per env; it also advances the sensor clocks), cast (one wavefront per env), and the tree launch for rays that
+// broke the z-parallel hint -- it only looks at the flag unless there are such rays, and it is left out altogether when
+// the caller has checked the pattern (ILX_RAYS_Z_PARALLEL_CHECKED) and the mesh has a column grid for the rays that
+// leave the height-grid path.
+static void launch_lattice(ilx_mesh_t mesh, ScanArgs a, int hints, void* ws, void* stream) {
+    float4* pattern = static_cast<float4*>(ws);
+    LatEnvRec* recs = reinterpret_cast<LatEnvRec*>(static_cast<char*>(ws) + lattice_workspace_bytes(0, a.r));
+    hipLaunchKernelGGL(raycaster_prepare_kernel, dim3(blocks_for(a.n)), dim3(256), 0, as_stream(stream), a, recs, pattern);
+    hipLaunchKernelGGL(raycaster_update_lattice_kernel, dim3(static_cast<unsigned>((a.n + kLatWaves - 1) / kLatWaves)),
+                       dim3(64 * kLatWaves), 0, as_stream(stream), a, recs, pattern);
+    if ((hints & ILX_RAYS_Z_PARALLEL_CHECKED) && mesh->h.d_cells) return;
+    a.outdated = nullptr;
+    hipLaunchKernelGGL(raycaster_update_kernel, dim3(std::min(ray_grid(a.n * a.r), 256u)), dim3(kRayBlock), 0, as_stream(stream), a);
+}
+
+// The workspace of `stream` with room for `bytes`.
+static int lattice_workspace(ilx_mesh_t mesh, void* stream, size_t bytes, void** out) {
+    MeshHost& h = mesh->h;
+    std::lock_guard<std::mutex> guard(h.ws_lock);
+    auto& slot = h.ws_by_stream[stream];
+    if (slot.second < bytes) {
+        void* fresh = nullptr;
+        const size_t cap = std::max<size_t>(bytes + bytes / 4, size_t(1) << 16);
+        const int rc = check_hip(hipMalloc(&fresh, cap), "ilx_raycaster: hipMalloc(workspace)");
+        if (rc != ILX_OK) return rc;
+        if (slot.first) h.ws_retired.push_back(slot.first);
+        slot = {fresh, cap};
+    }
+    *out = slot.first;
+    return ILX_OK;
+}
 
 // A flag slot and a non-zero ticket for one hinted cast.  A slot is reused every kFlagSlots calls; its old value can
 // never equal the new ticket, so nothing has to be cleared between calls.
@@ -1599,13 +1674,13 @@ extern "C" int ilx_raycaster_refresh(const ilx_raycaster* rc, void* stream) {
 static int launch_scan(ilx_mesh_t mesh, ScanArgs a, int hints, void* stream) {
     const int64_t rays = a.n * a.r;
     if ((hints & ILX_RAYS_Z_PARALLEL) && a.yaw_only && mesh->h.dev.num_patches > 0 && a.r <= kLatMaxRays && a.n < (int64_t(1) << 31)) {
-        // the height-field patches, one wavefront per env; the launch also advances the sensor clocks, so the tree launch
-        // behind it only looks at the flag (a small grid: it has work only when rays broke the hint)
+        // height-field patches: a preparation launch (one thread per env; it also advances the sensor clocks), the cast
+        // (one wavefront per env), and the tree launch, which only looks at the flag: it has work when rays broke the hint
+        void* ws = nullptr;
+        const int rc = lattice_workspace(mesh, stream, lattice_workspace_bytes(a.n, a.r), &ws);
+        if (rc != ILX_OK) return rc;
         take_ticket(mesh, a.ticket, a.off_grid);
-        hipLaunchKernelGGL(raycaster_update_lattice_kernel, dim3(static_cast<unsigned>((a.n + kLatEnvs - 1) / kLatEnvs)),
-                           dim3(64 * kLatEnvs), 0, as_stream(stream), a);
-        a.outdated = nullptr;
-        hipLaunchKernelGGL(raycaster_update_kernel, dim3(std::min(ray_grid(rays), 256u)), dim3(kRayBlock), 0, as_stream(stream), a);
+        launch_lattice(mesh, a, hints, ws, stream);
         return ILX_OK;
     }
     if ((hints & ILX_RAYS_Z_PARALLEL) && mesh->h.d_cells) {

@@ -75,7 +75,8 @@ class RayCaster:
         # z-parallel world rays (a yaw-only scanner looking straight down) take the column-grid kernel
         self._hints = 0
         if cfg.attach_yaw_only and bool((self.ray_directions[:, :2] == 0).all()):
-            self._hints = _abi.RAYS_Z_PARALLEL
+            # ... and the check just made is the promise that lets the library drop the launch for other rays
+            self._hints = _abi.RAYS_Z_PARALLEL | _abi.RAYS_Z_PARALLEL_CHECKED
         self.drift = torch.zeros(n, 3, device=dev)
         self._has_drift = cfg.drift_range[0] != 0.0 or cfg.drift_range[1] != 0.0
         self._data = RayCasterData(pos_w=torch.zeros(n, 3, device=dev), quat_w=torch.zeros(n, 4, device=dev),

@@ -29,10 +29,13 @@ def refresh():
                                      _abi.ptr(hits), None, 0.0, n, R, _abi.RAYS_Z_PARALLEL, _abi.stream()))
 
 
-mesh.lattice_counter(True)
+if len(sys.argv) > 2 and sys.argv[2] == "count":   # not under --pmc: the counting launch is slow (one atomic per ray)
+    mesh.lattice_counter(True)
+    refresh()
+    torch.cuda.synchronize()
+    print("served by the height grid: %d of %d rays" % (mesh.lattice_counter(False), n * R))
 refresh()
 torch.cuda.synchronize()
-print("served by the height grid: %d of %d rays" % (mesh.lattice_counter(False), n * R))
 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 a.record()
 for _ in range(reps):
