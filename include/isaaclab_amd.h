@@ -714,6 +714,14 @@ typedef struct ilx_raycaster {
     uint8_t* is_outdated;
 } ilx_raycaster;
 int ilx_raycaster_refresh(const ilx_raycaster* rc, void* stream);
+/* ilx_raycaster_refresh for callers that cannot allocate (no counterpart in the reference): code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc.  Same arguments, same results.  Where
+ * ilx_raycaster_refresh keeps the scan pattern and one record per env between its launches in a per-stream workspace that
+ * it grows with hipMalloc, this entry point uses a 3,162,144-byte buffer built into the library's code object (one per
+ * GPU, held until the process ends) and calls no allocating routine.  Limit: 32,768 envs per call (at up to 1,024 rays
+ * each); more is refused with ILX_ESHAPE before anything is queued.  All calls on one GPU share that buffer: calls that
+ * overlap on one GPU (different streams or threads of the process) race -- keep them on one stream.  Nothing in the buffer has to be cleared between calls. */
+int ilx_raycaster_refresh_static(const ilx_raycaster* rc, void* stream);
 
 /* RayCasterCamera._update_buffers_impl (sensors/ray_caster/ray_caster_camera.py:257-318) for the cameras flagged in
  * is_outdated (NULL = all), without temporaries:

@@ -180,6 +180,7 @@ DEPTH_CLIP = {"none": 0, "max": 1, "zero": 2}
 raycaster_camera_refresh = _sig("ilx_raycaster_camera_refresh", ctypes.POINTER(RayCasterCameraDesc), P)
 scene_update = _sig("ilx_scene_update", ctypes.POINTER(Scene), P)
 raycaster_refresh = _sig("ilx_raycaster_refresh", ctypes.POINTER(RayCasterDesc), P)
+raycaster_refresh_static = _sig("ilx_raycaster_refresh_static", ctypes.POINTER(RayCasterDesc), P)
 
 
 def row_view(t: torch.Tensor, width: int):

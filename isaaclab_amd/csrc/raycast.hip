@@ -553,6 +553,12 @@ struct alignas(16) LatEnvRec {
     uint32_t z_off, line_off, mask_off, pad;
 };
 static_assert(sizeof(LatEnvRec) == 96, "six 16-byte words");
+// ilx_raycaster_refresh_static: the most envs its built-in buffer serves (at up to kLatMaxRays rays each), and the
+// buffer's size: the pattern (16 bytes per ray, padded to whole records) and one record per env = 3,162,144 bytes.
+constexpr int kStaticEnvs = 32768;
+constexpr size_t kStaticScratchBytes =
+    (static_cast<size_t>(kLatMaxRays) * 16 + sizeof(LatEnvRec) - 1) / sizeof(LatEnvRec) * sizeof(LatEnvRec) +
+    static_cast<size_t>(kStaticEnvs) * sizeof(LatEnvRec);
 
 // What one wavefront keeps in LDS for its env.
 struct LatStage {
@@ -1547,7 +1553,8 @@ static unsigned ray_grid(int64_t rays) {
     return static_cast<unsigned>(std::min<int64_t>(want, 256 * 12));
 }
 
-static int launch_scan(ilx_mesh_t mesh, ScanArgs a, int hints, void* stream);
+// `fixed_ws` (optional): a workspace of `fixed_bytes` that the launches use instead of the mesh's per-stream one.
+static int launch_scan(ilx_mesh_t mesh, ScanArgs a, int hints, void* stream, void* fixed_ws = nullptr, size_t fixed_bytes = 0);
 
 // Bytes between the two launches of the height-field refresh: the scan pattern (16 bytes per ray, padded to whole env
 // records), then one record per env.
@@ -1669,16 +1676,75 @@ extern "C" int ilx_raycaster_refresh(const ilx_raycaster* rc, void* stream) {
     return ILX_OK;
 }
 
+// ilx_raycaster_refresh for callers that must not allocate.  What ilx_raycaster_refresh keeps between its launches in
+// a workspace grown with hipMalloc lives here in one array of the code object, per GPU: every call on a GPU shares it.
+// Nothing in it has to start at zero: the preparation launch writes the pattern and every env record before the cast
+// reads them, and records beyond the call's envs are never read.
+static __device__ __align__(256) unsigned char scratch[kStaticScratchBytes];
+
+// The array's address on the current device (in host code `scratch` itself is only a handle for the runtime, not a
+// device address), looked up on the first call per device.
+static int static_scratch(void** out) {
+    constexpr int kMaxDevices = 64;
+    static std::mutex lock;
+    static void* address[kMaxDevices] = {};
+    int device = -1;
+    int rc = check_hip(hipGetDevice(&device), "ilx_raycaster_refresh_static: hipGetDevice");
+    if (rc != ILX_OK) return rc;
+    ILX_REQUIRE(device >= 0 && device < kMaxDevices, ILX_EINVAL, "ilx_raycaster_refresh_static: device %d out of range", device);
+    std::lock_guard<std::mutex> guard(lock);
+    if (!address[device]) {
+        void* ptr = nullptr;
+        rc = check_hip(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)), "ilx_raycaster_refresh_static: hipGetSymbolAddress");
+        if (rc != ILX_OK) return rc;
+        ILX_REQUIRE(ptr, ILX_EHIP, "ilx_raycaster_refresh_static: no device address for the built-in buffer");
+        address[device] = ptr;
+    }
+    *out = address[device];
+    return ILX_OK;
+}
+
+extern "C" int ilx_raycaster_refresh_static(const ilx_raycaster* rc, void* stream) {
+    ILX_REQUIRE(rc, ILX_EINVAL, "ilx_raycaster_refresh_static: descriptor is NULL");
+    const ilx_raycaster& d = *rc;
+    ILX_REQUIRE(d.mesh, ILX_EINVAL, "ilx_raycaster_refresh_static: mesh is NULL");
+    ILX_REQUIRE(d.num_envs >= 0 && d.num_rays > 0, ILX_EINVAL, "ilx_raycaster_refresh_static: bad shape (%lld, %d)",
+                (long long)d.num_envs, d.num_rays);
+    if (d.num_envs == 0) return ILX_OK;
+    ILX_REQUIRE(d.pose_pos && d.pose_quat && d.ray_starts_local && d.ray_directions_local && d.pos_w && d.quat_w &&
+                    d.ray_hits_w && d.timestamp && d.timestamp_last_update && d.is_outdated,
+                ILX_EINVAL, "ilx_raycaster_refresh_static: NULL operand");
+    ILX_REQUIRE(d.pose_pos_stride >= 3 && d.pose_quat_stride >= 4, ILX_EINVAL, "ilx_raycaster_refresh_static: bad pose strides");
+    void* ws = nullptr;
+    int status = static_scratch(&ws);
+    if (status != ILX_OK) return status;
+    ScanArgs a{d.mesh->h.dev, d.pose_pos, d.pose_quat, d.pose_pos_stride, d.pose_quat_stride, d.drift, d.pos_w, d.quat_w,
+               d.ray_starts_local, d.ray_directions_local, d.is_outdated, d.attach_yaw_only, d.max_distance, d.ray_hits_w,
+               d.height_scan, d.height_offset, d.num_envs, d.num_rays, 0, nullptr, d.timestamp, d.timestamp_last_update,
+               d.is_outdated};
+    status = launch_scan(d.mesh, a, d.hints, stream, ws, kStaticScratchBytes);
+    if (status != ILX_OK) return status;
+    ILX_LAUNCH_CHECK("ilx_raycaster_refresh_static");
+    return ILX_OK;
+}
+
 // Column kernel + tree kernel for the rays it left out (that launch also advances the sensor clocks, and is otherwise a
 // no-op when there are none), or the tree kernel alone followed by the clock update.
-static int launch_scan(ilx_mesh_t mesh, ScanArgs a, int hints, void* stream) {
+static int launch_scan(ilx_mesh_t mesh, ScanArgs a, int hints, void* stream, void* fixed_ws, size_t fixed_bytes) {
     const int64_t rays = a.n * a.r;
     if ((hints & ILX_RAYS_Z_PARALLEL) && a.yaw_only && mesh->h.dev.num_patches > 0 && a.r <= kLatMaxRays && a.n < (int64_t(1) << 31)) {
         // height-field patches: a preparation launch (one thread per env; it also advances the sensor clocks), the cast
         // (one wavefront per env), and the tree launch, which only looks at the flag: it has work when rays broke the hint
-        void* ws = nullptr;
-        const int rc = lattice_workspace(mesh, stream, lattice_workspace_bytes(a.n, a.r), &ws);
-        if (rc != ILX_OK) return rc;
+        void* ws = fixed_ws;
+        if (fixed_ws) {
+            ILX_REQUIRE(lattice_workspace_bytes(a.n, a.r) <= fixed_bytes, ILX_ESHAPE,
+                        "ilx_raycaster_refresh_static: %lld envs x %d rays need %zu bytes between the launches, the built-in "
+                        "buffer holds %zu (at most %d envs at %d rays); use ilx_raycaster_refresh",
+                        (long long)a.n, a.r, lattice_workspace_bytes(a.n, a.r), fixed_bytes, kStaticEnvs, kLatMaxRays);
+        } else {
+            const int rc = lattice_workspace(mesh, stream, lattice_workspace_bytes(a.n, a.r), &ws);
+            if (rc != ILX_OK) return rc;
+        }
         take_ticket(mesh, a.ticket, a.off_grid);
         launch_lattice(mesh, a, hints, ws, stream);
         return ILX_OK;

@@ -84,6 +84,9 @@ class RayCaster:
         self._pose_pos = torch.zeros(n, 3, device=dev)
         self._pose_quat = torch.zeros(n, 4, device=dev)
         self._pose_quat[:, 0] = 1.0
+        # True: refresh through the entry point that allocates nothing (a buffer built into the library, shared by all
+        # calls on the GPU, limited to 32,768 envs); for callers under graph capture or otherwise unable to allocate
+        self.static_workspace = False
 
     @property
     def num_instances(self) -> int:
@@ -144,4 +147,7 @@ class RayCaster:
             pos_w=_abi.ptr(d.pos_w), quat_w=_abi.ptr(d.quat_w), ray_hits_w=_abi.ptr(d.ray_hits_w),
             height_scan=_abi.ptr(height_out), height_offset=float(height_offset), timestamp=_abi.ptr(self._timestamp),
             timestamp_last_update=_abi.ptr(self._timestamp_last_update), is_outdated=self._is_outdated.data_ptr())
-        _abi.check(_abi.raycaster_refresh(ctypes.byref(rc), _abi.stream()), "ilx_raycaster_refresh")
+        if self.static_workspace:
+            _abi.check(_abi.raycaster_refresh_static(ctypes.byref(rc), _abi.stream()), "ilx_raycaster_refresh_static")
+        else:
+            _abi.check(_abi.raycaster_refresh(ctypes.byref(rc), _abi.stream()), "ilx_raycaster_refresh")
