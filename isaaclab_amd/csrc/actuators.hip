@@ -501,6 +501,86 @@ __global__ void __launch_bounds__(256, 2) mlp_mfma_resident_kernel(NetArgs a) {
     }
 }
 
+// One 32-row tile per wavefront, weights in LDS.  The launch is 6,144 tiles on 1,024 SIMDs: with every tile its own
+// wavefront and few registers per wavefront (the A operands come from LDS one instruction ahead of their MFMA instead
+// of living in ~100 registers), all tiles of a SIMD are resident together, so one tile's loads, activations (VALU) and
+// stores run under the other tiles' MFMAs, and nobody waits for a weight prologue of a hundred loads per lane.
+// LDS image (floats), L hidden layers of 32 units, acc_unit as above:
+//   [ks0][64]        first-layer A operands, as in `packed`
+//   (L-1) x [16][64] hidden A operands, as in `packed` (a permutation of the 32 x 32 matrix: nothing is replicated)
+//   L x [32]         hidden biases by unit
+//   [32]             output weights by unit
+//   [1]              output bias
+// Operation order is that of mlp_mfma_kernel, so both give the same bits.
+template <int ACT, int NHID>
+__global__ void __launch_bounds__(256, 8) mlp_mfma_tile_kernel(NetArgs a) {
+    __shared__ float img[kResidentHist * 64 + (NHID - 1) * 1024 + NHID * 32 + 32 + 4];
+    const int lane = threadIdx.x & 63;
+    const int half = lane >> 5;
+    const int64_t tiles = (a.rows + 31) / 32;
+    const int64_t tile = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+    const bool live = tile < tiles;  // wave-uniform
+
+    // the tile's first row is wave-uniform, so its env / joint split is scalar work and a lane only adds its offset
+    // (< 32) with a small exact division
+    const uint32_t j = static_cast<uint32_t>(a.j);
+    const uint32_t row0 = static_cast<uint32_t>(live ? tile : 0) * 32u;
+    const uint32_t env0 = row0 / j, joint0 = row0 - env0 * j;
+    const uint32_t x = joint0 + (lane & 31);  // < j + 32
+    uint32_t q = static_cast<uint32_t>(static_cast<float>(x) * (1.0f / static_cast<float>(j)));  // exact up to +-1 for x < 2^22
+    q = (q * j > x) ? q - 1 : q;
+    q = ((q + 1) * j <= x) ? q + 1 : q;
+    const uint32_t env = env0 + q, joint = x - q * j, row = row0 + (lane & 31);
+    const bool valid = live && row < static_cast<uint32_t>(a.rows);
+    const RowAt<uint32_t> at = {valid ? row : 0u, valid ? env * static_cast<uint32_t>(a.hist_len) * j + joint : 0u,
+                                valid ? (a.per_env ? row : joint) : 0u};
+    // row inputs first: they travel while the weights are copied
+    RowRawT<kResidentHist> raw;
+    issue_row(a, at, valid, raw);
+    for (int i = threadIdx.x; i < a.net.image_floats; i += 256) img[i] = a.net.image[i];
+    __syncthreads();
+    if (!live) return;
+    RowInT<kResidentHist> cur;
+    finish_row(a, raw, cur);
+
+    const int ks0 = a.net.ks0;
+    const float* w0 = img + lane;
+    const float* wh = img + ks0 * 64 + lane;
+    const float* bias = img + ks0 * 64 + (NHID - 1) * 1024 + 4 * half;
+    const float* wo = bias + NHID * 32;
+    const float bo = img[ks0 * 64 + (NHID - 1) * 1024 + NHID * 32 + 32];
+
+    f32x16 acc;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) acc[k] = bias[acc_unit(k, 0)];
+#pragma unroll
+    for (int s = 0; s < kResidentHist; ++s) {
+        if (s < ks0) {
+            const float bop = half ? cur.feat[2 * s + 1] : cur.feat[2 * s];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w0[s * 64], bop, acc, 0, 0, 0);
+        }
+    }
+    acc = activate16<ACT>(acc);
+#pragma unroll
+    for (int l = 1; l < NHID; ++l) {
+        f32x16 y;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) y[k] = bias[l * 32 + acc_unit(k, 0)];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) y = __builtin_amdgcn_mfma_f32_32x32x2f32(wh[(l - 1) * 1024 + k * 64], acc[k], y, 0, 0, 0);
+        acc = activate16<ACT>(y);
+    }
+    float part = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) part = fmaf_(wo[acc_unit(k, 0)], acc[k], part);
+    const float other = __shfl_xor(part, 32, 64);
+    const float out = (half ? other + part : part + other) + bo;
+    if (valid) {
+        if (half == 0) store_torque(a, at, out, cur);
+        store_history(a, at, cur, half == 0, half == 1);
+    }
+}
+
 }  // namespace ilx
 
 using namespace ilx;
@@ -538,6 +618,8 @@ extern "C" int ilx_mlp_create(int num_layers, const int32_t* dims, int activatio
                                      "ilx_mlp_create: hipMemcpy");
     h.dev.raw = h.d_raw;
     h.dev.packed = nullptr;
+    h.dev.image = nullptr;
+    h.dev.image_floats = 0;
     h.raw_floats = static_cast<int>(raw.size());
 
     bool mfma = num_layers >= 2;
@@ -568,10 +650,24 @@ extern "C" int ilx_mlp_create(int num_layers, const int32_t* dims, int activatio
         if (rc == ILX_OK) rc = check_hip(hipMemcpy(h.d_packed, pk.data(), pk.size() * sizeof(float), hipMemcpyHostToDevice),
                                          "ilx_mlp_create: hipMemcpy");
         h.dev.packed = h.d_packed;
+        // the LDS image of mlp_mfma_tile_kernel: the A operands of `packed`, then biases and output weights by unit
+        std::vector<float> img;
+        img.insert(img.end(), pk.begin(), pk.begin() + ks0 * 64);
+        const float* hidden_a = pk.data() + ks0 * 64 + nhid * 1024;
+        img.insert(img.end(), hidden_a, hidden_a + (nhid - 1) * 1024);
+        for (int l = 0; l < nhid; ++l) img.insert(img.end(), biases_host[l], biases_host[l] + 32);
+        img.insert(img.end(), weights_host[nhid], weights_host[nhid] + 32);
+        img.push_back(biases_host[nhid][0]);
+        if (rc == ILX_OK) rc = check_hip(hipMalloc(&h.d_image, img.size() * sizeof(float)), "ilx_mlp_create: hipMalloc");
+        if (rc == ILX_OK) rc = check_hip(hipMemcpy(h.d_image, img.data(), img.size() * sizeof(float), hipMemcpyHostToDevice),
+                                         "ilx_mlp_create: hipMemcpy");
+        h.dev.image = h.d_image;
+        h.dev.image_floats = static_cast<int>(img.size());
     }
     if (rc != ILX_OK) {
         if (h.d_raw) (void)hipFree(h.d_raw);
         if (h.d_packed) (void)hipFree(h.d_packed);
+        if (h.d_image) (void)hipFree(h.d_image);
         delete obj;
         return rc;
     }
@@ -583,6 +679,7 @@ extern "C" void ilx_mlp_destroy(ilx_mlp_t net) {
     if (!net) return;
     if (net->h.d_raw) (void)hipFree(net->h.d_raw);
     if (net->h.d_packed) (void)hipFree(net->h.d_packed);
+    if (net->h.d_image) (void)hipFree(net->h.d_image);
     delete net;
 }
 
@@ -634,7 +731,13 @@ static void launch_mlp(const NetArgs& a, bool force_generic, hipStream_t s) {
         const unsigned resident_blocks = static_cast<unsigned>(std::min<int64_t>((tiles + 3) / 4, int64_t(2) * num_cus()));
         const bool small = a.hist_len <= kResidentHist && a.n_feat <= 2 * kResidentHist && a.j < (1 << 20) &&
                            a.rows * a.hist_len < (int64_t(1) << 31);
-        if (nhid == 3 && small)
+        const bool tile_kernel = getenv("ILX_MLP_RESIDENT") == nullptr;
+        const unsigned tile_blocks = static_cast<unsigned>((tiles + 3) / 4);
+        if (nhid == 3 && small && tile_kernel)
+            hipLaunchKernelGGL((mlp_mfma_tile_kernel<ACT, 3>), dim3(tile_blocks), dim3(256), 0, s, a);
+        else if (nhid == 2 && small && tile_kernel)
+            hipLaunchKernelGGL((mlp_mfma_tile_kernel<ACT, 2>), dim3(tile_blocks), dim3(256), 0, s, a);
+        else if (nhid == 3 && small)
             hipLaunchKernelGGL((mlp_mfma_resident_kernel<ACT, 3>), dim3(resident_blocks), dim3(256), 0, s, a);
         else if (nhid == 2 && small)
             hipLaunchKernelGGL((mlp_mfma_resident_kernel<ACT, 2>), dim3(resident_blocks), dim3(256), 0, s, a);

@@ -36,12 +36,15 @@ struct MlpDev {
     const float* raw;             // per layer: W (out x in, row-major) then b (out)
     const float* packed;          // MFMA operand order, or nullptr
     int ks0;                      // k-steps of the first layer (ceil(in/2))
+    const float* image;           // the weights as mlp_mfma_tile_kernel keeps them in LDS (with `packed`), or nullptr
+    int image_floats;
 };
 
 struct MlpHost {
     MlpDev dev;
     float* d_raw = nullptr;
     float* d_packed = nullptr;
+    float* d_image = nullptr;
     int device = 0;
     int raw_floats = 0;           // length of `raw`
 };
