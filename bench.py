@@ -142,8 +142,10 @@ def time_kernels(env, state, device, actuator_kernel, reps=20):
     return out
 
 
-def cpu_baseline(seed, sample_envs=2048, steps=3):
-    """The oracle step (unfused PyTorch CPU ops + C ray cast) on a bounded sample of the same workload."""
+def cpu_baseline(seed, envs=NUM_ENVS, warmup=2, steps=10):
+    """The oracle step (unfused PyTorch CPU ops + C ray cast) at the workload's full env count on the host's cores:
+    `warmup` untimed steps, then `steps` timed ones between perf_counter reads -- the step-loop timing of
+    scripts/benchmarks/benchmark_non_rl.py:154-179 without the simulator inside the step."""
     from isaaclab_amd import synth
     from isaaclab_amd.tasks import locomotion_velocity as LV
     from isaaclab_amd.utils.string import resolve_matching_names_values
@@ -151,9 +153,11 @@ def cpu_baseline(seed, sample_envs=2048, steps=3):
     from oracle.step_locomotion import AnymalRoughOracle
 
     cores = os.cpu_count() or 1
-    threads = min(cores, 16)
+    # every core this process may run on (a GPU box gives one GPU's share of the machine, not all of os.cpu_count())
+    threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else cores
+    threads = max(1, min(threads, int(os.environ.get("OMP_NUM_THREADS", threads))))
     torch.set_num_threads(threads)
-    os.environ.setdefault("OMP_NUM_THREADS", str(threads))
+    sample_envs = envs
     verts, tris, height_at = synth.rough_terrain_mesh(seed=3)
     ws, bs = synth.actuator_mlp_weights()
     idx, _, vals = resolve_matching_names_values(LV.ANYMAL_DEFAULT_JOINT_POS, LV.ANYMAL_JOINTS)
@@ -167,14 +171,16 @@ def cpu_baseline(seed, sample_envs=2048, steps=3):
     g = torch.Generator().manual_seed(1)
     noise = torch.rand(sample_envs, 235, generator=g)
     samples = torch.rand(sample_envs, 7, generator=g)
-    o.step(state["raw_action"], noise, samples, samples)  # warm-up
+    for _ in range(warmup):
+        o.step(state["raw_action"], noise, samples, samples)
     t0 = time.perf_counter()
     for _ in range(steps):
         o.step(state["raw_action"], noise, samples, samples)
     dt = (time.perf_counter() - t0) / steps
-    return {"value": sample_envs / dt, "unit": "env-steps/s", "cores": threads, "kind": "port",
-            "sample": f"{steps} steps of {sample_envs} envs (same step, same terrain mesh of {tris.shape[0]} triangles): "
-                      f"{dt * 1e3:.1f} ms/step; torch {torch.__version__} CPU ops + C BVH ray cast"}
+    return {"value": sample_envs / dt, "unit": "env-steps/s", "cores": cores, "threads": threads, "kind": "port",
+            "sample": f"{warmup} warm-up + {steps} timed steps of all {sample_envs} envs (same step, same terrain mesh of "
+                      f"{tris.shape[0]} triangles): {dt * 1e3:.1f} ms/step; torch {torch.__version__} CPU ops on {threads} "
+                      f"threads + C BVH ray cast"}
 
 
 def main():
@@ -231,10 +237,19 @@ def main():
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    # what the collective group saw: the number of ranks that took part (a sum of ones over RCCL) and the spread of the
+    # per-rank step time; `value` is priced on the slowest rank
+    rccl_ranks, rank_ms = None, [elapsed / args.steps * 1e3] * 2
     if dist is not None:
+        ones = torch.ones(1, device=device)
+        dist.all_reduce(ones)
+        rccl_ranks = int(ones.item())
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        t_min = t.clone()
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t_min, op=dist.ReduceOp.MIN)
         elapsed = float(t.item())
+        rank_ms = [float(t_min.item()) / args.steps * 1e3, elapsed / args.steps * 1e3]
 
     act_kernel = "actuator_net_" + args.actuator
     kern = time_kernels(env, state, device, act_kernel)
@@ -279,6 +294,9 @@ def main():
             "step_hbm_frac": BYTES_PER_ENV_STEP * args.envs / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "roofline": roofline,
             "kernels_us": {k: round(v, 2) for k, v in kern.items()},
+            "mfma_frac": (MLP_FLOP_PER_ENV * args.envs / (kern[act_kernel] * 1e-6) / 1e12 / MFMA_F32_PEAK_TFLOPS
+                          if args.actuator == "mlp" else None),
+            "rccl_ranks": rccl_ranks, "ms_per_step_min_rank": rank_ms[0], "ms_per_step_max_rank": rank_ms[1],
         }
         if not args.no_cpu_baseline and world == 1 and args.actuator == "mlp":
             line["cpu_baseline"] = cpu_baseline(3000)

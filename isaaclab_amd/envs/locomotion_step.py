@@ -41,7 +41,7 @@ class LocomotionVelocityStep:
         elif robot == "h1":
             joints, bodies = LV.H1_JOINTS, LV.H1_BODIES
             terms = LV.h1_rough_terms()
-            default = {".*": 0.0}
+            default = LV.H1_DEFAULT_JOINT_POS
         else:
             raise ValueError(f"unknown robot '{robot}'")
         self.joint_names, self.body_names = joints, bodies
@@ -51,8 +51,11 @@ class LocomotionVelocityStep:
         self.data.default_joint_pos[:, idx] = torch.tensor(vals, device=dev)
         lim = torch.stack([self.data.default_joint_pos - 1.5, self.data.default_joint_pos + 1.5], dim=-1)
         mean, rng = (lim[..., 0] + lim[..., 1]) / 2, lim[..., 1] - lim[..., 0]
-        self.data.soft_joint_pos_limits[..., 0] = mean - 0.5 * rng * 0.95  # articulation.py:1230-1237
-        self.data.soft_joint_pos_limits[..., 1] = mean + 0.5 * rng * 0.95
+        factor = LV.H1_SOFT_JOINT_POS_LIMIT_FACTOR if robot == "h1" else 0.95
+        self.data.soft_joint_pos_limits[..., 0] = mean - 0.5 * rng * factor  # articulation.py:1230-1237
+        self.data.soft_joint_pos_limits[..., 1] = mean + 0.5 * rng * factor
+        # the body the height scanner hangs on (None: the articulation root)
+        self.scanner_body = bodies.index(LV.H1_SCANNER_BODY) if robot == "h1" else None
         # actuators (one group over all joints)
         if robot == "anymal_c":
             net = actuator_net
@@ -89,7 +92,8 @@ class LocomotionVelocityStep:
         # managers: one fused plan
         self.mdp = FM.FusedMdp(n, dev, num_joints=j, num_bodies=b, num_sensor_bodies=b, history_len=LV.CONTACT_SENSOR["history_length"],
                                num_rays=self.scanner.num_rays, action_dim=j, command_dim=3, step_dt=LV.STEP_DT,
-                               max_episode_length=LV.MAX_EPISODE_LENGTH, command=LV.VELOCITY_COMMAND, seed=seed, **terms)
+                               max_episode_length=LV.MAX_EPISODE_LENGTH,
+                               command=LV.H1_VELOCITY_COMMAND if robot == "h1" else LV.VELOCITY_COMMAND, seed=seed, **terms)
         self._bind()
 
     def _bind(self):
@@ -128,6 +132,8 @@ class LocomotionVelocityStep:
         self.contact._is_outdated.fill_(False)
         self.scanner._is_outdated.fill_(False)
         self.physics = {k: s[k].to(dev).contiguous() for k in ("joint_pos", "joint_vel", "net_forces", "root_state_w")}
+        if "body_state_w" in s:
+            self.data.body_state_w.copy_(s["body_state_w"])
 
     def step(self, raw_action: torch.Tensor, noise_u=None, command_samples=None, reset_command_samples=None):
         """One env step on the synthetic physics sequence installed by :meth:`load_state`."""
@@ -148,7 +154,11 @@ class LocomotionVelocityStep:
             self.scene.update(LV.PHYSICS_DT)                             # joint_acc, contact sensor, scanner clock: one launch
         d.set_sim_state(root_state_w=self.physics["root_state_w"])
         # -- height scanner: refreshed once per env step (update_period = step_dt), lazily in the reference
-        self.scanner.set_pose(d.root_state_w[:, :3], d.root_state_w[:, 3:7])
+        if self.scanner_body is None:
+            self.scanner.set_pose(d.root_state_w[:, :3], d.root_state_w[:, 3:7])
+        else:  # strided views of the body's rows: the kernel reads them in place
+            pose = d.body_state_w[:, self.scanner_body]
+            self.scanner.set_pose(pose[:, :3], pose[:, 3:7])
         self.scanner._update_outdated_buffers()
         # -- post-physics managers: one launch
         m = self.mdp

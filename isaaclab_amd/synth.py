@@ -92,7 +92,7 @@ def _quat_from_rpy(roll, pitch, yaw):
 
 def locomotion_state(n: int, seed: int, *, num_joints: int, num_bodies: int, default_joint_pos: torch.Tensor,
                      feet_ids, decimation: int = 4, height_at=None, extent=(80.0, 160.0), history_len: int = 3,
-                     max_episode_length: int = 1000, joint_vel_std: float = 2.0):
+                     max_episode_length: int = 1000, joint_vel_std: float = 2.0, with_bodies: bool = False):
     """Seeded stand-in for what PhysX hands the rollout step of a legged robot on rough terrain.
 
     Per physics substep k < decimation: joint positions / velocities and net contact forces; once per step: root
@@ -145,6 +145,11 @@ def locomotion_state(n: int, seed: int, *, num_joints: int, num_bodies: int, def
     s["episode_length_buf"] = torch.randint(0, max_episode_length, (n,), generator=g)
     s["pos_error_history"] = torch.randn(n, 3, j, generator=g) * 0.2
     s["vel_history"] = torch.randn(n, 3, j, generator=g) * joint_vel_std
+    if with_bodies:  # link states (n, b, 13): near the root, orientation the root's plus a small tilt, own velocities
+        bpos = pos.unsqueeze(1) + torch.randn(n, b, 3, generator=g) * torch.tensor([0.15, 0.15, 0.3])
+        tilt = torch.randn(n, b, 2, generator=g) * 0.05
+        bquat = _quat_from_rpy(rp[:, None, 0] + tilt[..., 0], rp[:, None, 1] + tilt[..., 1], yaw[:, None] + torch.randn(n, b, generator=g) * 0.1)
+        s["body_state_w"] = torch.cat([bpos, bquat, torch.randn(n, b, 6, generator=g) * 0.5], dim=-1).float()
     return s
 
 

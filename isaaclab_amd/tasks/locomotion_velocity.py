@@ -94,6 +94,12 @@ H1_DAMPING = {".*_hip_yaw": 5.0, ".*_hip_roll": 5.0, ".*_hip_pitch": 5.0, ".*_kn
 H1_EFFORT_LIMIT = {".*_hip_.*": 300.0, ".*_knee": 300.0, "torso": 300.0, ".*_ankle": 100.0, ".*_shoulder_.*": 300.0,
                    ".*_elbow": 300.0}
 H1_VELOCITY_LIMIT = 100.0
+H1_DEFAULT_JOINT_POS = {".*_hip_yaw": 0.0, ".*_hip_roll": 0.0, ".*_hip_pitch": -0.28, ".*_knee": 0.79, ".*_ankle": -0.52,
+                        "torso": 0.0, ".*_shoulder_pitch": 0.28, ".*_shoulder_roll": 0.0, ".*_shoulder_yaw": 0.0,
+                        ".*_elbow": 0.52}  # unitree.py:199-212
+H1_SOFT_JOINT_POS_LIMIT_FACTOR = 0.9  # unitree.py:213
+H1_VELOCITY_COMMAND = dict(VELOCITY_COMMAND, ranges=[(0.0, 1.0), (0.0, 0.0), (-1.0, 1.0), (-math.pi, math.pi)])  # h1/rough_env_cfg.py:108-110
+H1_SCANNER_BODY = "torso_link"  # h1/rough_env_cfg.py:80-81
 
 
 def h1_rough_terms(joints=H1_JOINTS, bodies=H1_BODIES):

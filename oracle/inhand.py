@@ -124,7 +124,9 @@ class InHandOracle:
         self.cfg, self.actuated, self.fingers, self.decimation = cfg, list(actuated), list(finger_bodies), decimation
         self.s = {k: v.clone() for k, v in state.items() if torch.is_tensor(v)}
 
-    def step(self, actions, goal_samples, reset_goal_samples):
+    def step(self, actions, goal_samples, reset_goal_samples, reduce_stats=None):
+        """``reduce_stats`` (optional): applied to the two success sums before they enter ``consecutive_successes`` -- the
+        all-reduce over the env shards of a multi-GPU run; the sums it returned are kept in ``self.last_stats``."""
         s, c = self.s, self.cfg
         for _ in range(self.decimation):
             s["cur_targets"], s["prev_targets"] = apply_action(actions, s["cur_targets"], s["prev_targets"], s["lower"], s["upper"],
@@ -138,6 +140,9 @@ class InHandOracle:
         reward, goal_resets, s["successes"], resets = reward_terms(reset_buf, s["reset_goal_buf"], s["successes"], object_pos,
                                                                    object_rot, s["in_hand_pos"], s["goal_rot"], actions, c)
         stats = success_stats(s["successes"], resets)
+        if reduce_stats is not None:
+            stats = reduce_stats(stats)
+        self.last_stats = stats
         s["consecutive_successes"] = consecutive_successes(stats, s["consecutive_successes"], c.av_factor)
         s["reset_goal_buf"] = goal_resets
         # :168-171 goal resets, then direct_rl_env.py:369-371 + :200-247 env resets

@@ -102,10 +102,19 @@ def _reach_physics(g, n, q_mean):
 
 @pytest.mark.parametrize("arm_action", ["joint_pos", "ik_rel", "ik_abs"])
 def test_reach_step(dev, arm_action):
+    run_reach(dev, arm_action, 384)
+
+
+@pytest.mark.parametrize("arm_action", ["joint_pos", "ik_rel"])
+def test_reach_step_at_benchmark_size(dev, arm_action):
+    """8,192 envs (the size the configuration is quoted at): index-width and grid-size errors show here, not at 384."""
+    run_reach(dev, arm_action, 8192)
+
+
+def run_reach(dev, arm_action, n):
     from isaaclab_amd.envs.manager_based_step import ReachStep
     from isaaclab_amd.tasks import reach as RE
 
-    n = 384
     g = torch.Generator().manual_seed(2002)
     env = ReachStep(n, dev, arm_action=arm_action)
     default = torch.tensor([0.0, -0.569, 0.0, -2.81, 0.0, 3.037, 0.741, 0.04, 0.04]).repeat(n, 1)   # franka.py:38-48

@@ -76,3 +76,31 @@ def test_inhand_second_step_and_generator(dev):
     changed = (outs[0] != s["goal_rot"]).any(dim=1)
     assert changed.sum() > 10
     assert_close(outs[0].norm(dim=1), torch.ones(512), rtol=1e-5, what="generated goals are unit quaternions")
+
+
+def test_inhand_step_at_benchmark_size(dev):
+    """8,192 envs (one GPU's shard of the configuration): every env against the oracle, two steps; the global
+    success statistic is a sum over all of them."""
+    from isaaclab_amd import synth
+
+    n = 8192
+    s = synth.inhand_state(n, seed=77)
+    s["actuated"], s["fingers"] = torch.tensor(s["actuated"]), torch.tensor(s["fingers"])
+    env = make_env(dev, s, 0.8, 50)
+    cfg = IH.InHandCfg(act_moving_average=0.8, max_consecutive_success=50)
+    o = IH.InHandOracle(cfg, s, s["actuated"].tolist(), s["fingers"].tolist())
+    gen = torch.Generator().manual_seed(4)
+    for step in range(2):
+        actions = s["actions"] if step == 0 else torch.rand(n, s["actions"].shape[1], generator=gen) * 2 - 1
+        gs, rs = torch.rand(n, 2, generator=gen) * 2 - 1, torch.rand(n, 2, generator=gen) * 2 - 1
+        r = o.step(actions, gs, rs)
+        obs, reward, terminated, time_outs = env.step(actions.to(dev), gs.to(dev), rs.to(dev))
+        assert_exact(terminated, r["terminated"], f"terminated step {step}")
+        assert_exact(time_outs, r["time_outs"], f"time_outs step {step}")
+        assert_exact(env.successes, o.s["successes"], f"successes step {step}")
+        assert_exact(env.cur_targets, o.s["cur_targets"], f"targets step {step}")
+        assert_exact(env.episode_length_buf, o.s["episode_length_buf"], f"episode_length_buf step {step}")
+        assert_close(reward, r["reward"], rtol=1e-5, atol=1e-5, what=f"reward step {step}")
+        assert_close(obs, r["obs"], rtol=1e-5, atol=2e-6, what=f"obs step {step}")
+        assert_close(env.consecutive_successes, o.s["consecutive_successes"], rtol=1e-5, what=f"consecutive successes step {step}")
+        assert r["terminated"].sum() > 50 and (step > 0 or r["goal_resets"].sum() > 20)

@@ -1,5 +1,7 @@
-"""GPU: the complete non-physics env step of Isaac-Velocity-Rough-Anymal-C (HIP, through the C ABI) against the
-oracle step, two consecutive steps, all buffers."""
+"""GPU: the complete non-physics env step of the rough-terrain velocity tasks (HIP, through the C ABI) against the
+oracle step: Isaac-Velocity-Rough-Anymal-C (ActuatorNetMLP) and Isaac-Velocity-Rough-H1 (DC-motor actuators,
+scanner on torso_link), two consecutive steps, all buffers, every env; and the ANYmal step at the benchmark's env
+count against the oracle on a sample of its envs."""
 
 import numpy as np
 import pytest
@@ -10,85 +12,150 @@ from conftest import assert_close, assert_exact
 pytestmark = pytest.mark.gpu
 
 
-def build(dev, n, seed, rows=2, cols=3):
+def build(dev, n, seed, rows=2, cols=3, robot="anymal_c"):
     from isaaclab_amd import synth
     from isaaclab_amd.envs.locomotion_step import LocomotionVelocityStep
     from isaaclab_amd.tasks import locomotion_velocity as LV
     from isaaclab_amd.utils.mesh import convert_to_mesh
     from isaaclab_amd.utils.string import resolve_matching_names_values
     from oracle import raycast as RC
-    from oracle.step_locomotion import AnymalRoughOracle
+    from oracle import step_locomotion as SL
 
     verts, tris, height_at = synth.rough_terrain_mesh(seed=seed, rows=rows, cols=cols)
     mesh = convert_to_mesh(verts, tris, str(dev))
-    ws, bs = synth.actuator_mlp_weights()
-    idx, _, vals = resolve_matching_names_values(LV.ANYMAL_DEFAULT_JOINT_POS, LV.ANYMAL_JOINTS)
-    default = torch.zeros(12)
-    default[idx] = torch.tensor(vals)
-    state = synth.locomotion_state(n, seed, num_joints=12, num_bodies=17, default_joint_pos=default, feet_ids=[13, 14, 15, 16],
-                                   height_at=height_at, extent=(rows * 8.0, cols * 8.0))
-    # force a few time-outs and base contacts so that the reset path runs
+    if robot == "anymal_c":
+        ws, bs = synth.actuator_mlp_weights()
+        idx, _, vals = resolve_matching_names_values(LV.ANYMAL_DEFAULT_JOINT_POS, LV.ANYMAL_JOINTS)
+        default = torch.zeros(12)
+        default[idx] = torch.tensor(vals)
+        state = synth.locomotion_state(n, seed, num_joints=12, num_bodies=17, default_joint_pos=default, feet_ids=[13, 14, 15, 16],
+                                       height_at=height_at, extent=(rows * 8.0, cols * 8.0))
+        env = LocomotionVelocityStep(n, dev, mesh, "anymal_c", actuator_net=dict(weights=ws, biases=bs, activation="softsign"))
+        make_oracle = lambda st: SL.AnymalRoughOracle(st["joint_pos"].shape[1], st, ws, bs, default, RC.CMesh(verts, tris))  # noqa: E731
+    else:
+        assert LV.H1_JOINTS == SL.H1_JOINTS and LV.H1_BODIES == SL.H1_BODIES
+        idx, _, vals = resolve_matching_names_values(LV.H1_DEFAULT_JOINT_POS, LV.H1_JOINTS)
+        default = torch.zeros(19)
+        default[idx] = torch.tensor(vals)
+        feet = [i for i, b in enumerate(LV.H1_BODIES) if b.endswith("ankle_link")]
+        # joint velocities large enough for the DC-motor envelope to bite on some joints (velocity limit 100 rad/s)
+        state = synth.locomotion_state(n, seed, num_joints=19, num_bodies=20, default_joint_pos=default, feet_ids=feet,
+                                       height_at=height_at, extent=(rows * 8.0, cols * 8.0), joint_vel_std=40.0, with_bodies=True)
+        env = LocomotionVelocityStep(n, dev, mesh, "h1")
+        make_oracle = lambda st: SL.H1RoughOracle(st["joint_pos"].shape[1], st, RC.CMesh(verts, tris))  # noqa: E731
+    # force a few time-outs so that the reset path runs (base contacts come with the synthetic forces)
     state["episode_length_buf"][:3] = 999
-    env = LocomotionVelocityStep(n, dev, mesh, "anymal_c", actuator_net=dict(weights=ws, biases=bs, activation="softsign"))
     env.load_state(state)
-    oracle = AnymalRoughOracle(n, state, ws, bs, default, RC.CMesh(verts, tris))
-    return env, oracle, state
+    return env, make_oracle, state
 
 
-def test_anymal_full_step_matches_oracle(dev):
-    from oracle import command as C
+def kernel_ray_xy(hits):
+    """x / y of the world ray starts the kernel used: exact in its hits (vertical rays); NaN where the ray missed."""
+    xy = hits[..., :2].clone()
+    xy[torch.isinf(hits[..., 2])] = float("nan")
+    return xy
 
+
+def check_step(env, oracle, ref, obs, reward, terminated, time_outs, step, rows=slice(None), robot="anymal_c"):
+    """Everything one step produced, for the envs `rows` of the kernel's buffers against the oracle's."""
+    cut = lambda t: t.cpu()[rows]  # noqa: E731
+    cut1 = lambda t: t.cpu()[:, rows]  # noqa: E731  ([term][env] buffers)
+    # decisions: bit exact
+    assert_exact(cut(terminated), ref["terminated"], f"terminated step {step}")
+    assert_exact(cut(time_outs), ref["time_outs"], f"time_outs step {step}")
+    assert_exact(cut1(env.mdp.term_dones), ref["term_dones"], f"term_dones step {step}")
+    assert_exact(cut(env.mdp.episode_length_buf), oracle.s["episode_length_buf"], f"episode_length_buf step {step}")
+    assert_exact(cut(env.mdp.command_counter), oracle.cmd.command_counter, f"command_counter step {step}")
+    assert_exact(cut(env.mdp.is_standing_env), oracle.cmd.is_standing_env, f"is_standing_env step {step}")
+    assert_exact(cut(env.mdp.time_left), oracle.cmd.time_left, f"time_left step {step}")
+    c = env.contact._data
+    assert_exact(cut(env.contact.ordered_history()), oracle.s["net_forces_w_history"], f"contact history step {step}")
+    for k in ("current_air_time", "last_air_time", "current_contact_time", "last_contact_time"):
+        assert_exact(cut(getattr(c, k)), oracle.s[k], f"{k} step {step}")
+    assert_exact(cut(env.data.joint_acc), ref["joint_acc"], f"joint_acc step {step}")
+    # ray hits: the oracle cast the kernel's own ray x / y, so every ray compares bit for bit
+    hits = cut(env.scanner._data.ray_hits_w)
+    assert_exact(hits, ref["ray_hits_w"], f"ray hits step {step}")
+    # float terms: 1e-5 relative (atol for values near zero)
+    if robot == "anymal_c":
+        assert_exact(cut(env.actuator._joint_pos_error_history), oracle.s["pos_error_history"], f"pos error history step {step}")
+        assert_close(cut(env.data.computed_torque), ref["computed_torque"], atol=2e-5, what=f"computed torque step {step}")
+        assert_close(cut(env.data.applied_torque), ref["applied_torque"], atol=2e-5, what=f"applied torque step {step}")
+    else:
+        assert_exact(cut(env.data.computed_torque), ref["computed_torque"], f"computed torque step {step}")
+        assert_exact(cut(env.data.applied_torque), ref["applied_torque"], f"applied torque step {step}")
+        assert (ref["computed_torque"] != ref["applied_torque"]).any(), "the DC-motor envelope clipped something"
+    # observations: 1e-5 relative; the height-scan columns to 1e-5 m absolute (rays start 20 m up: one ulp of t is 2e-6 m)
+    assert_close(cut(obs)[:, :48], ref["obs"][:, :48], atol=2e-6, what=f"proprioceptive obs step {step}")
+    assert_close(cut(obs), ref["obs"], atol=1.2e-5, what=f"obs step {step}")
+    assert_close(cut(reward), ref["reward"], atol=1e-6 if robot == "anymal_c" else 2e-5, what=f"reward step {step}")
+    assert_close(cut(env.mdp.step_reward), ref["step_reward"], atol=5e-5, rtol=2e-5, what=f"step_reward step {step}")
+    assert_close(cut1(env.mdp.episode_sums), ref["episode_sums"], atol=1e-6 if robot == "anymal_c" else 2e-5, what=f"episode_sums step {step}")
+    assert_close(cut(env.mdp.command), oracle.cmd.vel_command_b, atol=1e-6, what=f"command step {step}")
+
+
+def draws(gen, n, obs_dim):
+    noise_u = torch.rand(n, obs_dim, generator=gen)
+    samples = torch.rand(n, 7, generator=gen) * 2 - 1
+    samples[:, 0] = 10.0
+    samples[:, 5:] = torch.rand(n, 2, generator=gen)
+    return noise_u, samples, samples.flip(0).contiguous()
+
+
+@pytest.mark.parametrize("robot", ["anymal_c", "h1"])
+def test_full_step_matches_oracle(dev, robot):
     n = 512
-    env, oracle, state = build(dev, n, seed=21)
+    env, make_oracle, state = build(dev, n, seed=21 if robot == "anymal_c" else 22, robot=robot)
+    oracle = make_oracle(state)
+    j, obs_dim = state["raw_action"].shape[1], 48 + 187 if robot == "anymal_c" else 3 * 4 + 3 * 19 + 187
+    nr = oracle.num_rewards
     gen = torch.Generator().manual_seed(99)
     for step in range(2):
-        raw = state["raw_action"] if step == 0 else torch.rand(n, 12, generator=gen) * 2 - 1
-        noise_u = torch.rand(n, 235, generator=gen)
-        samples = torch.rand(n, 7, generator=gen) * 2 - 1
-        samples[:, 0] = 10.0
-        samples[:, 5:] = torch.rand(n, 2, generator=gen)
-        reset_samples = samples.flip(0).contiguous()
-        ref = oracle.step(raw, noise_u, samples, reset_samples)
+        raw = state["raw_action"] if step == 0 else torch.rand(n, j, generator=gen) * 2 - 1
+        noise_u, samples, reset_samples = draws(gen, n, obs_dim)
         obs, reward, terminated, time_outs = env.step(raw.to(dev), noise_u.to(dev), samples.to(dev), reset_samples.to(dev))
-        # decisions: bit exact
-        assert_exact(terminated, ref["terminated"], f"terminated step {step}")
-        assert_exact(time_outs, ref["time_outs"], f"time_outs step {step}")
-        assert_exact(env.mdp.term_dones, ref["term_dones"], f"term_dones step {step}")
-        assert_exact(env.mdp.episode_length_buf, oracle.s["episode_length_buf"], f"episode_length_buf step {step}")
-        assert_exact(env.mdp.command_counter, oracle.cmd.command_counter, f"command_counter step {step}")
-        assert_exact(env.mdp.is_standing_env, oracle.cmd.is_standing_env, f"is_standing_env step {step}")
-        assert_exact(env.mdp.time_left, oracle.cmd.time_left, f"time_left step {step}")
-        c = env.contact._data
-        assert_exact(env.contact.ordered_history(), oracle.s["net_forces_w_history"], f"contact history step {step}")
-        for k in ("current_air_time", "last_air_time", "current_contact_time", "last_contact_time"):
-            assert_exact(getattr(c, k), oracle.s[k], f"{k} step {step}")
-        assert_exact(env.actuator._joint_pos_error_history, oracle.s["pos_error_history"], f"pos error history step {step}")
-        assert_exact(env.data.joint_acc, ref["joint_acc"], f"joint_acc step {step}")
-        # ray hits: same rays up to the yaw rotation of the starts (sin/cos), so positions agree to ~1e-6 m; the
-        # terrain has 5-23 cm steps, a ray within that distance of a step edge may land on the other side
-        hits, rhits = env.scanner._data.ray_hits_w.cpu(), ref["ray_hits_w"]
-        assert_exact(torch.isinf(hits[..., 2]), torch.isinf(rhits[..., 2]), "hit/miss pattern")
-        ok = ~torch.isinf(rhits[..., 2])
-        dz = (hits[..., 2] - rhits[..., 2])[ok].abs()
-        assert (dz > 1e-5).float().mean() < 2e-3, f"ray hit heights: {(dz > 1e-5).float().mean():.2e} of rays differ"
-        # float terms: 1e-5 relative (atol for near-zero values and for the 23 cm-step rays above)
-        assert_close(env.data.computed_torque, ref["computed_torque"], atol=2e-5, what=f"computed torque step {step}")
-        assert_close(env.data.applied_torque, ref["applied_torque"], atol=2e-5, what=f"applied torque step {step}")
-        same_rays = ((hits[..., 2] - rhits[..., 2]).abs() <= 1e-5) | ~ok
-        good = same_rays.all(dim=1)
-        assert good.float().mean() > 0.9
-        # height-scan columns: absolute 1e-5 m (rays start 20 m up: 1 ulp of t is 2e-6 m, and the yaw of the ray
-        # starts goes through sin/cos)
-        assert_close(obs.cpu()[good], ref["obs"][good], atol=1.2e-5, what=f"obs step {step}")
-        assert_close(obs.cpu()[:, :48], ref["obs"][:, :48], atol=2e-6, what=f"proprioceptive obs step {step}")
-        assert_close(reward, ref["reward"], atol=1e-6, what=f"reward step {step}")
-        assert_close(env.mdp.step_reward, ref["step_reward"], atol=5e-5, what=f"step_reward step {step}")
-        assert_close(env.mdp.episode_sums, ref["episode_sums"], atol=1e-6, what=f"episode_sums step {step}")
-        assert_close(env.mdp.command, oracle.cmd.vel_command_b, atol=1e-6, what=f"command step {step}")
+        assert obs.shape == (n, obs_dim)
+        xy = kernel_ray_xy(env.scanner._data.ray_hits_w.cpu())
+        own_xy = oracle.world_rays()[0][..., :2]
+        hit = torch.isfinite(xy)
+        # the only difference between the two ray sets: yaw -> (cos, sin) of the half angle in two math libraries
+        assert (xy - own_xy)[hit].abs().max() <= 2e-6, "world ray starts (x, y)"
+        ref = oracle.step(raw, noise_u, samples, reset_samples, ray_xy=xy)
+        check_step(env, oracle, ref, obs, reward, terminated, time_outs, step, robot=robot)
         nd = int(ref["dones"].sum())
         assert nd > 0 and ref["terminated"].any() and ref["time_outs"].any()
         log = env.mdp.log_sums.cpu()
         assert log[-1].item() == nd
-        assert_close(log[:11] / nd / 20.0, ref["reward_log"], rtol=1e-4, atol=1e-6, what="episode reward log")
-        assert_exact(log[11:13].long(), ref["term_log"], "termination counts")
+        assert_close(log[:nr] / nd / 20.0, ref["reward_log"], rtol=1e-4, atol=1e-6, what="episode reward log")
+        assert_exact(log[nr:nr + 2].long(), ref["term_log"], "termination counts")
+        env.mdp.log_sums.zero_()
+
+
+def subset_state(state, ids):
+    """The synthetic state of the envs `ids`: per-substep arrays carry the env axis second."""
+    out = {}
+    for k, v in state.items():
+        out[k] = v[:, ids].clone() if k in ("joint_pos", "joint_vel", "net_forces") else v[ids].clone()
+    return out
+
+
+def test_anymal_step_at_benchmark_size(dev):
+    """16,384 envs (the benchmark's shard): catches index-width and grid-size errors that 512 envs cannot.  The oracle
+    runs on 512 of the envs -- the first and last 64 and random ones; every per-env buffer of those rows is compared."""
+    n = 16384
+    env, make_oracle, state = build(dev, n, seed=5, rows=3, cols=3)
+    gen = torch.Generator().manual_seed(17)
+    ids = torch.cat([torch.arange(64), torch.arange(n - 64, n), torch.randperm(n - 128, generator=gen)[:384] + 64]).sort().values
+    oracle = make_oracle(subset_state(state, ids))
+    for step in range(2):
+        raw = state["raw_action"] if step == 0 else torch.rand(n, 12, generator=gen) * 2 - 1
+        noise_u, samples, reset_samples = draws(gen, n, 235)
+        obs, reward, terminated, time_outs = env.step(raw.to(dev), noise_u.to(dev), samples.to(dev), reset_samples.to(dev))
+        xy = kernel_ray_xy(env.scanner._data.ray_hits_w.cpu()[ids])
+        ref = oracle.step(raw[ids], noise_u[ids], samples[ids], reset_samples[ids], ray_xy=xy)
+        check_step(env, oracle, ref, obs, reward, terminated, time_outs, step, rows=ids)
+        # the whole shard: finite outputs, plausible reset counts, the logging vector counts every done env
+        assert torch.isfinite(obs).all() and torch.isfinite(reward).all()
+        done = (terminated | time_outs).cpu()
+        assert env.mdp.log_sums.cpu()[-1].item() == int(done.sum()) > 0
         env.mdp.log_sums.zero_()
