@@ -31,83 +31,16 @@ MFMA_F32_PEAK_TFLOPS = 157.3  # dense fp32 MFMA peak (256 CUs x 256 FLOP/clk/CU 
 # 6-32-32-32-1 MLP: multiply-adds per row x 2, rows = envs x 12 joints
 MLP_FLOP_PER_ENV = 12 * 2 * (6 * 32 + 32 * 32 + 32 * 32 + 32 * 1)
 
-# Algorithmic bytes per env per launch (each distinct input read once, each output written once; fp32 = 4 B,
-# bool = 1 B, int64 = 8 B; per-joint constants, network weights and the terrain mesh excluded).  J=12, B=17, R=187.
-BYTES = {
-    # read q_des, q, qd (3*48); read+write pos-error / velocity histories (2 * 2 * 144); write computed, applied (2*48)
-    "actuator_net_mlp": 3 * 48 + 4 * 144 + 2 * 48,
-    # InteractiveScene.update in one launch -- contact: read net forces 204, write net_forces_w 204, write one history
-    # row 204 (ring) + head 8, read+write 4 timers 8*68, clock 18; joint_acc: read vel 48, read+write previous vel 96,
-    # write acc 48; scanner clock 18
-    "scene_update": 204 + 204 + 204 + 8 + 8 * 68 + 18 + 48 + 96 + 48 + 18,
-    # read pose 28 + clock 9, write pose 28, ray hits 187*12, clock 5
-    "raycaster_refresh": 28 + 9 + 28 + 187 * 12 + 5,
-    # read root 52, joints (pos, vel, acc, torque, default) 5*48, actions 2*48, contact history 612, timers 2*68,
-    # ray hit z 748, sensor pos 12, command state r+w ~2*41, ep_len r+w 16, noise 880 (parity mode only: not counted);
-    # write obs 940, reward 4, step_reward 44, episode sums r+w 72, flags 5
-    "mdp_step": 52 + 240 + 96 + 612 + 136 + 748 + 12 + 82 + 16 + 940 + 4 + 44 + 72 + 5,
-    "joint_action_process": 48 + 2 * 48 + 48 + 48,
-    # --actuator lstm: read q_des, q, qd (3*48); read+write hidden and cell state (2 * 2 * 2 layers * 8 * 4 B * 12 joints);
-    # write computed, applied (2*48)
-    "actuator_net_lstm": 3 * 48 + 2 * 2 * 768 + 2 * 48,
-}
-
-
-def bytes_per_env_step(actuator_kernel):
-    return (4 * (BYTES[actuator_kernel] + BYTES["scene_update"]) + BYTES["raycaster_refresh"] + BYTES["mdp_step"]
-            + BYTES["joint_action_process"])
-
-
 def build_env(device, num_envs, seed, actuator="mlp"):
-    from isaaclab_amd import synth
-    from isaaclab_amd.envs.locomotion_step import LocomotionVelocityStep
-    from isaaclab_amd.tasks import locomotion_velocity as LV
-    from isaaclab_amd.utils.mesh import convert_to_mesh
-    from isaaclab_amd.utils.string import resolve_matching_names_values
+    """The headline configuration's step object and its synthetic state (what the probe scripts under tools/ use)."""
+    import bench_configs as BC
 
-    verts, tris, height_at = synth.rough_terrain_mesh(seed=3)
-    mesh = convert_to_mesh(verts, tris, str(device))
-    ws, bs = synth.actuator_mlp_weights()
-    idx, _, vals = resolve_matching_names_values(LV.ANYMAL_DEFAULT_JOINT_POS, LV.ANYMAL_JOINTS)
-    default = torch.zeros(12)
-    default[idx] = torch.tensor(vals)
-    state = synth.locomotion_state(num_envs, seed, num_joints=12, num_bodies=17, default_joint_pos=default,
-                                   feet_ids=[13, 14, 15, 16], height_at=height_at)
-    net = synth.actuator_lstm_weights() if actuator == "lstm" else dict(weights=ws, biases=bs, activation="softsign")
-    env = LocomotionVelocityStep(num_envs, device, mesh, "anymal_c", actuator_net=net, seed=seed)
-    env.load_state(state)
-    return env, state, (verts, tris, ws, bs, default)
+    cfg = BC.build("anymal", device, num_envs, seed, actuator)
+    return cfg.env, cfg.state, None
 
 
-def time_kernels(env, state, device, actuator_kernel, reps=20):
-    """Average duration of each kernel of the step, measured with events on the stream the kernels run on."""
-    from isaaclab_amd import _abi
-    from isaaclab_amd.envs import fused_mdp as FM
-    from isaaclab_amd.tasks import locomotion_velocity as LV
-    from isaaclab_amd.utils.types import ArticulationActions
-
-    d = env.data
-    raw = state["raw_action"].to(device)
-
-    def actuator():
-        ca = ArticulationActions(joint_positions=d.joint_pos_target, joint_velocities=d.joint_vel_target,
-                                 joint_efforts=d.joint_effort_target)
-        env.actuator.compute(ca, d.joint_pos, d.joint_vel)
-
-    def scene():
-        env.scene.update(LV.PHYSICS_DT)
-
-    def rays():
-        env.scanner._update_outdated_buffers()
-
-    def mdp():
-        env.mdp.step(FM.PHASE_ALL)
-
-    def action():
-        _abi.check(_abi.joint_action_process(_abi.ptr(raw), _abi.ptr(env.action), _abi.ptr(env.prev_action), None, 0.5,
-                                             _abi.ptr(d.default_joint_pos), 0.0, None, _abi.ptr(d.joint_pos_target), env.n, 12,
-                                             _abi.stream()))
-
+def time_kernels(cfg, device, reps=20):
+    """Average duration of each launch of the step, measured with events on the stream the kernels run on."""
     # The launches of one measurement are queued behind a long-running blocker, so that they run back to back on the
     # device: the host (Python + ctypes, ~10 us per call) would otherwise pace the short kernels and the events would
     # time its gaps.  Measured per launch = (event span over `reps` queued launches) / reps.
@@ -128,18 +61,34 @@ def time_kernels(env, state, device, actuator_kernel, reps=20):
         torch.cuda.synchronize()
         return a.elapsed_time(b) * 1e3 / reps  # microseconds per call
 
-    def due():
-        env.scanner._is_outdated.fill_(True)  # every env is due, as once per env step
-
-    def rays_due():
-        due()
-        rays()
-
     out = {}
-    for name, fn in ((actuator_kernel, actuator), ("scene_update", scene), ("mdp_step", mdp), ("joint_action_process", action)):
-        out[name] = span(fn)
-    out["raycaster_refresh"] = span(rays_due) - span(due)
+    for name, (fn, _) in cfg.launches.items():
+        # (fn, setup): the launch needs a setup launch before each call, whose own span is taken off
+        out[name] = span(fn[0]) - span(fn[1]) if isinstance(fn, tuple) else span(fn)
     return out
+
+
+def time_graph(cfg, steps, warmup):
+    """The same env step captured once into a HIP graph and replayed: what remains when the host's launch calls are
+    taken out.  Kernel arguments are those of the captured step (host-side clocks and generator counters do not advance
+    between replays), so this is a timing of the same work, not a second product path."""
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(3):       # per-stream workspaces are created here, outside the capture
+            cfg.step()
+    side.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        cfg.step()
+    for _ in range(warmup):
+        graph.replay()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        graph.replay()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps
 
 
 def cpu_baseline(seed, envs=NUM_ENVS, warmup=2, steps=10):
@@ -184,16 +133,23 @@ def cpu_baseline(seed, envs=NUM_ENVS, warmup=2, steps=10):
 
 
 def main():
+    import bench_configs as BC
+
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--envs", type=int, default=NUM_ENVS, help="environments per GPU")
+    ap.add_argument("--config", choices=tuple(BC.ENVS), default="anymal",
+                    help="which configuration's step to run; the default is the one the headline metric is quoted on")
+    ap.add_argument("--envs", type=int, default=None, help="environments per GPU (default: the configuration's own count)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", action="store_true",
+                    help="also time the step replayed from a HIP graph (always done for the launch-bound configurations)")
     ap.add_argument("--actuator", choices=("mlp", "lstm"), default="mlp",
-                    help="actuator network: the headline 6-32-32-32-1 MLP, or the ANYdrive-shaped LSTM(2, 8, 2) + head "
-                         "(no CPU baseline, reported as a side measurement)")
+                    help="anymal only -- actuator network: the headline 6-32-32-32-1 MLP, or the ANYdrive-shaped LSTM(2, 8, 2) + "
+                         "head (no CPU baseline, reported as a side measurement)")
     args = ap.parse_args()
+    args.envs = args.envs or BC.ENVS[args.config]
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -210,19 +166,22 @@ def main():
 
     from isaaclab_amd.distributed import OverlappedLogReducer
 
-    env, state, _ = build_env(device, args.envs, seed=3000 + rank, actuator=args.actuator)
-    raw = state["raw_action"].to(device)
-    n_log = env.mdp.log_sums.numel()
+    cfg_id = list(BC.ENVS).index(args.config) + 1
+    cfg = BC.build(args.config, device, args.envs, seed=cfg_id * 1000 + rank, actuator=args.actuator)
 
-    # episode statistics of the done envs: the only cross-rank exchange of the path, one all-reduce per step, started
-    # after the step and completed beside the next two (nothing in the step consumes it)
-    reducer = OverlappedLogReducer(n_log, device)
+    if cfg.log_sums is not None:
+        # episode statistics of the done envs: the only cross-rank exchange of the path, one all-reduce per step, started
+        # after the step and completed beside the next two (nothing in the step consumes it)
+        reducer = OverlappedLogReducer(cfg.log_sums.numel(), device)
 
-    def one_step():
-        buf, _ = reducer.begin_step()
-        env.mdp.bind(log_sums=buf)
-        env.step(raw)
-        reducer.end_step()
+        def one_step():
+            buf, _ = reducer.begin_step()
+            cfg.bind_log_sums(buf)
+            cfg.step()
+            reducer.end_step()
+    else:  # the in-hand env reduces its two success sums inside the step (the statistic of the same step needs them)
+        reducer = None
+        one_step = cfg.step
 
     for _ in range(args.warmup):
         one_step()
@@ -232,7 +191,8 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         one_step()
-    reducer.finish()
+    if reducer is not None:
+        reducer.finish()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -251,55 +211,66 @@ def main():
         elapsed = float(t.item())
         rank_ms = [float(t_min.item()) / args.steps * 1e3, elapsed / args.steps * 1e3]
 
-    act_kernel = "actuator_net_" + args.actuator
-    kern = time_kernels(env, state, device, act_kernel)
-    BYTES_PER_ENV_STEP = bytes_per_env_step(act_kernel)
+    kern = time_kernels(cfg, device)
+    graph_s = None
+    if world == 1 and (args.graph or args.config != "anymal"):
+        if cfg.log_sums is not None:
+            cfg.bind_log_sums(cfg.log_sums)
+        graph_s = time_graph(cfg, args.steps, args.warmup)
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         value = args.envs * world * args.steps / elapsed
-        launches = {act_kernel: 4, "scene_update": 4, "raycaster_refresh": 1, "mdp_step": 1, "joint_action_process": 1}
+        launches = {k: n for k, (_, n) in cfg.launches.items()}
+        nbytes = cfg.bytes_per_env
         dominant = max(kern, key=lambda k: kern[k] * launches[k])
         # HBM-side bytes per launch of that kernel from the committed counter passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
-        # of this same command, corrected as stated in the file); only meaningful for the env count it was taken at
+        # of this same command, corrected as stated in the file); only meaningful for the config and env count it was taken at
         traffic = None
         try:
-            with open(os.path.join(ROOT, "profiles", "r1_hbm_traffic.json")) as f:
+            with open(os.path.join(ROOT, "profiles", "r2_hbm_traffic.json")) as f:
                 prof = json.load(f)
-            if prof.get("envs") == args.envs:
+            if prof.get("envs") == args.envs and prof.get("config", "anymal") == args.config:
                 traffic = prof["kernels"][dominant]["hbm_bytes_per_launch"]
         except (OSError, KeyError, ValueError):
             pass
-        if dominant == "actuator_net_mlp":  # the one kernel of the step that is matrix work
+        mlp = "actuator_net_mlp"
+        mfma_frac = MLP_FLOP_PER_ENV * args.envs / (kern[mlp] * 1e-6) / 1e12 / MFMA_F32_PEAK_TFLOPS if mlp in kern else None
+        if dominant == mlp:  # the one kernel of the step that is matrix work
             achieved = MLP_FLOP_PER_ENV * args.envs / (kern[dominant] * 1e-6) / 1e12
             roofline = {"bound": "mfma", "kernel": dominant, "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": achieved / MFMA_F32_PEAK_TFLOPS, "traffic": traffic, "launch_us": kern[dominant],
                         "algorithmic_flop_per_launch": MLP_FLOP_PER_ENV * args.envs}
         else:
-            achieved = BYTES[dominant] * args.envs / (kern[dominant] * 1e-6) / 1e9
+            achieved = nbytes[dominant] * args.envs / (kern[dominant] * 1e-6) / 1e9
             roofline = {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "launch_us": kern[dominant],
-                        "algorithmic_bytes_per_launch": BYTES[dominant] * args.envs}
+                        "algorithmic_bytes_per_launch": nbytes[dominant] * args.envs}
+        per_step = cfg.bytes_per_env_step()
         line = {
-            "metric": "env-steps/sec (non-physics step) ANYmal-C rough", "value": value, "unit": "env-steps/s",
+            "metric": "env-steps/sec (non-physics step) ANYmal-C rough" if args.config == "anymal" else
+                      f"env-steps/sec (non-physics step) {args.config}",
+            "value": value, "unit": "env-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "Isaac-Velocity-Rough-Anymal-C-v0 non-physics step", "envs_per_gpu": args.envs,
-                       "decimation": 4, "joints": 12, "bodies": 17, "rays": 187, "obs_dim": 235,
-                       "terrain_triangles": int(env.scanner.meshes["/World/ground"].num_triangles),
-                       "actuator": ("ActuatorNetMLP 6-32-32-32-1 softsign (fp32 MFMA)" if args.actuator == "mlp" else
-                                    "ActuatorNetLSTM LSTM(2, 8, 2 layers) + 8-32-1 softsign head"),
-                       "parallelism": f"env-shard x{world}"},
-            "env_term_steps_per_s": value * TERM_EVALS_PER_ENV_STEP,
-            "algorithmic_bytes_per_env_step": BYTES_PER_ENV_STEP,
-            "step_hbm_frac": BYTES_PER_ENV_STEP * args.envs / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "config": dict({"workload": BC.WORKLOAD[args.config], "envs_per_gpu": args.envs}, **cfg.info,
+                           parallelism=f"env-shard x{world}"),
+            "algorithmic_bytes_per_env_step": per_step,
+            "step_hbm_frac": per_step * args.envs / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "roofline": roofline,
             "kernels_us": {k: round(v, 2) for k, v in kern.items()},
-            "mfma_frac": (MLP_FLOP_PER_ENV * args.envs / (kern[act_kernel] * 1e-6) / 1e12 / MFMA_F32_PEAK_TFLOPS
-                          if args.actuator == "mlp" else None),
+            "launches_per_step": launches,
+            "bytes_per_env_per_launch": nbytes,
+            "mfma_frac": mfma_frac,
             "rccl_ranks": rccl_ranks, "ms_per_step_min_rank": rank_ms[0], "ms_per_step_max_rank": rank_ms[1],
         }
-        if not args.no_cpu_baseline and world == 1 and args.actuator == "mlp":
-            line["cpu_baseline"] = cpu_baseline(3000)
+        if args.config == "anymal":
+            line["env_term_steps_per_s"] = value * TERM_EVALS_PER_ENV_STEP
+        if graph_s is not None:
+            line["hip_graph"] = {"ms_per_step": graph_s * 1e3, "value": args.envs / graph_s,
+                                 "step_hbm_frac": per_step * args.envs / graph_s / 1e9 / HBM_PEAK_GBS,
+                                 "note": "the same launches replayed from one captured graph (no host launch calls)"}
+        if not args.no_cpu_baseline and world == 1 and args.config == "anymal" and args.actuator == "mlp":
+            line["cpu_baseline"] = cpu_baseline(3000, envs=args.envs)
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line))

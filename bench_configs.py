@@ -1,0 +1,276 @@
+"""The five configurations `bench.py --config` can run: for each, the step object on synthetic state, the step's
+launches (name -> callable, launches per env step) and the algorithmic bytes per env of each launch.
+
+Byte rule (same for every table): each distinct per-env input field read once and each output field written once by
+a launch that has to exist; fp32 = 4 B, bool = 1 B, int64 = 8 B; per-joint constants (gains, limits, defaults), network
+weights and the terrain mesh are not counted.  J = joints, B = bodies, R = rays.
+"""
+
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+
+import torch
+
+ENVS = {"cartpole": 4096, "reach": 8192, "anymal": 16384, "h1": 4096, "shadow": 8192}
+WORKLOAD = {
+    "cartpole": "Isaac-Cartpole-v0 non-physics step",
+    "reach": "Isaac-Reach-Franka-v0 non-physics step (joint-position arm action)",
+    "anymal": "Isaac-Velocity-Rough-Anymal-C-v0 non-physics step",
+    "h1": "Isaac-Velocity-Rough-H1-v0 non-physics step",
+    "shadow": "Isaac-Repose-Cube-Shadow-Direct-v0 non-physics step",
+}
+
+
+@dataclass
+class Config:
+    name: str
+    envs: int
+    step: callable                       # one env step of the hot path (all launches, in order)
+    launches: dict                       # kernel name -> (callable issuing ONE launch of it, launches per env step)
+    bytes_per_env: dict                  # kernel name -> algorithmic bytes per env per launch
+    info: dict = field(default_factory=dict)   # goes into the JSON line's "config"
+    log_sums: torch.Tensor | None = None       # the statistics vector the multi-GPU all-reduce carries (manager-based)
+    bind_log_sums: callable = None
+
+    def bytes_per_env_step(self):
+        return sum(self.bytes_per_env[k] * n for k, (_, n) in self.launches.items())
+
+
+def _locomotion_bytes(j, b, r, obs_dim, n_rewards, actuator):
+    f = 4 * j           # one fp32 per joint
+    out = {
+        # InteractiveScene.update in one launch -- contact: read net forces, write net_forces_w, write one history row
+        # (ring) + head 8, read+write 4 timers, clock 18; joint_acc: read vel, read+write previous vel, write acc;
+        # scanner clock 18
+        "scene_update": 3 * 12 * b + 8 + 8 * 4 * b + 18 + 4 * f + 18,
+        # read pose 28 + clock 9, write pose 28, ray hits R*12, clock 5
+        "raycaster_refresh": 28 + 9 + 28 + r * 12 + 5,
+        # read root 52, joints (pos, vel, acc, torque, default) 5f, actions 2f, contact history 3*B*12, timers 2*4B,
+        # ray hit z 4R, sensor pos 12, command state r+w ~82, ep_len r+w 16 (noise: parity mode only, not counted);
+        # write obs, reward 4, step_reward, episode sums r+w, flags 5
+        "mdp_step": 52 + 5 * f + 2 * f + 36 * b + 8 * b + 4 * r + 12 + 82 + 16 + 4 * obs_dim + 4 + 4 * n_rewards + 8 * n_rewards + 5,
+        # read raw, write action + previous action, read default, write target
+        "joint_action_process": 5 * f,
+    }
+    if actuator == "actuator_net_mlp":
+        # read q_des, q, qd; read+write pos-error / velocity histories (3 deep); write computed, applied
+        out[actuator] = 3 * f + 4 * 3 * f + 2 * f
+    elif actuator == "actuator_net_lstm":
+        # read q_des, q, qd; read+write hidden and cell state (2 x 2 layers x 8 x 4 B per joint); write computed, applied
+        out[actuator] = 3 * f + 2 * 2 * 64 * j + 2 * f
+    else:
+        # read q_des, qd_des, tau_ff, q, qd; write computed, applied
+        out[actuator] = 7 * f
+    return out
+
+
+def build_locomotion(device, envs, seed, robot="anymal_c", actuator="mlp", static_scan=False):
+    from isaaclab_amd import synth
+    from isaaclab_amd.envs import fused_mdp as FM
+    from isaaclab_amd.envs.locomotion_step import LocomotionVelocityStep
+    from isaaclab_amd.tasks import locomotion_velocity as LV
+    from isaaclab_amd.utils.mesh import convert_to_mesh
+    from isaaclab_amd.utils.string import resolve_matching_names_values
+    from isaaclab_amd.utils.types import ArticulationActions
+    from isaaclab_amd import _abi
+
+    verts, tris, height_at = synth.rough_terrain_mesh(seed=3)
+    mesh = convert_to_mesh(verts, tris, str(device))
+    if robot == "anymal_c":
+        joints, bodies, default_cfg = LV.ANYMAL_JOINTS, LV.ANYMAL_BODIES, LV.ANYMAL_DEFAULT_JOINT_POS
+        feet = [13, 14, 15, 16]
+        act_kernel = "actuator_net_" + actuator
+        ws, bs = synth.actuator_mlp_weights()
+        net = synth.actuator_lstm_weights() if actuator == "lstm" else dict(weights=ws, biases=bs, activation="softsign")
+    else:
+        joints, bodies, default_cfg = LV.H1_JOINTS, LV.H1_BODIES, LV.H1_DEFAULT_JOINT_POS
+        feet = [i for i, b in enumerate(bodies) if b.endswith("ankle_link")]
+        act_kernel, net = "actuator_dc_motor", None
+    j, b = len(joints), len(bodies)
+    idx, _, vals = resolve_matching_names_values(default_cfg, joints)
+    default = torch.zeros(j)
+    default[idx] = torch.tensor(vals)
+    state = synth.locomotion_state(envs, seed, num_joints=j, num_bodies=b, default_joint_pos=default, feet_ids=feet,
+                                   height_at=height_at, with_bodies=robot == "h1")
+    env = LocomotionVelocityStep(envs, device, mesh, robot, actuator_net=net, seed=seed)
+    env.load_state(state)
+    env.scanner.static_workspace = static_scan
+    raw = state["raw_action"].to(device)
+    d = env.data
+
+    def actuate():
+        ca = ArticulationActions(joint_positions=d.joint_pos_target, joint_velocities=d.joint_vel_target,
+                                 joint_efforts=d.joint_effort_target)
+        env.actuator.compute(ca, d.joint_pos, d.joint_vel)
+
+    def rays():
+        env.scanner._is_outdated.fill_(True)   # every env is due, as once per env step
+        env.scanner._update_outdated_buffers()
+
+    def rays_overhead():
+        env.scanner._is_outdated.fill_(True)
+
+    def action():
+        _abi.check(_abi.joint_action_process(_abi.ptr(raw), _abi.ptr(env.action), _abi.ptr(env.prev_action), None, 0.5,
+                                             _abi.ptr(d.default_joint_pos), 0.0, None, _abi.ptr(d.joint_pos_target), env.n, j,
+                                             _abi.stream()))
+
+    launches = {act_kernel: (actuate, LV.DECIMATION), "scene_update": (lambda: env.scene.update(LV.PHYSICS_DT), LV.DECIMATION),
+                "raycaster_refresh": ((rays, rays_overhead), 1), "mdp_step": (lambda: env.mdp.step(FM.PHASE_ALL), 1),
+                "joint_action_process": (action, 1)}
+    r = env.scanner.num_rays
+    n_rewards = int(env.mdp.step_reward.shape[1])
+    info = {"decimation": LV.DECIMATION, "joints": j, "bodies": b, "rays": r, "obs_dim": int(env.mdp.obs_dim),
+            "terrain_triangles": int(env.scanner.meshes["/World/ground"].num_triangles)}
+    if robot == "anymal_c":
+        info["actuator"] = ("ActuatorNetMLP 6-32-32-32-1 softsign (fp32 MFMA)" if actuator == "mlp" else
+                            "ActuatorNetLSTM LSTM(2, 8, 2 layers) + 8-32-1 softsign head")
+    else:
+        info["actuator"] = "DCMotor (PD + torque-speed envelope)"
+    cfg = Config("anymal" if robot == "anymal_c" else "h1", envs, lambda: env.step(raw), launches,
+                 _locomotion_bytes(j, b, r, int(env.mdp.obs_dim), n_rewards, act_kernel), info,
+                 env.mdp.log_sums, lambda buf: env.mdp.bind(log_sums=buf))
+    cfg.env, cfg.state = env, state
+    return cfg
+
+
+def build_cartpole(device, envs, seed):
+    from isaaclab_amd.envs import fused_mdp as FM
+    from isaaclab_amd.envs.manager_based_step import CartpoleStep
+    from isaaclab_amd.tasks import cartpole as CP
+
+    g = torch.Generator().manual_seed(seed)
+    n = envs
+    env = CartpoleStep(n, device, seed=seed)
+    # cart position U(-3.2, 3.2) (about 6 % beyond the +-3 m bound), pole angle U(-pi, pi)
+    q0 = torch.stack([torch.rand(n, generator=g) * 6.4 - 3.2, (torch.rand(n, generator=g) * 2 - 1) * math.pi], -1)
+    qd0 = torch.randn(n, 2, generator=g)
+    env.data.joint_pos, env.data.joint_vel = q0.to(device), qd0.to(device)
+    env.data._previous_joint_vel.copy_(qd0)
+    env.mdp.episode_length_buf.copy_(torch.randint(0, CP.MAX_EPISODE_LENGTH, (n,), generator=g))
+    root = torch.zeros(n, 13)
+    root[:, 3] = 1.0
+    env.load_physics(dict(joint_pos=torch.stack([q0 + 0.3 * torch.randn(n, 2, generator=g) for _ in range(CP.DECIMATION)]),
+                          joint_vel=torch.stack([torch.randn(n, 2, generator=g) for _ in range(CP.DECIMATION)]), root_state_w=root))
+    raw = (torch.rand(n, 1, generator=g) * 2 - 1).to(device)
+    launches = {"joint_action_process": (lambda: env.process_action(raw), 1), "actuator_pd": (env.apply_action, CP.DECIMATION),
+                "scene_update": (lambda: env.scene.update(CP.PHYSICS_DT), CP.DECIMATION),
+                "mdp_step": (lambda: env.mdp.step(FM.PHASE_ALL), 1)}
+    nb = {
+        "joint_action_process": 4 + 8 + 4,          # read raw; write action, previous action; write the scaled effort
+        # effort target of the cart 4 + read q_des, qd_des, tau_ff, q, qd (5 x 8); write computed, applied (2 x 8)
+        "actuator_pd": 4 + 7 * 8,
+        "scene_update": 8 + 16 + 8,                 # joint_acc: read vel, read+write previous vel, write acc
+        # read joint pos, vel 16; ep_len r+w 16; action + previous action (zeroed on reset) 8; write obs 16, reward 4,
+        # step_reward 20, episode sums r+w 40, flags 5
+        "mdp_step": 16 + 16 + 8 + 16 + 4 + 20 + 40 + 5,
+    }
+    info = {"decimation": CP.DECIMATION, "joints": 2, "bodies": len(CP.BODIES), "obs_dim": int(env.mdp.obs_dim),
+            "actuator": "ImplicitActuator (PD estimate)"}
+    cfg = Config("cartpole", n, lambda: env.step(raw), launches, nb, info, env.mdp.log_sums, lambda buf: env.mdp.bind(log_sums=buf))
+    cfg.env = env
+    return cfg
+
+
+def build_reach(device, envs, seed):
+    from isaaclab_amd.envs import fused_mdp as FM
+    from isaaclab_amd.envs.manager_based_step import ReachStep
+    from isaaclab_amd.tasks import reach as RE
+
+    g = torch.Generator().manual_seed(seed)
+    n = envs
+    env = ReachStep(n, device, arm_action="joint_pos", seed=seed)
+    default = torch.tensor([0.0, -0.569, 0.0, -2.81, 0.0, 3.037, 0.741, 0.04, 0.04]).repeat(n, 1)   # franka.py:38-48
+    env.set_default_joint_pos(default)
+    q = default + 0.3 * torch.randn(n, 9, generator=g)
+    env.data.joint_pos, env.data.joint_vel = q.to(device), torch.zeros(n, 9, device=device)
+    env.mdp.episode_length_buf.copy_(torch.randint(0, RE.MAX_EPISODE_LENGTH, (n,), generator=g))
+    quat = torch.randn(n, 4, generator=g)
+    env.mdp.command.copy_(torch.cat([torch.rand(n, 3, generator=g) * 0.5, quat / quat.norm(dim=-1, keepdim=True)], -1))
+    env.mdp.time_left.copy_(torch.rand(n, generator=g) * 4.0)
+    root = torch.zeros(n, 13)
+    root[:, :3] = torch.randn(n, 3, generator=g)
+    yaw = torch.rand(n, generator=g) * 6.28 - 3.14
+    root[:, 3], root[:, 6] = torch.cos(yaw / 2), torch.sin(yaw / 2)
+    nb_bodies = len(RE.FRANKA_BODIES)
+    body = torch.zeros(n, nb_bodies, 13)
+    body[..., :3] = root[:, None, :3] + 0.4 * torch.randn(n, nb_bodies, 3, generator=g)
+    bq = torch.randn(n, nb_bodies, 4, generator=g)
+    body[..., 3:7] = bq / bq.norm(dim=-1, keepdim=True)
+    env.load_physics(dict(joint_pos=torch.stack([default + 0.2 * torch.randn(n, 9, generator=g) for _ in range(RE.DECIMATION)]),
+                          joint_vel=torch.stack([0.5 * torch.randn(n, 9, generator=g) for _ in range(RE.DECIMATION)]),
+                          root_state_w=root, body_state_w=body))
+    raw = (torch.rand(n, 7, generator=g) * 2 - 1).to(device)
+    launches = {"joint_action_process": (lambda: env.process_action(raw), 1), "actuator_pd": (env.apply_action, RE.DECIMATION),
+                "scene_update": (lambda: env.scene.update(RE.PHYSICS_DT), RE.DECIMATION),
+                "mdp_step": (lambda: env.mdp.step(FM.PHASE_ALL), 1)}
+    nb = {
+        "joint_action_process": 5 * 28,             # read raw, default; write action, previous action, arm target (7 joints)
+        # arm target into the 9-joint target 28 + read q_des, qd_des, tau_ff, q, qd (5 x 36); write computed, applied (2 x 36)
+        "actuator_pd": 28 + 7 * 36,
+        "scene_update": 36 + 72 + 36,               # joint_acc: read vel, read+write previous vel, write acc
+        # read root 52, end-effector pose 28, joint pos / vel 72, actions 56; command r+w 56, time_left r+w 8, counter r+w
+        # 16, ep_len r+w 16; write obs 4 x 32, reward 4, step_reward 20, episode sums r+w 40, flags 3
+        "mdp_step": 52 + 28 + 72 + 56 + 56 + 8 + 16 + 16 + 4 * int(env.mdp.obs_dim) + 4 + 20 + 40 + 3,
+    }
+    info = {"decimation": RE.DECIMATION, "joints": 9, "bodies": nb_bodies, "obs_dim": int(env.mdp.obs_dim),
+            "actuator": "ImplicitActuator (PD estimate)", "arm_action": "JointPositionAction scale 0.5"}
+    cfg = Config("reach", n, lambda: env.step(raw), launches, nb, info, env.mdp.log_sums, lambda buf: env.mdp.bind(log_sums=buf))
+    cfg.env = env
+    return cfg
+
+
+def build_shadow(device, envs, seed):
+    import ctypes
+
+    from isaaclab_amd import _abi, synth
+    from isaaclab_amd.envs import inhand_step as IS
+
+    n = envs
+    s = synth.inhand_state(n, seed=seed)
+    env = IS.InHandManipulationStep(IS.InHandManipulationCfg(act_moving_average=1.0, max_consecutive_success=0), n, device,
+                                    num_joints=24, num_bodies=26, actuated_dof_indices=s["actuated"], finger_bodies=s["fingers"],
+                                    lower_limits=s["lower"], upper_limits=s["upper"], in_hand_pos=s["in_hand_pos"],
+                                    env_origins=s["env_origins"], seed=seed)
+    for k in ("cur_targets", "prev_targets", "goal_rot", "successes", "consecutive_successes", "episode_length_buf"):
+        getattr(env, k).copy_(s[k])
+    env.set_sim_state(s["joint_pos"].to(device), s["joint_vel"].to(device), s["body_state"].to(device), s["object_state"].to(device))
+    actions = s["actions"].to(device)
+    env.step(actions)   # fills the descriptor the single launches below reuse
+
+    def one(fn):
+        return lambda: _abi.check(fn(ctypes.byref(env.desc), _abi.stream()))
+
+    launches = {"inhand_apply_action": (one(IS._apply_action), env.cfg.decimation), "inhand_step": (one(IS._step), 1),
+                "inhand_finish": (one(IS._finish), 1)}
+    a, j, tips = 20, 24, 5
+    nb = {
+        # read actions 4A; read+write cur_targets and prev_targets (4J each way)
+        "inhand_apply_action": 4 * a + 4 * 4 * j,
+        # read joint pos / vel 8J, object state 52, fingertip states 52 each, goal_rot r+w 32, actions 4A, successes r+w 8,
+        # reset_goal_buf r+w 2, ep_len r+w 16; write obs 4 x 157, reward 4, flags 3
+        "inhand_step": 8 * j + 52 + 52 * tips + 32 + 4 * a + 8 + 2 + 16 + 4 * env.obs_dim + 4 + 3,
+        "inhand_finish": 0,                          # two floats for the whole shard
+    }
+    info = {"decimation": env.cfg.decimation, "joints": j, "actuated": a, "bodies": 26, "fingertips": tips, "obs_dim": env.obs_dim,
+            "actuator": "implicit (targets only)"}
+    cfg = Config("shadow", n, lambda: env.step(actions), launches, nb, info)
+    cfg.env = env
+    return cfg
+
+
+def build(name, device, envs=None, seed=0, actuator="mlp", static_scan=False):
+    envs = envs or ENVS[name]
+    if name == "anymal":
+        return build_locomotion(device, envs, seed, "anymal_c", actuator, static_scan)
+    if name == "h1":
+        return build_locomotion(device, envs, seed, "h1", static_scan=static_scan)
+    if name == "cartpole":
+        return build_cartpole(device, envs, seed)
+    if name == "reach":
+        return build_reach(device, envs, seed)
+    if name == "shadow":
+        return build_shadow(device, envs, seed)
+    raise ValueError(f"unknown config '{name}'")

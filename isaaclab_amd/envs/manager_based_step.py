@@ -164,6 +164,9 @@ class ReachStep(ManagerBasedStep):
         n, dev = num_envs, self.device
         arm = resolve_matching_names(["panda_joint.*"], RE.FRANKA_JOINTS)[0]
         self._arm = arm
+        # the same joints as an index that costs no host-to-device copy per use: a slice when they are consecutive
+        self._arm_index = (slice(arm[0], arm[-1] + 1) if arm == list(range(arm[0], arm[-1] + 1)) else
+                           torch.tensor(arm, dtype=torch.long, device=dev))
         cfg = ImplicitActuatorCfg(effort_limit={"panda_joint[1-4]": 87.0, "panda_joint[5-7]": 12.0, "panda_finger_joint.*": 200.0},
                                   velocity_limit={"panda_joint[1-4]": 2.175, "panda_joint[5-7]": 2.61, "panda_finger_joint.*": 0.2},
                                   stiffness={"panda_joint.*": 80.0, "panda_finger_joint.*": 2e3},
@@ -183,7 +186,7 @@ class ReachStep(ManagerBasedStep):
 
     def set_default_joint_pos(self, default: torch.Tensor):
         self.data.default_joint_pos[:] = default.to(self.device)
-        self._arm_default = self.data.default_joint_pos[:, self._arm].contiguous()
+        self._arm_default = self.data.default_joint_pos[:, self._arm_index].contiguous()
 
     def load_physics(self, physics: dict):
         super().load_physics(physics)
@@ -206,7 +209,7 @@ class ReachStep(ManagerBasedStep):
     def apply_action(self):
         d = self.data
         if self.ik is None:
-            d.joint_pos_target[:, self._arm] = self._arm_target
+            d.joint_pos_target[:, self._arm_index] = self._arm_target
         else:
             self.ik.apply_actions()
         ca = ArticulationActions(joint_positions=d.joint_pos_target, joint_velocities=d.joint_vel_target,
