@@ -66,29 +66,28 @@ class ActuatorBase(ABC):
         raise NotImplementedError
 
     def _parse_joint_parameter(self, cfg_value, default_value) -> torch.Tensor:
-        """actuator_base.py:192-250: float / regex-dict from the cfg, else the default (float or (N,J) tensor)."""
-        param = torch.zeros(self._num_envs, self.num_joints, device=self._device)
-        if cfg_value is not None:
-            if isinstance(cfg_value, (float, int)):
-                param[:] = float(cfg_value)
-            elif isinstance(cfg_value, dict):
-                indices, _, values = string_utils.resolve_matching_names_values(cfg_value, self.joint_names)
-                param[:, indices] = torch.tensor(values, dtype=torch.float, device=self._device)
-            else:
-                raise TypeError(f"Invalid type for parameter value: {type(cfg_value)} for actuator on joints "
-                                f"{self.joint_names}. Expected float or dict.")
-        elif default_value is not None:
-            if isinstance(default_value, (float, int)):
-                param[:] = float(default_value)
-            elif isinstance(default_value, torch.Tensor):
-                if default_value.shape == (self._num_envs, self.num_joints):
-                    param = default_value.float().to(self._device)
-                else:
-                    raise ValueError("Invalid default value tensor shape.\n"
-                                     f"Got: {default_value.shape}\nExpected: {(self._num_envs, self.num_joints)}")
-            else:
-                raise TypeError(f"Invalid type for default value: {type(default_value)} for actuator on joints "
-                                f"{self.joint_names}. Expected float or Tensor.")
-        else:
+        """One (num_envs, num_joints) tensor per actuator parameter: the cfg entry (a number, or a dict of joint-name
+        patterns) wins over the default handed down by the asset (a number or a full tensor).  Argument checks, exception
+        types and messages as actuator_base.py:192-250."""
+        shape = (self._num_envs, self.num_joints)
+        names = self.joint_names
+        if cfg_value is None and default_value is None:
             raise ValueError("The parameter value is None and no default value is provided.")
-        return param
+        if cfg_value is None:
+            if isinstance(default_value, torch.Tensor):
+                if tuple(default_value.shape) != shape:
+                    raise ValueError(f"Invalid default value tensor shape.\nGot: {default_value.shape}\nExpected: {shape}")
+                return default_value.float().to(self._device)
+            if not isinstance(default_value, (float, int)):
+                raise TypeError(f"Invalid type for default value: {type(default_value)} for actuator on joints {names}. "
+                                "Expected float or Tensor.")
+            return torch.full(shape, float(default_value), device=self._device)
+        if isinstance(cfg_value, dict):
+            param = torch.zeros(shape, device=self._device)
+            columns, _, values = string_utils.resolve_matching_names_values(cfg_value, names)
+            param[:, columns] = torch.tensor(values, dtype=torch.float, device=self._device)
+            return param
+        if not isinstance(cfg_value, (float, int)):
+            raise TypeError(f"Invalid type for parameter value: {type(cfg_value)} for actuator on joints {names}. "
+                            "Expected float or dict.")
+        return torch.full(shape, float(cfg_value), device=self._device)

@@ -79,9 +79,11 @@ class Articulation:
     # -- state writers used by the reset events (articulation.py:300-420): into the buffers the step reads
     def write_root_pose_to_sim(self, root_pose, env_ids=None):
         self.data.root_state_w[env_ids if env_ids is not None else slice(None), :7] = root_pose
+        self.data._derived_timestamp = -1.0   # base-frame velocities, projected gravity and heading follow the new pose
 
     def write_root_velocity_to_sim(self, root_velocity, env_ids=None):
         self.data.root_state_w[env_ids if env_ids is not None else slice(None), 7:] = root_velocity
+        self.data._derived_timestamp = -1.0
 
     def write_joint_state_to_sim(self, position, velocity, joint_ids=None, env_ids=None):
         at = self._index(env_ids, joint_ids)

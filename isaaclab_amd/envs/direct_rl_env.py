@@ -17,7 +17,7 @@ import torch
 
 from ..managers import EventManager
 from ..utils import math as math_utils
-from ..utils.noise import set_noise_seed
+from ..utils import rng
 
 
 @dataclass
@@ -43,10 +43,7 @@ class DirectRLEnv:
         self.sim = SimpleNamespace(get_physics_dt=lambda: self.cfg.sim_dt, device=self.device)
         self.seed = 0
         if cfg.seed is not None:
-            self.seed = int(cfg.seed)
-            torch.manual_seed(self.seed)
-            math_utils.set_sampling_seed(self.seed)
-            set_noise_seed(self.seed)
+            self.seed = self.seed_all(cfg.seed)
         n, dev = self.num_envs, self.device
         self._sim_step_counter = 0
         self.common_step_counter = 0
@@ -83,14 +80,18 @@ class DirectRLEnv:
     def max_episode_length(self) -> int:
         return math.ceil(self.max_episode_length_s / self.step_dt)
 
+    @staticmethod
+    def seed_all(seed: int) -> int:
+        """direct_rl_env.py:388-404: torch's generators and every device-side generator (one seed; their shared draw
+        counter restarts)."""
+        torch.manual_seed(int(seed))
+        return rng.seed_all(seed)
+
     # -- operations
     def reset(self, seed: int | None = None):
         """direct_rl_env.py:252-290."""
         if seed is not None:
-            self.seed = int(seed)
-            torch.manual_seed(self.seed)
-            math_utils.set_sampling_seed(self.seed)
-            set_noise_seed(self.seed)
+            self.seed = self.seed_all(seed)
         self._reset_idx(torch.arange(self.num_envs, dtype=torch.int64, device=self.device))
         self._write_data_to_sim()
         return self._get_observations(), self.extras

@@ -15,6 +15,7 @@ from ctypes import POINTER, c_float, c_int32, c_int64, c_uint8, c_uint64, c_void
 import torch
 
 from .. import _abi
+from ..utils import rng as _rng
 
 # ---- enums (keep in sync with include/isaaclab_amd_mdp.h) ------------------------------------------
 REW = {name: i for i, name in enumerate([
@@ -126,13 +127,19 @@ class FusedMdp:
 
     ``tensors`` maps descriptor field names to GPU tensors (kept alive here); scalar fields are passed as keyword
     arguments.  Output buffers that are not supplied are allocated.
+
+    The in-kernel generator (observation noise, command resampling) is keyed by ``(seed, step_index, env, column)``.
+    ``seed`` None (what the managers pass): every launch takes the seed the environment installed and a draw index
+    that no other launch of the process shares (:mod:`isaaclab_amd.utils.rng`), so two plans -- two observation groups,
+    say -- never draw the same noise, and re-seeding the environment replays.  An explicit ``seed`` gives the plan a
+    generator of its own whose ``step_index`` counts its launches from 0.
     """
 
     def __init__(self, num_envs: int, device, *, num_joints: int, num_bodies: int = 1, num_sensor_bodies: int = 0,
                  history_len: int = 0, num_rays: int = 0, action_dim: int = 0, command_dim: int = 3,
                  terminations=(), rewards=(), observations=(), step_dt: float = 0.02, max_episode_length: int = 1000,
                  max_episode_length_s: float | None = None, gravity=(0.0, 0.0, -1.0), command: dict | None = None,
-                 seed: int = 0, external_obs_dims=()):
+                 seed: int | None = 0, external_obs_dims=()):
         self.n, self.device = num_envs, torch.device(device)
         self.terminations, self.rewards, self.observations = list(terminations), list(rewards), list(observations)
         d = self.desc = MdpDesc()
@@ -143,7 +150,8 @@ class FusedMdp:
         d.max_episode_length = max_episode_length
         d.max_episode_length_s = max_episode_length * step_dt if max_episode_length_s is None else max_episode_length_s
         d.gravity_dir = (c_float * 3)(*gravity)
-        d.seed, d.step_index, d.phases = seed, 0, PHASE_ALL
+        self._own_generator = seed is not None
+        d.seed, d.step_index, d.phases = (seed if seed is not None else 0), 0, PHASE_ALL
         if len(external_obs_dims) > MAX_EXTERNAL_OBS:
             raise ValueError(f"a plan reads at most {MAX_EXTERNAL_OBS} external observation buffers, not {len(external_obs_dims)}")
         for slot, width in enumerate(external_obs_dims):   # widths of the buffers ILX_OBS_EXTERNAL terms copy (slot = the term's aux)
@@ -254,6 +262,8 @@ class FusedMdp:
         self.desc.phases = phases
         if step_index is not None:
             self.desc.step_index = step_index
+        elif not self._own_generator:
+            self.desc.seed, self.desc.step_index = _rng.seed(), _rng.next_draw("fused_mdp")
         _abi.check(_abi.lib.ilx_mdp_step(self.plan, ctypes.byref(self.desc), _abi.stream()), "ilx_mdp_step")
         self.desc.step_index += 1
 

@@ -21,7 +21,7 @@ import torch
 from ..managers import ActionManager, CommandManager, EventManager, ObservationManager, RewardManager, TerminationManager
 from .mdp.curriculums import CurriculumManager
 from ..utils import math as math_utils
-from ..utils.noise import set_noise_seed
+from ..utils import rng
 
 
 @dataclass
@@ -77,11 +77,10 @@ class ManagerBasedRLEnv:
 
     @staticmethod
     def seed_all(seed: int) -> int:
-        """manager_based_env.py:412-430: torch's generators and the device samplers."""
+        """manager_based_env.py:412-430: torch's generators and every device-side generator (events, commands,
+        observation noise, samplers, terrain curriculum): one seed, and their shared draw counter restarts."""
         torch.manual_seed(seed)
-        math_utils.set_sampling_seed(seed)
-        set_noise_seed(seed)
-        return seed
+        return rng.seed_all(seed)
 
     def load_managers(self):
         """manager_based_rl_env.py:137-160: commands first (terms of the other managers read them), then actions,

@@ -184,7 +184,7 @@ def make_plan(env, group: str, specs, weights=None, posts=None, step_dt: float =
     extra[kw] = terms
     max_len = int(getattr(env, "max_episode_length", 1000))
     return FM.FusedMdp(env.num_envs, env.device, step_dt=step_dt, max_episode_length=max_len,
-                       command={"kind": "none"}, external_obs_dims=external_dims, **sz, **extra)
+                       command={"kind": "none"}, external_obs_dims=external_dims, seed=None, **sz, **extra)
 
 
 _PHASE = {"termination": FM.PHASE_TERMINATION, "reward": FM.PHASE_REWARD, "observation": FM.PHASE_OBSERVATION}

@@ -4,7 +4,6 @@
 from __future__ import annotations
 
 import ctypes
-import itertools
 from collections.abc import Sequence
 from ctypes import c_float, c_int32, c_int64, c_uint64, c_void_p
 from dataclasses import dataclass, field
@@ -12,6 +11,7 @@ from dataclasses import dataclass, field
 import torch
 
 from .... import _abi
+from ....utils import rng as _rng
 from ....managers.command_manager import CommandTermCfg
 
 
@@ -31,7 +31,6 @@ class Pose2dDesc(ctypes.Structure):
 
 _compute = _abi._sig("ilx_pose2d_command_compute", ctypes.POINTER(Pose2dDesc), c_float, _abi.P)
 _reset = _abi._sig("ilx_pose2d_command_reset", ctypes.POINTER(Pose2dDesc), _abi.P, _abi.P, _abi.P)
-_draws = itertools.count(1)
 
 
 @dataclass
@@ -92,7 +91,7 @@ class UniformPose2dCommand:
                        reset_samples=_abi.ptr(self._reset_samples),
                        patch_ids=None if self._patch_ids is None else self._patch_ids.data_ptr(),
                        reset_patch_ids=None if self._reset_patch_ids is None else self._reset_patch_ids.data_ptr(),
-                       seed=int(getattr(self._env, "seed", 0) or 0), draw=next(_draws))
+                       seed=_rng.seed(), draw=_rng.next_draw("pose_2d_command"))
         d.resampling_time_range = (c_float * 2)(*c.resampling_time_range)
         d.pos_x, d.pos_y = (c_float * 2)(*r.pos_x), (c_float * 2)(*r.pos_y)
         d.heading = (c_float * 2)(*(r.heading if r.heading is not None else (0.0, 0.0)))

@@ -3,13 +3,13 @@
 from __future__ import annotations
 
 import ctypes
-import itertools
 from collections.abc import Sequence
 from ctypes import c_float, c_int64, c_uint64, c_void_p
 
 import torch
 
 from .... import _abi
+from ....utils import rng as _rng
 from ....managers.command_manager import CommandTerm
 
 
@@ -65,7 +65,6 @@ class NormalVelDesc(ctypes.Structure):
 
 _normal_compute = _abi._sig("ilx_normal_velocity_command_compute", ctypes.POINTER(NormalVelDesc), c_float, _abi.P)
 _normal_reset = _abi._sig("ilx_normal_velocity_command_reset", ctypes.POINTER(NormalVelDesc), _abi.P, _abi.P, _abi.P)
-_draws = itertools.count(1)
 
 
 class NormalVelocityCommand:
@@ -116,7 +115,7 @@ class NormalVelocityCommand:
                           is_standing_env=self.is_standing_env.data_ptr(), time_left=_abi.ptr(self.time_left),
                           command_counter=self.command_counter.data_ptr(), error_vel_xy=_abi.ptr(self.metrics["error_vel_xy"]),
                           error_vel_yaw=_abi.ptr(self.metrics["error_vel_yaw"]), samples=_abi.ptr(self._samples),
-                          reset_samples=_abi.ptr(self._reset_samples), seed=int(getattr(self._env, "seed", 0) or 0), draw=next(_draws))
+                          reset_samples=_abi.ptr(self._reset_samples), seed=_rng.seed(), draw=_rng.next_draw("velocity_command"))
         d.mean_vel, d.std_vel, d.zero_prob = (c_float * 3)(*r.mean_vel), (c_float * 3)(*r.std_vel), (c_float * 3)(*r.zero_prob)
         d.resampling_time_range = (c_float * 2)(*c.resampling_time_range)
         return d

@@ -3,22 +3,22 @@
 Same signatures as the reference: ``func(env, env_ids, <ranges>, asset_cfg)``.  The reference hands the new state to the
 simulator through ``asset.write_*_to_sim``; here it is written into the asset's state buffers
 (``data.root_state_w`` / ``joint_pos`` / ``joint_vel``), and the asset's ``write_*_to_sim`` methods are called with the
-new rows as well when it has them.  Random numbers come from Philox on the device, keyed by ``env.event_seed`` (0 when
-absent) and a per-call counter; ``_u`` injects unit-interval draws instead (parity tests).
+new rows as well when it has them.  Random numbers come from Philox on the device, keyed by the seed the environment's
+``seed`` / ``reset(seed=)`` installed (:mod:`isaaclab_amd.utils.rng`) and that module's draw counter; ``_u`` injects
+unit-interval draws instead (parity tests).
 """
 
 from __future__ import annotations
 
 import ctypes
-import itertools
 
 import torch
 
 from ... import _abi
+from ...utils import rng as _generators
 from ...managers.scene_entity_cfg import SceneEntityCfg
 
 _AXES = ("x", "y", "z", "roll", "pitch", "yaw")
-_draws = itertools.count(1)
 
 
 def _range12(d: dict):
@@ -33,15 +33,27 @@ def _ids(env_ids, n, device) -> torch.Tensor:
     return torch.as_tensor(env_ids, dtype=torch.long, device=device).contiguous()
 
 
+def _data(asset):
+    """The asset's data container; a scene may hold a bare ArticulationData in place of an Articulation."""
+    return getattr(asset, "data", asset)
+
+
+def _root_state_written(d):
+    """A kernel wrote ``d.root_state_w`` in place: the quantities derived from it (root velocities in the base frame,
+    projected gravity, heading) must be recomputed at their next read, as the reference does at every read."""
+    if hasattr(d, "_derived_timestamp"):
+        d._derived_timestamp = -1.0
+
+
 def _rng(env, u):
-    return (None if u is None else _abi.ptr(_abi.f32c(u)), int(getattr(env, "event_seed", 0)), next(_draws))
+    return (None if u is None else _abi.ptr(_abi.f32c(u)), _generators.seed(), _generators.next_draw("events"))
 
 
 def reset_root_state_uniform(env, env_ids, pose_range: dict, velocity_range: dict, asset_cfg: SceneEntityCfg = SceneEntityCfg("robot"),
                              *, _u=None):
     """events.py:638-680."""
     asset = env.scene[asset_cfg.name]
-    d = asset.data
+    d = _data(asset)
     ids = _ids(env_ids, d.root_state_w.shape[0], d.root_state_w.device)
     origins = getattr(env.scene, "env_origins", None)
     up, seed, draw = _rng(env, _u)
@@ -49,6 +61,7 @@ def reset_root_state_uniform(env, env_ids, pose_range: dict, velocity_range: dic
                                                    None if origins is None else _abi.ptr(_abi.f32c(origins)), _range12(pose_range),
                                                    _range12(velocity_range), up, seed, draw, _abi.ptr(d.root_state_w), _abi.stream()),
                "ilx_event_reset_root_state_uniform")
+    _root_state_written(d)
     if hasattr(asset, "write_root_pose_to_sim"):
         asset.write_root_pose_to_sim(d.root_state_w[ids, :7], env_ids=ids)
         asset.write_root_velocity_to_sim(d.root_state_w[ids, 7:], env_ids=ids)
@@ -64,7 +77,7 @@ def reset_root_state_from_terrain(env, env_ids, pose_range: dict, velocity_range
     if valid_positions is None:
         raise ValueError("The event term 'reset_root_state_from_terrain' requires valid flat patches under 'init_pos'."
                          f" Found: {list(terrain.flat_patches.keys())}")
-    d = asset.data
+    d = _data(asset)
     n = d.root_state_w.shape[0]
     ids = _ids(env_ids, n, d.root_state_w.device)
     if ids.numel() != n:
@@ -77,6 +90,7 @@ def reset_root_state_from_terrain(env, env_ids, pose_range: dict, velocity_range
         terrain.terrain_types.data_ptr(), valid.shape[1], valid.shape[2], None if picks is None else picks.data_ptr(),
         _range12(pose_range), _range12(velocity_range), up, seed, draw, _abi.ptr(d.root_state_w), _abi.stream()),
         "ilx_event_reset_root_state_from_terrain")
+    _root_state_written(d)
     if hasattr(asset, "write_root_pose_to_sim"):
         asset.write_root_pose_to_sim(d.root_state_w[ids, :7], env_ids=ids)
         asset.write_root_velocity_to_sim(d.root_state_w[ids, 7:], env_ids=ids)
@@ -84,7 +98,7 @@ def reset_root_state_from_terrain(env, env_ids, pose_range: dict, velocity_range
 
 def _reset_joints(by_scale, env, env_ids, position_range, velocity_range, asset_cfg, u):
     asset = env.scene[asset_cfg.name]
-    d = asset.data
+    d = _data(asset)
     n, j = d.joint_pos.shape
     ids = _ids(env_ids, n, d.joint_pos.device)
     up, seed, draw = _rng(env, u)
@@ -110,11 +124,12 @@ def reset_joints_by_offset(env, env_ids, position_range, velocity_range, asset_c
 def push_by_setting_velocity(env, env_ids, velocity_range: dict, asset_cfg: SceneEntityCfg = SceneEntityCfg("robot"), *, _u=None):
     """events.py:610-635."""
     asset = env.scene[asset_cfg.name]
-    d = asset.data
+    d = _data(asset)
     ids = _ids(env_ids, d.root_state_w.shape[0], d.root_state_w.device)
     up, seed, draw = _rng(env, _u)
     _abi.check(_abi.event_push_by_setting_velocity(ids.data_ptr(), ids.numel(), _range12(velocity_range), up, seed, draw,
                                                    _abi.ptr(d.root_state_w), _abi.stream()), "ilx_event_push_by_setting_velocity")
+    _root_state_written(d)
     if hasattr(asset, "write_root_velocity_to_sim"):
         asset.write_root_velocity_to_sim(d.root_state_w[ids, 7:], env_ids=ids)
 
@@ -124,7 +139,7 @@ def reset_root_state_with_random_orientation(env, env_ids, pose_range: dict, vel
     """events.py:683-732.  ``_u`` (count, 9) unit-interval draws (3 position, 6 velocity) and ``_z`` (count, 4) standard
     normal draws replay the reference's; they are given together."""
     asset = env.scene[asset_cfg.name]
-    d = asset.data
+    d = _data(asset)
     ids = _ids(env_ids, d.root_state_w.shape[0], d.root_state_w.device)
     origins = getattr(env.scene, "env_origins", None)
     up, seed, draw = _rng(env, _u)
@@ -132,6 +147,7 @@ def reset_root_state_with_random_orientation(env, env_ids, pose_range: dict, vel
         ids.data_ptr(), ids.numel(), _abi.ptr(d.default_root_state), None if origins is None else _abi.ptr(_abi.f32c(origins)),
         _range12(pose_range), _range12(velocity_range), up, None if _z is None else _abi.ptr(_abi.f32c(_z)), seed, draw,
         _abi.ptr(d.root_state_w), _abi.stream()), "ilx_event_reset_root_state_random_orientation")
+    _root_state_written(d)
     if hasattr(asset, "write_root_pose_to_sim"):
         asset.write_root_pose_to_sim(d.root_state_w[ids, :7], env_ids=ids)
         asset.write_root_velocity_to_sim(d.root_state_w[ids, 7:], env_ids=ids)
@@ -176,7 +192,8 @@ def reset_scene_to_default(env, env_ids):
                                                      _abi.ptr(d.default_joint_pos), _abi.ptr(d.default_joint_vel), _abi.ptr(d.joint_pos),
                                                      _abi.ptr(d.joint_vel), d.joint_pos.shape[1], _abi.stream()),
                    "ilx_event_reset_scene_to_default")
-        if hasattr(asset, "write_root_pose_to_sim"):
+        _root_state_written(d)
+    if hasattr(asset, "write_root_pose_to_sim"):
             asset.write_root_pose_to_sim(d.root_state_w[ids, :7], env_ids=ids)
             asset.write_root_velocity_to_sim(d.root_state_w[ids, 7:], env_ids=ids)
             asset.write_joint_state_to_sim(d.joint_pos[ids], d.joint_vel[ids], env_ids=ids)

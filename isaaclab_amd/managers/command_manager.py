@@ -41,7 +41,7 @@ class CommandTerm:
         self.num_envs, self.device = env.num_envs, torch.device(env.device)
         k = self._kernel_cfg()
         self._mdp = FM.FusedMdp(self.num_envs, self.device, num_joints=k.pop("num_joints", 1), num_bodies=k.pop("num_bodies", 1),
-                                command_dim=k.pop("command_dim"), step_dt=env.step_dt, command=k, seed=getattr(env, "seed", 0) or 0)
+                                command_dim=k.pop("command_dim"), step_dt=env.step_dt, command=k, seed=None)
         m = self._mdp
         self.time_left, self.command_counter = m.time_left, m.command_counter
         self.metrics = {self.metric_names[0]: m.command_metrics[0], self.metric_names[1]: m.command_metrics[1]}

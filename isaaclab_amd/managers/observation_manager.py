@@ -109,6 +109,15 @@ class ObservationManager:
             post, col = [], 0
             for name, c, spec in zip(self._group_obs_term_names[group], cfgs, mdp.observations):
                 width = mdp._obs_dim(spec)
+                if c.scale is not None:   # observation_manager.py:425-440: checked once, when the manager is built
+                    if not isinstance(c.scale, (float, int, tuple, torch.Tensor)):
+                        raise TypeError(f"Scale for observation term '{name}' in group '{group}' is not of type float, int or tuple."
+                                        f" Received: '{type(c.scale)}'.")
+                    if isinstance(c.scale, (tuple, torch.Tensor)):
+                        if len(c.scale) != width:
+                            raise ValueError(f"Scale for observation term '{name}' in group '{group}' does not match the dimensions"
+                                             f" of the observation. Expected: {width} but received: {len(c.scale)}.")
+                        c.scale = torch.as_tensor(c.scale, dtype=torch.float, device=self._env.device)
                 if self._needs_post(c):
                     for mod_cfg in c.modifiers or ():   # class modifiers are built once with the term's shape (:449-458)
                         if inspect.isclass(mod_cfg.func):
@@ -181,11 +190,8 @@ class ObservationManager:
                 _mod.apply(_mod.CLIP, obs, out=obs, p0=float(cfg.clip[0]), p1=float(cfg.clip[1]), has_lo=1, has_hi=1)
             if cfg.scale is not None and isinstance(cfg.scale, (int, float)):
                 _mod.apply(_mod.SCALE, obs, out=obs, p0=float(cfg.scale))
-            elif cfg.scale is not None:   # one factor per column
-                factors = torch.as_tensor(cfg.scale, dtype=torch.float32, device=obs.device)
-                if factors.numel() != c1 - c0:
-                    raise ValueError(f"Term scale must have as many entries as the term has columns: expected {c1 - c0} but received: {factors.numel()}.")
-                obs = constant_noise(obs, ConstantNoiseCfg(bias=factors, operation="scale"))
+            elif cfg.scale is not None:   # one factor per column (the tensor was built when the group was planned)
+                obs = constant_noise(obs, ConstantNoiseCfg(bias=cfg.scale, operation="scale"))
             if obs.data_ptr() != cols.data_ptr():
                 _mod.apply(_mod.COPY, obs, out=cols)
         rows = self._history_rows.get(group_name)

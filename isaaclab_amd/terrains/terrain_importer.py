@@ -5,7 +5,6 @@ simulator's business; the collision mesh reaches the ray caster through :func:`i
 
 from __future__ import annotations
 
-import itertools
 from dataclasses import dataclass
 from types import SimpleNamespace
 
@@ -13,8 +12,8 @@ import numpy as np
 import torch
 
 from .. import _abi
+from ..utils import rng as _rng
 
-_draws = itertools.count(1)
 
 
 @dataclass
@@ -28,12 +27,17 @@ class TerrainImporterCfg:
 
 
 class TerrainImporter:
-    def __init__(self, cfg: TerrainImporterCfg, device, seed: int = 0):
-        self.cfg, self.device, self.seed = cfg, torch.device(device), seed
+    def __init__(self, cfg: TerrainImporterCfg, device, seed: int | None = None):
+        # seed None: the seed the environment installed (utils/rng.py), read at every draw
+        self.cfg, self.device, self._seed = cfg, torch.device(device), seed
         self.terrain_origins = None
         self.env_origins = None
         self.terrain_levels = self.terrain_types = None
         self.max_terrain_level = 0
+
+    @property
+    def seed(self) -> int:
+        return _rng.seed() if self._seed is None else int(self._seed)
 
     def configure_env_origins(self, origins=None):
         """terrain_importer.py:283-305: sub-terrain origins (num_rows, num_cols, 3) -> curriculum placement, else a grid."""
@@ -55,7 +59,7 @@ class TerrainImporter:
             half_size, max_episode_length_s, None if move_up is None else move_up.data_ptr(),
             None if move_down is None else move_down.data_ptr(), self.terrain_levels.data_ptr(), self.terrain_types.data_ptr(),
             _abi.ptr(self.terrain_origins), rows, cols, None if random_levels is None else random_levels.data_ptr(), self.seed,
-            next(_draws), _abi.ptr(self.env_origins), _abi.stream()), "ilx_curriculum_terrain_levels")
+            _rng.next_draw("terrain"), _abi.ptr(self.env_origins), _abi.stream()), "ilx_curriculum_terrain_levels")
 
     def _ids(self, env_ids) -> torch.Tensor:
         if env_ids is None or (isinstance(env_ids, slice) and env_ids == slice(None)):

@@ -64,12 +64,21 @@ class CircularBuffer:
     def _launch(self, data=None, ordered=None, lags=None, delayed=None):
         n = self._batch_size
         src, s_stride = (None, 0) if data is None else _rows(data, n)
-        o_stride = 0 if ordered is None else _rows(ordered, n)[1]
-        d_stride = 0 if delayed is None else _rows(delayed, n)[1]
+        o_stride = 0 if ordered is None else self._out_stride(ordered, n, "ordered_out")
+        d_stride = 0 if delayed is None else self._out_stride(delayed, n, "delayed_out")
         desc = self._desc()
         _abi.check(_append(ctypes.byref(desc), None if src is None else src.data_ptr(), s_stride,
                            None if ordered is None else ordered.data_ptr(), o_stride, None if lags is None else lags.data_ptr(),
                            None if delayed is None else delayed.data_ptr(), d_stride, _abi.stream()), "ilx_circular_buffer_append")
+
+    @staticmethod
+    def _out_stride(out: torch.Tensor, n: int, what: str) -> int:
+        """Row stride of an output tensor the kernel writes in place; a tensor that would have to be copied or cast
+        (not float32, or without unit inner stride) is refused -- the kernel would write the copy, not the tensor."""
+        rows, stride = _rows(out, n)
+        if rows.data_ptr() != out.data_ptr() or rows.dtype != out.dtype:
+            raise _abi.IlxError(f"CircularBuffer: {what} must be a float32 GPU tensor whose rows have unit inner stride")
+        return stride
 
     @property
     def buffer(self) -> torch.Tensor:

@@ -26,23 +26,25 @@ class DelayBuffer:
     time_lags = property(lambda self: self._time_lags)
 
     def set_time_lag(self, time_lag: int | torch.Tensor, batch_ids: Sequence[int] | None = None):
-        """delay_buffer.py:105-147."""
-        if batch_ids is None:
-            batch_ids = slice(None)
-        if isinstance(time_lag, int):
-            self._time_lags[batch_ids] = time_lag
-        elif isinstance(time_lag, torch.Tensor):
-            if time_lag.dtype not in [torch.int, torch.long]:
+        """Install the lag (in appended samples) of the listed batch rows; same argument checks, exception types and
+        messages as delay_buffer.py:105-147."""
+        rows = slice(None) if batch_ids is None else batch_ids
+        if isinstance(time_lag, torch.Tensor):
+            if time_lag.dtype not in (torch.int, torch.long):
                 raise TypeError(f"Invalid dtype for time_lag: {time_lag.dtype}. Expected torch.int or torch.long.")
-            self._time_lags[batch_ids] = time_lag.to(device=self.device, dtype=torch.int)
+            lags = time_lag.to(device=self.device, dtype=torch.int)
+        elif isinstance(time_lag, int):
+            lags = time_lag
         else:
             raise TypeError(f"Invalid type for time_lag: {type(time_lag)}. Expected int or integer tensor.")
-        self._min_time_lag = int(torch.min(self._time_lags).item())
-        self._max_time_lag = int(torch.max(self._time_lags).item())
-        if self._min_time_lag < 0:
-            raise ValueError(f"The minimum time lag cannot be negative. Received: {self._min_time_lag}")
-        if self._max_time_lag > self._history_length:
-            raise ValueError(f"The maximum time lag cannot be larger than the history length. Received: {self._max_time_lag}")
+        self._time_lags[rows] = lags
+        # both bounds with one device-to-host copy
+        lo, hi = (int(v) for v in torch.aminmax(self._time_lags))
+        self._min_time_lag, self._max_time_lag = lo, hi
+        if lo < 0:
+            raise ValueError(f"The minimum time lag cannot be negative. Received: {lo}")
+        if hi > self._history_length:
+            raise ValueError(f"The maximum time lag cannot be larger than the history length. Received: {hi}")
 
     def reset(self, batch_ids: Sequence[int] | None = None):
         """delay_buffer.py:149-156."""

@@ -10,6 +10,7 @@ from __future__ import annotations
 import torch
 
 from .. import _abi
+from . import rng as _rng
 
 # op ids: keep in sync with enum ilx_math_op in include/isaaclab_amd.h
 (QUAT_ROTATE, QUAT_ROTATE_INVERSE, QUAT_APPLY, QUAT_APPLY_YAW, YAW_QUAT, QUAT_MUL, QUAT_CONJUGATE, QUAT_INV,
@@ -273,13 +274,12 @@ def transform_points(points, pos=None, quat=None):
 # ---- samplers (math.py:1225-1390) ---------------------------------------------------------------------------------
 # The reference draws with torch.rand / torch.randn on the global generator; these draw on the device with Philox keyed
 # by (seed, call counter, row, column).  ``_u`` / ``_z`` hand in unit-interval / standard-normal draws instead.
-_sampling = {"seed": 0, "draw": 0}
 SAMPLE_UNIFORM, SAMPLE_LOG_UNIFORM, SAMPLE_TRIANGLE, SAMPLE_GAUSSIAN, SAMPLE_RANDOM_ORIENTATION, SAMPLE_RANDOM_YAW_ORIENTATION = range(6)
 
 
 def set_sampling_seed(seed: int):
-    """Seed of the device samplers (the call counter restarts)."""
-    _sampling["seed"], _sampling["draw"] = int(seed), 0
+    """Seed of the device generators (the samplers share it with every other drawing module; the draw counter restarts)."""
+    _rng.seed_all(seed)
 
 
 def _operand(v, rows: int, width: int, device):
@@ -313,9 +313,8 @@ def _sample(kind: int, a, b, size, device, u=None, z=None) -> torch.Tensor:
     out = torch.empty(size, device=dev)
     ap, ar, ac, asc, _ka = _operand(a, rows, width, dev)
     bp, br, bc, bsc, _kb = _operand(b, rows, width, dev)
-    _sampling["draw"] += 1
     _abi.check(_abi.sample(kind, ap, ar, ac, asc, bp, br, bc, bsc, None if u is None else _abi.ptr(_abi.f32c(u.to(dev))),
-                           None if z is None else _abi.ptr(_abi.f32c(z.to(dev))), _sampling["seed"], _sampling["draw"], _abi.ptr(out),
+                           None if z is None else _abi.ptr(_abi.f32c(z.to(dev))), _rng.seed(), _rng.next_draw("sampling"), _abi.ptr(out),
                            rows, width, _abi.stream()), "ilx_sample")
     return out
 

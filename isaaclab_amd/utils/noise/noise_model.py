@@ -7,24 +7,21 @@ the sampling seed, a call counter, the row and the column, or are handed in thro
 from __future__ import annotations
 
 import ctypes
-import itertools
 from collections.abc import Sequence
 from ctypes import c_float, c_int32, c_int64, c_uint64, c_void_p
 
 import torch
 
 from ... import _abi
+from .. import rng as _rng
 
 CONSTANT, UNIFORM, GAUSSIAN = range(3)
 _OPS = {"add": 0, "scale": 1, "abs": 2}
-_calls = itertools.count(1)
-_seed = 0
 
 
 def set_noise_seed(seed: int):
-    """Seed of the Philox streams the noise functions draw from."""
-    global _seed
-    _seed = int(seed)
+    """Seed of the device generators (the noise functions share it with every other drawing module)."""
+    _rng.seed_all(seed)
 
 
 class NoiseDesc(ctypes.Structure):
@@ -85,7 +82,7 @@ def _run(kind: int, data: torch.Tensor, operation: str, a, b=0.0, *, out=None, r
     desc = NoiseDesc(data=src.data_ptr(), out=dst.data_ptr(), data_stride=d, out_stride=d, n=n_rows, d=d,
                      row_ids=None if ids is None else ids.data_ptr(), a=a_s, b=b_s, range=float(b_s - a_s) if not per_col else 0.0,
                      a_cols=_abi.ptr(a_t) if per_col else None, b_cols=_abi.ptr(b_t) if per_col else None, draws=_abi.ptr(draws),
-                     row_bias=_abi.ptr(row_bias), seed=_seed, draw=next(_calls))
+                     row_bias=_abi.ptr(row_bias), seed=_rng.seed(), draw=_rng.next_draw("noise"))
     _abi.check(_apply(kind, _OPS[operation], ctypes.byref(desc), _abi.stream()), "ilx_noise_apply")
     return dst.view(data.shape) if out is None else out
 

@@ -10,6 +10,7 @@ from ctypes import c_float, c_int32, c_int64, c_uint64
 import torch
 
 from .. import _abi
+from . import rng as _rng
 
 POSE_MAKE, POSE_INV, POSE_MUL, POSE_COPYSIGN, POSE_IS_IDENTITY = range(5)
 CAMERA_ORTHOGONALIZE, CAMERA_UNPROJECT, CAMERA_PROJECT = range(3)
@@ -171,8 +172,7 @@ def sample_cylinder(radius: float, h_range: tuple[float, float], size, device, *
     n = int(math.prod(shape))
     out = torch.empty(shape + (3,), dtype=torch.float32, device=device)
     u = None if _u is None else _abi.f32c(_u.to(device)).reshape(2, n)
-    M._sampling["draw"] += 1
-    _abi.check(_cylinder(float(radius), float(h_range[0]), float(h_range[1]), _abi.ptr(u), M._sampling["seed"], M._sampling["draw"],
+    _abi.check(_cylinder(float(radius), float(h_range[0]), float(h_range[1]), _abi.ptr(u), _rng.seed(), _rng.next_draw("sampling"),
                          _abi.ptr(out), n, _abi.stream()), "ilx_sample_cylinder")
     return out
 

@@ -129,7 +129,7 @@ def test_event_manager_on_device_with_hip_term(dev):
     n = 64
     data = NS(root_state_w=torch.zeros(n, 13, device=dev))
     scene = {"robot": NS(data=data)}
-    env = NS(num_envs=n, device=dev, scene=scene, event_seed=5)
+    env = NS(num_envs=n, device=dev, scene=scene)
     cfg = dict(push_robot=EventTermCfg(func=mdp.push_by_setting_velocity, mode="interval", interval_range_s=(0.1, 0.3),
                                        params={"velocity_range": {"x": (-0.5, 0.5), "y": (-0.5, 0.5)},
                                                "asset_cfg": SceneEntityCfg("robot")}))

@@ -29,7 +29,7 @@ def _env(g, dev):
     d.root_state_w[:, 7:] = g["root_vel_w"].to(dev)
     scene = Scene(robot=types.SimpleNamespace(data=d))
     scene.env_origins = g["env_origins"].to(dev)
-    return types.SimpleNamespace(scene=scene, event_seed=77), d
+    return types.SimpleNamespace(scene=scene), d
 
 
 def test_events_match_reference(dev):
@@ -62,18 +62,22 @@ def test_events_match_reference(dev):
 def test_events_device_rng(dev):
     """Without injected draws: reproducible per (seed, draw), inside the ranges, and different between envs."""
     from isaaclab_amd.envs import mdp
-    from isaaclab_amd.envs.mdp import events as EV
-    import itertools
+    from isaaclab_amd.utils import rng
 
     g = load_golden("events")
     env, d = _env(g, dev)
     n = d.root_state_w.shape[0]
-    EV._draws = itertools.count(1)
+    rng.seed_all(77)
     mdp.reset_root_state_uniform(env, None, POSE, VEL)
     first = d.root_state_w.clone()
-    EV._draws = itertools.count(1)
+    rng.seed_all(77)
     mdp.reset_root_state_uniform(env, slice(None), POSE, VEL)
-    assert_exact(d.root_state_w, first, "same seed and draw counter -> same reset")
+    assert_exact(d.root_state_w, first, "same seed, draw counter restarted -> same reset")
+    rng.seed_all(78)
+    mdp.reset_root_state_uniform(env, None, POSE, VEL)
+    assert not torch.equal(d.root_state_w, first), "another seed draws other values"
+    rng.seed_all(77)
+    mdp.reset_root_state_uniform(env, None, POSE, VEL)
     mdp.reset_root_state_uniform(env, None, POSE, VEL)
     assert not torch.equal(d.root_state_w, first)
     off = (first[:, :3].cpu() - g["default_root_state"][:, :3] - g["env_origins"])
@@ -164,3 +168,38 @@ def test_reset_root_state_from_terrain(dev):
     env.scene.terrain.flat_patches = {"target": None}
     with pytest.raises(ValueError, match="requires valid flat patches under 'init_pos'"):
         mdp.reset_root_state_from_terrain(env, None, pose_range, VEL)
+
+
+def test_derived_root_quantities_follow_event_writes(dev):
+    """root_lin_vel_b / projected_gravity_b read before and after a push or a reset within one sim step: the second read
+    sees the new root state (the reference recomputes these at every read, articulation_data.py:502-518)."""
+    from isaaclab_amd.assets.articulation import Articulation
+    from isaaclab_amd.envs import mdp
+    from oracle import mathx as MX
+
+    g = load_golden("events")
+    for bare in (True, False):
+        env, d = _env(g, dev)
+        if bare:                                   # the scene holds the data container itself
+            env.scene["robot"] = d
+        d.root_state_w[:, 3] = 1.0
+        d.root_state_w[:, 4:7] = 0.0
+        first = d.root_lin_vel_b.clone()
+        mdp.push_by_setting_velocity(env, None, PUSH)
+        assert not torch.equal(d.root_lin_vel_b, first), "the pushed velocity is visible at the next read"
+        assert_close(d.root_lin_vel_b, MX.quat_rotate_inverse(d.root_state_w[:, 3:7].cpu(), d.root_state_w[:, 7:10].cpu()), atol=1e-6,
+                     what="root_lin_vel_b after the push")
+        grav = d.projected_gravity_b.clone()
+        mdp.reset_root_state_uniform(env, None, POSE, VEL)
+        assert not torch.equal(d.projected_gravity_b, grav), "the reset orientation is visible at the next read"
+    # the asset's own writers (what reset events call on an Articulation)
+    art = Articulation.__new__(Articulation)
+    art.data = d
+    before = d.root_ang_vel_b.clone()
+    art.write_root_velocity_to_sim(torch.ones(d.root_state_w.shape[0], 6, device=dev))
+    assert not torch.equal(d.root_ang_vel_b, before)
+    heading = d.heading_w.clone()
+    pose = d.root_state_w[:, :7].clone()
+    pose[:, 3:7] = torch.tensor([0.0, 0.0, 0.0, 1.0], device=dev)   # yaw of pi
+    art.write_root_pose_to_sim(pose)
+    assert not torch.equal(d.heading_w, heading)

@@ -165,6 +165,38 @@ def test_observation_manager_per_column_scale(dev):
     raw = om.compute_group("plain").cpu()
     want = torch.cat([raw[:, :3].clip(-0.5, 0.5) * torch.tensor([2.0, -1.0, 0.5]), raw[:, 3:] * 3.0], dim=1)
     assert_close(om.compute_group("scaled"), want, rtol=1e-6, atol=1e-6, what="per-column scale")
-    bad = ObservationManager(dict(p=dict(v=ObsTerm(mdp.base_lin_vel, {}, scale=(1.0, 2.0)))), env)
-    with pytest.raises(ValueError, match="as many entries as the term has columns"):
-        bad.compute_group("p")
+    # observation_manager.py:425-437: checked when the manager is built (or at the first use of a lazily planned group)
+    with pytest.raises(ValueError, match="does not match the dimensions of the observation. Expected: 3 but received: 2"):
+        ObservationManager(dict(p=dict(v=ObsTerm(mdp.base_lin_vel, {}, scale=(1.0, 2.0)))), env).compute_group("p")
+    with pytest.raises(TypeError, match="is not of type float, int or tuple"):
+        ObservationManager(dict(p=dict(v=ObsTerm(mdp.base_lin_vel, {}, scale="2"))), env).compute_group("p")
+
+
+def test_fused_noise_follows_the_environment_seed(dev):
+    """Observation noise drawn inside the fused launch: two corrupted groups of one manager draw different noise for
+    the same env and column, a re-seeded run replays, another seed draws other values."""
+    from isaaclab_amd.envs import mdp
+    from isaaclab_amd.managers import ObservationManager, ObservationTermCfg as ObsTerm
+    from isaaclab_amd.utils import noise as N
+    from isaaclab_amd.utils import rng
+    from test_terms_gpu import make_env
+
+    g = load_golden("managers_anymal")
+    steps = g["reward"].shape[0]
+    env = make_env({k: v[0] for k, v in g.items() if v.shape[:1] == (steps,)}, dev)
+
+    def group():
+        return dict(enable_corruption=True, v=ObsTerm(mdp.base_lin_vel, {}, noise=N.UniformNoiseCfg(-0.1, 0.1)),
+                    q=ObsTerm(mdp.joint_pos_rel, {}, noise=N.UniformNoiseCfg(-0.01, 0.01)))
+
+    def run(seed):
+        rng.seed_all(seed)
+        om = ObservationManager(dict(policy=group(), critic=group()), env)
+        return [(om.compute_group("policy").clone(), om.compute_group("critic").clone()) for _ in range(2)]
+
+    a, b, c = run(11), run(11), run(12)
+    assert not torch.equal(a[0][0], a[0][1]), "two groups, same env and column: different noise"
+    assert not torch.equal(a[0][0], a[1][0]), "a new step draws anew"
+    for (p0, c0), (p1, c1) in zip(a, b):
+        assert torch.equal(p0, p1) and torch.equal(c0, c1), "same seed replays"
+    assert not torch.equal(a[0][0], c[0][0]), "another seed draws other values"

@@ -1,31 +1,36 @@
-"""GPU probe: time the fused MDP kernel by phase subset on the benchmark workload (diagnostics, not a test)."""
+"""GPU probe: time the fused MDP kernel by phase subset (diagnostics, not a test).
+
+    python tools/mdp_probe.py [config] [envs]
+Launches are queued behind a long-running blocker so that the device, not the host, paces them."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-import bench
+import bench_configs as BC
 from isaaclab_amd.envs import fused_mdp as FM
 
+name = sys.argv[1] if len(sys.argv) > 1 else "anymal"
+envs = int(sys.argv[2]) if len(sys.argv) > 2 else BC.ENVS[name]
 dev = torch.device("cuda:0")
-env, state, _ = bench.build_env(dev, 16384, 3000)
-raw = state["raw_action"].to(dev)
+cfg = BC.build(name, dev, envs, 3000)
 for _ in range(3):
-    env.step(raw)
+    cfg.step()
 torch.cuda.synchronize()
+blk = torch.randn(4096, 4096, device=dev)
+out = torch.empty_like(blk)
 
-def timeit(fn, reps=20):
-    fn(); torch.cuda.synchronize()
+def span(fn, reps=20):
+    for _ in range(3): fn()
+    torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for _ in range(2): torch.mm(blk, blk, out=out)
     a.record()
     for _ in range(reps): fn()
     b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b) / reps * 1e3
 
-m = env.mdp
-for name, ph in (("all", FM.PHASE_ALL), ("termination", FM.PHASE_TERMINATION), ("term+reward", FM.PHASE_TERMINATION | FM.PHASE_REWARD),
-                 ("term+reward+reset", 7), ("command", FM.PHASE_COMMAND), ("observation", FM.PHASE_OBSERVATION)):
-    print(f"{name:20s} {timeit(lambda: m.step(ph)):8.1f} us")
-ls = m.t.pop("log_sums"); m.desc.log_sums = None
-print(f"{'all, no log_sums':20s} {timeit(lambda: m.step(FM.PHASE_ALL)):8.1f} us")
-m.bind(log_sums=ls)
-m.bind(noise_u=torch.rand(16384, 235, device=dev))
-print(f"{'all, injected noise':20s} {timeit(lambda: m.step(FM.PHASE_ALL)):8.1f} us")
+m = cfg.env.mdp
+print(f"{name} {envs} envs")
+for label, ph in (("all", FM.PHASE_ALL), ("termination", FM.PHASE_TERMINATION), ("term+reward", FM.PHASE_TERMINATION | FM.PHASE_REWARD),
+                  ("term+reward+reset", 7), ("command", FM.PHASE_COMMAND), ("observation", FM.PHASE_OBSERVATION),
+                  ("all but observation", 15)):
+    print(f"{label:20s} {span(lambda: m.step(ph)):8.1f} us")
