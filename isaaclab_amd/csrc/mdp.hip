@@ -30,8 +30,8 @@ constexpr int kE = 16;             // environments per block
 constexpr int kBlock = 256;        // threads per block (measured on the ANYmal-C plan, envs x threads -> us:
                                    // 8x256 66, 16x256 46, 32x256 56, 16x512 77, 32x512 45)
 constexpr int kWaves = kBlock / 64;
-constexpr int kEmitLanes = kBlock / kE;  // threads that write one env's observation row
 constexpr int kMaxLdsBytes = 64 * 1024;
+constexpr int kMaxSegs = 160;      // STAGE copy instructions per block (a kernel-argument table of 16-byte records)
 
 enum Need : uint32_t {
     kNeedJoint = 1u, kNeedForces = 2u, kNeedTimers = 4u, kNeedBodyVel = 8u, kNeedBodyAcc = 16u, kNeedAction = 32u,
@@ -44,6 +44,7 @@ struct Layout {
     int q, qd, qdd, tau_a, tau_c, q0, qd0, vlim, lim;  // joints (lim: 2 per joint)
     int act, pact;                                     // action columns
     int air, last_air, contact_t, fpeak;               // sensor bodies
+    int fraw;                                          // force history [env][history][body][3] as it lies in memory
     int bvx, bvy, bacc;                                // asset bodies
     int cmd, root;                                     // command row, 13-wide root state
     int eps, srew;                                     // episode sums [term][env], step reward [env][term]
@@ -51,19 +52,45 @@ struct Layout {
     int derived;                                       // [env][kDerived]
     int bits;                                          // term bit mask per env, then done flag per env
     int logp;                                          // per-block partial sums of the logging vector
-    int colterm, tstart;                               // observation columns: term index per column (u8), first column per term
+    int coldesc;                                       // observation columns: one 16-byte ColDesc each
+    int zero;                                          // one word of 0.0f (the subtrahend of columns that subtract nothing)
     int total;
 };
 constexpr int kDerived = 10;  // lin_b(3) ang_b(3) grav_b(3) sensor_z
+static_assert(sizeof(Layout) <= 32 * 4, "ColDesc names a Layout field with 5 bits");
 
-struct MdpDev {
+// How the EMIT stage produces one observation column, prepared once per plan.  Almost every column is a word of the
+// block's LDS image (minus another one for the *_rel terms): `row` names the image row by its field in Layout, `k` the
+// column inside an env's part of it, `stride` the width of that part.
+enum ColMode : uint32_t { kColAffine = 0, kColScan = 1, kColGeneric = 2 };
+struct alignas(16) ColDesc {
+    uint32_t mode_term;  // ColMode | observation term index << 8
+    uint32_t src;        // affine: Layout field (word index in the struct) << 16 | k;  others: column inside the term
+    uint32_t sub;        // the same for the subtrahend; columns that subtract nothing name the image's zero word
+    uint32_t stride;     // stride of src | stride of sub << 16 (0 for the zero word)
+};
+// The words of an ilx_term the EMIT stage reads, as two aligned 16-byte halves (terms lie 48 bytes apart in LDS).
+struct alignas(16) TermHead {
+    int32_t kind, flags;
+    float weight, p0, p1, p2, p3, aux;
+};
+static_assert(sizeof(ilx_term) == 48 && offsetof(ilx_term, aux) == 28, "TermHead mirrors the head of ilx_term");
+template <typename T>
+ILX_DEV __attribute__((address_space(1))) T* as_global(T* p) {  // pointers read back from LDS have lost their address space
+    return (__attribute__((address_space(1))) T*)p;
+}
+
+struct alignas(16) MdpDev {
     ilx_mdp d;                // by-value copy; the HOST pointers inside are nulled
     const ilx_term* terms;    // device: [terminations | rewards | observations]
     const int32_t* ids;       // device
-    const uint32_t* cols;     // device: [ceil(obs_dim / 4) packed u8 term indices | first column per obs term]
+    const uint32_t* cols;     // device: one ColDesc per observation column
     uint32_t need;
     int any_noise;            // some observation term draws noise
+    uint32_t noisy_terms;     // bit i: observation term i draws noise (kMaxTerms = 32)
     Layout L;
+    int num_segs;             // STAGE work list, see StageSeg
+    uint4 segs[kMaxSegs];
 };
 
 // One environment as seen by its lane in the DECIDE stage.
@@ -376,73 +403,110 @@ struct CmdState {
     float c[7] = {0, 0, 0, 0, 0, 0, 0};
 };
 
-// sample s of the command term: injected value, or generated in the stated range
-ILX_DEV float cmd_sample(const ilx_mdp& d, const float* injected, int64_t env, int s, bool unit, uint32_t salt) {
-    if (injected) return injected[env * 7 + s];
-    const float u = philox_uniform(d.seed, d.step_index, static_cast<uint64_t>(env), 0x40000000u + salt + s);
-    if (unit) return u;
-    return u * (d.cmd_range[s][1] - d.cmd_range[s][0]) + d.cmd_range[s][0];
+// The seven samples a resampling env consumes: injected values, or two generator calls mapped to the term's ranges
+// (the two coin flips of the velocity term stay in [0, 1)).
+ILX_DEV void command_draws(const ilx_mdp& d, const float* injected, int64_t env, uint32_t salt, float (&smp)[7]) {
+    if (injected) {
+#pragma unroll
+        for (int k = 0; k < 7; ++k) smp[k] = injected[env * 7 + k];
+        return;
+    }
+    const u4 a = philox4(d.seed, d.step_index, static_cast<uint64_t>(env), 0x40000000u + salt),
+             b = philox4(d.seed, d.step_index, static_cast<uint64_t>(env), 0x40000001u + salt);
+    const float u[7] = {u01(a.x), u01(a.y), u01(a.z), u01(a.w), u01(b.x), u01(b.y), u01(b.z)};
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+        const bool coin = d.command_kind == ILX_CMD_VELOCITY && k >= 5;
+        smp[k] = coin ? u[k] : u[k] * (d.cmd_range[k][1] - d.cmd_range[k][0]) + d.cmd_range[k][0];
+    }
 }
 
 // CommandTerm._resample for one env: command_manager.py:172-187 + the term's _resample_command
 ILX_DEV void command_resample(const ilx_mdp& d, int64_t env, const float* injected, uint32_t salt, CmdState& s) {
-    s.time_left = cmd_sample(d, injected, env, 0, false, salt);
+    float v[7];
+    command_draws(d, injected, env, salt, v);
+    s.time_left = v[0];
     s.counter += 1;
     if (d.command_kind == ILX_CMD_VELOCITY) {  // velocity_command.py:123-138
-        s.c[0] = cmd_sample(d, injected, env, 1, false, salt);
-        s.c[1] = cmd_sample(d, injected, env, 2, false, salt);
-        s.c[2] = cmd_sample(d, injected, env, 3, false, salt);
+        s.c[0] = v[1], s.c[1] = v[2], s.c[2] = v[3];
         if (d.heading_command) {
-            s.heading_target = cmd_sample(d, injected, env, 4, false, salt);
-            s.is_heading = cmd_sample(d, injected, env, 5, true, salt) <= d.rel_heading_envs;
+            s.heading_target = v[4];
+            s.is_heading = v[5] <= d.rel_heading_envs;
         }
-        s.is_standing = cmd_sample(d, injected, env, 6, true, salt) <= d.rel_standing_envs;
+        s.is_standing = v[6] <= d.rel_standing_envs;
     } else if (d.command_kind == ILX_CMD_POSE) {  // pose_command.py:107-120
-        s.c[0] = cmd_sample(d, injected, env, 1, false, salt);
-        s.c[1] = cmd_sample(d, injected, env, 2, false, salt);
-        s.c[2] = cmd_sample(d, injected, env, 3, false, salt);
-        f4 q = quat_from_euler_xyz(cmd_sample(d, injected, env, 4, false, salt), cmd_sample(d, injected, env, 5, false, salt),
-                                   cmd_sample(d, injected, env, 6, false, salt));
+        s.c[0] = v[1], s.c[1] = v[2], s.c[2] = v[3];
+        f4 q = quat_from_euler_xyz(v[4], v[5], v[6]);
         if (d.make_quat_unique) q = quat_unique(q);
         s.c[3] = q.w, s.c[4] = q.x, s.c[5] = q.y, s.c[6] = q.z;
     }
 }
 
-// coalesced copy of the block's chunk of an [env][width] array into LDS
-ILX_DEV void stage_rows(float* dst, const float* src, int64_t env0, int ne, int width) {
-    const float* p = src + env0 * width;
-    for (int i = threadIdx.x; i < ne * width; i += kBlock) dst[i] = p[i];
+// STAGE is a work list.  Every array a block stages is one contiguous chunk for its kE consecutive envs (or a table that
+// is the same for all blocks); the host cuts each chunk into segments of one asynchronous global->LDS copy instruction
+// (`global_load_lds`: the wavefront's 64 lanes write 64 consecutive 4- or 16-byte words straight into LDS, no register
+// destination, so every copy of the block is in flight at once) and hands the list over as 16-byte records in the
+// kernel arguments.  Wavefront w takes records w, w + 4, ...: one vector load brings them in (lane j holds record
+// w + 4 j), a uniform loop reads them lane by lane.  The data is in LDS after the next vmcnt(0) + barrier.
+//   x, y  address of the array's row of env 0 (bytes)
+//   z     words per env (0: a table) | first word of this segment within the chunk / 64 << 16
+//   w     LDS word offset of the chunk | total words of a table << 16 | 16-byte copies allowed << 31
+typedef __attribute__((address_space(3))) void LdsPtr;
+typedef const __attribute__((address_space(1))) void GlobalPtr;
+typedef const __attribute__((address_space(4))) char KernargBytes;
+
+ILX_DEV void stage_segments(float* S, const uint4 rec, int count, int64_t env0, int ne) {
+    const uint32_t lane = threadIdx.x & 63;
+    for (int j = 0; j < count; ++j) {
+        const uint32_t lo = __builtin_amdgcn_readlane(rec.x, j), hi = __builtin_amdgcn_readlane(rec.y, j),
+                       a = __builtin_amdgcn_readlane(rec.z, j), b = __builtin_amdgcn_readlane(rec.w, j);
+        const uint32_t per_env = a & 0xffffu, first = (a >> 16) << 6, dst = b & 0xffffu;
+        const uint32_t total = per_env ? static_cast<uint32_t>(ne) * per_env : ((b >> 16) & 0x7fffu);
+        const uint64_t base = ((static_cast<uint64_t>(hi) << 32) | lo) + static_cast<uint64_t>(env0) * per_env * 4u;
+        const uint32_t* p = reinterpret_cast<const uint32_t*>(base) + first;
+        uint32_t* q = reinterpret_cast<uint32_t*>(S) + dst + first;
+        if ((b >> 31) && (ne == kE || per_env == 0)) {  // 256 words in one instruction
+            if (first + 4 * lane < total) __builtin_amdgcn_global_load_lds((GlobalPtr*)(p + 4 * lane), (LdsPtr*)q, 16, 0, 0);
+        } else {  // word copies: unaligned arrays, and the ragged last block (16-byte lanes would read past the chunk)
+            const uint32_t reps = (b >> 31) ? 4u : 1u;
+            for (uint32_t r = 0; r < reps; ++r)
+                if (first + 64 * r + lane < total)
+                    __builtin_amdgcn_global_load_lds((GlobalPtr*)(p + 64 * r + lane), (LdsPtr*)(q + 64 * r), 4, 0, 0);
+        }
+    }
 }
 
-// A block's chunk of an [env][width] array, taken in two steps: issue() puts every thread's loads in flight (two floats
-// per thread cover rows up to 32 wide; indices past the chunk read its last element instead of branching), commit()
-// writes them to LDS.  With all issues of the STAGE section ahead of all commits the global round trips overlap; one
-// copy loop per array instead costs a full memory latency per array.
-struct Staged {
-    float a, b;
-};
-ILX_DEV Staged issue_rows(const float* src, int64_t env0, int ne, int width) {
-    const float* p = src + env0 * width;
-    const int n = ne * width, t = threadIdx.x;
-    return {p[t < n ? t : n - 1], p[t + kBlock < n ? t + kBlock : n - 1]};
-}
-ILX_DEV void commit_rows(float* dst, Staged r, const float* src, int64_t env0, int ne, int width) {
-    const int n = ne * width, t = threadIdx.x;
-    if (t < n) dst[t] = r.a;
-    if (t + kBlock < n) dst[t + kBlock] = r.b;
-    const float* p = src + env0 * width;
-    for (int i = t + 2 * kBlock; i < n; i += kBlock) dst[i] = p[i];
-}
+#ifdef ILX_MDP_STAMPS  // diagnostics build only: wall-clock stamps (10 ns ticks) of thread 0 of the first blocks
+__device__ unsigned long long g_mdp_stamps[16 * 2048];
+#define ILX_STAMP(k) \
+    if (threadIdx.x == 0 && blockIdx.x < 2048) g_mdp_stamps[blockIdx.x * 16 + (k)] = wall_clock64();
+#else
+#define ILX_STAMP(k)
+#endif
 
-__global__ void __launch_bounds__(kBlock) mdp_step_kernel(MdpDev m) {
+__global__ void __launch_bounds__(kBlock, 4) mdp_step_kernel(MdpDev args) {
     extern __shared__ float S[];
+    // The kernel arguments (descriptor, layout, work list: a few KB) go into LDS first, one 16-byte load per thread, and
+    // are read from there.  Read in place they are scalar loads spread over the whole kernel, and each first touch of
+    // one of their ~50 cache lines stalls its wavefront for a full memory latency.
+    {
+        const auto* src = reinterpret_cast<const __attribute__((address_space(4))) uint32_t*>(
+            (KernargBytes*)__builtin_amdgcn_kernarg_segment_ptr());
+        uint32_t* dst = reinterpret_cast<uint32_t*>(S);
+        for (int i = threadIdx.x; i < static_cast<int>(sizeof(MdpDev) / 16); i += kBlock) {
+            const uint32_t a = src[4 * i], b = src[4 * i + 1], c = src[4 * i + 2], e = src[4 * i + 3];
+            dst[4 * i] = a, dst[4 * i + 1] = b, dst[4 * i + 2] = c, dst[4 * i + 3] = e;
+        }
+        __syncthreads();
+    }
+    const MdpDev& m = *reinterpret_cast<const MdpDev*>(S);
     const ilx_mdp& d = m.d;
     const Layout& L = m.L;
-    const int NT = d.num_terminations, NR = d.num_rewards, NO = d.num_observations;
+    const int NT = d.num_terminations, NR = d.num_rewards;
     const int64_t N = d.num_envs;
     const int64_t env0 = static_cast<int64_t>(blockIdx.x) * kE;
     const int ne = static_cast<int>(N - env0 < kE ? N - env0 : kE);
-    const int J = d.num_joints, B = d.num_bodies, CB = d.num_sensor_bodies, A = d.action_dim, CD = d.command_dim;
+    const int B = d.num_bodies, CB = d.num_sensor_bodies, CD = d.command_dim;
     const int tid = threadIdx.x;
     const bool ph_term = d.phases & ILX_PHASE_TERMINATION, ph_rew = d.phases & ILX_PHASE_REWARD,
                ph_reset = d.phases & ILX_PHASE_RESET, ph_obs = d.phases & ILX_PHASE_OBSERVATION;
@@ -452,85 +516,17 @@ __global__ void __launch_bounds__(kBlock) mdp_step_kernel(MdpDev m) {
     const ilx_term* terms = reinterpret_cast<const ilx_term*>(S + L.terms);
     const int32_t* ids = reinterpret_cast<const int32_t*>(S + L.ids);
 
+    ILX_STAMP(0)
     // ================= STAGE =================
-    const bool sj = m.need & kNeedJoint, sa = m.need & kNeedAction, spa = sa && d.prev_action, st = m.need & kNeedTimers,
-               sc = d.command != nullptr;
-    const Staged zero{0.0f, 0.0f};
-    const Staged r_root = issue_rows(d.root_state_w, env0, ne, 13);
-    const Staged r_q = sj ? issue_rows(d.joint_pos, env0, ne, J) : zero, r_qd = sj ? issue_rows(d.joint_vel, env0, ne, J) : zero,
-                 r_qdd = sj ? issue_rows(d.joint_acc, env0, ne, J) : zero, r_ta = sj ? issue_rows(d.applied_torque, env0, ne, J) : zero,
-                 r_tc = sj ? issue_rows(d.computed_torque, env0, ne, J) : zero, r_q0 = sj ? issue_rows(d.default_joint_pos, env0, ne, J) : zero,
-                 r_qd0 = sj ? issue_rows(d.default_joint_vel, env0, ne, J) : zero,
-                 r_vl = sj ? issue_rows(d.soft_joint_vel_limits, env0, ne, J) : zero,
-                 r_lim = sj ? issue_rows(d.soft_joint_pos_limits, env0, ne, 2 * J) : zero;
-    const Staged r_act = sa ? issue_rows(d.action, env0, ne, A) : zero, r_pact = spa ? issue_rows(d.prev_action, env0, ne, A) : zero;
-    const Staged r_air = st ? issue_rows(d.current_air_time, env0, ne, CB) : zero, r_lair = st ? issue_rows(d.last_air_time, env0, ne, CB) : zero,
-                 r_ct = st ? issue_rows(d.current_contact_time, env0, ne, CB) : zero;
-    const Staged r_cmd = sc ? issue_rows(d.command, env0, ne, CD) : zero;
-    // the term tables (cold in L2 at the start of a launch) are fetched while the row loads above are in flight
-    {
-        const int32_t* src = reinterpret_cast<const int32_t*>(m.terms);
-        int32_t* dst = reinterpret_cast<int32_t*>(S + L.terms);
-        const int words = (NT + NR + NO) * static_cast<int>(sizeof(ilx_term) / 4);
-        for (int i = tid; i < words; i += kBlock) dst[i] = src[i];
-        int32_t* idst = reinterpret_cast<int32_t*>(S + L.ids);
-        for (int i = tid; i < d.num_ids; i += kBlock) idst[i] = m.ids[i];
-        uint32_t* cdst = reinterpret_cast<uint32_t*>(S + L.colterm);  // colterm and tstart are adjacent
-        const int cwords = ((d.obs_dim + 3) >> 2) + NO;
-        if (ph_obs)
-            for (int i = tid; i < cwords; i += kBlock) cdst[i] = m.cols[i];
-        for (int i = tid; i < NR + NT + 3; i += kBlock) S[L.logp + i] = 0.0f;
-    }
-    commit_rows(S + L.root, r_root, d.root_state_w, env0, ne, 13);
-    if (sj) {
-        commit_rows(S + L.q, r_q, d.joint_pos, env0, ne, J);
-        commit_rows(S + L.qd, r_qd, d.joint_vel, env0, ne, J);
-        commit_rows(S + L.qdd, r_qdd, d.joint_acc, env0, ne, J);
-        commit_rows(S + L.tau_a, r_ta, d.applied_torque, env0, ne, J);
-        commit_rows(S + L.tau_c, r_tc, d.computed_torque, env0, ne, J);
-        commit_rows(S + L.q0, r_q0, d.default_joint_pos, env0, ne, J);
-        commit_rows(S + L.qd0, r_qd0, d.default_joint_vel, env0, ne, J);
-        commit_rows(S + L.vlim, r_vl, d.soft_joint_vel_limits, env0, ne, J);
-        commit_rows(S + L.lim, r_lim, d.soft_joint_pos_limits, env0, ne, 2 * J);
-    }
-    if (sa) commit_rows(S + L.act, r_act, d.action, env0, ne, A);
-    if (spa) commit_rows(S + L.pact, r_pact, d.prev_action, env0, ne, A);
-    if (st) {
-        commit_rows(S + L.air, r_air, d.current_air_time, env0, ne, CB);
-        commit_rows(S + L.last_air, r_lair, d.last_air_time, env0, ne, CB);
-        commit_rows(S + L.contact_t, r_ct, d.current_contact_time, env0, ne, CB);
-    }
-    if (sc) commit_rows(S + L.cmd, r_cmd, d.command, env0, ne, CD);
-    if (ph_rew || ph_reset) {  // episode sums: [term][env] in memory and in LDS
-        for (int i = tid; i < NR * kE; i += kBlock) {
-            const int term = i / kE, e = i - term * kE;
-            if (e < ne) S[L.eps + i] = d.episode_sums[static_cast<int64_t>(term) * N + env0 + e];
-        }
-    }
-    if (m.need & kNeedBodyVel) {
-        for (int i = tid; i < ne * B; i += kBlock) {
-            const float* v = d.body_state_w + 13 * (env0 * B + i) + 7;
-            S[L.bvx + i] = v[0], S[L.bvy + i] = v[1];
-        }
-    }
-    if (m.need & kNeedBodyAcc) {
-        for (int i = tid; i < ne * B; i += kBlock) S[L.bacc + i] = norm3(load3(d.body_lin_acc_w + 3 * (env0 * B + i)));
-    }
-    if (m.need & kNeedForces) {  // max over the history of |F| per (env, body): rewards.py:266 / terminations.py:157
-        const int H = d.history_len;
-        for (int i = tid; i < ne * CB; i += kBlock) {
-            const int e = i / CB, b = i - e * CB;
-            float mx = -__builtin_inff();
-#pragma unroll 4
-            for (int h = 0; h < H; ++h) mx = fmaxf(mx, norm3(load3(d.net_forces_w_history + 3 * (((env0 + e) * H + h) * CB + b))));
-            S[L.fpeak + i] = mx;
-        }
-    }
-    // per-env scalars of the DECIDE lanes (coalesced over the 16 lanes), loaded before the barrier
+    const bool sa = m.need & kNeedAction, spa = sa && d.prev_action;
     const int wave = tid >> 6, lane = tid & 63;
+    uint4 my_segs = {0u, 0u, 0u, 0u};
+    if (wave + kWaves * lane < m.num_segs) my_segs = m.segs[wave + kWaves * lane];
     const bool decide = lane < ne;
     const int e = lane;
     const int64_t env = env0 + (decide ? e : 0);
+    // per-env scalars of the DECIDE lanes (coalesced over the 16 lanes): their loads go out first and come back while
+    // the row copies below are in flight
     int64_t ep_len = 0;
     CmdState cs;
     float sensor_z = 0.0f;
@@ -555,8 +551,64 @@ __global__ void __launch_bounds__(kBlock) mdp_step_kernel(MdpDev m) {
             for (int i = 0; i < NT; ++i) term_bits |= d.term_dones[static_cast<int64_t>(i) * N + env] ? (1u << i) : 0u;
         }
     }
-    __syncthreads();
+    // strided rows (two columns of the 13-wide body states, 3-vectors of the body accelerations) come through registers
+    float bv[2][2] = {{0.0f, 0.0f}, {0.0f, 0.0f}}, ba[2] = {0.0f, 0.0f};
+    if (m.need & kNeedBodyVel) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int i = tid + k * kBlock;
+            if (i < ne * B) {
+                const float* v = d.body_state_w + 13 * (env0 * B + i) + 7;
+                bv[k][0] = v[0], bv[k][1] = v[1];
+            }
+        }
+    }
+    if (m.need & kNeedBodyAcc) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int i = tid + k * kBlock;
+            if (i < ne * B) ba[k] = norm3(load3(d.body_lin_acc_w + 3 * (env0 * B + i)));
+        }
+    }
+    // every contiguous chunk and table: the work list (one memory round trip for all of it)
+    stage_segments(S, my_segs, (m.num_segs - wave + kWaves - 1) / kWaves, env0, ne);
+    for (int i = tid; i < NR + NT + 3; i += kBlock) S[L.logp + i] = 0.0f;
+    if (tid == 0) S[L.zero] = 0.0f;
+    if (m.need & kNeedBodyVel) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int i = tid + k * kBlock;
+            if (i < ne * B) S[L.bvx + i] = bv[k][0], S[L.bvy + i] = bv[k][1];
+        }
+        for (int i = tid + 2 * kBlock; i < ne * B; i += kBlock) {
+            const float* v = d.body_state_w + 13 * (env0 * B + i) + 7;
+            S[L.bvx + i] = v[0], S[L.bvy + i] = v[1];
+        }
+    }
+    if (m.need & kNeedBodyAcc) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int i = tid + k * kBlock;
+            if (i < ne * B) S[L.bacc + i] = ba[k];
+        }
+        for (int i = tid + 2 * kBlock; i < ne * B; i += kBlock) S[L.bacc + i] = norm3(load3(d.body_lin_acc_w + 3 * (env0 * B + i)));
+    }
+    ILX_STAMP(1)
+    __syncthreads();  // waits for this wave's copies (vmcnt(0)), then for every wave's
+    ILX_STAMP(2)
+    if (m.need & kNeedForces) {  // max over the history of |F| per (env, body): rewards.py:266 / terminations.py:157
+        const int H = d.history_len;
+        for (int i = tid; i < ne * CB; i += kBlock) {
+            const int ee = i / CB, b = i - ee * CB;
+            float mx = -__builtin_inff();
+#pragma unroll 4
+            for (int h = 0; h < H; ++h) mx = fmaxf(mx, norm3(load3(S + L.fraw + 3 * ((ee * H + h) * CB + b))));
+            S[L.fpeak + i] = mx;
+        }
+        __syncthreads();
+    }
 
+    ILX_STAMP(3)
     // ================= DECIDE: one lane per env; the four waves split the reward terms =================
     Env en{m, S, ids, e, env};
     const float dt = d.step_dt;
@@ -581,6 +633,7 @@ __global__ void __launch_bounds__(kBlock) mdp_step_kernel(MdpDev m) {
                 if (t.flags & 1) time_out = time_out || v; else terminated = terminated || v;
             }
         }
+        ILX_STAMP(4)
         // ---- rewards (reward_manager.py:128-157): this wave's share of the terms
         if (ph_rew) {
             float partial = 0.0f;
@@ -595,8 +648,10 @@ __global__ void __launch_bounds__(kBlock) mdp_step_kernel(MdpDev m) {
             S[L.ptotal + wave * kE + e] = partial;
         }
     }
+    ILX_STAMP(5)
     __syncthreads();
     if (decide && wave == 0) {
+        ILX_STAMP(6)
         const bool done = terminated || time_out;
         if (ph_term) {
             d.terminated[env] = terminated;
@@ -693,6 +748,7 @@ __global__ void __launch_bounds__(kBlock) mdp_step_kernel(MdpDev m) {
                 d.is_standing_env[env] = cs.is_standing;
             }
         }
+        ILX_STAMP(7)
         float* der = S + L.derived + kDerived * e;
         der[0] = en.lin_b.x, der[1] = en.lin_b.y, der[2] = en.lin_b.z;
         der[3] = en.ang_b.x, der[4] = en.ang_b.y, der[5] = en.ang_b.z;
@@ -701,6 +757,7 @@ __global__ void __launch_bounds__(kBlock) mdp_step_kernel(MdpDev m) {
     }
     __syncthreads();
 
+    ILX_STAMP(8)
     // ================= EMIT =================
     const uint32_t* bits = reinterpret_cast<const uint32_t*>(S + L.bits);
     if (ph_term) {
@@ -727,70 +784,117 @@ __global__ void __launch_bounds__(kBlock) mdp_step_kernel(MdpDev m) {
         const float v = S[L.logp + tid];
         if (v != 0.0f) unsafeAtomicAdd(d.log_sums + tid, v);  // hardware float add at L2, no return value
     }
-    // ---- observations (observation_manager.py:260-335).  The concatenated row is cut into groups of 4 columns;
-    // 16 threads per env take group g, g + 16, ...; a group's noise is one Philox4x32 call.
+    ILX_STAMP(9)
+    // ---- observations (observation_manager.py:260-335).  The concatenated row is cut into groups of 4 columns (a
+    // group's noise is one Philox4x32 call).  A lane owns one group and walks down the block's envs with it, so the
+    // columns' descriptors and their terms' noise / clip / scale parameters are fetched once per lane; a wavefront
+    // covers 64 / (groups, rounded up to a power of two) envs per trip.  Per column and env what is left is the
+    // value's LDS word (or its ray hit), the pipeline arithmetic and the store.
     if (ph_obs) {
-        const int ee = tid / kEmitLanes, g = tid % kEmitLanes;
-        if (ee < ne) {
-            const int64_t oenv = env0 + ee;
-            const int O = d.obs_dim;
-            float* row = d.obs + oenv * O;
-            const uint32_t* colterm = reinterpret_cast<const uint32_t*>(S + L.colterm);
-            const int32_t* tstart = reinterpret_cast<const int32_t*>(S + L.tstart);
-            const ilx_term* oterms = terms + NT + NR;
-            for (int cg = g; 4 * cg < O; cg += kEmitLanes) {
-                const uint32_t packed = colterm[cg];
-                int cur = static_cast<int>(packed & 255u);
-                ilx_term t = oterms[cur];
-                float u[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-                if (!d.noise_u && m.any_noise) {
-                    const u4 r = philox4(d.seed, d.step_index, static_cast<uint64_t>(oenv), static_cast<uint32_t>(cg));
+        const int O = d.obs_dim;
+        const int G = (O + 3) >> 2;
+        int gp = 1;
+        while (gp < G && gp < 64) gp <<= 1;
+        const int per = 64 / gp, g_in = lane & (gp - 1), esub = lane / gp;
+        const ilx_term* oterms = terms + NT + NR;
+        const int32_t* ltab = reinterpret_cast<const int32_t*>(&m.L);   // the layout, as words
+        const ColDesc* cdesc = reinterpret_cast<const ColDesc*>(S + L.coldesc);
+        const auto* hits = as_global(d.ray_hits_w);
+        const auto* noise_in = as_global(d.noise_u);
+        const int R = d.num_rays;
+        const bool generate = !d.noise_u;
+        for (int g = g_in; g < G; g += 64) {
+            // The lane's four columns.  Every read below is unconditional and the reads of one step are independent, so
+            // each step costs one LDS latency: descriptors; then the terms' flags and the rows' offsets.
+            ColDesc cd[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) cd[c] = cdesc[4 * g + c < O ? 4 * g + c : O - 1];  // past the row: like the last column, not stored
+            uint32_t what[4], where[4], stride[4];  // mode | term << 8 | flags << 16;  LDS words of value | subtrahend << 16
+            uint32_t all_flags = 0, all_modes = 0;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const uint32_t flags = static_cast<uint32_t>(oterms[cd[c].mode_term >> 8].flags);
+                const uint32_t a = static_cast<uint32_t>(ltab[(cd[c].src >> 16) & 31u]), b = static_cast<uint32_t>(ltab[(cd[c].sub >> 16) & 31u]);
+                const bool affine = (cd[c].mode_term & 255u) == kColAffine;
+                what[c] = cd[c].mode_term | (flags << 16);
+                // value and subtrahend of the other kinds: the zero word
+                where[c] = affine ? ((a + (cd[c].src & 0xffffu)) | ((b + (cd[c].sub & 0xffffu)) << 16)) : static_cast<uint32_t>(L.zero) * 0x10001u;
+                stride[c] = affine ? cd[c].stride : 0u;
+                all_flags |= flags, all_modes |= cd[c].mode_term & 255u;
+            }
+            // the terms' pipeline parameters, neutral where a step is switched off: the env loop then runs without
+            // branches or selects on them (x + u * 0 + 0 and x * 1 leave x as it is)
+            float n_off[4], n_rng[4], c_lo[4], c_hi[4], scl[4], hgt[4];
+            uint32_t zoff[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const TermHead th = *reinterpret_cast<const TermHead*>(oterms + ((what[c] >> 8) & 255u));
+                const uint32_t flags = what[c] >> 16;
+                n_off[c] = (flags & ILX_OBS_FLAG_NOISE) ? th.p0 : 0.0f, n_rng[c] = (flags & ILX_OBS_FLAG_NOISE) ? th.p1 : 0.0f;
+                c_lo[c] = th.p2, c_hi[c] = th.p3;
+                scl[c] = (flags & ILX_OBS_FLAG_SCALE) ? th.weight : 1.0f;
+                hgt[c] = th.aux;
+                zoff[c] = (what[c] & 255u) == kColScan ? 3u * cd[c].src + 2u : 2u;
+            }
+            const bool any_noise = all_flags & ILX_OBS_FLAG_NOISE, any_scan = all_modes & kColScan;
+            ILX_STAMP(11)
+            for (int ee = wave * per + esub; ee < ne; ee += kWaves * per) {
+                const int64_t oenv = env0 + ee;
+                auto* row = as_global(d.obs) + oenv * O;
+                // values from memory (ray hits, injected noise) are requested first; the generator call hides their latency
+                float zv[4] = {0.0f, 0.0f, 0.0f, 0.0f}, u[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+                if (any_scan) {
+                    const auto* env_hits = hits + 3 * (oenv * R);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) zv[c] = env_hits[zoff[c]];  // columns of other kinds read the first ray (unused)
+                }
+                if (!generate && any_noise) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) u[c] = noise_in[oenv * O + (4 * g + c < O ? 4 * g + c : O - 1)];
+                }
+                // LDS: value and subtrahend, the sensor height
+                float val[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    val[c] = S[(where[c] & 0xffffu) + ee * (stride[c] & 0xffffu)] - S[(where[c] >> 16) + ee * (stride[c] >> 16)];
+                const float sensor_height = S[L.derived + kDerived * ee + 9];
+                if (ee < 4) { ILX_STAMP(12) }
+                if (generate && any_noise) {
+                    const u4 r = philox4(d.seed, d.step_index, static_cast<uint64_t>(oenv), static_cast<uint32_t>(g));
                     u[0] = u01(r.x), u[1] = u01(r.y), u[2] = u01(r.z), u[3] = u01(r.w);
                 }
-                if (t.kind == ILX_OBS_HEIGHT_SCAN && packed == static_cast<uint32_t>(cur) * 0x01010101u && 4 * cg + 3 < O) {
-                    // Four columns of the height scan (most of a locomotion observation) with their hit heights read
-                    // back to back; through the per-column path below each load sits in its own branch of the term switch
-                    // and waits for the one before it.
-                    const float* z = d.ray_hits_w + 3 * (oenv * d.num_rays + (4 * cg - tstart[cur])) + 2;
-                    const float z0 = z[0], z1 = z[3], z2 = z[6], z3 = z[9];
-                    float un[4] = {u[0], u[1], u[2], u[3]};
-                    if ((t.flags & ILX_OBS_FLAG_NOISE) && d.noise_u) {
-                        const float* nu = d.noise_u + oenv * O + 4 * cg;
-                        un[0] = nu[0], un[1] = nu[1], un[2] = nu[2], un[3] = nu[3];
-                    }
-                    const float sensor_height = S[L.derived + kDerived * ee + 9];
-                    float v[4] = {sensor_height - z0 - t.aux, sensor_height - z1 - t.aux, sensor_height - z2 - t.aux,
-                                  sensor_height - z3 - t.aux};
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        if (t.flags & ILX_OBS_FLAG_NOISE) v[c] = v[c] + un[c] * t.p[1] + t.p[0];
-                        if (t.flags & ILX_OBS_FLAG_CLIP) v[c] = fminf(fmaxf(v[c], t.p[2]), t.p[3]);
-                        if (t.flags & ILX_OBS_FLAG_SCALE) v[c] = v[c] * t.weight;
-                        row[4 * cg + c] = v[c];
-                    }
-                    continue;
-                }
+                if (ee < 4) { ILX_STAMP(13) }
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    const int col = 4 * cg + c;
-                    if (col >= O) break;
-                    const int ti = static_cast<int>((packed >> (8 * c)) & 255u);
-                    if (ti != cur) {
-                        cur = ti;
-                        t = oterms[cur];
+                    const uint32_t mode = what[c] & 255u, flags = what[c] >> 16;
+                    float v = mode == kColScan ? sensor_height - zv[c] - hgt[c] : val[c];        // observations.py:165-173
+                    v = v + u[c] * n_rng[c] + n_off[c];                                          // noise_model.py:63-64
+                    v = (flags & ILX_OBS_FLAG_CLIP) ? fminf(fmaxf(v, c_lo[c]), c_hi[c]) : v;     // observation_manager.py:315-316
+                    v = v * scl[c];                                                              // :317-318
+                    if (4 * g + c < O && mode != kColGeneric) row[4 * g + c] = v;
+                }
+                if (ee < 4) { ILX_STAMP(14) }
+                // columns of the other kinds (root position with env origins, unique quaternions, normalised joint limits,
+                // external buffers): one at a time through the term switch
+                if (all_modes & kColGeneric) {
+#pragma unroll 1
+                    for (int c = 0; c < 4; ++c) {
+                        const uint32_t w = c == 0 ? what[0] : c == 1 ? what[1] : c == 2 ? what[2] : what[3];
+                        if ((w & 255u) != kColGeneric || 4 * g + c >= O) continue;
+                        const uint32_t k = cdesc[4 * g + c].src;
+                        const float uc = c == 0 ? u[0] : c == 1 ? u[1] : c == 2 ? u[2] : u[3];
+                        const ilx_term& t = oterms[(w >> 8) & 255u];
+                        float v = eval_obs(m, S, ids, ee, oenv, t, static_cast<int>(k));
+                        if (t.flags & ILX_OBS_FLAG_NOISE) v = v + uc * t.p[1] + t.p[0];
+                        if (t.flags & ILX_OBS_FLAG_CLIP) v = fminf(fmaxf(v, t.p[2]), t.p[3]);
+                        if (t.flags & ILX_OBS_FLAG_SCALE) v = v * t.weight;
+                        row[4 * g + c] = v;
                     }
-                    float v = eval_obs(m, S, ids, ee, oenv, t, col - tstart[cur]);
-                    if (t.flags & ILX_OBS_FLAG_NOISE) {  // noise_model.py:63-64: data + rand * (max - min) + min
-                        const float uu = d.noise_u ? d.noise_u[oenv * O + col] : u[c];
-                        v = v + uu * t.p[1] + t.p[0];
-                    }
-                    if (t.flags & ILX_OBS_FLAG_CLIP) v = fminf(fmaxf(v, t.p[2]), t.p[3]);  // :315-316
-                    if (t.flags & ILX_OBS_FLAG_SCALE) v = v * t.weight;                    // :317-318
-                    row[col] = v;
                 }
             }
         }
     }
+    ILX_STAMP(10)
 }
 
 }  // namespace ilx
@@ -800,8 +904,10 @@ using namespace ilx;
 struct ilx_mdp_plan_s {
     ilx_term* d_terms = nullptr;  // [terminations | rewards | observations]
     int32_t* d_ids = nullptr;
-    uint32_t* d_cols = nullptr;  // packed term index per observation column, then the first column of every term
+    uint32_t* d_cols = nullptr;  // one ColDesc per observation column
+    int dims[3] = {0, 0, 0};     // num_joints, action_dim, command_dim the column descriptors were made for
     bool any_noise = false;
+    uint32_t noisy_terms = 0;
     int nt = 0, nr = 0, no = 0, nids = 0;
     int obs_dim = 0;
     // data the term tables read, per phase group (checked against NULL at every step)
@@ -947,19 +1053,61 @@ extern "C" int ilx_mdp_plan_create(const ilx_mdp* desc, ilx_mdp_plan_t* out) {
                            "ilx_mdp_plan_create: hipMemcpy");
     }
     if (rc == ILX_OK && d.num_observations > 0) {
-        ILX_REQUIRE(d.obs_dim <= 16384, ILX_ESHAPE, "ilx_mdp_plan_create: %d observation columns (max 16384)", d.obs_dim);
-        const int groups = (d.obs_dim + 3) / 4;
-        std::vector<uint32_t> cols(static_cast<size_t>(groups) + d.num_observations, 0u);
+        ILX_REQUIRE(d.obs_dim <= 8192, ILX_ESHAPE, "ilx_mdp_plan_create: %d observation columns (max 8192)", d.obs_dim);
+        ILX_REQUIRE(d.num_joints <= 0xffff && d.action_dim <= 0xffff && d.command_dim <= 0xffff, ILX_ESHAPE,
+                    "ilx_mdp_plan_create: rows wider than 65535 columns");
+        auto field = [](int Layout::*f) {  // word index of a Layout field inside the struct
+            Layout probe{};
+            return static_cast<uint32_t>(reinterpret_cast<const char*>(&(probe.*f)) - reinterpret_cast<const char*>(&probe)) / 4u;
+        };
+        std::vector<ColDesc> cols(static_cast<size_t>(d.obs_dim));
         int col = 0;
         for (int i = 0; i < d.num_observations; ++i) {
-            cols[groups + i] = static_cast<uint32_t>(col);
-            const int dim = host_obs_dim(d, d.observations[i]);
-            for (int k = 0; k < dim; ++k, ++col) cols[col >> 2] |= static_cast<uint32_t>(i) << (8 * (col & 3));
-            p->any_noise |= (d.observations[i].flags & ILX_OBS_FLAG_NOISE) != 0;
+            const ilx_term& t = d.observations[i];
+            const int dim = host_obs_dim(d, t);
+            const uint32_t J = static_cast<uint32_t>(d.num_joints);
+            for (int k = 0; k < dim; ++k, ++col) {
+                ColDesc c{kColGeneric | (static_cast<uint32_t>(i) << 8), static_cast<uint32_t>(k), field(&Layout::zero) << 16, 0u};
+                auto affine = [&](int Layout::*row, uint32_t kk, uint32_t stride) {
+                    c.mode_term = kColAffine | (static_cast<uint32_t>(i) << 8);
+                    c.src = (field(row) << 16) | kk;
+                    c.stride = stride;
+                };
+                auto minus = [&](int Layout::*row, uint32_t kk, uint32_t stride) {
+                    c.sub = (field(row) << 16) | kk;
+                    c.stride |= stride << 16;
+                };
+                const uint32_t jk = static_cast<uint32_t>(t.ids_cnt < 0 ? k : d.ids[t.ids_off + k]);
+                switch (t.kind) {
+                    case ILX_OBS_BASE_POS_Z: affine(&Layout::root, 2u, 13u); break;
+                    case ILX_OBS_BASE_LIN_VEL: affine(&Layout::derived, static_cast<uint32_t>(k), kDerived); break;
+                    case ILX_OBS_BASE_ANG_VEL: affine(&Layout::derived, 3u + k, kDerived); break;
+                    case ILX_OBS_PROJECTED_GRAVITY: affine(&Layout::derived, 6u + k, kDerived); break;
+                    case ILX_OBS_ROOT_QUAT_W:
+                        if (!(t.flags & ILX_OBS_FLAG_QUAT_UNIQUE)) affine(&Layout::root, 3u + k, 13u);
+                        break;
+                    case ILX_OBS_ROOT_LIN_VEL_W: affine(&Layout::root, 7u + k, 13u); break;
+                    case ILX_OBS_ROOT_ANG_VEL_W: affine(&Layout::root, 10u + k, 13u); break;
+                    case ILX_OBS_JOINT_POS: affine(&Layout::q, jk, J); break;
+                    case ILX_OBS_JOINT_POS_REL: affine(&Layout::q, jk, J), minus(&Layout::q0, jk, J); break;
+                    case ILX_OBS_JOINT_VEL: affine(&Layout::qd, jk, J); break;
+                    case ILX_OBS_JOINT_VEL_REL: affine(&Layout::qd, jk, J), minus(&Layout::qd0, jk, J); break;
+                    case ILX_OBS_LAST_ACTION: affine(&Layout::act, static_cast<uint32_t>(k), static_cast<uint32_t>(d.action_dim)); break;
+                    case ILX_OBS_GENERATED_COMMANDS:
+                        affine(&Layout::cmd, static_cast<uint32_t>(k), static_cast<uint32_t>(d.command_dim));
+                        break;
+                    case ILX_OBS_HEIGHT_SCAN: c.mode_term = kColScan | (static_cast<uint32_t>(i) << 8); break;
+                    default: break;  // root position (env origins), unique quaternions, normalised limits, external buffers
+                }
+                cols[col] = c;
+            }
+            p->any_noise |= (t.flags & ILX_OBS_FLAG_NOISE) != 0;
+            if (t.flags & ILX_OBS_FLAG_NOISE) p->noisy_terms |= 1u << i;
         }
-        rc = check_hip(hipMalloc(&p->d_cols, cols.size() * sizeof(uint32_t)), "ilx_mdp_plan_create: hipMalloc");
+        p->dims[0] = d.num_joints, p->dims[1] = d.action_dim, p->dims[2] = d.command_dim;
+        rc = check_hip(hipMalloc(&p->d_cols, cols.size() * sizeof(ColDesc)), "ilx_mdp_plan_create: hipMalloc");
         if (rc == ILX_OK)
-            rc = check_hip(hipMemcpy(p->d_cols, cols.data(), cols.size() * sizeof(uint32_t), hipMemcpyHostToDevice),
+            rc = check_hip(hipMemcpy(p->d_cols, cols.data(), cols.size() * sizeof(ColDesc), hipMemcpyHostToDevice),
                            "ilx_mdp_plan_create: hipMemcpy");
     }
     if (rc != ILX_OK) {
@@ -978,6 +1126,12 @@ extern "C" void ilx_mdp_plan_destroy(ilx_mdp_plan_t plan) {
     delete plan;
 }
 
+#ifdef ILX_MDP_STAMPS
+extern "C" int ilx_debug_mdp_stamps(unsigned long long* out, int count) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(ilx::g_mdp_stamps), sizeof(unsigned long long) * count) == hipSuccess ? 0 : 1;
+}
+#endif
+
 extern "C" int ilx_mdp_step(ilx_mdp_plan_t plan, const ilx_mdp* desc, void* stream) {
     ILX_REQUIRE(plan && desc, ILX_EINVAL, "ilx_mdp_step: NULL argument");
     const ilx_mdp& d = *desc;
@@ -985,6 +1139,8 @@ extern "C" int ilx_mdp_step(ilx_mdp_plan_t plan, const ilx_mdp* desc, void* stre
     ILX_REQUIRE(d.num_terminations == plan->nt && d.num_rewards == plan->nr && d.num_observations == plan->no &&
                     d.obs_dim == plan->obs_dim,
                 ILX_EINVAL, "ilx_mdp_step: term counts differ from the plan");
+    ILX_REQUIRE(plan->no == 0 || (d.num_joints == plan->dims[0] && d.action_dim == plan->dims[1] && d.command_dim == plan->dims[2]),
+                ILX_EINVAL, "ilx_mdp_step: joint / action / command widths differ from the plan");
     if (d.num_envs == 0 || d.phases == 0) return ILX_OK;
     ILX_REQUIRE(d.root_state_w, ILX_EINVAL, "ilx_mdp_step: root_state_w is NULL");
     ILX_REQUIRE(d.num_joints >= 0 && d.num_bodies >= 0 && d.num_sensor_bodies >= 0 && d.action_dim >= 0 &&
@@ -1041,6 +1197,7 @@ extern "C" int ilx_mdp_step(ilx_mdp_plan_t plan, const ilx_mdp* desc, void* stre
     m.ids = plan->d_ids;
     m.cols = plan->d_cols;
     m.any_noise = plan->any_noise;
+    m.noisy_terms = plan->noisy_terms;
     m.need = 0;
     if ((pt && plan->t_joint) || (pr && plan->r_joint) || (po && plan->o_joint)) m.need |= kNeedJoint;
     if ((pt && plan->t_contact) || (pr && plan->r_contact)) m.need |= kNeedForces;
@@ -1051,7 +1208,7 @@ extern "C" int ilx_mdp_step(ilx_mdp_plan_t plan, const ilx_mdp* desc, void* stre
     if (po && plan->o_rays) m.need |= kNeedRays;
     // LDS image of one block (kE envs)
     Layout& L = m.L;
-    int w = 0;
+    int w = static_cast<int>(sizeof(MdpDev) / 4);  // the image starts behind the block's copy of the kernel arguments
     auto take = [&](int words) { const int at = w; w += (words + 3) & ~3; return at; };
     const int J = d.num_joints, B = d.num_bodies, CB = d.num_sensor_bodies, A = d.action_dim, CD = d.command_dim;
     L.terms = take((plan->nt + plan->nr + plan->no) * static_cast<int>(sizeof(ilx_term) / 4));
@@ -1065,14 +1222,15 @@ extern "C" int ilx_mdp_step(ilx_mdp_plan_t plan, const ilx_mdp* desc, void* stre
     const bool ntm = m.need & kNeedTimers;
     L.air = take(ntm ? kE * CB : 0), L.last_air = take(ntm ? kE * CB : 0), L.contact_t = take(ntm ? kE * CB : 0);
     L.fpeak = take((m.need & kNeedForces) ? kE * CB : 0);
+    L.fraw = take((m.need & kNeedForces) ? kE * 3 * d.history_len * CB : 0);
     L.bvx = take((m.need & kNeedBodyVel) ? kE * B : 0), L.bvy = take((m.need & kNeedBodyVel) ? kE * B : 0);
     L.bacc = take((m.need & kNeedBodyAcc) ? kE * B : 0);
     L.cmd = take(kE * CD), L.root = take(kE * 13);
     L.eps = take(kE * plan->nr), L.srew = take(kE * plan->nr), L.ptotal = take(kWaves * kE);
     L.derived = take(kE * kDerived), L.bits = take(2 * kE);
     L.logp = take(plan->nr + plan->nt + 3);
-    L.colterm = take((plan->obs_dim + 3) / 4 + plan->no);  // one block: tstart follows the packed term indices directly
-    L.tstart = L.colterm + (plan->obs_dim + 3) / 4;
+    L.coldesc = take(po ? plan->obs_dim * static_cast<int>(sizeof(ColDesc) / 4) : 0);
+    L.zero = take(1);
     L.total = w;
     const size_t lds_bytes = static_cast<size_t>(w) * 4;
     ILX_REQUIRE(lds_bytes <= kMaxLdsBytes, ILX_ESHAPE,
@@ -1080,6 +1238,46 @@ extern "C" int ilx_mdp_step(ilx_mdp_plan_t plan, const ilx_mdp* desc, void* stre
                 kMaxLdsBytes);
     m.d.terminations = m.d.rewards = m.d.observations = nullptr;
     m.d.ids = nullptr;
+    // STAGE work list (see stage_segments): one record per copy instruction of a full block
+    m.num_segs = 0;
+    bool fits = true;
+    auto add = [&](const void* src, int per_env_words, int table_words, int dst) {
+        const int total = per_env_words ? kE * per_env_words : table_words;
+        if (!src || total <= 0) return;
+        fits = fits && per_env_words <= 0xffff && table_words <= 0x7fff && dst <= 0xffff;
+        const bool wide = reinterpret_cast<uintptr_t>(src) % 16 == 0 && dst % 4 == 0 && (per_env_words || table_words % 4 == 0);
+        const uint64_t addr = reinterpret_cast<uintptr_t>(src);
+        for (int first = 0; first < total; first += wide ? 256 : 64) {
+            if (m.num_segs == kMaxSegs) {
+                fits = false;
+                return;
+            }
+            m.segs[m.num_segs++] = uint4{static_cast<uint32_t>(addr), static_cast<uint32_t>(addr >> 32),
+                                         static_cast<uint32_t>(per_env_words) | (static_cast<uint32_t>(first >> 6) << 16),
+                                         static_cast<uint32_t>(dst) | (static_cast<uint32_t>(per_env_words ? 0 : table_words) << 16) |
+                                             (wide ? 0x80000000u : 0u)};
+        }
+    };
+    add(d.root_state_w, 13, 0, L.root);
+    if (nj) {
+        add(d.joint_pos, J, 0, L.q), add(d.joint_vel, J, 0, L.qd), add(d.joint_acc, J, 0, L.qdd);
+        add(d.applied_torque, J, 0, L.tau_a), add(d.computed_torque, J, 0, L.tau_c);
+        add(d.default_joint_pos, J, 0, L.q0), add(d.default_joint_vel, J, 0, L.qd0);
+        add(d.soft_joint_vel_limits, J, 0, L.vlim), add(d.soft_joint_pos_limits, 2 * J, 0, L.lim);
+    }
+    if (na) add(d.action, A, 0, L.act), add(d.prev_action, A, 0, L.pact);
+    if (ntm) {
+        add(d.current_air_time, CB, 0, L.air), add(d.last_air_time, CB, 0, L.last_air);
+        add(d.current_contact_time, CB, 0, L.contact_t);
+    }
+    add(d.command, CD, 0, L.cmd);
+    if (m.need & kNeedForces) add(d.net_forces_w_history, 3 * d.history_len * CB, 0, L.fraw);
+    if (pr || (d.phases & ILX_PHASE_RESET))  // episode sums: [term][env] in memory and in LDS, one short run per term
+        for (int i = 0; i < plan->nr; ++i) add(d.episode_sums + static_cast<int64_t>(i) * d.num_envs, 1, 0, L.eps + i * kE);
+    add(plan->d_terms, 0, (plan->nt + plan->nr + plan->no) * static_cast<int>(sizeof(ilx_term) / 4), L.terms);
+    add(plan->d_ids, 0, plan->nids, L.ids);
+    if (po) add(plan->d_cols, 0, plan->obs_dim * static_cast<int>(sizeof(ColDesc) / 4), L.coldesc);
+    ILX_REQUIRE(fits, ILX_ESHAPE, "ilx_mdp_step: the plan's per-block state needs more than %d staging copies", kMaxSegs);
     const unsigned blocks = static_cast<unsigned>((d.num_envs + kE - 1) / kE);
     hipLaunchKernelGGL(mdp_step_kernel, dim3(blocks), dim3(kBlock), lds_bytes, as_stream(stream), m);
     ILX_LAUNCH_CHECK("ilx_mdp_step");
