@@ -89,7 +89,8 @@ struct alignas(16) MdpDev {
     int any_noise;            // some observation term draws noise
     uint32_t noisy_terms;     // bit i: observation term i draws noise (kMaxTerms = 32)
     Layout L;
-    int num_segs;             // STAGE work list, see StageSeg
+    uint32_t inv_sensor_bodies, inv_rewards;  // ceil(2^32 / n): i / n == umulhi(i, inv) for the i < 2^16 of a block
+    int num_segs;             // STAGE work list, see stage_segments
     uint4 segs[kMaxSegs];
 };
 
@@ -448,30 +449,35 @@ ILX_DEV void command_resample(const ilx_mdp& d, int64_t env, const float* inject
 // destination, so every copy of the block is in flight at once) and hands the list over as 16-byte records in the
 // kernel arguments.  Wavefront w takes records w, w + 4, ...: one vector load brings them in (lane j holds record
 // w + 4 j), a uniform loop reads them lane by lane.  The data is in LDS after the next vmcnt(0) + barrier.
-//   x, y  address of the array's row of env 0 (bytes)
-//   z     words per env (0: a table) | first word of this segment within the chunk / 64 << 16
-//   w     LDS word offset of the chunk | total words of a table << 16 | 16-byte copies allowed << 31
+//   x, y  address of the segment's first word in the array's row of env 0 (bytes)
+//   z     words per env (0: a table) | lanes that copy in a block of kE envs << 16 | 16-byte copies << 23
+//   w     LDS word of the segment's first word | first word of the segment within the chunk / 64 << 16
+// Only the last block of a launch can hold fewer than kE envs; it recomputes the lane bounds and copies word by word
+// (16-byte lanes could read past the end of the array).
 typedef __attribute__((address_space(3))) void LdsPtr;
 typedef const __attribute__((address_space(1))) void GlobalPtr;
 typedef const __attribute__((address_space(4))) char KernargBytes;
 
 ILX_DEV void stage_segments(float* S, const uint4 rec, int count, int64_t env0, int ne) {
     const uint32_t lane = threadIdx.x & 63;
+    const bool full = ne == kE;
     for (int j = 0; j < count; ++j) {
         const uint32_t lo = __builtin_amdgcn_readlane(rec.x, j), hi = __builtin_amdgcn_readlane(rec.y, j),
                        a = __builtin_amdgcn_readlane(rec.z, j), b = __builtin_amdgcn_readlane(rec.w, j);
-        const uint32_t per_env = a & 0xffffu, first = (a >> 16) << 6, dst = b & 0xffffu;
-        const uint32_t total = per_env ? static_cast<uint32_t>(ne) * per_env : ((b >> 16) & 0x7fffu);
-        const uint64_t base = ((static_cast<uint64_t>(hi) << 32) | lo) + static_cast<uint64_t>(env0) * per_env * 4u;
-        const uint32_t* p = reinterpret_cast<const uint32_t*>(base) + first;
-        uint32_t* q = reinterpret_cast<uint32_t*>(S) + dst + first;
-        if ((b >> 31) && (ne == kE || per_env == 0)) {  // 256 words in one instruction
-            if (first + 4 * lane < total) __builtin_amdgcn_global_load_lds((GlobalPtr*)(p + 4 * lane), (LdsPtr*)q, 16, 0, 0);
-        } else {  // word copies: unaligned arrays, and the ragged last block (16-byte lanes would read past the chunk)
-            const uint32_t reps = (b >> 31) ? 4u : 1u;
-            for (uint32_t r = 0; r < reps; ++r)
+        const uint32_t per_env = a & 0xffffu, lanes = (a >> 16) & 127u;
+        const bool wide = (a >> 23) & 1u;
+        const uint64_t base = ((static_cast<uint64_t>(hi) << 32) | lo) + static_cast<uint64_t>(env0) * (per_env * 4u);
+        uint32_t* q = reinterpret_cast<uint32_t*>(S) + (b & 0xffffu);
+        if (full || per_env == 0) {
+            if (lane < lanes) {
+                if (wide) __builtin_amdgcn_global_load_lds((GlobalPtr*)(base + 16u * lane), (LdsPtr*)q, 16, 0, 0);
+                else __builtin_amdgcn_global_load_lds((GlobalPtr*)(base + 4u * lane), (LdsPtr*)q, 4, 0, 0);
+            }
+        } else {
+            const uint32_t first = (b >> 16) << 6, total = static_cast<uint32_t>(ne) * per_env;
+            for (uint32_t r = 0; r < (wide ? 4u : 1u); ++r)
                 if (first + 64 * r + lane < total)
-                    __builtin_amdgcn_global_load_lds((GlobalPtr*)(p + 64 * r + lane), (LdsPtr*)(q + 64 * r), 4, 0, 0);
+                    __builtin_amdgcn_global_load_lds((GlobalPtr*)(base + 4u * (64 * r + lane)), (LdsPtr*)(q + 64 * r), 4, 0, 0);
         }
     }
 }
@@ -532,23 +538,38 @@ __global__ void __launch_bounds__(kBlock, 4) mdp_step_kernel(MdpDev args) {
     float sensor_z = 0.0f;
     bool terminated = false, time_out = false;
     uint32_t term_bits = 0;
-    if (decide) {
-        if (d.episode_length_buf) ep_len = d.episode_length_buf[env];
-        if (d.time_left) cs.time_left = d.time_left[env];
-        if (d.command_counter) cs.counter = d.command_counter[env];
-        if (cmd_state && wave == 0) {
-            cs.metric0 = d.command_metrics[env], cs.metric1 = d.command_metrics[N + env];
-            if (d.command_kind == ILX_CMD_VELOCITY) {
-                cs.heading_target = d.heading_target[env];
-                cs.is_heading = d.is_heading_env[env] != 0;
-                cs.is_standing = d.is_standing_env[env] != 0;
+    {
+        // the pointers first (one batch of LDS reads), then the loads they guard
+        const auto* p_len = as_global(d.episode_length_buf);
+        const auto* p_left = as_global(d.time_left);
+        const auto* p_count = as_global(d.command_counter);
+        const auto* p_metric = as_global(d.command_metrics);
+        const auto* p_head = as_global(d.heading_target);
+        const auto* p_is_head = as_global(d.is_heading_env);
+        const auto* p_is_stand = as_global(d.is_standing_env);
+        const auto* p_sensor = as_global(d.sensor_pos_w);
+        const auto* p_term = as_global(d.terminated);
+        const auto* p_tout = as_global(d.time_outs);
+        const auto* p_dones = as_global(d.term_dones);
+        const bool velocity = d.command_kind == ILX_CMD_VELOCITY, rays = m.need & kNeedRays;
+        if (decide) {
+            if (p_len) ep_len = p_len[env];
+            if (p_left) cs.time_left = p_left[env];
+            if (p_count) cs.counter = p_count[env];
+            if (cmd_state && wave == 0) {
+                cs.metric0 = p_metric[env], cs.metric1 = p_metric[N + env];
+                if (velocity) {
+                    cs.heading_target = p_head[env];
+                    cs.is_heading = p_is_head[env] != 0;
+                    cs.is_standing = p_is_stand[env] != 0;
+                }
             }
-        }
-        if ((m.need & kNeedRays) && wave == 0) sensor_z = d.sensor_pos_w[3 * env + 2];
-        if (!ph_term && d.terminated) {
-            terminated = d.terminated[env] != 0;
-            time_out = d.time_outs[env] != 0;
-            for (int i = 0; i < NT; ++i) term_bits |= d.term_dones[static_cast<int64_t>(i) * N + env] ? (1u << i) : 0u;
+            if (rays && wave == 0) sensor_z = p_sensor[3 * env + 2];
+            if (!ph_term && p_term) {
+                terminated = p_term[env] != 0;
+                time_out = p_tout[env] != 0;
+                for (int i = 0; i < NT; ++i) term_bits |= p_dones[static_cast<int64_t>(i) * N + env] ? (1u << i) : 0u;
+            }
         }
     }
     // strided rows (two columns of the 13-wide body states, 3-vectors of the body accelerations) come through registers
@@ -599,7 +620,8 @@ __global__ void __launch_bounds__(kBlock, 4) mdp_step_kernel(MdpDev args) {
     if (m.need & kNeedForces) {  // max over the history of |F| per (env, body): rewards.py:266 / terminations.py:157
         const int H = d.history_len;
         for (int i = tid; i < ne * CB; i += kBlock) {
-            const int ee = i / CB, b = i - ee * CB;
+            const int ee = CB > 1 ? static_cast<int>(__umulhi(static_cast<uint32_t>(i), m.inv_sensor_bodies)) : i;  // i / CB
+            const int b = i - ee * CB;
             float mx = -__builtin_inff();
 #pragma unroll 4
             for (int h = 0; h < H; ++h) mx = fmaxf(mx, norm3(load3(S + L.fraw + 3 * ((ee * H + h) * CB + b))));
@@ -650,6 +672,31 @@ __global__ void __launch_bounds__(kBlock, 4) mdp_step_kernel(MdpDev args) {
     }
     ILX_STAMP(5)
     __syncthreads();
+    // Reset bookkeeping that needs nothing but the env's done flag runs beside wave 0's command work: wave 1 adds the
+    // episode sums of the done envs to the logging partials (reward_manager.py:115-121, termination_manager.py:142-144),
+    // wave 2 restarts their action history (action_manager.py:309-311: the observations of this launch already see
+    // zeros; the rewards above used the step's own actions).
+    if (decide && ph_reset && (terminated || time_out) && wave == (1 % kWaves) && wave != 0) {
+        float* logp = S + L.logp;
+        for (int i = 0; i < NR; ++i) {
+            atomicAdd(logp + i, S[L.eps + i * kE + e]);  // per-block partials in LDS (ds_add_f32), one global atomic per entry and block
+            S[L.eps + i * kE + e] = 0.0f;
+        }
+        for (int i = 0; i < NT; ++i)
+            if (term_bits & (1u << i)) atomicAdd(logp + NR + i, 1.0f);
+        atomicAdd(logp + NR + NT + 2, 1.0f);
+    }
+    if (decide && ph_reset && (terminated || time_out) && wave == (2 % kWaves) && wave != 0) {
+        auto* act = as_global(d.action);
+        auto* pact = as_global(d.prev_action);
+        const int A = d.action_dim;
+        for (int k = 0; k < A; ++k) {
+            if (act) act[env * A + k] = 0.0f;
+            if (pact) pact[env * A + k] = 0.0f;
+            if (sa) S[L.act + e * A + k] = 0.0f;
+            if (spa) S[L.pact + e * A + k] = 0.0f;
+        }
+    }
     if (decide && wave == 0) {
         ILX_STAMP(6)
         const bool done = terminated || time_out;
@@ -675,30 +722,14 @@ __global__ void __launch_bounds__(kBlock, 4) mdp_step_kernel(MdpDev args) {
         // ---- reset bookkeeping of the managers for done envs (manager_based_rl_env.py:364-391)
         bool cmd_dirty = false;
         if (ph_reset && done) {
-            // logging sums go through per-block partials in LDS (ds_add_f32), one global atomic per entry and block
-            float* logp = S + L.logp;
-            for (int i = 0; i < NR; ++i) {  // reward_manager.py:115-121
-                atomicAdd(logp + i, S[L.eps + i * kE + e]);
-                S[L.eps + i * kE + e] = 0.0f;
-            }
-            for (int i = 0; i < NT; ++i)  // termination_manager.py:142-144
-                if (term_bits & (1u << i)) atomicAdd(logp + NR + i, 1.0f);
-            atomicAdd(logp + NR + NT + 2, 1.0f);
             if (has_cmd_term) {  // command_manager.py:120-149
+                float* logp = S + L.logp;
                 atomicAdd(logp + NR + NT, cs.metric0);
                 atomicAdd(logp + NR + NT + 1, cs.metric1);
                 cs.metric0 = cs.metric1 = 0.0f;
                 cs.counter = 0;
                 command_resample(d, env, d.reset_command_samples, 16u, cs);
                 cmd_dirty = true;
-            }
-            // action_manager.py:309-311: the action history of a done env restarts at zero (the observations of this
-            // launch already see it; the rewards above used the step's own actions)
-            for (int k = 0; k < d.action_dim; ++k) {
-                if (d.action) d.action[env * d.action_dim + k] = 0.0f;
-                if (d.prev_action) d.prev_action[env * d.action_dim + k] = 0.0f;
-                if (sa) S[L.act + e * d.action_dim + k] = 0.0f;
-                if (spa) S[L.pact + e * d.action_dim + k] = 0.0f;
             }
             ep_len = 0;  // manager_based_rl_env.py:391
         }
@@ -775,7 +806,7 @@ __global__ void __launch_bounds__(kBlock, 4) mdp_step_kernel(MdpDev args) {
         }
         if (ph_rew) {
             for (int i = tid; i < ne * NR; i += kBlock) {
-                const int term = i % NR;
+                const int term = NR > 1 ? i - static_cast<int>(__umulhi(static_cast<uint32_t>(i), m.inv_rewards)) * NR : 0;  // i % NR
                 if (terms[NT + term].weight != 0.0f) d.step_reward[env0 * NR + i] = S[L.srew + i];
             }
         }
@@ -1047,7 +1078,8 @@ extern "C" int ilx_mdp_plan_create(const ilx_mdp* desc, ilx_mdp_plan_t* out) {
                            "ilx_mdp_plan_create: hipMemcpy");
     }
     if (rc == ILX_OK && d.num_ids > 0) {
-        rc = check_hip(hipMalloc(&p->d_ids, d.num_ids * sizeof(int32_t)), "ilx_mdp_plan_create: hipMalloc");
+        // padded to whole 16-byte words: the staging copies move four at a time
+        rc = check_hip(hipMalloc(&p->d_ids, ((d.num_ids + 3) & ~3) * sizeof(int32_t)), "ilx_mdp_plan_create: hipMalloc");
         if (rc == ILX_OK)
             rc = check_hip(hipMemcpy(p->d_ids, d.ids, d.num_ids * sizeof(int32_t), hipMemcpyHostToDevice),
                            "ilx_mdp_plan_create: hipMemcpy");
@@ -1198,6 +1230,8 @@ extern "C" int ilx_mdp_step(ilx_mdp_plan_t plan, const ilx_mdp* desc, void* stre
     m.cols = plan->d_cols;
     m.any_noise = plan->any_noise;
     m.noisy_terms = plan->noisy_terms;
+    auto inverse = [](int n) { return n > 1 ? static_cast<uint32_t>((0x100000000ull + n - 1) / n) : 0xffffffffu; };
+    m.inv_sensor_bodies = inverse(d.num_sensor_bodies), m.inv_rewards = inverse(d.num_rewards);
     m.need = 0;
     if ((pt && plan->t_joint) || (pr && plan->r_joint) || (po && plan->o_joint)) m.need |= kNeedJoint;
     if ((pt && plan->t_contact) || (pr && plan->r_contact)) m.need |= kNeedForces;
@@ -1244,18 +1278,23 @@ extern "C" int ilx_mdp_step(ilx_mdp_plan_t plan, const ilx_mdp* desc, void* stre
     auto add = [&](const void* src, int per_env_words, int table_words, int dst) {
         const int total = per_env_words ? kE * per_env_words : table_words;
         if (!src || total <= 0) return;
-        fits = fits && per_env_words <= 0xffff && table_words <= 0x7fff && dst <= 0xffff;
-        const bool wide = reinterpret_cast<uintptr_t>(src) % 16 == 0 && dst % 4 == 0 && (per_env_words || table_words % 4 == 0);
+        fits = fits && per_env_words <= 0xffff;
+        // 16-byte copies: aligned source and destination; a table that is not a multiple of four words long is padded by
+        // its owner (the plan's device tables are)
+        const bool wide = reinterpret_cast<uintptr_t>(src) % 16 == 0 && dst % 4 == 0;
         const uint64_t addr = reinterpret_cast<uintptr_t>(src);
-        for (int first = 0; first < total; first += wide ? 256 : 64) {
+        const int step = wide ? 256 : 64, unit = wide ? 4 : 1;
+        fits = fits && dst + total <= 0xffff && total <= (0xffff << 6);
+        for (int first = 0; first < total; first += step) {
             if (m.num_segs == kMaxSegs) {
                 fits = false;
                 return;
             }
-            m.segs[m.num_segs++] = uint4{static_cast<uint32_t>(addr), static_cast<uint32_t>(addr >> 32),
-                                         static_cast<uint32_t>(per_env_words) | (static_cast<uint32_t>(first >> 6) << 16),
-                                         static_cast<uint32_t>(dst) | (static_cast<uint32_t>(per_env_words ? 0 : table_words) << 16) |
-                                             (wide ? 0x80000000u : 0u)};
+            const uint64_t at = addr + 4u * static_cast<uint64_t>(first);
+            const int lanes = ((total - first < step ? total - first : step) + unit - 1) / unit;
+            m.segs[m.num_segs++] = uint4{static_cast<uint32_t>(at), static_cast<uint32_t>(at >> 32),
+                                         static_cast<uint32_t>(per_env_words) | (static_cast<uint32_t>(lanes) << 16) | (wide ? 1u << 23 : 0u),
+                                         static_cast<uint32_t>(dst + first) | (static_cast<uint32_t>(first >> 6) << 16)};
         }
     };
     add(d.root_state_w, 13, 0, L.root);
