@@ -68,27 +68,30 @@ def time_kernels(cfg, device, reps=20):
     return out
 
 
-def time_graph(cfg, steps, warmup):
-    """The same env step captured once into a HIP graph and replayed: what remains when the host's launch calls are
-    taken out.  Kernel arguments are those of the captured step (host-side clocks and generator counters do not advance
-    between replays), so this is a timing of the same work, not a second product path."""
+def capture_step(cfg, reducer):
+    """The env step recorded once into a HIP graph per statistics vector (the only argument that alternates between
+    steps); a replay issues the same launches with the same arguments without the host's launch calls.  The fused MDP
+    launch keeps its generator's step count in device memory, advanced inside the graph, so replays draw fresh numbers;
+    sensor clocks and histories live in device memory anyway."""
+    mdp = getattr(cfg.env, "mdp", None)
+    if mdp is not None:
+        mdp.count_steps_on_device()
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
         for _ in range(3):       # per-stream workspaces are created here, outside the capture
             cfg.step()
     side.synchronize()
-    graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph, stream=side):
-        cfg.step()
-    for _ in range(warmup):
-        graph.replay()
+    graphs = []
+    for i in range(2 if reducer is not None else 1):
+        if reducer is not None:
+            cfg.bind_log_sums(reducer.buffer(i))
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            cfg.step()
+        graphs.append(graph)
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        graph.replay()
-    torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / steps
+    return graphs
 
 
 def cpu_baseline(seed, envs=NUM_ENVS, warmup=2, steps=10):
@@ -143,8 +146,8 @@ def main():
                     help="which configuration's step to run; the default is the one the headline metric is quoted on")
     ap.add_argument("--envs", type=int, default=None, help="environments per GPU (default: the configuration's own count)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--graph", action="store_true",
-                    help="also time the step replayed from a HIP graph (always done for the launch-bound configurations)")
+    ap.add_argument("--eager", action="store_true",
+                    help="measure the step issued launch by launch from the host (default: replayed from a HIP graph)")
     ap.add_argument("--actuator", choices=("mlp", "lstm"), default="mlp",
                     help="anymal only -- actuator network: the headline 6-32-32-32-1 MLP, or the ANYdrive-shaped LSTM(2, 8, 2) + "
                          "head (no CPU baseline, reported as a side measurement)")
@@ -169,34 +172,62 @@ def main():
     cfg_id = list(BC.ENVS).index(args.config) + 1
     cfg = BC.build(args.config, device, args.envs, seed=cfg_id * 1000 + rank, actuator=args.actuator)
 
-    if cfg.log_sums is not None:
-        # episode statistics of the done envs: the only cross-rank exchange of the path, one all-reduce per step, started
-        # after the step and completed beside the next two (nothing in the step consumes it)
-        reducer = OverlappedLogReducer(cfg.log_sums.numel(), device)
+    # episode statistics of the done envs: the only cross-rank exchange of the path, one all-reduce per step, started
+    # after the step and completed beside the next two (nothing in the step consumes it).  The in-hand env reduces its two
+    # success sums inside the step instead (the statistic of the same step needs them).
+    reducer = OverlappedLogReducer(cfg.log_sums.numel(), device) if cfg.log_sums is not None else None
 
-        def one_step():
+    def eager_step():
+        if reducer is not None:
             buf, _ = reducer.begin_step()
             cfg.bind_log_sums(buf)
-            cfg.step()
+        cfg.step()
+        if reducer is not None:
             reducer.end_step()
-    else:  # the in-hand env reduces its two success sums inside the step (the statistic of the same step needs them)
-        reducer = None
-        one_step = cfg.step
 
-    for _ in range(args.warmup):
-        one_step()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        one_step()
+    graphs = None
+
+    def graph_step():
+        i = 0
+        if reducer is not None:
+            i = reducer.index
+            reducer.begin_step()
+        graphs[i].replay()
+        if reducer is not None:
+            reducer.end_step()
+
+    def timed(one_step):
+        for _ in range(args.warmup):
+            one_step()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            one_step()
+        if reducer is not None:
+            reducer.finish()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        return time.perf_counter() - t0
+
+    # The step is eleven short launches (2-40 us each): issued one by one from the host they are launch-bound, so the
+    # measured mode records the step in a HIP graph and replays it.  The in-hand env (four launches, a collective between
+    # them on several GPUs) is measured eagerly.  The other mode is timed as well and reported beside the headline.
+    use_graph = not args.eager and args.config != "shadow"
+    other_s = None
+    if use_graph:
+        other_s = timed(eager_step)
+        graphs = capture_step(cfg, reducer)
+        elapsed = timed(graph_step)
+    else:
+        elapsed = timed(eager_step)
+        if world == 1 and args.config != "shadow":
+            graphs = capture_step(cfg, reducer)
+            other_s = timed(graph_step)
     if reducer is not None:
-        reducer.finish()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
+        cfg.bind_log_sums(cfg.log_sums)
     # what the collective group saw: the number of ranks that took part (a sum of ones over RCCL) and the spread of the
     # per-rank step time; `value` is priced on the slowest rank
     rccl_ranks, rank_ms = None, [elapsed / args.steps * 1e3] * 2
@@ -212,11 +243,6 @@ def main():
         rank_ms = [float(t_min.item()) / args.steps * 1e3, elapsed / args.steps * 1e3]
 
     kern = time_kernels(cfg, device)
-    graph_s = None
-    if world == 1 and (args.graph or args.config != "anymal"):
-        if cfg.log_sums is not None:
-            cfg.bind_log_sums(cfg.log_sums)
-        graph_s = time_graph(cfg, args.steps, args.warmup)
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         value = args.envs * world * args.steps / elapsed
@@ -265,10 +291,12 @@ def main():
         }
         if args.config == "anymal":
             line["env_term_steps_per_s"] = value * TERM_EVALS_PER_ENV_STEP
-        if graph_s is not None:
-            line["hip_graph"] = {"ms_per_step": graph_s * 1e3, "value": args.envs / graph_s,
-                                 "step_hbm_frac": per_step * args.envs / graph_s / 1e9 / HBM_PEAK_GBS,
-                                 "note": "the same launches replayed from one captured graph (no host launch calls)"}
+        line["launch_mode"] = ("hip-graph replay: the step's launches recorded once per statistics vector, replayed per step"
+                               if use_graph else "eager: one host call per launch")
+        if other_s is not None:
+            line["eager" if use_graph else "hip_graph"] = {
+                "ms_per_step": other_s / args.steps * 1e3, "value": args.envs * world * args.steps / other_s,
+                "note": "the same step " + ("issued launch by launch from the host" if use_graph else "replayed from a captured graph")}
         if not args.no_cpu_baseline and world == 1 and args.config == "anymal" and args.actuator == "mlp":
             line["cpu_baseline"] = cpu_baseline(3000, envs=args.envs)
         else:

@@ -220,6 +220,10 @@ typedef struct ilx_mdp {
     /* buffers read by ILX_OBS_EXTERNAL terms: slot s is (n, external_obs_dim[s]) float32, dense */
     const float* external_obs[ILX_MAX_EXTERNAL_OBS];
     int32_t external_obs_dim[ILX_MAX_EXTERNAL_OBS];
+    /* generator, continued: when not NULL, one device word that is added to step_index.  A launch recorded in a HIP
+     * graph replays its arguments; with the step count kept in device memory (and advanced by the caller between
+     * replays, e.g. by a one-element add recorded in the same graph) every replay still draws fresh numbers. */
+    const uint64_t* step_index_device;
 } ilx_mdp;
 
 /* Opaque prepared plan: term tables and id lists copied to the device once. */

@@ -388,118 +388,7 @@ __global__ void __launch_bounds__(256) mlp_mfma_kernel(NetArgs a) {
     }
 }
 
-// The same evaluation for the common depths (2 or 3 hidden layers), arranged for the latency-bound regime this
-// launch lives in (a few tiles per SIMD): every wave keeps ALL packed weights in registers (~100), walks several
-// tiles, and has the inputs of its next tile in flight while it computes the current one, so neither weight loads
-// nor the HBM round trip of the row inputs sit between MFMAs.  Two waves per SIMD: one wave's activations (VALU)
-// run under the other wave's MFMAs.  Operation order is that of mlp_mfma_kernel, so both give the same bits.
-// (Measured alternatives: weights in LDS with 3-6 waves per SIMD -- the compiler hoists the loop-invariant reads
-// back into registers and spills; one tile per wave at 6 waves per SIMD is 8-10 % slower; two tiles per wave staggered
-// by half a layer, one MFMA then one element's activation, at one wave per SIMD: 23 us against 19 -- per tile the
-// kernel issues ~525 vector instructions besides its 35 MFMAs, about as many cycles as the MFMAs themselves, and
-// only a second wave on the SIMD hides those.)
-constexpr int kResidentHist = 4;  // the resident kernel serves histories and input index lists up to this length
-
-template <int ACT, int NHID>
-__global__ void __launch_bounds__(256, 2) mlp_mfma_resident_kernel(NetArgs a) {
-    const int lane = threadIdx.x & 63;
-    const int half = lane >> 5;
-    const int64_t tiles = (a.rows + 31) / 32;
-    const int64_t nwaves = static_cast<int64_t>(gridDim.x) * (blockDim.x >> 6);
-    int64_t tile = static_cast<int64_t>(blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (tile >= tiles) return;  // wave-uniform
-    const float* pk = a.net.packed;
-    const int ks0 = a.net.ks0;
-    float w0[kResidentHist];
-#pragma unroll
-    for (int s = 0; s < kResidentHist; ++s) w0[s] = s < ks0 ? pk[s * 64 + lane] : 0.0f;
-    const float* bias_p = pk + ks0 * 64;
-    const float* wts_p = bias_p + NHID * 1024;
-    f32x16 bias[NHID];
-    float wh[NHID > 1 ? NHID - 1 : 1][16];
-    float wo[16];
-#pragma unroll
-    for (int l = 0; l < NHID; ++l)
-#pragma unroll
-        for (int k = 0; k < 16; ++k) bias[l][k] = bias_p[l * 1024 + k * 64 + lane];
-#pragma unroll
-    for (int l = 0; l + 1 < NHID; ++l)
-#pragma unroll
-        for (int k = 0; k < 16; ++k) wh[l][k] = wts_p[l * 1024 + k * 64 + lane];
-#pragma unroll
-    for (int k = 0; k < 16; ++k) wo[k] = wts_p[(NHID - 1) * 1024 + k * 64 + lane];
-    const float bo = wts_p[(NHID - 1) * 1024 + 1024];
-
-    // rows of a tile: the tile's first row is wave-uniform, so its env / joint split is scalar work and a lane only
-    // adds its offset (< 32) with a small exact division
-    const uint32_t j = static_cast<uint32_t>(a.j);
-    const float inv_j = 1.0f / static_cast<float>(j);
-    auto tile_row = [&](int64_t t) {
-        const uint32_t row0 = static_cast<uint32_t>(t) * 32u;
-        const uint32_t env0 = row0 / j, joint0 = row0 - env0 * j;
-        const uint32_t x = joint0 + (lane & 31);                      // < j + 32
-        uint32_t q = static_cast<uint32_t>(static_cast<float>(x) * inv_j);  // exact up to +-1 for x < 2^22
-        q = (q * j > x) ? q - 1 : q;
-        q = ((q + 1) * j <= x) ? q + 1 : q;
-        const uint32_t env = env0 + q, joint = x - q * j, row = row0 + (lane & 31);
-        const bool valid = row < static_cast<uint32_t>(a.rows);
-        const RowAt<uint32_t> at = {valid ? row : 0u, valid ? env * static_cast<uint32_t>(a.hist_len) * j + joint : 0u,
-                                    valid ? (a.per_env ? row : joint) : 0u};
-        return at;
-    };
-    // Loop order per tile: issue the loads of the next tile, issue the STORES OF THE PREVIOUS tile, compute this tile,
-    // take in the next tile's loads.  A store keeps its data registers busy until it completes (~1-2 us); issued at the
-    // end of an iteration it would make the next iteration wait as soon as it reuses one of them, issued here it has a
-    // whole tile of MFMAs to complete under.
-    RowInT<kResidentHist> cur, done;
-    RowRawT<kResidentHist> ahead;
-    RowAt<uint32_t> at = tile_row(tile), at_next = at, at_done = at;
-    float out_done = 0.0f;
-    bool valid_done = false;
-    load_row(a, at, tile * 32 + (lane & 31) < a.rows, cur);
-    done = cur;
-    for (; tile < tiles; tile += nwaves) {
-        const bool valid = tile * 32 + (lane & 31) < a.rows;
-        const bool more = tile + nwaves < tiles;
-        if (more) {  // the next tile's inputs travel while this tile computes
-            at_next = tile_row(tile + nwaves);
-            issue_row(a, at_next, (tile + nwaves) * 32 + (lane & 31) < a.rows, ahead);
-        }
-        if (valid_done) {
-            if (half == 0) store_torque(a, at_done, out_done, done);
-            store_history(a, at_done, done, half == 0, half == 1);
-        }
-
-        f32x16 acc = bias[0];
-#pragma unroll
-        for (int s = 0; s < kResidentHist; ++s) {
-            if (s < ks0) {
-                const float bop = half ? cur.feat[2 * s + 1] : cur.feat[2 * s];
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w0[s], bop, acc, 0, 0, 0);
-            }
-        }
-        acc = activate16<ACT>(acc);
-#pragma unroll
-        for (int l = 1; l < NHID; ++l) {
-            f32x16 y = bias[l];
-#pragma unroll
-            for (int k = 0; k < 16; ++k) y = __builtin_amdgcn_mfma_f32_32x32x2f32(wh[l - 1][k], acc[k], y, 0, 0, 0);
-            acc = activate16<ACT>(y);
-        }
-        float part = 0.0f;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) part = fmaf_(wo[k], acc[k], part);
-        const float other = __shfl_xor(part, 32, 64);
-        out_done = (half ? other + part : part + other) + bo;
-        done = cur, at_done = at, valid_done = valid;
-        if (more) finish_row(a, ahead, cur);
-        at = at_next;
-    }
-    if (valid_done) {
-        if (half == 0) store_torque(a, at_done, out_done, done);
-        store_history(a, at_done, done, half == 0, half == 1);
-    }
-}
+constexpr int kResidentHist = 4;  // the tile kernels serve histories and input index lists up to this length
 
 // One 32-row tile per wavefront, weights in LDS.  The launch is 6,144 tiles on 1,024 SIMDs: with every tile its own
 // wavefront and few registers per wavefront (the A operands come from LDS one instruction ahead of their MFMA instead
@@ -581,6 +470,115 @@ __global__ void __launch_bounds__(256, 8) mlp_mfma_tile_kernel(NetArgs a) {
     }
 }
 
+// The tile kernel with the hidden layers on the f16 matrix cores.  An f32 MFMA runs on the vector ALUs at the packed-f32
+// rate, so in mlp_mfma_tile_kernel the matrix products and the activations share one pipe; a 32 x 32 x 16 f16 MFMA is 32
+// cycles on the matrix cores proper and runs beside other wavefronts' vector work.  To keep f32-grade results both
+// factors are split into an f16 head and an f16 remainder (x = hi + lo, |lo| <= 2^-10 |x|) and three of the four
+// products are accumulated in f32 (hi*hi + hi*lo + lo*hi; the dropped lo*lo is below 2^-20 of the product): six MFMAs
+// of 32 cycles per hidden layer instead of sixteen of 64, relative error of a product ~1e-6 (f32: 6e-8).  The
+// accumulator of one layer is the B operand of the next without lane movement: registers 8s..8s+7 of a lane are the
+// eight k-values of k-step s in the permuted order unit = 16 s + 8 (j >> 2) + 4 half + (j & 3), and the weights are
+// stored in that order.  The first layer (K = 2 x history length) stays on the f32 MFMA: its inputs are unscaled
+// physical quantities.
+// LDS image: [ks0][64] f32 first-layer operands | per hidden layer 4 x [64 lanes][8] f16 (hi s0, hi s1, lo s0, lo s1)
+//            | L x [32] biases | [32] output weights | output bias.
+using h8 = __attribute__((ext_vector_type(8))) _Float16;
+using h2 = __attribute__((ext_vector_type(2))) __fp16;
+
+ILX_DEV void split_f16(const f32x16& x, h8 (&hi)[2], h8 (&lo)[2]) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+#pragma unroll
+        for (int jj = 0; jj < 8; jj += 2) {
+            const float a = x[8 * s + jj], b = x[8 * s + jj + 1];
+            const h2 h = __builtin_amdgcn_cvt_pkrtz(a, b);  // truncation: the remainder is exact in f32
+            const h2 l = __builtin_amdgcn_cvt_pkrtz(a - static_cast<float>(h[0]), b - static_cast<float>(h[1]));
+            hi[s][jj] = static_cast<_Float16>(h[0]), hi[s][jj + 1] = static_cast<_Float16>(h[1]);
+            lo[s][jj] = static_cast<_Float16>(l[0]), lo[s][jj + 1] = static_cast<_Float16>(l[1]);
+        }
+    }
+}
+
+template <int ACT, int NHID>
+__global__ void __launch_bounds__(256, 8) mlp_mfma_split_kernel(NetArgs a) {
+    constexpr int kHiddenWords = (NHID - 1) * 1024;  // 4 fragments x 64 lanes x 16 bytes per hidden layer
+    __shared__ __attribute__((aligned(16))) float img[kResidentHist * 64 + kHiddenWords + NHID * 32 + 32 + 4];
+    const int lane = threadIdx.x & 63;
+    const int half = lane >> 5;
+    const int64_t tiles = (a.rows + 31) / 32;
+    const int64_t tile = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+    const bool live = tile < tiles;  // wave-uniform
+
+    const uint32_t j = static_cast<uint32_t>(a.j);
+    const uint32_t row0 = static_cast<uint32_t>(live ? tile : 0) * 32u;
+    const uint32_t env0 = row0 / j, joint0 = row0 - env0 * j;
+    const uint32_t x = joint0 + (lane & 31);  // < j + 32
+    uint32_t q = static_cast<uint32_t>(static_cast<float>(x) * (1.0f / static_cast<float>(j)));  // exact up to +-1 for x < 2^22
+    q = (q * j > x) ? q - 1 : q;
+    q = ((q + 1) * j <= x) ? q + 1 : q;
+    const uint32_t env = env0 + q, joint = x - q * j, row = row0 + (lane & 31);
+    const bool valid = live && row < static_cast<uint32_t>(a.rows);
+    const RowAt<uint32_t> at = {valid ? row : 0u, valid ? env * static_cast<uint32_t>(a.hist_len) * j + joint : 0u,
+                                valid ? (a.per_env ? row : joint) : 0u};
+    RowRawT<kResidentHist> raw;
+    issue_row(a, at, valid, raw);
+    // the image is padded to whole 16-byte words
+    {
+        const float4* src = reinterpret_cast<const float4*>(a.net.image16);
+        float4* dst = reinterpret_cast<float4*>(img);
+        for (int i = threadIdx.x; i < a.net.image16_floats / 4; i += 256) dst[i] = src[i];
+    }
+    __syncthreads();
+    if (!live) return;
+    RowInT<kResidentHist> cur;
+    finish_row(a, raw, cur);
+
+    const int ks0 = a.net.ks0;
+    const float* w0 = img + lane;
+    const h8* wh = reinterpret_cast<const h8*>(img + ks0 * 64) + lane;   // fragment f of layer l: wh[(4 (l - 1) + f) * 64]
+    const float* bias = img + ks0 * 64 + kHiddenWords + 4 * half;
+    const float* wo = bias + NHID * 32;
+    const float bo = img[ks0 * 64 + kHiddenWords + NHID * 32 + 32];
+
+    f32x16 acc;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) acc[k] = bias[acc_unit(k, 0)];
+#pragma unroll
+    for (int s = 0; s < kResidentHist; ++s) {
+        if (s < ks0) {
+            const float bop = half ? cur.feat[2 * s + 1] : cur.feat[2 * s];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w0[s * 64], bop, acc, 0, 0, 0);
+        }
+    }
+    acc = activate16<ACT>(acc);
+#pragma unroll
+    for (int l = 1; l < NHID; ++l) {
+        h8 xh[2], xl[2];
+        split_f16(acc, xh, xl);
+        f32x16 y;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) y[k] = bias[l * 32 + acc_unit(k, 0)];
+        const h8* w = wh + (l - 1) * 256;
+        // small terms first
+#pragma unroll
+        for (int s = 0; s < 2; ++s) y = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[(2 + s) * 64], xh[s], y, 0, 0, 0);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) y = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[s * 64], xl[s], y, 0, 0, 0);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) y = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[s * 64], xh[s], y, 0, 0, 0);
+        acc = activate16<ACT>(y);
+    }
+    float part = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) part = fmaf_(wo[acc_unit(k, 0)], acc[k], part);
+    const float other = __shfl_xor(part, 32, 64);
+    const float out = (half ? other + part : part + other) + bo;
+    if (valid) {
+        if (half == 0) store_torque(a, at, out, cur);
+        store_history(a, at, cur, half == 0, half == 1);
+    }
+}
+
 }  // namespace ilx
 
 using namespace ilx;
@@ -620,6 +618,8 @@ extern "C" int ilx_mlp_create(int num_layers, const int32_t* dims, int activatio
     h.dev.packed = nullptr;
     h.dev.image = nullptr;
     h.dev.image_floats = 0;
+    h.dev.image16 = nullptr;
+    h.dev.image16_floats = 0;
     h.raw_floats = static_cast<int>(raw.size());
 
     bool mfma = num_layers >= 2;
@@ -663,11 +663,44 @@ extern "C" int ilx_mlp_create(int num_layers, const int32_t* dims, int activatio
                                          "ilx_mlp_create: hipMemcpy");
         h.dev.image = h.d_image;
         h.dev.image_floats = static_cast<int>(img.size());
+        // the image of mlp_mfma_split_kernel: hidden weights as f16 head / remainder fragments in its k order
+        std::vector<float> img16(pk.begin(), pk.begin() + ks0 * 64);
+        for (int l = 1; l < nhid; ++l) {
+            std::vector<_Float16> frag(4 * 64 * 8);
+            for (int s2 = 0; s2 < 2; ++s2)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int jj = 0; jj < 8; ++jj) {
+                        const int unit = 16 * s2 + 8 * (jj >> 2) + 4 * (lane >> 5) + (jj & 3);
+                        const float w = weights_host[l][(lane & 31) * 32 + unit];
+                        const _Float16 hi = static_cast<_Float16>(w);
+                        frag[(s2 * 64 + lane) * 8 + jj] = hi;
+                        frag[((2 + s2) * 64 + lane) * 8 + jj] = static_cast<_Float16>(w - static_cast<float>(hi));
+                    }
+            const float* words = reinterpret_cast<const float*>(frag.data());
+            img16.insert(img16.end(), words, words + 1024);
+        }
+        for (int l = 0; l < nhid; ++l) img16.insert(img16.end(), biases_host[l], biases_host[l] + 32);
+        img16.insert(img16.end(), weights_host[nhid], weights_host[nhid] + 32);
+        img16.push_back(biases_host[nhid][0]);
+        while (img16.size() % 4) img16.push_back(0.0f);
+        // the split needs every hidden weight inside the f16 range; otherwise the f32 kernels serve the net
+        bool in_range = true;
+        for (int l = 1; l < nhid; ++l)
+            for (int i = 0; i < 32 * 32; ++i) in_range = in_range && std::fabs(weights_host[l][i]) < 6.0e4f;
+        if (rc == ILX_OK && in_range) {
+            rc = check_hip(hipMalloc(&h.d_image16, img16.size() * sizeof(float)), "ilx_mlp_create: hipMalloc");
+            if (rc == ILX_OK)
+                rc = check_hip(hipMemcpy(h.d_image16, img16.data(), img16.size() * sizeof(float), hipMemcpyHostToDevice),
+                               "ilx_mlp_create: hipMemcpy");
+            h.dev.image16 = h.d_image16;
+            h.dev.image16_floats = static_cast<int>(img16.size());
+        }
     }
     if (rc != ILX_OK) {
         if (h.d_raw) (void)hipFree(h.d_raw);
         if (h.d_packed) (void)hipFree(h.d_packed);
         if (h.d_image) (void)hipFree(h.d_image);
+        if (h.d_image16) (void)hipFree(h.d_image16);
         delete obj;
         return rc;
     }
@@ -680,6 +713,7 @@ extern "C" void ilx_mlp_destroy(ilx_mlp_t net) {
     if (net->h.d_raw) (void)hipFree(net->h.d_raw);
     if (net->h.d_packed) (void)hipFree(net->h.d_packed);
     if (net->h.d_image) (void)hipFree(net->h.d_image);
+    if (net->h.d_image16) (void)hipFree(net->h.d_image16);
     delete net;
 }
 
@@ -708,39 +742,24 @@ extern "C" int ilx_actuator_pd(int model, const float* q_des, const float* qd_de
     return ILX_OK;
 }
 
-// Compute units of the current device (queried once per device).
-static int num_cus() {
-    static int cached[64] = {0};
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (dev < 0 || dev >= 64) return 256;
-    if (cached[dev] == 0) {
-        int n = 0;
-        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-        cached[dev] = n;
-    }
-    return cached[dev];
-}
-
 template <int ACT>
-static void launch_mlp(const NetArgs& a, bool force_generic, hipStream_t s) {
+static void launch_mlp(const NetArgs& a, bool force_generic, bool exact_f32, hipStream_t s) {
     if (a.net.packed && !force_generic) {
         const int64_t tiles = (a.rows + 31) / 32;
         const int nhid = a.net.num_layers - 1;
-        // resident-weight kernel: two 4-wave blocks per CU, each wave walks tiles with that stride; it indexes with 32 bits
-        const unsigned resident_blocks = static_cast<unsigned>(std::min<int64_t>((tiles + 3) / 4, int64_t(2) * num_cus()));
+        // the tile kernels index with 32 bits
         const bool small = a.hist_len <= kResidentHist && a.n_feat <= 2 * kResidentHist && a.j < (1 << 20) &&
                            a.rows * a.hist_len < (int64_t(1) << 31);
-        const bool tile_kernel = getenv("ILX_MLP_RESIDENT") == nullptr;
         const unsigned tile_blocks = static_cast<unsigned>((tiles + 3) / 4);
-        if (nhid == 3 && small && tile_kernel)
-            hipLaunchKernelGGL((mlp_mfma_tile_kernel<ACT, 3>), dim3(tile_blocks), dim3(256), 0, s, a);
-        else if (nhid == 2 && small && tile_kernel)
-            hipLaunchKernelGGL((mlp_mfma_tile_kernel<ACT, 2>), dim3(tile_blocks), dim3(256), 0, s, a);
+        const bool split = a.net.image16 && !exact_f32;
+        if (nhid == 3 && small && split)
+            hipLaunchKernelGGL((mlp_mfma_split_kernel<ACT, 3>), dim3(tile_blocks), dim3(256), 0, s, a);
+        else if (nhid == 2 && small && split)
+            hipLaunchKernelGGL((mlp_mfma_split_kernel<ACT, 2>), dim3(tile_blocks), dim3(256), 0, s, a);
         else if (nhid == 3 && small)
-            hipLaunchKernelGGL((mlp_mfma_resident_kernel<ACT, 3>), dim3(resident_blocks), dim3(256), 0, s, a);
+            hipLaunchKernelGGL((mlp_mfma_tile_kernel<ACT, 3>), dim3(tile_blocks), dim3(256), 0, s, a);
         else if (nhid == 2 && small)
-            hipLaunchKernelGGL((mlp_mfma_resident_kernel<ACT, 2>), dim3(resident_blocks), dim3(256), 0, s, a);
+            hipLaunchKernelGGL((mlp_mfma_tile_kernel<ACT, 2>), dim3(tile_blocks), dim3(256), 0, s, a);
         else
             hipLaunchKernelGGL(mlp_mfma_kernel<ACT>, dim3(static_cast<unsigned>((tiles + 3) / 4)), dim3(256), 0, s, a);
     } else {
@@ -786,13 +805,13 @@ extern "C" int ilx_actuator_net_mlp(ilx_mlp_t net, const float* q_des, const flo
     a.rows = n * j, a.j = j;
     if (a.rows == 0) return ILX_OK;
     hipStream_t s = as_stream(stream);
-    const bool generic = (flags & ILX_MLP_FORCE_GENERIC) != 0;
+    const bool generic = (flags & ILX_MLP_FORCE_GENERIC) != 0, exact = (flags & ILX_MLP_EXACT_F32) != 0;
     switch (a.net.act) {
-        case ILX_ACT_SOFTSIGN: launch_mlp<ILX_ACT_SOFTSIGN>(a, generic, s); break;
-        case ILX_ACT_ELU: launch_mlp<ILX_ACT_ELU>(a, generic, s); break;
-        case ILX_ACT_TANH: launch_mlp<ILX_ACT_TANH>(a, generic, s); break;
-        case ILX_ACT_RELU: launch_mlp<ILX_ACT_RELU>(a, generic, s); break;
-        default: launch_mlp<ILX_ACT_IDENTITY>(a, generic, s); break;
+        case ILX_ACT_SOFTSIGN: launch_mlp<ILX_ACT_SOFTSIGN>(a, generic, exact, s); break;
+        case ILX_ACT_ELU: launch_mlp<ILX_ACT_ELU>(a, generic, exact, s); break;
+        case ILX_ACT_TANH: launch_mlp<ILX_ACT_TANH>(a, generic, exact, s); break;
+        case ILX_ACT_RELU: launch_mlp<ILX_ACT_RELU>(a, generic, exact, s); break;
+        default: launch_mlp<ILX_ACT_IDENTITY>(a, generic, exact, s); break;
     }
     ILX_LAUNCH_CHECK("ilx_actuator_net_mlp");
     return ILX_OK;

@@ -406,14 +406,14 @@ struct CmdState {
 
 // The seven samples a resampling env consumes: injected values, or two generator calls mapped to the term's ranges
 // (the two coin flips of the velocity term stay in [0, 1)).
-ILX_DEV void command_draws(const ilx_mdp& d, const float* injected, int64_t env, uint32_t salt, float (&smp)[7]) {
+ILX_DEV void command_draws(const ilx_mdp& d, uint64_t step, const float* injected, int64_t env, uint32_t salt, float (&smp)[7]) {
     if (injected) {
 #pragma unroll
         for (int k = 0; k < 7; ++k) smp[k] = injected[env * 7 + k];
         return;
     }
-    const u4 a = philox4(d.seed, d.step_index, static_cast<uint64_t>(env), 0x40000000u + salt),
-             b = philox4(d.seed, d.step_index, static_cast<uint64_t>(env), 0x40000001u + salt);
+    const u4 a = philox4(d.seed, step, static_cast<uint64_t>(env), 0x40000000u + salt),
+             b = philox4(d.seed, step, static_cast<uint64_t>(env), 0x40000001u + salt);
     const float u[7] = {u01(a.x), u01(a.y), u01(a.z), u01(a.w), u01(b.x), u01(b.y), u01(b.z)};
 #pragma unroll
     for (int k = 0; k < 7; ++k) {
@@ -423,9 +423,9 @@ ILX_DEV void command_draws(const ilx_mdp& d, const float* injected, int64_t env,
 }
 
 // CommandTerm._resample for one env: command_manager.py:172-187 + the term's _resample_command
-ILX_DEV void command_resample(const ilx_mdp& d, int64_t env, const float* injected, uint32_t salt, CmdState& s) {
+ILX_DEV void command_resample(const ilx_mdp& d, uint64_t step, int64_t env, const float* injected, uint32_t salt, CmdState& s) {
     float v[7];
-    command_draws(d, injected, env, salt, v);
+    command_draws(d, step, injected, env, salt, v);
     s.time_left = v[0];
     s.counter += 1;
     if (d.command_kind == ILX_CMD_VELOCITY) {  // velocity_command.py:123-138
@@ -521,6 +521,8 @@ __global__ void __launch_bounds__(kBlock, 4) mdp_step_kernel(MdpDev args) {
     const bool cmd_state = has_cmd_term && (d.phases & (ILX_PHASE_COMMAND | ILX_PHASE_RESET));
     const ilx_term* terms = reinterpret_cast<const ilx_term*>(S + L.terms);
     const int32_t* ids = reinterpret_cast<const int32_t*>(S + L.ids);
+    // the generator's step word: the argument, plus the caller's device-side count when there is one
+    const uint64_t gen_step = d.step_index + (d.step_index_device ? *as_global(d.step_index_device) : 0ull);
 
     ILX_STAMP(0)
     // ================= STAGE =================
@@ -728,7 +730,7 @@ __global__ void __launch_bounds__(kBlock, 4) mdp_step_kernel(MdpDev args) {
                 atomicAdd(logp + NR + NT + 1, cs.metric1);
                 cs.metric0 = cs.metric1 = 0.0f;
                 cs.counter = 0;
-                command_resample(d, env, d.reset_command_samples, 16u, cs);
+                command_resample(d, gen_step, env, d.reset_command_samples, 16u, cs);
                 cmd_dirty = true;
             }
             ep_len = 0;  // manager_based_rl_env.py:391
@@ -749,7 +751,7 @@ __global__ void __launch_bounds__(kBlock, 4) mdp_step_kernel(MdpDev args) {
                 cs.metric1 = norm3(aa);
             }
             cs.time_left = cs.time_left - dt;
-            if (cs.time_left <= 0.0f) command_resample(d, env, d.command_samples, 0u, cs);
+            if (cs.time_left <= 0.0f) command_resample(d, gen_step, env, d.command_samples, 0u, cs);
             if (d.command_kind == ILX_CMD_VELOCITY) {  // velocity_command.py:140-160
                 if (d.heading_command && cs.is_heading) {
                     const f3 fwd = quat_apply(en.quat, f3{1.0f, 0.0f, 0.0f});  // articulation_data.py:416-425
@@ -891,7 +893,7 @@ __global__ void __launch_bounds__(kBlock, 4) mdp_step_kernel(MdpDev args) {
                 const float sensor_height = S[L.derived + kDerived * ee + 9];
                 if (ee < 4) { ILX_STAMP(12) }
                 if (generate && any_noise) {
-                    const u4 r = philox4(d.seed, d.step_index, static_cast<uint64_t>(oenv), static_cast<uint32_t>(g));
+                    const u4 r = philox4(d.seed, gen_step, static_cast<uint64_t>(oenv), static_cast<uint32_t>(g));
                     u[0] = u01(r.x), u[1] = u01(r.y), u[2] = u01(r.z), u[3] = u01(r.w);
                 }
                 if (ee < 4) { ILX_STAMP(13) }

@@ -38,6 +38,8 @@ struct MlpDev {
     int ks0;                      // k-steps of the first layer (ceil(in/2))
     const float* image;           // the weights as mlp_mfma_tile_kernel keeps them in LDS (with `packed`), or nullptr
     int image_floats;
+    const float* image16;         // the image of mlp_mfma_split_kernel (hidden weights as f16 head / remainder), or nullptr
+    int image16_floats;
 };
 
 struct MlpHost {
@@ -45,6 +47,7 @@ struct MlpHost {
     float* d_raw = nullptr;
     float* d_packed = nullptr;
     float* d_image = nullptr;
+    float* d_image16 = nullptr;
     int device = 0;
     int raw_floats = 0;           // length of `raw`
 };

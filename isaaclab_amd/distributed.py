@@ -64,6 +64,16 @@ class OverlappedLogReducer:
         self._filled = [False, False]
         self._k = 0
 
+    def buffer(self, i: int) -> torch.Tensor:
+        """Statistics vector ``i`` (0 or 1); step k accumulates into ``buffer(k & 1)`` (launches recorded in a HIP graph
+        are recorded once per vector)."""
+        return self._bufs[i]
+
+    @property
+    def index(self) -> int:
+        """Which vector the step that begins next accumulates into."""
+        return self._k & 1
+
     def begin_step(self, want_totals: bool = False):
         i = self._k & 1
         if self._works[i] is not None:

@@ -75,6 +75,7 @@ class MdpDesc(ctypes.Structure):
         ("ids", POINTER(c_int32)), ("num_ids", c_int32),
         ("log_sums", c_void_p), ("seed", c_uint64), ("step_index", c_uint64), ("phases", c_int32),
         ("external_obs", c_void_p * 4), ("external_obs_dim", c_int32 * 4),
+        ("step_index_device", c_void_p),
     ]
 
 
@@ -151,6 +152,7 @@ class FusedMdp:
         d.max_episode_length_s = max_episode_length * step_dt if max_episode_length_s is None else max_episode_length_s
         d.gravity_dir = (c_float * 3)(*gravity)
         self._own_generator = seed is not None
+        self._step_counter = None
         d.seed, d.step_index, d.phases = (seed if seed is not None else 0), 0, PHASE_ALL
         if len(external_obs_dims) > MAX_EXTERNAL_OBS:
             raise ValueError(f"a plan reads at most {MAX_EXTERNAL_OBS} external observation buffers, not {len(external_obs_dims)}")
@@ -265,7 +267,20 @@ class FusedMdp:
         elif not self._own_generator:
             self.desc.seed, self.desc.step_index = _rng.seed(), _rng.next_draw("fused_mdp")
         _abi.check(_abi.lib.ilx_mdp_step(self.plan, ctypes.byref(self.desc), _abi.stream()), "ilx_mdp_step")
-        self.desc.step_index += 1
+        if self._step_counter is not None:
+            self._step_counter.add_(1)          # a device operation: recorded with the launch when a graph is captured
+        else:
+            self.desc.step_index += 1
+
+    def count_steps_on_device(self, enable: bool = True):
+        """Keep the generator's step count in device memory (advanced by a one-element add after every launch) instead
+        of on the host, so that a step recorded in a HIP graph draws fresh random numbers at every replay."""
+        if enable and self._step_counter is None:
+            self._step_counter = torch.zeros(1, dtype=torch.int64, device=self.device)
+            self.desc.step_index_device = self._step_counter.data_ptr()
+        elif not enable:
+            self._step_counter = None
+            self.desc.step_index_device = None
 
     def __getattr__(self, name):
         t = self.__dict__.get("t")

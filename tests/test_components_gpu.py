@@ -150,6 +150,39 @@ def test_actuator_net_mlp_anymal_shape_vs_oracle(dev):
             assert_close(act.applied_effort, app, atol=2e-5, what=f"n={n} applied step {s}")
 
 
+def test_actuator_net_mlp_split_and_f32_products(dev):
+    """The default evaluation (hidden layers on the f16 matrix cores, factors split into head and remainder) against
+    ILX_MLP_EXACT_F32 (every product in f32 on the f32 MFMA) and the generic kernel (plain fmaf chains, exact division in
+    softsign): all three within 1e-5 of the output scale, also with large hidden weights."""
+    from isaaclab_amd.actuators import ActuatorNetMLP, ActuatorNetMLPCfg
+    from isaaclab_amd.utils.types import ArticulationActions
+
+    gen = torch.Generator().manual_seed(17)
+    dims = [6, 32, 32, 32, 1]
+    n, j = 4096, 12
+    for gain in (1.0, 6.0):   # gain 6: pre-activations of tens, softsign saturated, large products
+        ws = [gain * torch.randn(dims[i + 1], dims[i], generator=gen) / dims[i] ** 0.5 for i in range(4)]
+        bs = [torch.randn(dims[i + 1], generator=gen) * 0.1 for i in range(4)]
+        out = {}
+        for flags in (0, 1, 2):
+            cfg = ActuatorNetMLPCfg(network=dict(weights=ws, biases=bs, activation="softsign"), pos_scale=-1.0, vel_scale=1.0,
+                                    torque_scale=1.0, input_order="pos_vel", input_idx=[0, 1, 2], effort_limit=1e6,
+                                    velocity_limit=7.5, saturation_effort=1e6)
+            act = ActuatorNetMLP(cfg, joint_names=_names(j), joint_ids=slice(None), num_envs=n, device=dev)
+            act._flags = flags
+            g2 = torch.Generator().manual_seed(3)
+            for _ in range(3):
+                q_des = torch.randn(n, j, generator=g2)
+                act.compute(ArticulationActions(joint_positions=q_des.to(dev)), (q_des + 0.3 * torch.randn(n, j, generator=g2)).to(dev),
+                            (3.0 * torch.randn(n, j, generator=g2)).to(dev))
+            out[flags] = act.computed_effort.clone()
+        scale = float(out[1].abs().max())
+        for flags, what in ((2, "f32 MFMA kernel"), (0, "split evaluation")):
+            err = float((out[flags] - out[1]).abs().max())
+            assert err <= 1e-5 * scale, f"gain {gain}: {what} off the generic kernel by {err:.3g} (outputs up to {scale:.3g})"
+        assert not torch.equal(out[0], out[2]), "the default path is the split one"
+
+
 def _lstm_net(g, tag, act):
     hidden, layers, nhead = (int(v) for v in g[f"{tag}_shape"])
     lstm = {f"{nm}_l{l}": g[f"{tag}_{nm}_l{l}"] for l in range(layers) for nm in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")}
