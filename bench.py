@@ -76,6 +76,8 @@ def capture_step(cfg, reducer):
     mdp = getattr(cfg.env, "mdp", None)
     if mdp is not None:
         mdp.count_steps_on_device()
+    if getattr(cfg, "overlap_in_graph", False):
+        cfg.env.concurrent_chains = True
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
@@ -91,6 +93,8 @@ def capture_step(cfg, reducer):
             cfg.step()
         graphs.append(graph)
     torch.cuda.synchronize()
+    if getattr(cfg, "overlap_in_graph", False):
+        cfg.env.concurrent_chains = False
     return graphs
 
 

@@ -133,6 +133,9 @@ def build_locomotion(device, envs, seed, robot="anymal_c", actuator="mlp", stati
                  _locomotion_bytes(j, b, r, int(env.mdp.obs_dim), n_rewards, act_kernel), info,
                  env.mdp.log_sums, lambda buf: env.mdp.bind(log_sums=buf))
     cfg.env, cfg.state = env, state
+    # replayed from a graph: the sensor chain as a parallel branch beside the actuator network (pays off for the network
+    # actuators; with H1's PD actuators there is nothing to run beside)
+    cfg.overlap_in_graph = robot == "anymal_c"
     return cfg
 
 

@@ -95,6 +95,10 @@ class LocomotionVelocityStep:
                                max_episode_length=LV.MAX_EPISODE_LENGTH,
                                command=LV.H1_VELOCITY_COMMAND if robot == "h1" else LV.VELOCITY_COMMAND, seed=seed, **terms)
         self._bind()
+        # see step(): worth it when the step is replayed from a HIP graph and the actuator chain is long (network
+        # actuators); issued launch by launch, the fork and join cost the host more than the overlap returns
+        self.concurrent_chains = False
+        self._side_stream = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
 
     def _bind(self):
         d, c = self.data, self.contact._data
@@ -139,27 +143,40 @@ class LocomotionVelocityStep:
         """One env step on the synthetic physics sequence installed by :meth:`load_state`."""
         d, dev = self.data, self.device
         n, j = self.n, d._j
+        # With the simulator's results of all substeps at hand, the step is two chains that share no buffer until the
+        # managers read them: (A) process_action and the actuator model of every substep, (B) scene.update of every
+        # substep and the height-scanner refresh.  (B) is issued on a second stream between a fork and a join; recorded
+        # in a HIP graph the two become parallel branches, so the memory-bound sensor updates run beside the
+        # compute-bound actuator network.  Each chain keeps the reference's order (manager_based_rl_env.py:172-195).
+        main = torch.cuda.current_stream()
+        side = self._side_stream if self.concurrent_chains else main
+        if side is not main:
+            side.wait_stream(main)
+        with torch.cuda.stream(side):
+            for k in range(LV.DECIMATION):
+                # <sim.step would run here; its results for this substep are self.physics[...][k]>
+                d.joint_pos, d.joint_vel = self.physics["joint_pos"][k], self.physics["joint_vel"][k]
+                self.contact.set_net_contact_forces(self.physics["net_forces"][k])
+                self.scene.update(LV.PHYSICS_DT)                         # joint_acc, contact sensor, scanner clock: one launch
+            d.set_sim_state(root_state_w=self.physics["root_state_w"])
+            # -- height scanner: refreshed once per env step (update_period = step_dt), lazily in the reference
+            if self.scanner_body is None:
+                self.scanner.set_pose(d.root_state_w[:, :3], d.root_state_w[:, 3:7])
+            else:  # strided views of the body's rows: the kernel reads them in place
+                pose = d.body_state_w[:, self.scanner_body]
+                self.scanner.set_pose(pose[:, :3], pose[:, 3:7])
+            self.scanner._update_outdated_buffers()
         # -- process_action (manager_based_rl_env.py:172)
         _abi.check(_abi.joint_action_process(_abi.ptr(raw_action), _abi.ptr(self.action), _abi.ptr(self.prev_action), None,
                                              self.action_scale, _abi.ptr(d.default_joint_pos), 0.0, None,
                                              _abi.ptr(d.joint_pos_target), n, j, _abi.stream()), "ilx_joint_action_process")
-        # -- decimation loop (:181-195)
         for k in range(LV.DECIMATION):
             d.joint_pos, d.joint_vel = self.physics["joint_pos"][k], self.physics["joint_vel"][k]
             ca = ArticulationActions(joint_positions=d.joint_pos_target, joint_velocities=d.joint_vel_target,
                                      joint_efforts=d.joint_effort_target, joint_indices=slice(None))
             self.actuator.compute(ca, d.joint_pos, d.joint_vel)          # write_data_to_sim
-            # <sim.step would run here; its results for this substep are self.physics[...][k]>
-            self.contact.set_net_contact_forces(self.physics["net_forces"][k])
-            self.scene.update(LV.PHYSICS_DT)                             # joint_acc, contact sensor, scanner clock: one launch
-        d.set_sim_state(root_state_w=self.physics["root_state_w"])
-        # -- height scanner: refreshed once per env step (update_period = step_dt), lazily in the reference
-        if self.scanner_body is None:
-            self.scanner.set_pose(d.root_state_w[:, :3], d.root_state_w[:, 3:7])
-        else:  # strided views of the body's rows: the kernel reads them in place
-            pose = d.body_state_w[:, self.scanner_body]
-            self.scanner.set_pose(pose[:, :3], pose[:, 3:7])
-        self.scanner._update_outdated_buffers()
+        if side is not main:
+            main.wait_stream(side)
         # -- post-physics managers: one launch
         m = self.mdp
         m.bind(root_state_w=d.root_state_w, joint_pos=d.joint_pos, joint_vel=d.joint_vel, noise_u=noise_u,

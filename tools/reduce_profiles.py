@@ -5,6 +5,7 @@
 
 profiles/<tag>_bench_kernel_stats.csv  the --kernel-trace --stats table, as rocprofv3 wrote it
 profiles/<tag>_bench_line.json         the bench line of the same tree
+profiles/<tag>_sq_counters.json        per-kernel SQ counters per launch (busy cycles, waves, VALU / SALU / MFMA instructions)
 profiles/<tag>_hbm_traffic.json        per-kernel FETCH_SIZE / WRITE_SIZE per launch (KB; FETCH_SIZE doubled: gfx950 tallies its
                                        128-byte requests as 64 bytes) -> bytes that crossed the L2 <-> fabric boundary
 """
@@ -67,7 +68,7 @@ def main():
     if fetch and write:
         f = counter_per_launch(fetch[0], "FETCH_SIZE")
         w = counter_per_launch(write[0], "WRITE_SIZE")
-        out = {"command": "rocprofv3 --pmc FETCH_SIZE -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline  (and a separate pass "
+        out = {"command": "rocprofv3 --pmc FETCH_SIZE -- python3 bench.py --eager --steps 3 --warmup 1 --no-cpu-baseline  (and a separate pass "
                           "with --pmc WRITE_SIZE)",
                "correction": "FETCH_SIZE doubled (gfx950 tallies 128-byte requests at 64 bytes); counts L2 fabric-side requests, "
                              "Infinity Cache hits included",
@@ -78,6 +79,17 @@ def main():
             out["kernels"][k] = {"FETCH_SIZE_KB_per_launch": round(2.0 * fk, 1), "launches_sampled": n,
                                  "WRITE_SIZE_KB_per_launch": round(wk, 1), "hbm_bytes_per_launch": int((2.0 * fk + wk) * 1024)}
         json.dump(out, open(os.path.join(dst, f"{tag}_hbm_traffic.json"), "w"), indent=1)
+    sq = glob.glob(os.path.join(src, "pmc_sq", "**", "*counter_collection.csv"), recursive=True)
+    if sq:
+        rows = list(csv.DictReader(open(sq[0])))
+        names = sorted({r["Counter_Name"] for r in rows})
+        out = {"command": "rocprofv3 --pmc " + " ".join(names) + " -- python3 bench.py --eager --steps 3 --warmup 1 --no-cpu-baseline",
+               "note": "per launch, summed over the shader engines as rocprofv3 reports them; full-size launches only", "envs": envs,
+               "kernels": {}}
+        for c in names:
+            for k, (v, n) in counter_per_launch(sq[0], c).items():
+                out["kernels"].setdefault(k, {"launches_sampled": n})[c] = round(v, 1)
+        json.dump(out, open(os.path.join(dst, f"{tag}_sq_counters.json"), "w"), indent=1)
     print("profiles written for", tag)
 
 
