@@ -125,7 +125,7 @@ def build_locomotion(device, envs, seed, robot="anymal_c", actuator="mlp", stati
     info = {"decimation": LV.DECIMATION, "joints": j, "bodies": b, "rays": r, "obs_dim": int(env.mdp.obs_dim),
             "terrain_triangles": int(env.scanner.meshes["/World/ground"].num_triangles)}
     if robot == "anymal_c":
-        info["actuator"] = ("ActuatorNetMLP 6-32-32-32-1 softsign (fp32 MFMA)" if actuator == "mlp" else
+        info["actuator"] = ("ActuatorNetMLP 6-32-32-32-1 softsign (f32 first layer, hidden layers as split-f16 MFMA)" if actuator == "mlp" else
                             "ActuatorNetLSTM LSTM(2, 8, 2 layers) + 8-32-1 softsign head")
     else:
         info["actuator"] = "DCMotor (PD + torque-speed envelope)"
