@@ -45,10 +45,10 @@ def _locomotion_bytes(j, b, r, obs_dim, n_rewards, actuator):
         # (ring) + head 8, read+write 4 timers, clock 18; joint_acc: read vel, read+write previous vel, write acc;
         # scanner clock 18
         "scene_update": 3 * 12 * b + 8 + 8 * 4 * b + 18 + 4 * f + 18,
-        # read pose 28 + clock 9, write pose 28, ray hits R*12, clock 5
-        "raycaster_refresh": 28 + 9 + 28 + r * 12 + 5,
+        # read pose 28 + clock 9, write pose 28, ray hits R*12, height scan R*4, clock 5
+        "raycaster_refresh": 28 + 9 + 28 + r * 12 + r * 4 + 5,
         # read root 52, joints (pos, vel, acc, torque, default) 5f, actions 2f, contact history 3*B*12, timers 2*4B,
-        # ray hit z 4R, sensor pos 12, command state r+w ~82, ep_len r+w 16 (noise: parity mode only, not counted);
+        # height scan 4R, sensor pos 12, command state r+w ~82, ep_len r+w 16 (noise: parity mode only, not counted);
         # write obs, reward 4, step_reward, episode sums r+w, flags 5
         "mdp_step": 52 + 5 * f + 2 * f + 36 * b + 8 * b + 4 * r + 12 + 82 + 16 + 4 * obs_dim + 4 + 4 * n_rewards + 8 * n_rewards + 5,
         # read raw, write action + previous action, read default, write target
@@ -107,7 +107,7 @@ def build_locomotion(device, envs, seed, robot="anymal_c", actuator="mlp", stati
 
     def rays():
         env.scanner._is_outdated.fill_(True)   # every env is due, as once per env step
-        env.scanner._update_outdated_buffers()
+        env.scanner._update_outdated_buffers(height_out=env.height_scan, height_offset=env.height_scan_offset)
 
     def rays_overhead():
         env.scanner._is_outdated.fill_(True)

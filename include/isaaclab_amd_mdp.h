@@ -224,6 +224,11 @@ typedef struct ilx_mdp {
      * graph replays its arguments; with the step count kept in device memory (and advanced by the caller between
      * replays, e.g. by a one-element add recorded in the same graph) every replay still draws fresh numbers. */
     const uint64_t* step_index_device;
+    /* (n, num_rays) or NULL: the height scan as ilx_raycaster_refresh writes it (`height_scan` there, computed with
+     * `height_offset` = the observation term's offset): sensor height - hit height - offset.  When given, the
+     * height_scan observation columns are read from it instead of being formed from ray_hits_w / sensor_pos_w -- the
+     * same float operations, a third of the bytes (the hits are 12-byte records of which the term needs one word). */
+    const float* height_scan;
 } ilx_mdp;
 
 /* Opaque prepared plan: term tables and id lists copied to the device once. */

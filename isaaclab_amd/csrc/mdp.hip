@@ -832,7 +832,8 @@ __global__ void __launch_bounds__(kBlock, 4) mdp_step_kernel(MdpDev args) {
         const ilx_term* oterms = terms + NT + NR;
         const int32_t* ltab = reinterpret_cast<const int32_t*>(&m.L);   // the layout, as words
         const ColDesc* cdesc = reinterpret_cast<const ColDesc*>(S + L.coldesc);
-        const auto* hits = as_global(d.ray_hits_w);
+        const bool dense_scan = d.height_scan != nullptr;  // the ray caster's own height scan: value as it is
+        const auto* hits = as_global(dense_scan ? d.height_scan : d.ray_hits_w);
         const auto* noise_in = as_global(d.noise_u);
         const int R = d.num_rays;
         const bool generate = !d.noise_u;
@@ -867,7 +868,7 @@ __global__ void __launch_bounds__(kBlock, 4) mdp_step_kernel(MdpDev args) {
                 c_lo[c] = th.p2, c_hi[c] = th.p3;
                 scl[c] = (flags & ILX_OBS_FLAG_SCALE) ? th.weight : 1.0f;
                 hgt[c] = th.aux;
-                zoff[c] = (what[c] & 255u) == kColScan ? 3u * cd[c].src + 2u : 2u;
+                zoff[c] = (what[c] & 255u) == kColScan ? (dense_scan ? cd[c].src : 3u * cd[c].src + 2u) : 0u;
             }
             const bool any_noise = all_flags & ILX_OBS_FLAG_NOISE, any_scan = all_modes & kColScan;
             ILX_STAMP(11)
@@ -877,7 +878,7 @@ __global__ void __launch_bounds__(kBlock, 4) mdp_step_kernel(MdpDev args) {
                 // values from memory (ray hits, injected noise) are requested first; the generator call hides their latency
                 float zv[4] = {0.0f, 0.0f, 0.0f, 0.0f}, u[4] = {0.0f, 0.0f, 0.0f, 0.0f};
                 if (any_scan) {
-                    const auto* env_hits = hits + 3 * (oenv * R);
+                    const auto* env_hits = hits + (dense_scan ? 1 : 3) * (oenv * R);
 #pragma unroll
                     for (int c = 0; c < 4; ++c) zv[c] = env_hits[zoff[c]];  // columns of other kinds read the first ray (unused)
                 }
@@ -900,7 +901,7 @@ __global__ void __launch_bounds__(kBlock, 4) mdp_step_kernel(MdpDev args) {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     const uint32_t mode = what[c] & 255u, flags = what[c] >> 16;
-                    float v = mode == kColScan ? sensor_height - zv[c] - hgt[c] : val[c];        // observations.py:165-173
+                    float v = mode == kColScan ? (dense_scan ? zv[c] : sensor_height - zv[c] - hgt[c]) : val[c];  // observations.py:165-173
                     v = v + u[c] * n_rng[c] + n_off[c];                                          // noise_model.py:63-64
                     v = (flags & ILX_OBS_FLAG_CLIP) ? fminf(fmaxf(v, c_lo[c]), c_hi[c]) : v;     // observation_manager.py:315-316
                     v = v * scl[c];                                                              // :317-318
@@ -1214,7 +1215,8 @@ extern "C" int ilx_mdp_step(ilx_mdp_plan_t plan, const ilx_mdp* desc, void* stre
     }
     if (d.phases & ILX_PHASE_OBSERVATION) {
         ILX_REQUIRE(!plan->o_joint || joints, ILX_EINVAL, "ilx_mdp_step: an observation term needs the joint state arrays");
-        ILX_REQUIRE(!plan->o_rays || (d.ray_hits_w && d.sensor_pos_w), ILX_EINVAL, "ilx_mdp_step: height_scan needs ray_hits_w and sensor_pos_w");
+        ILX_REQUIRE(!plan->o_rays || d.height_scan || (d.ray_hits_w && d.sensor_pos_w), ILX_EINVAL,
+                    "ilx_mdp_step: height_scan needs ray_hits_w and sensor_pos_w, or the ray caster's height_scan");
         for (int slot = 0; slot < ILX_MAX_EXTERNAL_OBS; ++slot)
             ILX_REQUIRE(!(plan->o_external & (1u << slot)) || d.external_obs[slot], ILX_EINVAL,
                         "ilx_mdp_step: external observation buffer %d is NULL", slot);

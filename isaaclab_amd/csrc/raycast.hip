@@ -95,6 +95,10 @@ struct MeshDev {
     const float* lat_lines;
     const uint32_t* lat_mask;
     int32_t num_patches;
+    // patch finder: kPatchBins x kPatchBins bins over the union of the patch extents, up to four patches that overlap a
+    // bin (-1: none; -2 in the first entry: more than four, search them all)
+    const short4* patch_bins;
+    float pb_x0, pb_y0, pb_inv_x, pb_inv_y;
     unsigned long long* lat_served;  // diagnostics: rays served from the height grid are counted here (null: not counted)
 };
 
@@ -582,6 +586,8 @@ ILX_DEV float wave_max(float v) {
 //   pos_w / quat_w of RayCasterData, the sensor clocks (sensor_base.py:284-293), the yaw quaternion, the rectangle
 //   that the rotated scan pattern covers, the patch that holds it and the window of lattice lines -> LatEnvRec.
 // The pattern's xy box is reduced by every workgroup for itself (a few loads per thread).
+constexpr int kPatchBins = 64;
+
 __global__ void __launch_bounds__(256) raycaster_prepare_kernel(ScanArgs a, LatEnvRec* __restrict__ recs, float4* __restrict__ pattern) {
     __shared__ float box_s[4][4];
     const float inf = __builtin_inff();
@@ -648,12 +654,21 @@ __global__ void __launch_bounds__(256) raycaster_prepare_kernel(ScanArgs a, LatE
             // the patch whose extent holds the rectangle (any such patch will do: where patches overlap, the cells are
             // not simple)
             int sel = -1;
-            for (int p = 0; p < a.mesh.num_patches; ++p) {
+            auto holds = [&](int p) {
                 const float4 ext = *reinterpret_cast<const float4*>(&a.mesh.patches[p].x0);  // x0, y0, x1, y1
-                if (mnx >= ext.x && mxx <= ext.z && mny >= ext.y && mxy <= ext.w) {
-                    sel = p;
-                    break;
-                }
+                return mnx >= ext.x && mxx <= ext.z && mny >= ext.y && mxy <= ext.w;
+            };
+            // a patch that holds the rectangle overlaps the bin of its centre: at most four candidates, tested together
+            const int bx = max(0, min(kPatchBins - 1, static_cast<int>((0.5f * (mnx + mxx) - a.mesh.pb_x0) * a.mesh.pb_inv_x)));
+            const int by = max(0, min(kPatchBins - 1, static_cast<int>((0.5f * (mny + mxy) - a.mesh.pb_y0) * a.mesh.pb_inv_y)));
+            const short4 cand = a.mesh.patch_bins[by * kPatchBins + bx];
+            if (cand.x == -2) {
+                for (int p = 0; p < a.mesh.num_patches && sel < 0; ++p)
+                    if (holds(p)) sel = p;
+            } else {
+                const bool h0 = cand.x >= 0 && holds(max(0, static_cast<int>(cand.x))), h1 = cand.y >= 0 && holds(max(0, static_cast<int>(cand.y))),
+                           h2 = cand.z >= 0 && holds(max(0, static_cast<int>(cand.z))), h3 = cand.w >= 0 && holds(max(0, static_cast<int>(cand.w)));
+                sel = h0 ? cand.x : h1 ? cand.y : h2 ? cand.z : h3 ? cand.w : -1;
             }
             if (sel >= 0) {
                 const LatticePatch P = a.mesh.patches[sel];
@@ -993,6 +1008,7 @@ struct MeshHost {
     float4* d_col_verts = nullptr;
     GridStats grid{};
     LatticePatch* d_patches = nullptr;
+    short4* d_patch_bins = nullptr;
     float* d_lat_z = nullptr;
     float* d_lat_lines = nullptr;
     uint32_t* d_lat_mask = nullptr;
@@ -1422,8 +1438,43 @@ extern "C" int ilx_mesh_create(const float* verts_host, int64_t num_verts, const
         if (rc == ILX_OK) rc = upload(&h.d_col_tris, col_tris, "column triangles");
         if (rc == ILX_OK) rc = upload(&h.d_col_verts, col_verts, "column vertices");
     }
+    // patch finder of the sensor refresh (see MeshDev::patch_bins)
+    std::vector<short4> patch_bins;
+    float pb[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (!lat.patches.empty() && lat.patches.size() < 32768) {
+        float ux0 = lat.patches[0].x0, uy0 = lat.patches[0].y0, ux1 = lat.patches[0].x1, uy1 = lat.patches[0].y1;
+        for (const LatticePatch& P : lat.patches)
+            ux0 = std::min(ux0, P.x0), uy0 = std::min(uy0, P.y0), ux1 = std::max(ux1, P.x1), uy1 = std::max(uy1, P.y1);
+        pb[0] = ux0, pb[1] = uy0;
+        pb[2] = ux1 > ux0 ? kPatchBins / (ux1 - ux0) : 0.0f, pb[3] = uy1 > uy0 ? kPatchBins / (uy1 - uy0) : 0.0f;
+        patch_bins.assign(kPatchBins * kPatchBins, short4{-1, -1, -1, -1});
+        std::vector<int> fill(kPatchBins * kPatchBins, 0);
+        // the kernel's own bin arithmetic, widened by one bin for its rounding
+        auto bin_of = [&](float v, int axis) {
+            return std::max(0, std::min(kPatchBins - 1, static_cast<int>((v - pb[axis]) * pb[2 + axis])));
+        };
+        for (size_t p = 0; p < lat.patches.size(); ++p) {
+            const LatticePatch& P = lat.patches[p];
+            for (int by = std::max(0, bin_of(P.y0, 1) - 1); by <= std::min(kPatchBins - 1, bin_of(P.y1, 1) + 1); ++by)
+                for (int bx = std::max(0, bin_of(P.x0, 0) - 1); bx <= std::min(kPatchBins - 1, bin_of(P.x1, 0) + 1); ++bx) {
+                    short4& b = patch_bins[by * kPatchBins + bx];
+                    int& n = fill[by * kPatchBins + bx];
+                    const short id = static_cast<short>(p);
+                    if (n == 0) b.x = id;
+                    else if (n == 1) b.y = id;
+                    else if (n == 2) b.z = id;
+                    else if (n == 3) b.w = id;
+                    ++n;
+                }
+        }
+        for (int i = 0; i < kPatchBins * kPatchBins; ++i)
+            if (fill[i] > 4) patch_bins[i] = short4{-2, -1, -1, -1};
+    } else if (!lat.patches.empty()) {
+        patch_bins.assign(kPatchBins * kPatchBins, short4{-2, -1, -1, -1});
+    }
     if (rc == ILX_OK && !lat.patches.empty()) {
         rc = upload(&h.d_patches, lat.patches, "lattice patches");
+        if (rc == ILX_OK) rc = upload(&h.d_patch_bins, patch_bins, "lattice patch finder");
         if (rc == ILX_OK) rc = upload(&h.d_lat_z, lat.z, "lattice heights");
         if (rc == ILX_OK) rc = upload(&h.d_lat_lines, lat.lines, "lattice lines");
         if (rc == ILX_OK) rc = upload(&h.d_lat_mask, lat.mask, "lattice cell bits");
@@ -1445,6 +1496,7 @@ extern "C" int ilx_mesh_create(const float* verts_host, int64_t num_verts, const
         if (h.d_col_tris) (void)hipFree(h.d_col_tris);
         if (h.d_col_verts) (void)hipFree(h.d_col_verts);
         if (h.d_patches) (void)hipFree(h.d_patches);
+        if (h.d_patch_bins) (void)hipFree(h.d_patch_bins);
         if (h.d_lat_z) (void)hipFree(h.d_lat_z);
         if (h.d_lat_lines) (void)hipFree(h.d_lat_lines);
         if (h.d_lat_mask) (void)hipFree(h.d_lat_mask);
@@ -1458,6 +1510,7 @@ extern "C" int ilx_mesh_create(const float* verts_host, int64_t num_verts, const
     h.dev.nx = gnx, h.dev.ny = gny, h.dev.ntx = ntx;
     h.dev.patches = h.d_patches, h.dev.lat_z = h.d_lat_z, h.dev.lat_lines = h.d_lat_lines, h.dev.lat_mask = h.d_lat_mask;
     h.dev.num_patches = h.d_patches ? static_cast<int32_t>(lat.patches.size()) : 0;
+    h.dev.patch_bins = h.d_patch_bins, h.dev.pb_x0 = pb[0], h.dev.pb_y0 = pb[1], h.dev.pb_inv_x = pb[2], h.dev.pb_inv_y = pb[3];
     h.lat_cells = lat.cells, h.lat_simple = lat.simple, h.lat_faces = lat.faces;
     h.grid = gstats;
     h.depth = bld.max_depth, h.num_verts = num_verts;
@@ -1476,6 +1529,7 @@ extern "C" void ilx_mesh_destroy(ilx_mesh_t mesh) {
     if (mesh->h.d_col_tris) (void)hipFree(mesh->h.d_col_tris);
     if (mesh->h.d_col_verts) (void)hipFree(mesh->h.d_col_verts);
     if (mesh->h.d_patches) (void)hipFree(mesh->h.d_patches);
+    if (mesh->h.d_patch_bins) (void)hipFree(mesh->h.d_patch_bins);
     if (mesh->h.d_lat_z) (void)hipFree(mesh->h.d_lat_z);
     if (mesh->h.d_lat_lines) (void)hipFree(mesh->h.d_lat_lines);
     if (mesh->h.d_lat_mask) (void)hipFree(mesh->h.d_lat_mask);

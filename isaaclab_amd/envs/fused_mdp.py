@@ -75,7 +75,7 @@ class MdpDesc(ctypes.Structure):
         ("ids", POINTER(c_int32)), ("num_ids", c_int32),
         ("log_sums", c_void_p), ("seed", c_uint64), ("step_index", c_uint64), ("phases", c_int32),
         ("external_obs", c_void_p * 4), ("external_obs_dim", c_int32 * 4),
-        ("step_index_device", c_void_p),
+        ("step_index_device", c_void_p), ("height_scan", c_void_p),
     ]
 
 

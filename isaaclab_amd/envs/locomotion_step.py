@@ -94,6 +94,9 @@ class LocomotionVelocityStep:
                                num_rays=self.scanner.num_rays, action_dim=j, command_dim=3, step_dt=LV.STEP_DT,
                                max_episode_length=LV.MAX_EPISODE_LENGTH,
                                command=LV.H1_VELOCITY_COMMAND if robot == "h1" else LV.VELOCITY_COMMAND, seed=seed, **terms)
+        # the height_scan observation term's input, written by the scanner refresh with the term's offset
+        self.height_scan = torch.zeros(n, self.scanner.num_rays, device=dev)
+        self.height_scan_offset = next(float(t.aux) for t in self.mdp.observations if t.kind == "height_scan")
         self._bind()
         # see step(): worth it when the step is replayed from a HIP graph and the actuator chain is long (network
         # actuators); issued launch by launch, the fork and join cost the host more than the overlap returns
@@ -109,7 +112,8 @@ class LocomotionVelocityStep:
                       net_forces_w_history=c.net_forces_w_history, current_air_time=c.current_air_time,
                       last_air_time=c.last_air_time, current_contact_time=c.current_contact_time,
                       last_contact_time=c.last_contact_time, ray_hits_w=self.scanner._data.ray_hits_w,
-                      sensor_pos_w=self.scanner._data.pos_w, action=self.action, prev_action=self.prev_action)
+                      sensor_pos_w=self.scanner._data.pos_w, action=self.action, prev_action=self.prev_action,
+                      height_scan=self.height_scan)
 
     def load_state(self, s: dict):
         """Install persistent buffers from :func:`isaaclab_amd.synth.locomotion_state` (host tensors)."""
@@ -165,7 +169,8 @@ class LocomotionVelocityStep:
             else:  # strided views of the body's rows: the kernel reads them in place
                 pose = d.body_state_w[:, self.scanner_body]
                 self.scanner.set_pose(pose[:, :3], pose[:, 3:7])
-            self.scanner._update_outdated_buffers()
+            # the refresh also writes the height scan the observation term reads (sensor height - hit height - offset)
+            self.scanner._update_outdated_buffers(height_out=self.height_scan, height_offset=self.height_scan_offset)
         # -- process_action (manager_based_rl_env.py:172)
         _abi.check(_abi.joint_action_process(_abi.ptr(raw_action), _abi.ptr(self.action), _abi.ptr(self.prev_action), None,
                                              self.action_scale, _abi.ptr(d.default_joint_pos), 0.0, None,
