@@ -159,3 +159,41 @@ def test_anymal_step_at_benchmark_size(dev):
         done = (terminated | time_outs).cpu()
         assert env.mdp.log_sums.cpu()[-1].item() == int(done.sum()) > 0
         env.mdp.log_sums.zero_()
+
+
+def test_step_replayed_from_a_graph_equals_eager(dev):
+    """The step recorded in a HIP graph -- the sensor chain as a branch beside the actuator chain, the generator's step
+    count kept on the device -- and replayed three times gives, bit for bit, what three eager steps of an identical env
+    give: same launches, same arguments, fresh random numbers at every replay."""
+    n = 1024
+    outs = []
+    for graph in (False, True):
+        env, _, state = build(dev, n, seed=31)
+        raw = state["raw_action"].to(dev)
+        env.mdp.count_steps_on_device()      # both envs draw with the same (seed, step) keys
+        env.concurrent_chains = graph
+        env.step(raw)                        # first step eagerly in both: per-stream workspaces come into being here
+        steps = []
+        if graph:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=side):
+                env.step(raw)
+            for _ in range(3):
+                g.replay()
+                torch.cuda.synchronize()
+                steps.append([t.clone() for t in (env.mdp.obs, env.mdp.reward_buf, env.mdp.terminated, env.mdp.command,
+                                                  env.contact.ordered_history(), env.actuator._joint_vel_history)])
+        else:
+            for _ in range(3):
+                env.step(raw)
+                torch.cuda.synchronize()
+                steps.append([t.clone() for t in (env.mdp.obs, env.mdp.reward_buf, env.mdp.terminated, env.mdp.command,
+                                                  env.contact.ordered_history(), env.actuator._joint_vel_history)])
+        outs.append(steps)
+    names = ("obs", "reward", "terminated", "command", "contact history", "velocity history")
+    for k in range(3):
+        for name, a, b in zip(names, outs[0][k], outs[1][k]):
+            assert_exact(b, a, f"{name}, step {k}: graph replay vs eager")
+    assert not torch.equal(outs[1][0][0], outs[1][1][0]), "a replay draws new observation noise"
