@@ -404,6 +404,19 @@ struct CmdState {
     float c[7] = {0, 0, 0, 0, 0, 0, 0};
 };
 
+// A term record as wave-uniform values.  The record's LDS address is the same in every lane, but a plain copy lands in
+// vector registers and the compiler then treats `kind`, the id ranges and the parameters as per-lane data: the dispatch
+// on `kind` becomes thirty exec-masked compare-and-skip blocks and every loop bound a vector compare.  Through
+// readfirstlane the record sits in scalar registers: one scalar branch tree, scalar loop control.
+ILX_DEV ilx_term uniform_term(const ilx_term* src) {
+    ilx_term t;
+    const int32_t* in = reinterpret_cast<const int32_t*>(src);
+    int32_t* out = reinterpret_cast<int32_t*>(&t);
+#pragma unroll
+    for (int w = 0; w < static_cast<int>(sizeof(ilx_term) / 4); ++w) out[w] = __builtin_amdgcn_readfirstlane(in[w]);
+    return t;
+}
+
 // The seven samples a resampling env consumes: injected values, or two generator calls mapped to the term's ranges
 // (the two coin flips of the velocity term stay in [0, 1)).
 ILX_DEV void command_draws(const ilx_mdp& d, uint64_t step, const float* injected, int64_t env, uint32_t salt, float (&smp)[7]) {
@@ -527,7 +540,7 @@ __global__ void __launch_bounds__(kBlock, 4) mdp_step_kernel(MdpDev args) {
     ILX_STAMP(0)
     // ================= STAGE =================
     const bool sa = m.need & kNeedAction, spa = sa && d.prev_action;
-    const int wave = tid >> 6, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     uint4 my_segs = {0u, 0u, 0u, 0u};
     if (wave + kWaves * lane < m.num_segs) my_segs = m.segs[wave + kWaves * lane];
     const bool decide = lane < ne;
@@ -651,7 +664,7 @@ __global__ void __launch_bounds__(kBlock, 4) mdp_step_kernel(MdpDev args) {
         if (ph_term) {
             ep_len += 1;
             for (int i = 0; i < NT; ++i) {
-                const ilx_term t = terms[i];
+                const ilx_term t = uniform_term(terms + i);
                 const bool v = eval_termination(en, t, ep_len);
                 term_bits |= v ? (1u << i) : 0u;
                 if (t.flags & 1) time_out = time_out || v; else terminated = terminated || v;
@@ -662,7 +675,7 @@ __global__ void __launch_bounds__(kBlock, 4) mdp_step_kernel(MdpDev args) {
         if (ph_rew) {
             float partial = 0.0f;
             for (int i = wave; i < NR; i += kWaves) {
-                const ilx_term t = terms[NT + i];
+                const ilx_term t = uniform_term(terms + NT + i);
                 if (t.weight == 0.0f) continue;  // :145-146 (episode sums and step_reward keep their values)
                 const float value = eval_reward(en, t, terminated, time_out, term_bits) * t.weight * dt;
                 partial += value;
