@@ -90,6 +90,8 @@ def capture_step(cfg, reducer):
             cfg.bind_log_sums(reducer.buffer(i))
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph, stream=side):
+            if reducer is not None:
+                reducer.buffer(i).zero_()    # recorded: the vector starts every replay at zero
             cfg.step()
         graphs.append(graph)
     torch.cuda.synchronize()
@@ -195,7 +197,7 @@ def main():
         i = 0
         if reducer is not None:
             i = reducer.index
-            reducer.begin_step()
+            reducer.begin_step(zero=False)   # the graph zeroes the vector itself
         graphs[i].replay()
         if reducer is not None:
             reducer.end_step()

@@ -220,16 +220,21 @@ typedef struct ilx_mdp {
     /* buffers read by ILX_OBS_EXTERNAL terms: slot s is (n, external_obs_dim[s]) float32, dense */
     const float* external_obs[ILX_MAX_EXTERNAL_OBS];
     int32_t external_obs_dim[ILX_MAX_EXTERNAL_OBS];
-    /* generator, continued: when not NULL, one device word that is added to step_index.  A launch recorded in a HIP
-     * graph replays its arguments; with the step count kept in device memory (and advanced by the caller between
-     * replays, e.g. by a one-element add recorded in the same graph) every replay still draws fresh numbers. */
-    const uint64_t* step_index_device;
+    /* generator, continued: when not NULL, a device counter that makes the step word advance without the host: an array
+     * of ILX_MDP_STEP_COUNTER_WORDS uint64 (zero it at set-up; the count is spread over 64 words on cache lines of their
+     * own so that the blocks' additions do not queue on one address).  Every block of a launch adds one when it is done,
+     * and the launch draws with step_index + (sum of the array) / blocks, blocks = ceil(num_envs / 16) -- constant over
+     * a launch, one more at the next.  A launch recorded in a HIP graph replays its arguments; with the count in
+     * device memory every replay still draws fresh numbers.  Keep num_envs fixed while a counter is in use. */
+    uint64_t* step_index_device;
     /* (n, num_rays) or NULL: the height scan as ilx_raycaster_refresh writes it (`height_scan` there, computed with
      * `height_offset` = the observation term's offset): sensor height - hit height - offset.  When given, the
      * height_scan observation columns are read from it instead of being formed from ray_hits_w / sensor_pos_w -- the
      * same float operations, a third of the bytes (the hits are 12-byte records of which the term needs one word). */
     const float* height_scan;
 } ilx_mdp;
+
+#define ILX_MDP_STEP_COUNTER_WORDS 1024 /* 64 slots, 128 bytes apart */
 
 /* Opaque prepared plan: term tables and id lists copied to the device once. */
 typedef struct ilx_mdp_plan_s* ilx_mdp_plan_t;

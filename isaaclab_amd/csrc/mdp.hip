@@ -55,9 +55,10 @@ struct Layout {
     int coldesc;                                       // observation columns: one 16-byte ColDesc each
     int zero;                                          // one word of 0.0f (the subtrahend of columns that subtract nothing)
     int total;
+    int gstep;                                         // the generator's step word of this launch (two words)
 };
 constexpr int kDerived = 10;  // lin_b(3) ang_b(3) grav_b(3) sensor_z
-static_assert(sizeof(Layout) <= 32 * 4, "ColDesc names a Layout field with 5 bits");
+static_assert(offsetof(Layout, total) < 32 * 4, "ColDesc names a Layout field (all those before `total`) with 5 bits");
 
 // How the EMIT stage produces one observation column, prepared once per plan.  Almost every column is a word of the
 // block's LDS image (minus another one for the *_rel terms): `row` names the image row by its field in Layout, `k` the
@@ -534,8 +535,12 @@ __global__ void __launch_bounds__(kBlock, 4) mdp_step_kernel(MdpDev args) {
     const bool cmd_state = has_cmd_term && (d.phases & (ILX_PHASE_COMMAND | ILX_PHASE_RESET));
     const ilx_term* terms = reinterpret_cast<const ilx_term*>(S + L.terms);
     const int32_t* ids = reinterpret_cast<const int32_t*>(S + L.ids);
-    // the generator's step word: the argument, plus the caller's device-side count when there is one
-    const uint64_t gen_step = d.step_index + (d.step_index_device ? *as_global(d.step_index_device) : 0ull);
+    // The generator's step word: the argument, plus the caller's device-side count when there is one (finished blocks of
+    // all earlier launches / blocks per launch: every block of this launch reads the counter before the last one has
+    // added to it, so all of them see the same quotient).  One thread divides; the others read the word from LDS after
+    // the staging barrier.
+    uint64_t counted = 0;  // wave 0: this lane's slot of the counter (the load travels while the staging is issued)
+    if (threadIdx.x < 64 && d.step_index_device) counted = as_global(d.step_index_device)[16 * threadIdx.x];
 
     ILX_STAMP(0)
     // ================= STAGE =================
@@ -630,7 +635,19 @@ __global__ void __launch_bounds__(kBlock, 4) mdp_step_kernel(MdpDev args) {
         for (int i = tid + 2 * kBlock; i < ne * B; i += kBlock) S[L.bacc + i] = norm3(load3(d.body_lin_acc_w + 3 * (env0 * B + i)));
     }
     ILX_STAMP(1)
+    if (threadIdx.x < 64) {
+        uint32_t lo = static_cast<uint32_t>(counted), hi = static_cast<uint32_t>(counted >> 32);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {  // 64-bit sum over the wave
+            const uint32_t olo = __shfl_xor(lo, off, 64), ohi = __shfl_xor(hi, off, 64);
+            const uint64_t sum = ((static_cast<uint64_t>(hi) << 32) | lo) + ((static_cast<uint64_t>(ohi) << 32) | olo);
+            lo = static_cast<uint32_t>(sum), hi = static_cast<uint32_t>(sum >> 32);
+        }
+        if (threadIdx.x == 0)
+            *reinterpret_cast<uint64_t*>(S + L.gstep) = d.step_index + (((static_cast<uint64_t>(hi) << 32) | lo) / gridDim.x);
+    }
     __syncthreads();  // waits for this wave's copies (vmcnt(0)), then for every wave's
+    const uint64_t gen_step = *reinterpret_cast<const uint64_t*>(S + L.gstep);
     ILX_STAMP(2)
     if (m.need & kNeedForces) {  // max over the history of |F| per (env, body): rewards.py:266 / terminations.py:157
         const int H = d.history_len;
@@ -942,6 +959,9 @@ __global__ void __launch_bounds__(kBlock, 4) mdp_step_kernel(MdpDev args) {
         }
     }
     ILX_STAMP(10)
+    // the device-side count: one more finished block (no return value: nothing waits for it)
+    if (d.step_index_device && tid == 0)
+        __hip_atomic_fetch_add(as_global(d.step_index_device) + 16 * (blockIdx.x & 63), 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 }  // namespace ilx
@@ -1282,6 +1302,7 @@ extern "C" int ilx_mdp_step(ilx_mdp_plan_t plan, const ilx_mdp* desc, void* stre
     L.logp = take(plan->nr + plan->nt + 3);
     L.coldesc = take(po ? plan->obs_dim * static_cast<int>(sizeof(ColDesc) / 4) : 0);
     L.zero = take(1);
+    L.gstep = take(2);
     L.total = w;
     const size_t lds_bytes = static_cast<size_t>(w) * 4;
     ILX_REQUIRE(lds_bytes <= kMaxLdsBytes, ILX_ESHAPE,

@@ -74,13 +74,15 @@ class OverlappedLogReducer:
         """Which vector the step that begins next accumulates into."""
         return self._k & 1
 
-    def begin_step(self, want_totals: bool = False):
+    def begin_step(self, want_totals: bool = False, zero: bool = True):
+        """``zero=False``: the caller clears the vector itself (a step recorded in a HIP graph does it inside the graph)."""
         i = self._k & 1
         if self._works[i] is not None:
             self._works[i].wait()
             self._works[i] = None
         totals = self._bufs[i].clone() if want_totals and self._filled[i] else None
-        self._bufs[i].zero_()
+        if zero:
+            self._bufs[i].zero_()
         return self._bufs[i], totals
 
     def end_step(self):

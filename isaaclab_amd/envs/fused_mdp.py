@@ -267,16 +267,14 @@ class FusedMdp:
         elif not self._own_generator:
             self.desc.seed, self.desc.step_index = _rng.seed(), _rng.next_draw("fused_mdp")
         _abi.check(_abi.lib.ilx_mdp_step(self.plan, ctypes.byref(self.desc), _abi.stream()), "ilx_mdp_step")
-        if self._step_counter is not None:
-            self._step_counter.add_(1)          # a device operation: recorded with the launch when a graph is captured
-        else:
+        if self._step_counter is None:          # otherwise the launch has advanced the device-side count itself
             self.desc.step_index += 1
 
     def count_steps_on_device(self, enable: bool = True):
-        """Keep the generator's step count in device memory (advanced by a one-element add after every launch) instead
-        of on the host, so that a step recorded in a HIP graph draws fresh random numbers at every replay."""
+        """Keep the generator's step count in device memory (every launch advances it) instead of on the host, so that a
+        step recorded in a HIP graph draws fresh random numbers at every replay."""
         if enable and self._step_counter is None:
-            self._step_counter = torch.zeros(1, dtype=torch.int64, device=self.device)
+            self._step_counter = torch.zeros(1024, dtype=torch.int64, device=self.device)   # ILX_MDP_STEP_COUNTER_WORDS
             self.desc.step_index_device = self._step_counter.data_ptr()
         elif not enable:
             self._step_counter = None
