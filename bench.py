@@ -76,8 +76,9 @@ def capture_step(cfg, reducer):
     mdp = getattr(cfg.env, "mdp", None)
     if mdp is not None:
         mdp.count_steps_on_device()
-    if getattr(cfg, "overlap_in_graph", False):
-        cfg.env.concurrent_chains = True
+    overlap = getattr(cfg, "overlap_in_graph", False)
+    if overlap:
+        cfg.env.concurrent_chains = True   # the sensor chain as a branch beside the actuator chain
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
@@ -95,7 +96,7 @@ def capture_step(cfg, reducer):
             cfg.step()
         graphs.append(graph)
     torch.cuda.synchronize()
-    if getattr(cfg, "overlap_in_graph", False):
+    if overlap:
         cfg.env.concurrent_chains = False
     return graphs
 

@@ -129,6 +129,10 @@ typedef struct ilx_term {
 #define ILX_PHASE_COMMAND 8
 #define ILX_PHASE_OBSERVATION 16
 #define ILX_PHASE_ALL 31
+/* Not a phase: with a device-side step count (step_index_device below), this launch draws with the count as it is and
+ * leaves it there.  An env step issued as several launches sets it on all but the last, so that every launch of the
+ * step draws with the same step word and the count still advances once per env step. */
+#define ILX_PHASE_HOLD_STEP_COUNT 256
 
 typedef struct ilx_mdp {
     /* sizes */

@@ -95,9 +95,51 @@ struct alignas(16) MdpDev {
     uint4 segs[kMaxSegs];
 };
 
+// A value that is the same in every lane, moved into scalar registers.  What the kernel reads from its LDS copy of the
+// arguments is such a value, but the compiler cannot know: left alone it keeps the value in a vector register, or reads
+// it again (one LDS load and one wait) wherever it is used, since nothing says that this part of LDS never changes.
+ILX_DEV int32_t uni(int32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+ILX_DEV uint32_t uni(uint32_t v) { return static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int32_t>(v))); }
+ILX_DEV float uni(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int32_t, v))); }
+ILX_DEV uint64_t uni(uint64_t v) {
+    return (static_cast<uint64_t>(uni(static_cast<uint32_t>(v >> 32))) << 32) | uni(static_cast<uint32_t>(v));
+}
+ILX_DEV int64_t uni(int64_t v) { return static_cast<int64_t>(uni(static_cast<uint64_t>(v))); }
+template <typename T>
+ILX_DEV __attribute__((address_space(1))) T* uni(T* p) {  // ... and a pointer, as a global-memory one
+    return (__attribute__((address_space(1))) T*)uni(reinterpret_cast<uint64_t>(p));
+}
+
+// Element access as a uniform 64-bit base (scalar registers, advanced to the block's first env with scalar arithmetic)
+// plus a 32-bit per-lane byte offset: the address costs no vector instruction beyond forming the offset.
+template <typename T>
+ILX_DEV T ld_at(const __attribute__((address_space(1))) T* base, uint32_t byte_off) {
+    return *reinterpret_cast<const __attribute__((address_space(1))) T*>(
+        reinterpret_cast<const __attribute__((address_space(1))) char*>(base) + byte_off);
+}
+template <typename T, typename V>
+ILX_DEV void st_at(__attribute__((address_space(1))) T* base, uint32_t byte_off, V v) {
+    *reinterpret_cast<__attribute__((address_space(1))) T*>(reinterpret_cast<__attribute__((address_space(1))) char*>(base) + byte_off) =
+        static_cast<T>(v);
+}
+
+// The layout and the descriptor's most used scalars: a second, small kernel argument that the kernel reads in place (a
+// few scalar loads at its start, straight into scalar registers).
+struct Hot {
+    Layout L;
+    int num_joints, num_bodies, num_sensor_bodies, command_dim, action_dim, num_rays, command_kind;
+    int num_terminations, num_rewards, obs_dim, history_len, num_segs;
+    uint32_t phases, need, inv_sensor_bodies, inv_rewards;
+    float step_dt, gravity[3];
+    int64_t num_envs;
+    uint64_t seed, step_index;
+    const ilx_term* terms;  // the plan's table in device memory: [terminations | rewards | observations]
+};
+
 // One environment as seen by its lane in the DECIDE stage.
 struct Env {
     const MdpDev& m;
+    const Hot& h;
     const float* S;      // LDS image
     const int32_t* ids;  // LDS copy of the index lists
     int e;               // env slot in the block
@@ -110,13 +152,13 @@ struct Env {
 
     ILX_DEV int id(const ilx_term& t, int k) const { return t.ids_cnt < 0 ? k : ids[t.ids_off + k]; }
     ILX_DEV int id2(const ilx_term& t, int k) const { return t.ids2_cnt < 0 ? k : ids[t.ids2_off + k]; }
-    ILX_DEV int jcount(const ilx_term& t) const { return t.ids_cnt < 0 ? m.d.num_joints : t.ids_cnt; }
-    ILX_DEV int bcount_sensor(const ilx_term& t) const { return t.ids_cnt < 0 ? m.d.num_sensor_bodies : t.ids_cnt; }
-    ILX_DEV int bcount_asset(const ilx_term& t) const { return t.ids_cnt < 0 ? m.d.num_bodies : t.ids_cnt; }
-    ILX_DEV float joint(int off, int j) const { return S[off + e * m.d.num_joints + j]; }
-    ILX_DEV float sbody(int off, int b) const { return S[off + e * m.d.num_sensor_bodies + b]; }
-    ILX_DEV float abody(int off, int b) const { return S[off + e * m.d.num_bodies + b]; }
-    ILX_DEV float cmd(int k) const { return S[m.L.cmd + e * m.d.command_dim + k]; }
+    ILX_DEV int jcount(const ilx_term& t) const { return t.ids_cnt < 0 ? h.num_joints : t.ids_cnt; }
+    ILX_DEV int bcount_sensor(const ilx_term& t) const { return t.ids_cnt < 0 ? h.num_sensor_bodies : t.ids_cnt; }
+    ILX_DEV int bcount_asset(const ilx_term& t) const { return t.ids_cnt < 0 ? h.num_bodies : t.ids_cnt; }
+    ILX_DEV float joint(int off, int j) const { return S[off + e * h.num_joints + j]; }
+    ILX_DEV float sbody(int off, int b) const { return S[off + e * h.num_sensor_bodies + b]; }
+    ILX_DEV float abody(int off, int b) const { return S[off + e * h.num_bodies + b]; }
+    ILX_DEV float cmd(int k) const { return S[h.L.cmd + e * h.command_dim + k]; }
     template <typename F>
     ILX_DEV float joint_sum(const ilx_term& t, F f) const {
         const int n = jcount(t);
@@ -145,7 +187,7 @@ struct Env {
 // --------------------------------------------------------------------------------------------------
 ILX_DEV bool eval_termination(const Env& e, const ilx_term& t, int64_t ep_len) {
     const ilx_mdp& d = e.m.d;
-    const Layout& L = e.m.L;
+    const Layout& L = e.h.L;
     switch (t.kind) {
         case ILX_TERM_TIME_OUT:  // terminations.py:30-32
             return ep_len >= d.max_episode_length;
@@ -178,8 +220,8 @@ ILX_DEV bool eval_termination(const Env& e, const ilx_term& t, int64_t ep_len) {
 
 ILX_DEV float eval_reward(const Env& e, const ilx_term& t, bool terminated, bool time_out, uint32_t term_bits) {
     const ilx_mdp& d = e.m.d;
-    const Layout& L = e.m.L;
-    const int B = d.num_bodies, A = d.action_dim;
+    const Layout& L = e.h.L;
+    const int B = e.h.num_bodies, A = e.h.action_dim, R = e.h.num_rays;
     switch (t.kind) {
         case ILX_REW_IS_ALIVE: return terminated ? 0.0f : 1.0f;       // rewards.py:31-33
         case ILX_REW_IS_TERMINATED: return terminated ? 1.0f : 0.0f;  // :36-38
@@ -192,8 +234,8 @@ ILX_DEV float eval_reward(const Env& e, const ilx_term& t, bool terminated, bool
             float target = t.p[0];
             if (t.flags & 1) {
                 float acc = 0.0f;
-                for (int k = 0; k < d.num_rays; ++k) acc += d.ray_hits_w[3 * (e.env * d.num_rays + k) + 2];
-                target = t.p[0] + div_(acc, static_cast<float>(d.num_rays));
+                for (int k = 0; k < R; ++k) acc += d.ray_hits_w[3 * (e.env * R + k) + 2];
+                target = t.p[0] + div_(acc, static_cast<float>(R));
             }
             const float dz = e.pos.z - target;
             return dz * dz;
@@ -217,7 +259,7 @@ ILX_DEV float eval_reward(const Env& e, const ilx_term& t, bool terminated, bool
         case ILX_REW_JOINT_POS_LIMITS:  // :182-196
             return e.joint_sum(t, [&](int j) {
                 const float q = e.joint(L.q, j);
-                const float lo = e.S[L.lim + 2 * (e.e * d.num_joints + j)], hi = e.S[L.lim + 2 * (e.e * d.num_joints + j) + 1];
+                const float lo = e.S[L.lim + 2 * (e.e * e.h.num_joints + j)], hi = e.S[L.lim + 2 * (e.e * e.h.num_joints + j) + 1];
                 return -fminf(q - lo, 0.0f) + fmaxf(q - hi, 0.0f);
             });
         case ILX_REW_JOINT_VEL_LIMITS:  // :199-218
@@ -350,10 +392,10 @@ ILX_DEV int obs_dim_of(const ilx_mdp& d, const ilx_term& t) {
 }
 
 // Column k of an observation term for env slot e (EMIT stage; everything except the height scan comes from LDS).
-ILX_DEV float eval_obs(const MdpDev& m, const float* S, const int32_t* ids, int e, int64_t env, const ilx_term& t, int k) {
+ILX_DEV float eval_obs(const MdpDev& m, const Hot& h, const float* S, const int32_t* ids, int e, int64_t env, const ilx_term& t, int k) {
     const ilx_mdp& d = m.d;
-    const Layout& L = m.L;
-    const int J = d.num_joints;
+    const Layout& L = h.L;
+    const int J = h.num_joints;
     const float* root = S + L.root + 13 * e;
     const float* der = S + L.derived + kDerived * e;
     auto jid = [&](int kk) { return e * J + (t.ids_cnt < 0 ? kk : ids[t.ids_off + kk]); };
@@ -386,9 +428,9 @@ ILX_DEV float eval_obs(const MdpDev& m, const float* S, const int32_t* ids, int 
             return S[L.qd + i] - S[L.qd0 + i];
         }
         case ILX_OBS_HEIGHT_SCAN:  // :165-173
-            return der[9] - d.ray_hits_w[3 * (env * d.num_rays + k) + 2] - t.aux;
-        case ILX_OBS_LAST_ACTION: return S[L.act + e * d.action_dim + k];          // :512-521
-        case ILX_OBS_GENERATED_COMMANDS: return S[L.cmd + e * d.command_dim + k];  // :529-531
+            return der[9] - d.ray_hits_w[3 * (env * h.num_rays + k) + 2] - t.aux;
+        case ILX_OBS_LAST_ACTION: return S[L.act + e * h.action_dim + k];          // :512-521
+        case ILX_OBS_GENERATED_COMMANDS: return S[L.cmd + e * h.command_dim + k];  // :529-531
         case ILX_OBS_EXTERNAL: {  // a buffer another component keeps per env (:177-230: body wrench, IMU readings)
             const int slot = static_cast<int>(t.aux);
             return d.external_obs[slot][env * d.external_obs_dim[slot] + k];
@@ -405,29 +447,31 @@ struct CmdState {
     float c[7] = {0, 0, 0, 0, 0, 0, 0};
 };
 
-// A term record as wave-uniform values.  The record's LDS address is the same in every lane, but a plain copy lands in
-// vector registers and the compiler then treats `kind`, the id ranges and the parameters as per-lane data: the dispatch
-// on `kind` becomes thirty exec-masked compare-and-skip blocks and every loop bound a vector compare.  Through
-// readfirstlane the record sits in scalar registers: one scalar branch tree, scalar loop control.
-ILX_DEV ilx_term uniform_term(const ilx_term* src) {
+// A term record as wave-uniform values, read from the plan's table in memory with scalar loads (three of them, through
+// the constant cache; no vector instruction).  A copy from the LDS image would land in vector registers and the
+// compiler would then treat `kind`, the id ranges and the parameters as per-lane data: the dispatch on `kind` becomes
+// thirty exec-masked compare-and-skip blocks and every loop bound a vector compare.
+ILX_DEV ilx_term uniform_term(const ilx_term* table, int index) {
     ilx_term t;
-    const int32_t* in = reinterpret_cast<const int32_t*>(src);
+    const auto* in = reinterpret_cast<const __attribute__((address_space(4))) int32_t*>(
+                         (const __attribute__((address_space(4))) char*)table) + index * static_cast<int>(sizeof(ilx_term) / 4);
     int32_t* out = reinterpret_cast<int32_t*>(&t);
 #pragma unroll
-    for (int w = 0; w < static_cast<int>(sizeof(ilx_term) / 4); ++w) out[w] = __builtin_amdgcn_readfirstlane(in[w]);
+    for (int w = 0; w < static_cast<int>(sizeof(ilx_term) / 4); ++w) out[w] = in[w];
     return t;
 }
 
 // The seven samples a resampling env consumes: injected values, or two generator calls mapped to the term's ranges
 // (the two coin flips of the velocity term stay in [0, 1)).
-ILX_DEV void command_draws(const ilx_mdp& d, uint64_t step, const float* injected, int64_t env, uint32_t salt, float (&smp)[7]) {
+template <typename P>
+ILX_DEV void command_draws(const ilx_mdp& d, uint64_t seed, uint64_t step, P injected, int64_t env, uint32_t salt, float (&smp)[7]) {
     if (injected) {
 #pragma unroll
         for (int k = 0; k < 7; ++k) smp[k] = injected[env * 7 + k];
         return;
     }
-    const u4 a = philox4(d.seed, step, static_cast<uint64_t>(env), 0x40000000u + salt),
-             b = philox4(d.seed, step, static_cast<uint64_t>(env), 0x40000001u + salt);
+    const u4 a = philox4(seed, step, static_cast<uint64_t>(env), 0x40000000u + salt),
+             b = philox4(seed, step, static_cast<uint64_t>(env), 0x40000001u + salt);
     const float u[7] = {u01(a.x), u01(a.y), u01(a.z), u01(a.w), u01(b.x), u01(b.y), u01(b.z)};
 #pragma unroll
     for (int k = 0; k < 7; ++k) {
@@ -437,9 +481,10 @@ ILX_DEV void command_draws(const ilx_mdp& d, uint64_t step, const float* injecte
 }
 
 // CommandTerm._resample for one env: command_manager.py:172-187 + the term's _resample_command
-ILX_DEV void command_resample(const ilx_mdp& d, uint64_t step, int64_t env, const float* injected, uint32_t salt, CmdState& s) {
+template <typename P>
+ILX_DEV void command_resample(const ilx_mdp& d, uint64_t seed, uint64_t step, int64_t env, P injected, uint32_t salt, CmdState& s) {
     float v[7];
-    command_draws(d, step, injected, env, salt, v);
+    command_draws(d, seed, step, injected, env, salt, v);
     s.time_left = v[0];
     s.counter += 1;
     if (d.command_kind == ILX_CMD_VELOCITY) {  // velocity_command.py:123-138
@@ -474,7 +519,26 @@ typedef const __attribute__((address_space(4))) char KernargBytes;
 
 ILX_DEV void stage_segments(float* S, const uint4 rec, int count, int64_t env0, int ne) {
     const uint32_t lane = threadIdx.x & 63;
-    const bool full = ne == kE;
+    if (ne == kE) {
+        // All lanes at once: the first byte of each lane's record for this block.  Per record the loop is then four lane
+        // reads, the lane bound and the copy.
+        const uint64_t mine = ((static_cast<uint64_t>(rec.y) << 32) | rec.x) +
+                              static_cast<uint64_t>(static_cast<uint32_t>(env0)) * ((rec.z & 0xffffu) * 4u);
+        const uint32_t mine_lo = static_cast<uint32_t>(mine), mine_hi = static_cast<uint32_t>(mine >> 32);
+        const uint32_t lane4 = 4u * lane, lane16 = 16u * lane;
+        for (int j = 0; j < count; ++j) {
+            const uint32_t lo = __builtin_amdgcn_readlane(mine_lo, j), hi = __builtin_amdgcn_readlane(mine_hi, j),
+                           a = __builtin_amdgcn_readlane(rec.z, j), b = __builtin_amdgcn_readlane(rec.w, j);
+            const uint64_t base = (static_cast<uint64_t>(hi) << 32) | lo;
+            uint32_t* q = reinterpret_cast<uint32_t*>(S) + (b & 0xffffu);
+            if (lane < ((a >> 16) & 127u)) {
+                if (a & (1u << 23)) __builtin_amdgcn_global_load_lds((GlobalPtr*)(base + lane16), (LdsPtr*)q, 16, 0, 0);
+                else __builtin_amdgcn_global_load_lds((GlobalPtr*)(base + lane4), (LdsPtr*)q, 4, 0, 0);
+            }
+        }
+        return;
+    }
+    // the launch's last block, with fewer envs: tables as they are, chunks word by word up to the block's own end
     for (int j = 0; j < count; ++j) {
         const uint32_t lo = __builtin_amdgcn_readlane(rec.x, j), hi = __builtin_amdgcn_readlane(rec.y, j),
                        a = __builtin_amdgcn_readlane(rec.z, j), b = __builtin_amdgcn_readlane(rec.w, j);
@@ -482,7 +546,7 @@ ILX_DEV void stage_segments(float* S, const uint4 rec, int count, int64_t env0, 
         const bool wide = (a >> 23) & 1u;
         const uint64_t base = ((static_cast<uint64_t>(hi) << 32) | lo) + static_cast<uint64_t>(env0) * (per_env * 4u);
         uint32_t* q = reinterpret_cast<uint32_t*>(S) + (b & 0xffffu);
-        if (full || per_env == 0) {
+        if (per_env == 0) {
             if (lane < lanes) {
                 if (wide) __builtin_amdgcn_global_load_lds((GlobalPtr*)(base + 16u * lane), (LdsPtr*)q, 16, 0, 0);
                 else __builtin_amdgcn_global_load_lds((GlobalPtr*)(base + 4u * lane), (LdsPtr*)q, 4, 0, 0);
@@ -498,13 +562,14 @@ ILX_DEV void stage_segments(float* S, const uint4 rec, int count, int64_t env0, 
 
 #ifdef ILX_MDP_STAMPS  // diagnostics build only: wall-clock stamps (10 ns ticks) of thread 0 of the first blocks
 __device__ unsigned long long g_mdp_stamps[16 * 2048];
+__device__ unsigned int g_mdp_hwid[8 * 2048];  // per block: the four wavefronts' HW_ID, then their XCC_ID
 #define ILX_STAMP(k) \
     if (threadIdx.x == 0 && blockIdx.x < 2048) g_mdp_stamps[blockIdx.x * 16 + (k)] = wall_clock64();
 #else
 #define ILX_STAMP(k)
 #endif
 
-__global__ void __launch_bounds__(kBlock, 4) mdp_step_kernel(MdpDev args) {
+__global__ void __launch_bounds__(kBlock, 4) mdp_step_kernel(MdpDev args, const Hot hot) {
     extern __shared__ float S[];
     // The kernel arguments (descriptor, layout, work list: a few KB) go into LDS first, one 16-byte load per thread, and
     // are read from there.  Read in place they are scalar loads spread over the whole kernel, and each first touch of
@@ -519,20 +584,29 @@ __global__ void __launch_bounds__(kBlock, 4) mdp_step_kernel(MdpDev args) {
         }
         __syncthreads();
     }
+    ILX_STAMP(15)
+#ifdef ILX_MDP_STAMPS
+    if ((threadIdx.x & 63) == 0 && blockIdx.x < 2048) {
+        g_mdp_hwid[blockIdx.x * 8 + (threadIdx.x >> 6)] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+        g_mdp_hwid[blockIdx.x * 8 + 4 + (threadIdx.x >> 6)] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+    }
+#endif
     const MdpDev& m = *reinterpret_cast<const MdpDev*>(S);
     const ilx_mdp& d = m.d;
-    const Layout& L = m.L;
-    const int NT = d.num_terminations, NR = d.num_rewards;
-    const int64_t N = d.num_envs;
+    const Layout& L = hot.L;
+    const int NT = hot.num_terminations, NR = hot.num_rewards;
+    const int64_t N = hot.num_envs;
     const int64_t env0 = static_cast<int64_t>(blockIdx.x) * kE;
     const int ne = static_cast<int>(N - env0 < kE ? N - env0 : kE);
-    const int B = d.num_bodies, CB = d.num_sensor_bodies, CD = d.command_dim;
+    const int B = hot.num_bodies, CB = hot.num_sensor_bodies, CD = hot.command_dim;
     const int tid = threadIdx.x;
-    const bool ph_term = d.phases & ILX_PHASE_TERMINATION, ph_rew = d.phases & ILX_PHASE_REWARD,
-               ph_reset = d.phases & ILX_PHASE_RESET, ph_obs = d.phases & ILX_PHASE_OBSERVATION;
-    const bool has_cmd_term = d.command_kind != ILX_CMD_NONE;
-    const bool ph_cmd = (d.phases & ILX_PHASE_COMMAND) && has_cmd_term;
-    const bool cmd_state = has_cmd_term && (d.phases & (ILX_PHASE_COMMAND | ILX_PHASE_RESET));
+    const uint32_t phases = hot.phases, need = hot.need;
+    const bool ph_term = phases & ILX_PHASE_TERMINATION, ph_rew = phases & ILX_PHASE_REWARD,
+               ph_reset = phases & ILX_PHASE_RESET, ph_obs = phases & ILX_PHASE_OBSERVATION;
+    const bool has_cmd_term = hot.command_kind != ILX_CMD_NONE;
+    const bool ph_cmd = (phases & ILX_PHASE_COMMAND) && has_cmd_term;
+    const bool cmd_state = has_cmd_term && (phases & (ILX_PHASE_COMMAND | ILX_PHASE_RESET));
+    const int num_segs = hot.num_segs;
     const ilx_term* terms = reinterpret_cast<const ilx_term*>(S + L.terms);
     const int32_t* ids = reinterpret_cast<const int32_t*>(S + L.ids);
     // The generator's step word: the argument, plus the caller's device-side count when there is one (finished blocks of
@@ -540,16 +614,21 @@ __global__ void __launch_bounds__(kBlock, 4) mdp_step_kernel(MdpDev args) {
     // added to it, so all of them see the same quotient).  One thread divides; the others read the word from LDS after
     // the staging barrier.
     uint64_t counted = 0;  // wave 0: this lane's slot of the counter (the load travels while the staging is issued)
-    if (threadIdx.x < 64 && d.step_index_device) counted = as_global(d.step_index_device)[16 * threadIdx.x];
+    auto* p_counter = uni(d.step_index_device);
+    const uint64_t step_arg = hot.step_index, seed = hot.seed;
+    if (threadIdx.x < 64 && p_counter) counted = p_counter[16 * threadIdx.x];
 
     ILX_STAMP(0)
     // ================= STAGE =================
-    const bool sa = m.need & kNeedAction, spa = sa && d.prev_action;
+    auto* p_action = uni(d.action);
+    auto* p_prev_action = uni(d.prev_action);
+    const bool sa = need & kNeedAction, spa = sa && p_prev_action;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     uint4 my_segs = {0u, 0u, 0u, 0u};
-    if (wave + kWaves * lane < m.num_segs) my_segs = m.segs[wave + kWaves * lane];
+    if (wave + kWaves * lane < num_segs) my_segs = m.segs[wave + kWaves * lane];
     const bool decide = lane < ne;
     const int e = lane;
+    const uint32_t ue = static_cast<uint32_t>(lane);
     const int64_t env = env0 + (decide ? e : 0);
     // per-env scalars of the DECIDE lanes (coalesced over the 16 lanes): their loads go out first and come back while
     // the row copies below are in flight
@@ -560,79 +639,88 @@ __global__ void __launch_bounds__(kBlock, 4) mdp_step_kernel(MdpDev args) {
     uint32_t term_bits = 0;
     {
         // the pointers first (one batch of LDS reads), then the loads they guard
-        const auto* p_len = as_global(d.episode_length_buf);
-        const auto* p_left = as_global(d.time_left);
-        const auto* p_count = as_global(d.command_counter);
-        const auto* p_metric = as_global(d.command_metrics);
-        const auto* p_head = as_global(d.heading_target);
-        const auto* p_is_head = as_global(d.is_heading_env);
-        const auto* p_is_stand = as_global(d.is_standing_env);
-        const auto* p_sensor = as_global(d.sensor_pos_w);
-        const auto* p_term = as_global(d.terminated);
-        const auto* p_tout = as_global(d.time_outs);
-        const auto* p_dones = as_global(d.term_dones);
-        const bool velocity = d.command_kind == ILX_CMD_VELOCITY, rays = m.need & kNeedRays;
+        const auto* p_len = uni(d.episode_length_buf);
+        const auto* p_left = uni(d.time_left);
+        const auto* p_count = uni(d.command_counter);
+        const auto* p_metric = uni(d.command_metrics);
+        const auto* p_head = uni(d.heading_target);
+        const auto* p_is_head = uni(d.is_heading_env);
+        const auto* p_is_stand = uni(d.is_standing_env);
+        const auto* p_sensor = uni(d.sensor_pos_w);
+        const auto* p_term = uni(d.terminated);
+        const auto* p_tout = uni(d.time_outs);
+        const auto* p_dones = uni(d.term_dones);
+        const bool velocity = hot.command_kind == ILX_CMD_VELOCITY, rays = need & kNeedRays;
         if (decide) {
-            if (p_len) ep_len = p_len[env];
-            if (p_left) cs.time_left = p_left[env];
-            if (p_count) cs.counter = p_count[env];
+            if (p_len) ep_len = ld_at(p_len + env0, 8u * ue);
+            if (p_left) cs.time_left = ld_at(p_left + env0, 4u * ue);
+            if (p_count) cs.counter = ld_at(p_count + env0, 8u * ue);
             if (cmd_state && wave == 0) {
-                cs.metric0 = p_metric[env], cs.metric1 = p_metric[N + env];
+                cs.metric0 = ld_at(p_metric + env0, 4u * ue), cs.metric1 = ld_at(p_metric + N + env0, 4u * ue);
                 if (velocity) {
-                    cs.heading_target = p_head[env];
-                    cs.is_heading = p_is_head[env] != 0;
-                    cs.is_standing = p_is_stand[env] != 0;
+                    cs.heading_target = ld_at(p_head + env0, 4u * ue);
+                    cs.is_heading = ld_at(p_is_head + env0, ue) != 0;
+                    cs.is_standing = ld_at(p_is_stand + env0, ue) != 0;
                 }
             }
-            if (rays && wave == 0) sensor_z = p_sensor[3 * env + 2];
+            if (rays && wave == 0) sensor_z = ld_at(p_sensor + 3 * env0, 12u * ue + 8u);
             if (!ph_term && p_term) {
-                terminated = p_term[env] != 0;
-                time_out = p_tout[env] != 0;
-                for (int i = 0; i < NT; ++i) term_bits |= p_dones[static_cast<int64_t>(i) * N + env] ? (1u << i) : 0u;
+                terminated = ld_at(p_term + env0, ue) != 0;
+                time_out = ld_at(p_tout + env0, ue) != 0;
+                for (int i = 0; i < NT; ++i) term_bits |= ld_at(p_dones + static_cast<int64_t>(i) * N + env0, ue) ? (1u << i) : 0u;
             }
         }
     }
     // strided rows (two columns of the 13-wide body states, 3-vectors of the body accelerations) come through registers
     float bv[2][2] = {{0.0f, 0.0f}, {0.0f, 0.0f}}, ba[2] = {0.0f, 0.0f};
-    if (m.need & kNeedBodyVel) {
+    const auto* p_body_state = uni(d.body_state_w);
+    const auto* p_body_acc = uni(d.body_lin_acc_w);
+    if (need & kNeedBodyVel) {
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const int i = tid + k * kBlock;
             if (i < ne * B) {
-                const float* v = d.body_state_w + 13 * (env0 * B + i) + 7;
-                bv[k][0] = v[0], bv[k][1] = v[1];
+                const auto* rows = p_body_state + 13 * (env0 * B) + 7;
+                bv[k][0] = ld_at(rows, 52u * i), bv[k][1] = ld_at(rows, 52u * i + 4u);
             }
         }
     }
-    if (m.need & kNeedBodyAcc) {
+    if (need & kNeedBodyAcc) {
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const int i = tid + k * kBlock;
-            if (i < ne * B) ba[k] = norm3(load3(d.body_lin_acc_w + 3 * (env0 * B + i)));
+            if (i < ne * B) {
+                const auto* rows = p_body_acc + 3 * (env0 * B);
+                ba[k] = norm3(ld_at(rows, 12u * i), ld_at(rows, 12u * i + 4u), ld_at(rows, 12u * i + 8u));
+            }
         }
     }
     // every contiguous chunk and table: the work list (one memory round trip for all of it)
-    stage_segments(S, my_segs, (m.num_segs - wave + kWaves - 1) / kWaves, env0, ne);
+    ILX_STAMP(14)
+    stage_segments(S, my_segs, (num_segs - wave + kWaves - 1) / kWaves, env0, ne);
     for (int i = tid; i < NR + NT + 3; i += kBlock) S[L.logp + i] = 0.0f;
     if (tid == 0) S[L.zero] = 0.0f;
-    if (m.need & kNeedBodyVel) {
+    if (need & kNeedBodyVel) {
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const int i = tid + k * kBlock;
             if (i < ne * B) S[L.bvx + i] = bv[k][0], S[L.bvy + i] = bv[k][1];
         }
         for (int i = tid + 2 * kBlock; i < ne * B; i += kBlock) {
-            const float* v = d.body_state_w + 13 * (env0 * B + i) + 7;
-            S[L.bvx + i] = v[0], S[L.bvy + i] = v[1];
+            const auto* rows = p_body_state + 13 * (env0 * B) + 7;
+            S[L.bvx + i] = ld_at(rows, 52u * i), S[L.bvy + i] = ld_at(rows, 52u * i + 4u);
         }
     }
-    if (m.need & kNeedBodyAcc) {
+    if (need & kNeedBodyAcc) {
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const int i = tid + k * kBlock;
             if (i < ne * B) S[L.bacc + i] = ba[k];
         }
-        for (int i = tid + 2 * kBlock; i < ne * B; i += kBlock) S[L.bacc + i] = norm3(load3(d.body_lin_acc_w + 3 * (env0 * B + i)));
+        for (int i = tid + 2 * kBlock; i < ne * B; i += kBlock) {
+            const auto* rows = p_body_acc + 3 * (env0 * B);
+            S[L.bacc + i] = norm3(ld_at(rows, 12u * i), ld_at(rows, 12u * i + 4u), ld_at(rows, 12u * i + 8u));
+        }
     }
     ILX_STAMP(1)
     if (threadIdx.x < 64) {
@@ -643,29 +731,41 @@ __global__ void __launch_bounds__(kBlock, 4) mdp_step_kernel(MdpDev args) {
             const uint64_t sum = ((static_cast<uint64_t>(hi) << 32) | lo) + ((static_cast<uint64_t>(ohi) << 32) | olo);
             lo = static_cast<uint32_t>(sum), hi = static_cast<uint32_t>(sum >> 32);
         }
-        if (threadIdx.x == 0)
-            *reinterpret_cast<uint64_t*>(S + L.gstep) = d.step_index + (((static_cast<uint64_t>(hi) << 32) | lo) / gridDim.x);
+        if (threadIdx.x == 0) {
+            // sum / blocks with the sum below 2^52: the quotient of the doubles, corrected by its remainder (a 64-bit
+            // integer division is a hundred instructions that the whole wavefront issues)
+            const uint64_t sum = (static_cast<uint64_t>(hi) << 32) | lo, blocks = gridDim.x;
+            uint64_t quo = static_cast<uint64_t>(static_cast<double>(sum) / static_cast<double>(blocks));
+            const int64_t rem = static_cast<int64_t>(sum - quo * blocks);
+            quo = rem < 0 ? quo - 1 : (rem >= static_cast<int64_t>(blocks) ? quo + 1 : quo);
+            *reinterpret_cast<uint64_t*>(S + L.gstep) = step_arg + quo;
+        }
     }
     __syncthreads();  // waits for this wave's copies (vmcnt(0)), then for every wave's
-    const uint64_t gen_step = *reinterpret_cast<const uint64_t*>(S + L.gstep);
+    const uint64_t gen_step = uni(*reinterpret_cast<const uint64_t*>(S + L.gstep));
     ILX_STAMP(2)
-    if (m.need & kNeedForces) {  // max over the history of |F| per (env, body): rewards.py:266 / terminations.py:157
-        const int H = d.history_len;
+    if (need & kNeedForces) {  // max over the history of |F| per (env, body): rewards.py:266 / terminations.py:157
+        const int H = hot.history_len;
+        const uint32_t inv = hot.inv_sensor_bodies;
         for (int i = tid; i < ne * CB; i += kBlock) {
-            const int ee = CB > 1 ? static_cast<int>(__umulhi(static_cast<uint32_t>(i), m.inv_sensor_bodies)) : i;  // i / CB
+            const int ee = CB > 1 ? static_cast<int>(__umulhi(static_cast<uint32_t>(i), inv)) : i;  // i / CB
             const int b = i - ee * CB;
-            float mx = -__builtin_inff();
+            // the largest sum of squares, then one square root: the root is monotonic and correctly rounded, so this is
+            // the largest norm, bit for bit
+            float mx = -1.0f;
+            const float* f = S + L.fraw + 3 * (ee * H * CB + b);
 #pragma unroll 4
-            for (int h = 0; h < H; ++h) mx = fmaxf(mx, norm3(load3(S + L.fraw + 3 * ((ee * H + h) * CB + b))));
-            S[L.fpeak + i] = mx;
+            for (int h = 0; h < H; ++h, f += 3 * CB) mx = fmaxf(mx, fmaf_(f[2], f[2], fmaf_(f[1], f[1], f[0] * f[0])));
+            S[L.fpeak + i] = mx < 0.0f ? -__builtin_inff() : sqrt_(mx);
         }
         __syncthreads();
     }
 
     ILX_STAMP(3)
     // ================= DECIDE: one lane per env; the four waves split the reward terms =================
-    Env en{m, S, ids, e, env};
-    const float dt = d.step_dt;
+    Env en{m, hot, S, ids, e, env};
+    const float dt = hot.step_dt;
+    const f3 gravity = {hot.gravity[0], hot.gravity[1], hot.gravity[2]};
     if (decide) {
         const float* rs = S + L.root + 13 * e;
         en.pos = {rs[0], rs[1], rs[2]};
@@ -675,13 +775,13 @@ __global__ void __launch_bounds__(kBlock, 4) mdp_step_kernel(MdpDev args) {
         // articulation_data.py:411-425, 502-518
         en.lin_b = quat_rotate_inverse(en.quat, en.lin_w);
         en.ang_b = quat_rotate_inverse(en.quat, en.ang_w);
-        en.grav_b = quat_rotate_inverse(en.quat, f3{d.gravity_dir[0], d.gravity_dir[1], d.gravity_dir[2]});
+        en.grav_b = quat_rotate_inverse(en.quat, gravity);
         en.time_left = cs.time_left, en.command_counter = cs.counter;
         // ---- terminations (manager_based_rl_env.py:199-202, termination_manager.py:151-174); every wave needs the result
         if (ph_term) {
             ep_len += 1;
             for (int i = 0; i < NT; ++i) {
-                const ilx_term t = uniform_term(terms + i);
+                const ilx_term t = uniform_term(hot.terms, i);
                 const bool v = eval_termination(en, t, ep_len);
                 term_bits |= v ? (1u << i) : 0u;
                 if (t.flags & 1) time_out = time_out || v; else terminated = terminated || v;
@@ -692,7 +792,7 @@ __global__ void __launch_bounds__(kBlock, 4) mdp_step_kernel(MdpDev args) {
         if (ph_rew) {
             float partial = 0.0f;
             for (int i = wave; i < NR; i += kWaves) {
-                const ilx_term t = uniform_term(terms + NT + i);
+                const ilx_term t = uniform_term(hot.terms, NT + i);
                 if (t.weight == 0.0f) continue;  // :145-146 (episode sums and step_reward keep their values)
                 const float value = eval_reward(en, t, terminated, time_out, term_bits) * t.weight * dt;
                 partial += value;
@@ -719,30 +819,51 @@ __global__ void __launch_bounds__(kBlock, 4) mdp_step_kernel(MdpDev args) {
         atomicAdd(logp + NR + NT + 2, 1.0f);
     }
     if (decide && ph_reset && (terminated || time_out) && wave == (2 % kWaves) && wave != 0) {
-        auto* act = as_global(d.action);
-        auto* pact = as_global(d.prev_action);
-        const int A = d.action_dim;
+        auto* act = p_action;
+        auto* pact = p_prev_action;
+        const int A = hot.action_dim;
         for (int k = 0; k < A; ++k) {
-            if (act) act[env * A + k] = 0.0f;
-            if (pact) pact[env * A + k] = 0.0f;
+            const uint32_t at = 4u * (static_cast<uint32_t>(e) * static_cast<uint32_t>(A) + k);
+            if (act) st_at(act + env0 * A, at, 0.0f);
+            if (pact) st_at(pact + env0 * A, at, 0.0f);
             if (sa) S[L.act + e * A + k] = 0.0f;
             if (spa) S[L.pact + e * A + k] = 0.0f;
         }
     }
-    if (decide && wave == 0) {
+    if (wave == 0) {
         ILX_STAMP(6)
+        // the descriptor's words this part uses, in one batch of LDS reads
+        auto* o_terminated = uni(d.terminated);
+        auto* o_time_outs = uni(d.time_outs);
+        auto* o_reset = uni(d.reset_buf);
+        auto* o_reward = uni(d.reward_buf);
+        auto* o_len = uni(d.episode_length_buf);
+        auto* o_command = uni(d.command);
+        auto* o_left = uni(d.time_left);
+        auto* o_count = uni(d.command_counter);
+        auto* o_metric = uni(d.command_metrics);
+        auto* o_head = uni(d.heading_target);
+        auto* o_is_head = uni(d.is_heading_env);
+        auto* o_is_stand = uni(d.is_standing_env);
+        const auto* in_reset_samples = uni(d.reset_command_samples);
+        const auto* in_samples = uni(d.command_samples);
+        const bool velocity = hot.command_kind == ILX_CMD_VELOCITY;
+        const float max_command_step = uni(d.max_command_step), stiffness = uni(d.heading_control_stiffness),
+                    yaw_lo = uni(d.cmd_range[3][0]), yaw_hi = uni(d.cmd_range[3][1]);
+        const bool heading_command = uni(d.heading_command) != 0;
+      if (decide) {
         const bool done = terminated || time_out;
         if (ph_term) {
-            d.terminated[env] = terminated;
-            d.time_outs[env] = time_out;
-            if (d.reset_buf) d.reset_buf[env] = done;
+            st_at(o_terminated + env0, ue, terminated);
+            st_at(o_time_outs + env0, ue, time_out);
+            if (o_reset) st_at(o_reset + env0, ue, done);
         }
         if (ph_rew)
         {
             float total = S[L.ptotal + e];
 #pragma unroll
             for (int w = 1; w < kWaves; ++w) total += S[L.ptotal + w * kE + e];
-            d.reward_buf[env] = total;
+            st_at(o_reward + env0, 4u * ue, total);
         }
         reinterpret_cast<uint32_t*>(S + L.bits)[e] = term_bits;
         reinterpret_cast<uint32_t*>(S + L.bits)[kE + e] = done ? 1u : 0u;
@@ -760,55 +881,55 @@ __global__ void __launch_bounds__(kBlock, 4) mdp_step_kernel(MdpDev args) {
                 atomicAdd(logp + NR + NT + 1, cs.metric1);
                 cs.metric0 = cs.metric1 = 0.0f;
                 cs.counter = 0;
-                command_resample(d, gen_step, env, d.reset_command_samples, 16u, cs);
+                command_resample(d, seed, gen_step, env, in_reset_samples, 16u, cs);
                 cmd_dirty = true;
             }
             ep_len = 0;  // manager_based_rl_env.py:391
         }
-        if (d.episode_length_buf && (ph_term || (ph_reset && done))) d.episode_length_buf[env] = ep_len;
+        if (o_len && (ph_term || (ph_reset && done))) st_at(o_len + env0, 8u * ue, ep_len);
         // ---- command term (command_manager.py:151-166)
         if (ph_cmd) {
-            if (d.command_kind == ILX_CMD_VELOCITY) {  // velocity_command.py:111-121
-                cs.metric0 = cs.metric0 + div_(norm2(cs.c[0] - en.lin_b.x, cs.c[1] - en.lin_b.y), d.max_command_step);
-                cs.metric1 = cs.metric1 + div_(fabsf(cs.c[2] - en.ang_b.z), d.max_command_step);
+            if (velocity) {  // velocity_command.py:111-121
+                cs.metric0 = cs.metric0 + div_(norm2(cs.c[0] - en.lin_b.x, cs.c[1] - en.lin_b.y), max_command_step);
+                cs.metric1 = cs.metric1 + div_(fabsf(cs.c[2] - en.ang_b.z), max_command_step);
             } else {  // pose_command.py:92-108 (metrics are overwritten each step)
                 f3 pw;
                 f4 qw;
                 combine_frame_transforms(en.pos, en.quat, f3{cs.c[0], cs.c[1], cs.c[2]}, f4{cs.c[3], cs.c[4], cs.c[5], cs.c[6]}, pw, qw);
-                const float* b = d.body_state_w + 13 * (env * B + d.pose_body_index);
+                const auto* b = p_body_state + 13 * (env * B + d.pose_body_index);
                 const f3 aa = axis_angle_from_quat(quat_error(qw, f4{b[3], b[4], b[5], b[6]}));
                 cs.metric0 = norm3(b[0] - pw.x, b[1] - pw.y, b[2] - pw.z);
                 cs.metric1 = norm3(aa);
             }
             cs.time_left = cs.time_left - dt;
-            if (cs.time_left <= 0.0f) command_resample(d, gen_step, env, d.command_samples, 0u, cs);
-            if (d.command_kind == ILX_CMD_VELOCITY) {  // velocity_command.py:140-160
-                if (d.heading_command && cs.is_heading) {
+            if (cs.time_left <= 0.0f) command_resample(d, seed, gen_step, env, in_samples, 0u, cs);
+            if (velocity) {  // velocity_command.py:140-160
+                if (heading_command && cs.is_heading) {
                     const f3 fwd = quat_apply(en.quat, f3{1.0f, 0.0f, 0.0f});  // articulation_data.py:416-425
                     const float err = wrap_to_pi(cs.heading_target - atan2f(fwd.y, fwd.x));
-                    cs.c[2] = fminf(fmaxf(d.heading_control_stiffness * err, d.cmd_range[3][0]), d.cmd_range[3][1]);
+                    cs.c[2] = fminf(fmaxf(stiffness * err, yaw_lo), yaw_hi);
                 }
                 if (cs.is_standing) cs.c[0] = cs.c[1] = cs.c[2] = 0.0f;
             }
             cmd_dirty = true;
         }
         if (cmd_dirty) {
-            const int width = d.command_kind == ILX_CMD_VELOCITY ? 3 : 7;
+            const int width = velocity ? 3 : 7;
 #pragma unroll
             for (int k = 0; k < 7; ++k) {
                 if (k < width) {
                     S[L.cmd + e * CD + k] = cs.c[k];
-                    d.command[env * CD + k] = cs.c[k];
+                    st_at(o_command + env0 * CD, 4u * (ue * static_cast<uint32_t>(CD) + k), cs.c[k]);
                 }
             }
-            d.time_left[env] = cs.time_left;
-            d.command_counter[env] = cs.counter;
-            d.command_metrics[env] = cs.metric0;
-            d.command_metrics[N + env] = cs.metric1;
-            if (d.command_kind == ILX_CMD_VELOCITY) {
-                d.heading_target[env] = cs.heading_target;
-                d.is_heading_env[env] = cs.is_heading;
-                d.is_standing_env[env] = cs.is_standing;
+            st_at(o_left + env0, 4u * ue, cs.time_left);
+            st_at(o_count + env0, 8u * ue, cs.counter);
+            st_at(o_metric + env0, 4u * ue, cs.metric0);
+            st_at(o_metric + N + env0, 4u * ue, cs.metric1);
+            if (velocity) {
+                st_at(o_head + env0, 4u * ue, cs.heading_target);
+                st_at(o_is_head + env0, ue, cs.is_heading);
+                st_at(o_is_stand + env0, ue, cs.is_standing);
             }
         }
         ILX_STAMP(7)
@@ -817,35 +938,43 @@ __global__ void __launch_bounds__(kBlock, 4) mdp_step_kernel(MdpDev args) {
         der[3] = en.ang_b.x, der[4] = en.ang_b.y, der[5] = en.ang_b.z;
         der[6] = en.grav_b.x, der[7] = en.grav_b.y, der[8] = en.grav_b.z;
         der[9] = sensor_z;
+      }
     }
     __syncthreads();
 
     ILX_STAMP(8)
     // ================= EMIT =================
     const uint32_t* bits = reinterpret_cast<const uint32_t*>(S + L.bits);
-    if (ph_term) {
-        for (int i = tid; i < NT * kE; i += kBlock) {
-            const int term = i / kE, ee = i - term * kE;
-            if (ee < ne) d.term_dones[static_cast<int64_t>(term) * N + env0 + ee] = (bits[ee] >> term) & 1u;
-        }
-    }
-    if (ph_rew || ph_reset) {
-        for (int i = tid; i < NR * kE; i += kBlock) {
-            const int term = i / kE, ee = i - term * kE;
-            if (ee >= ne) continue;
-            const bool active = ph_rew && terms[NT + term].weight != 0.0f;
-            if (active || (ph_reset && bits[kE + ee])) d.episode_sums[static_cast<int64_t>(term) * N + env0 + ee] = S[L.eps + i];
-        }
-        if (ph_rew) {
-            for (int i = tid; i < ne * NR; i += kBlock) {
-                const int term = NR > 1 ? i - static_cast<int>(__umulhi(static_cast<uint32_t>(i), m.inv_rewards)) * NR : 0;  // i % NR
-                if (terms[NT + term].weight != 0.0f) d.step_reward[env0 * NR + i] = S[L.srew + i];
+    {
+        auto* o_dones = uni(d.term_dones);
+        auto* o_sums = uni(d.episode_sums);
+        auto* o_step_reward = uni(d.step_reward);
+        auto* o_log = uni(d.log_sums);
+        const uint32_t inv = hot.inv_rewards;
+        if (ph_term) {
+            for (int i = tid; i < NT * kE; i += kBlock) {
+                const int term = i / kE, ee = i - term * kE;
+                if (ee < ne) o_dones[static_cast<int64_t>(term) * N + env0 + ee] = (bits[ee] >> term) & 1u;
             }
         }
-    }
-    if (ph_reset && d.log_sums && tid < NR + NT + 3) {
-        const float v = S[L.logp + tid];
-        if (v != 0.0f) unsafeAtomicAdd(d.log_sums + tid, v);  // hardware float add at L2, no return value
+        if (ph_rew || ph_reset) {
+            for (int i = tid; i < NR * kE; i += kBlock) {
+                const int term = i / kE, ee = i - term * kE;
+                if (ee >= ne) continue;
+                const bool active = ph_rew && terms[NT + term].weight != 0.0f;
+                if (active || (ph_reset && bits[kE + ee])) o_sums[static_cast<int64_t>(term) * N + env0 + ee] = S[L.eps + i];
+            }
+            if (ph_rew) {
+                for (int i = tid; i < ne * NR; i += kBlock) {
+                    const int term = NR > 1 ? i - static_cast<int>(__umulhi(static_cast<uint32_t>(i), inv)) * NR : 0;  // i % NR
+                    if (terms[NT + term].weight != 0.0f) st_at(o_step_reward + env0 * NR, 4u * i, S[L.srew + i]);
+                }
+            }
+        }
+        if (ph_reset && o_log && tid < NR + NT + 3) {
+            const float v = S[L.logp + tid];
+            if (v != 0.0f) unsafeAtomicAdd((float*)(o_log + tid), v);  // hardware float add at L2, no return value
+        }
     }
     ILX_STAMP(9)
     // ---- observations (observation_manager.py:260-335).  The concatenated row is cut into groups of 4 columns (a
@@ -854,19 +983,22 @@ __global__ void __launch_bounds__(kBlock, 4) mdp_step_kernel(MdpDev args) {
     // covers 64 / (groups, rounded up to a power of two) envs per trip.  Per column and env what is left is the
     // value's LDS word (or its ray hit), the pipeline arithmetic and the store.
     if (ph_obs) {
-        const int O = d.obs_dim;
+        const int O = hot.obs_dim;
         const int G = (O + 3) >> 2;
         int gp = 1;
         while (gp < G && gp < 64) gp <<= 1;
         const int per = 64 / gp, g_in = lane & (gp - 1), esub = lane / gp;
         const ilx_term* oterms = terms + NT + NR;
-        const int32_t* ltab = reinterpret_cast<const int32_t*>(&m.L);   // the layout, as words
+        const int32_t* ltab = reinterpret_cast<const int32_t*>(&m.L);   // the layout, as words (its LDS copy: indexed per lane)
         const ColDesc* cdesc = reinterpret_cast<const ColDesc*>(S + L.coldesc);
-        const bool dense_scan = d.height_scan != nullptr;  // the ray caster's own height scan: value as it is
-        const auto* hits = as_global(dense_scan ? d.height_scan : d.ray_hits_w);
-        const auto* noise_in = as_global(d.noise_u);
-        const int R = d.num_rays;
-        const bool generate = !d.noise_u;
+        const auto* p_scan = uni(d.height_scan);
+        const auto* p_hits = uni(d.ray_hits_w);
+        const bool dense_scan = p_scan != nullptr;  // the ray caster's own height scan: value as it is
+        const auto* hits = dense_scan ? p_scan : p_hits;
+        const auto* noise_in = uni(d.noise_u);
+        auto* o_obs = uni(d.obs);
+        const int R = hot.num_rays;
+        const bool generate = !noise_in;
         for (int g = g_in; g < G; g += 64) {
             // The lane's four columns.  Every read below is unconditional and the reads of one step are independent, so
             // each step costs one LDS latency: descriptors; then the terms' flags and the rows' offsets.
@@ -895,49 +1027,75 @@ __global__ void __launch_bounds__(kBlock, 4) mdp_step_kernel(MdpDev args) {
                 const TermHead th = *reinterpret_cast<const TermHead*>(oterms + ((what[c] >> 8) & 255u));
                 const uint32_t flags = what[c] >> 16;
                 n_off[c] = (flags & ILX_OBS_FLAG_NOISE) ? th.p0 : 0.0f, n_rng[c] = (flags & ILX_OBS_FLAG_NOISE) ? th.p1 : 0.0f;
-                c_lo[c] = th.p2, c_hi[c] = th.p3;
+                // clip as one median-of-three: no bounds when switched off; bounds given the wrong way round clip to the
+                // upper one, as torch.clip does
+                const bool clip = flags & ILX_OBS_FLAG_CLIP;
+                c_hi[c] = clip ? th.p3 : __builtin_inff();
+                c_lo[c] = clip ? fminf(th.p2, th.p3) : -__builtin_inff();
                 scl[c] = (flags & ILX_OBS_FLAG_SCALE) ? th.weight : 1.0f;
                 hgt[c] = th.aux;
-                zoff[c] = (what[c] & 255u) == kColScan ? (dense_scan ? cd[c].src : 3u * cd[c].src + 2u) : 0u;
+                zoff[c] = (what[c] & 255u) == kColScan ? (dense_scan ? 4u * cd[c].src : 12u * cd[c].src + 8u) : 0u;  // bytes into the env's hits
             }
             const bool any_noise = all_flags & ILX_OBS_FLAG_NOISE, any_scan = all_modes & kColScan;
+            // LDS byte addresses of value (low half) and subtrahend (high half) for the lane's first env, and what one
+            // trip of the env loop adds to them
+            const uint32_t ee0 = static_cast<uint32_t>(wave * per + esub), estep = static_cast<uint32_t>(kWaves * per);
+            uint32_t addr[4], astep[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const uint32_t sv = stride[c] & 0xffffu, ss = stride[c] >> 16;
+                addr[c] = (4u * ((where[c] & 0xffffu) + ee0 * sv)) | ((4u * ((where[c] >> 16) + ee0 * ss)) << 16);
+                astep[c] = (4u * estep * sv) | ((4u * estep * ss) << 16);
+            }
+            const char* lds = reinterpret_cast<const char*>(S);
             ILX_STAMP(11)
-            for (int ee = wave * per + esub; ee < ne; ee += kWaves * per) {
+            // memory: the block's rows as uniform bases, the lane's place in them as running 32-bit byte offsets
+            auto* rows = o_obs + env0 * O;
+            const auto* noise_rows = noise_in + env0 * O;
+            const auto* hit_rows = hits + (dense_scan ? 1 : 3) * (env0 * R);
+            const uint32_t hit_env_bytes = 4u * static_cast<uint32_t>((dense_scan ? 1 : 3) * R);
+            uint32_t row_at = 4u * (ee0 * static_cast<uint32_t>(O) + 4u * static_cast<uint32_t>(g));  // column 4 g of the lane's env
+            uint32_t hit_at = ee0 * hit_env_bytes;
+            const uint32_t row_step = 4u * estep * static_cast<uint32_t>(O), hit_step = estep * hit_env_bytes;
+            for (int ee = wave * per + esub; ee < ne; ee += kWaves * per, row_at += row_step, hit_at += hit_step) {
                 const int64_t oenv = env0 + ee;
-                auto* row = as_global(d.obs) + oenv * O;
                 // values from memory (ray hits, injected noise) are requested first; the generator call hides their latency
                 float zv[4] = {0.0f, 0.0f, 0.0f, 0.0f}, u[4] = {0.0f, 0.0f, 0.0f, 0.0f};
                 if (any_scan) {
-                    const auto* env_hits = hits + (dense_scan ? 1 : 3) * (oenv * R);
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) zv[c] = env_hits[zoff[c]];  // columns of other kinds read the first ray (unused)
+                    for (int c = 0; c < 4; ++c) zv[c] = ld_at(hit_rows, hit_at + zoff[c]);  // columns of other kinds read the first ray (unused)
                 }
                 if (!generate && any_noise) {
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) u[c] = noise_in[oenv * O + (4 * g + c < O ? 4 * g + c : O - 1)];
+                    for (int c = 0; c < 4; ++c) u[c] = ld_at(noise_rows, 4 * g + c < O ? row_at + 4u * c : row_at - 16u * g + 4u * (O - 1));
                 }
                 // LDS: value and subtrahend, the sensor height
                 float val[4];
 #pragma unroll
-                for (int c = 0; c < 4; ++c)
-                    val[c] = S[(where[c] & 0xffffu) + ee * (stride[c] & 0xffffu)] - S[(where[c] >> 16) + ee * (stride[c] >> 16)];
+                for (int c = 0; c < 4; ++c) {
+                    val[c] = *reinterpret_cast<const float*>(lds + (addr[c] & 0xffffu)) - *reinterpret_cast<const float*>(lds + (addr[c] >> 16));
+                    addr[c] += astep[c];
+                }
                 const float sensor_height = S[L.derived + kDerived * ee + 9];
                 if (ee < 4) { ILX_STAMP(12) }
                 if (generate && any_noise) {
-                    const u4 r = philox4(d.seed, gen_step, static_cast<uint64_t>(oenv), static_cast<uint32_t>(g));
+                    const u4 r = philox4(seed, gen_step, static_cast<uint64_t>(oenv), static_cast<uint32_t>(g));
                     u[0] = u01(r.x), u[1] = u01(r.y), u[2] = u01(r.z), u[3] = u01(r.w);
                 }
                 if (ee < 4) { ILX_STAMP(13) }
+                if (any_scan && !dense_scan) {  // observations.py:165-173 (the dense scan holds this difference already)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) zv[c] = sensor_height - zv[c] - hgt[c];
+                }
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    const uint32_t mode = what[c] & 255u, flags = what[c] >> 16;
-                    float v = mode == kColScan ? (dense_scan ? zv[c] : sensor_height - zv[c] - hgt[c]) : val[c];  // observations.py:165-173
+                    const uint32_t mode = what[c] & 255u;
+                    float v = mode == kColScan ? zv[c] : val[c];
                     v = v + u[c] * n_rng[c] + n_off[c];                                          // noise_model.py:63-64
-                    v = (flags & ILX_OBS_FLAG_CLIP) ? fminf(fmaxf(v, c_lo[c]), c_hi[c]) : v;     // observation_manager.py:315-316
+                    v = __builtin_amdgcn_fmed3f(v, c_lo[c], c_hi[c]);                            // observation_manager.py:315-316
                     v = v * scl[c];                                                              // :317-318
-                    if (4 * g + c < O && mode != kColGeneric) row[4 * g + c] = v;
+                    if (4 * g + c < O && mode != kColGeneric) st_at(rows, row_at + 4u * c, v);
                 }
-                if (ee < 4) { ILX_STAMP(14) }
                 // columns of the other kinds (root position with env origins, unique quaternions, normalised joint limits,
                 // external buffers): one at a time through the term switch
                 if (all_modes & kColGeneric) {
@@ -948,11 +1106,11 @@ __global__ void __launch_bounds__(kBlock, 4) mdp_step_kernel(MdpDev args) {
                         const uint32_t k = cdesc[4 * g + c].src;
                         const float uc = c == 0 ? u[0] : c == 1 ? u[1] : c == 2 ? u[2] : u[3];
                         const ilx_term& t = oterms[(w >> 8) & 255u];
-                        float v = eval_obs(m, S, ids, ee, oenv, t, static_cast<int>(k));
+                        float v = eval_obs(m, hot, S, ids, ee, oenv, t, static_cast<int>(k));
                         if (t.flags & ILX_OBS_FLAG_NOISE) v = v + uc * t.p[1] + t.p[0];
                         if (t.flags & ILX_OBS_FLAG_CLIP) v = fminf(fmaxf(v, t.p[2]), t.p[3]);
                         if (t.flags & ILX_OBS_FLAG_SCALE) v = v * t.weight;
-                        row[4 * g + c] = v;
+                        st_at(rows, row_at + 4u * c, v);
                     }
                 }
             }
@@ -960,8 +1118,8 @@ __global__ void __launch_bounds__(kBlock, 4) mdp_step_kernel(MdpDev args) {
     }
     ILX_STAMP(10)
     // the device-side count: one more finished block (no return value: nothing waits for it)
-    if (d.step_index_device && tid == 0)
-        __hip_atomic_fetch_add(as_global(d.step_index_device) + 16 * (blockIdx.x & 63), 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (p_counter && tid == 0 && !(phases & ILX_PHASE_HOLD_STEP_COUNT))
+        __hip_atomic_fetch_add(p_counter + 16 * (blockIdx.x & 63), 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 }  // namespace ilx
@@ -1195,6 +1353,9 @@ extern "C" void ilx_mdp_plan_destroy(ilx_mdp_plan_t plan) {
 }
 
 #ifdef ILX_MDP_STAMPS
+extern "C" int ilx_debug_mdp_hwid(unsigned int* out, int count) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(ilx::g_mdp_hwid), sizeof(unsigned int) * count) == hipSuccess ? 0 : 1;
+}
 extern "C" int ilx_debug_mdp_stamps(unsigned long long* out, int count) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(ilx::g_mdp_stamps), sizeof(unsigned long long) * count) == hipSuccess ? 0 : 1;
 }
@@ -1204,12 +1365,13 @@ extern "C" int ilx_mdp_step(ilx_mdp_plan_t plan, const ilx_mdp* desc, void* stre
     ILX_REQUIRE(plan && desc, ILX_EINVAL, "ilx_mdp_step: NULL argument");
     const ilx_mdp& d = *desc;
     ILX_REQUIRE(d.num_envs >= 0, ILX_EINVAL, "ilx_mdp_step: negative env count");
+    ILX_REQUIRE(d.num_envs < (1ll << 31), ILX_EINVAL, "ilx_mdp_step: more than 2^31 - 1 envs in one launch");
     ILX_REQUIRE(d.num_terminations == plan->nt && d.num_rewards == plan->nr && d.num_observations == plan->no &&
                     d.obs_dim == plan->obs_dim,
                 ILX_EINVAL, "ilx_mdp_step: term counts differ from the plan");
     ILX_REQUIRE(plan->no == 0 || (d.num_joints == plan->dims[0] && d.action_dim == plan->dims[1] && d.command_dim == plan->dims[2]),
                 ILX_EINVAL, "ilx_mdp_step: joint / action / command widths differ from the plan");
-    if (d.num_envs == 0 || d.phases == 0) return ILX_OK;
+    if (d.num_envs == 0 || (d.phases & ILX_PHASE_ALL) == 0) return ILX_OK;
     ILX_REQUIRE(d.root_state_w, ILX_EINVAL, "ilx_mdp_step: root_state_w is NULL");
     ILX_REQUIRE(d.num_joints >= 0 && d.num_bodies >= 0 && d.num_sensor_bodies >= 0 && d.action_dim >= 0 &&
                     d.command_dim >= 0 && d.history_len >= 0 && d.num_rays >= 0,
@@ -1356,7 +1518,19 @@ extern "C" int ilx_mdp_step(ilx_mdp_plan_t plan, const ilx_mdp* desc, void* stre
     if (po) add(plan->d_cols, 0, plan->obs_dim * static_cast<int>(sizeof(ColDesc) / 4), L.coldesc);
     ILX_REQUIRE(fits, ILX_ESHAPE, "ilx_mdp_step: the plan's per-block state needs more than %d staging copies", kMaxSegs);
     const unsigned blocks = static_cast<unsigned>((d.num_envs + kE - 1) / kE);
-    hipLaunchKernelGGL(mdp_step_kernel, dim3(blocks), dim3(kBlock), lds_bytes, as_stream(stream), m);
+    Hot hot;
+    hot.L = m.L;
+    hot.num_joints = J, hot.num_bodies = B, hot.num_sensor_bodies = CB, hot.command_dim = CD, hot.action_dim = A;
+    hot.num_rays = d.num_rays, hot.command_kind = d.command_kind;
+    hot.num_terminations = plan->nt, hot.num_rewards = plan->nr, hot.obs_dim = plan->obs_dim;
+    hot.history_len = d.history_len, hot.num_segs = m.num_segs;
+    hot.phases = d.phases, hot.need = m.need;
+    hot.inv_sensor_bodies = m.inv_sensor_bodies, hot.inv_rewards = m.inv_rewards;
+    hot.step_dt = d.step_dt;
+    for (int k = 0; k < 3; ++k) hot.gravity[k] = d.gravity_dir[k];
+    hot.num_envs = d.num_envs, hot.seed = d.seed, hot.step_index = d.step_index;
+    hot.terms = plan->d_terms;
+    hipLaunchKernelGGL(mdp_step_kernel, dim3(blocks), dim3(kBlock), lds_bytes, as_stream(stream), m, hot);
     ILX_LAUNCH_CHECK("ilx_mdp_step");
     return ILX_OK;
 }

@@ -36,6 +36,7 @@ MAX_EXTERNAL_OBS = 4
 OBS_NOISE, OBS_CLIP, OBS_SCALE, OBS_QUAT_UNIQUE = 1, 2, 4, 8
 CMD_NONE, CMD_VELOCITY, CMD_POSE = 0, 1, 2
 PHASE_TERMINATION, PHASE_REWARD, PHASE_RESET, PHASE_COMMAND, PHASE_OBSERVATION, PHASE_ALL = 1, 2, 4, 8, 16, 31
+PHASE_HOLD_STEP_COUNT = 256   # not a phase: this launch leaves the generator's step count as it is
 
 
 class Term(ctypes.Structure):
@@ -152,6 +153,7 @@ class FusedMdp:
         d.max_episode_length_s = max_episode_length * step_dt if max_episode_length_s is None else max_episode_length_s
         d.gravity_dir = (c_float * 3)(*gravity)
         self._own_generator = seed is not None
+        self._holding = False   # the last launch left the step count as it was (see step)
         self._step_counter = None
         d.seed, d.step_index, d.phases = (seed if seed is not None else 0), 0, PHASE_ALL
         if len(external_obs_dims) > MAX_EXTERNAL_OBS:
@@ -260,14 +262,17 @@ class FusedMdp:
         self._external[slot] = t
         self.desc.external_obs[slot] = t.data_ptr()
 
-    def step(self, phases: int = PHASE_ALL, step_index: int | None = None):
-        self.desc.phases = phases
+    def step(self, phases: int = PHASE_ALL, step_index: int | None = None, hold_step_count: bool = False):
+        """One launch of the given phases.  An env step issued as several launches passes ``hold_step_count=True`` on
+        all but the last: every launch of the step then draws with the same step word (host- or device-side count)."""
+        self.desc.phases = phases | (PHASE_HOLD_STEP_COUNT if hold_step_count else 0)
         if step_index is not None:
             self.desc.step_index = step_index
-        elif not self._own_generator:
+        elif not self._own_generator and not self._holding:
             self.desc.seed, self.desc.step_index = _rng.seed(), _rng.next_draw("fused_mdp")
         _abi.check(_abi.lib.ilx_mdp_step(self.plan, ctypes.byref(self.desc), _abi.stream()), "ilx_mdp_step")
-        if self._step_counter is None:          # otherwise the launch has advanced the device-side count itself
+        self._holding = hold_step_count
+        if self._step_counter is None and not hold_step_count:   # otherwise the launch has advanced the device-side count itself
             self.desc.step_index += 1
 
     def count_steps_on_device(self, enable: bool = True):

@@ -144,34 +144,49 @@ class LocomotionVelocityStep:
             self.data.body_state_w.copy_(s["body_state_w"])
 
     def step(self, raw_action: torch.Tensor, noise_u=None, command_samples=None, reset_command_samples=None):
-        """One env step on the synthetic physics sequence installed by :meth:`load_state`."""
-        d, dev = self.data, self.device
-        n, j = self.n, d._j
-        # With the simulator's results of all substeps at hand, the step is two chains that share no buffer until the
-        # managers read them: (A) process_action and the actuator model of every substep, (B) scene.update of every
-        # substep and the height-scanner refresh.  (B) is issued on a second stream between a fork and a join; recorded
-        # in a HIP graph the two become parallel branches, so the memory-bound sensor updates run beside the
-        # compute-bound actuator network.  Each chain keeps the reference's order (manager_based_rl_env.py:172-195).
+        """One env step on the synthetic physics sequence installed by :meth:`load_state`.
+
+        With the simulator's results of all substeps at hand, the step is two chains that share no buffer until the
+        managers read them: (A) process_action and the actuator model of every substep, :meth:`step_actuators`; (B)
+        scene.update of every substep and the height-scanner refresh, :meth:`step_sensors`.  Each keeps the reference's
+        order (manager_based_rl_env.py:172-195).  With ``concurrent_chains`` (B) is issued on a second stream between
+        a fork and a join, so the memory-bound sensor updates can run beside the compute-bound actuator network; a
+        caller that replays the step from HIP graphs can also record the three parts separately and launch (A) and (B)
+        on two streams of its own."""
         main = torch.cuda.current_stream()
         side = self._side_stream if self.concurrent_chains else main
         if side is not main:
             side.wait_stream(main)
         with torch.cuda.stream(side):
-            for k in range(LV.DECIMATION):
-                # <sim.step would run here; its results for this substep are self.physics[...][k]>
-                d.joint_pos, d.joint_vel = self.physics["joint_pos"][k], self.physics["joint_vel"][k]
-                self.contact.set_net_contact_forces(self.physics["net_forces"][k])
-                self.scene.update(LV.PHYSICS_DT)                         # joint_acc, contact sensor, scanner clock: one launch
-            d.set_sim_state(root_state_w=self.physics["root_state_w"])
-            # -- height scanner: refreshed once per env step (update_period = step_dt), lazily in the reference
-            if self.scanner_body is None:
-                self.scanner.set_pose(d.root_state_w[:, :3], d.root_state_w[:, 3:7])
-            else:  # strided views of the body's rows: the kernel reads them in place
-                pose = d.body_state_w[:, self.scanner_body]
-                self.scanner.set_pose(pose[:, :3], pose[:, 3:7])
-            # the refresh also writes the height scan the observation term reads (sensor height - hit height - offset)
-            self.scanner._update_outdated_buffers(height_out=self.height_scan, height_offset=self.height_scan_offset)
-        # -- process_action (manager_based_rl_env.py:172)
+            self.step_sensors()
+        self.step_actuators(raw_action)
+        if side is not main:
+            main.wait_stream(side)
+        return self.step_managers(noise_u, command_samples, reset_command_samples)
+
+    def step_sensors(self):
+        """Chain (B): per substep ``scene.update`` (joint_acc, contact sensor, sensor clocks: one launch), then the
+        height scanner's refresh (once per env step: update_period = step_dt; lazy in the reference)."""
+        d = self.data
+        for k in range(LV.DECIMATION):
+            # <sim.step would run here; its results for this substep are self.physics[...][k]>
+            d.joint_pos, d.joint_vel = self.physics["joint_pos"][k], self.physics["joint_vel"][k]
+            self.contact.set_net_contact_forces(self.physics["net_forces"][k])
+            self.scene.update(LV.PHYSICS_DT)
+        d.set_sim_state(root_state_w=self.physics["root_state_w"])
+        if self.scanner_body is None:
+            self.scanner.set_pose(d.root_state_w[:, :3], d.root_state_w[:, 3:7])
+        else:  # strided views of the body's rows: the kernel reads them in place
+            pose = d.body_state_w[:, self.scanner_body]
+            self.scanner.set_pose(pose[:, :3], pose[:, 3:7])
+        # the refresh also writes the height scan the observation term reads (sensor height - hit height - offset)
+        self.scanner._update_outdated_buffers(height_out=self.height_scan, height_offset=self.height_scan_offset)
+
+    def step_actuators(self, raw_action: torch.Tensor):
+        """Chain (A): process_action (manager_based_rl_env.py:172), then the actuator model of every substep
+        (write_data_to_sim)."""
+        d = self.data
+        n, j = self.n, d._j
         _abi.check(_abi.joint_action_process(_abi.ptr(raw_action), _abi.ptr(self.action), _abi.ptr(self.prev_action), None,
                                              self.action_scale, _abi.ptr(d.default_joint_pos), 0.0, None,
                                              _abi.ptr(d.joint_pos_target), n, j, _abi.stream()), "ilx_joint_action_process")
@@ -179,13 +194,22 @@ class LocomotionVelocityStep:
             d.joint_pos, d.joint_vel = self.physics["joint_pos"][k], self.physics["joint_vel"][k]
             ca = ArticulationActions(joint_positions=d.joint_pos_target, joint_velocities=d.joint_vel_target,
                                      joint_efforts=d.joint_effort_target, joint_indices=slice(None))
-            self.actuator.compute(ca, d.joint_pos, d.joint_vel)          # write_data_to_sim
-        if side is not main:
-            main.wait_stream(side)
-        # -- post-physics managers: one launch
+            self.actuator.compute(ca, d.joint_pos, d.joint_vel)
+
+    def step_managers(self, noise_u=None, command_samples=None, reset_command_samples=None, phases: int = FM.PHASE_ALL):
+        """The post-physics managers in one launch: terminations, rewards, resets, command, observations -- or, with
+        ``phases``, the launch of a step issued as two: everything but the observations (needs no ray hit), then the
+        observations."""
+        d = self.data
+        d.joint_pos, d.joint_vel = self.physics["joint_pos"][LV.DECIMATION - 1], self.physics["joint_vel"][LV.DECIMATION - 1]
+        if d.root_state_w.data_ptr() != self.physics["root_state_w"].data_ptr():
+            d.set_sim_state(root_state_w=self.physics["root_state_w"])
         m = self.mdp
         m.bind(root_state_w=d.root_state_w, joint_pos=d.joint_pos, joint_vel=d.joint_vel, noise_u=noise_u,
                command_samples=command_samples, reset_command_samples=reset_command_samples,
                sensor_pos_w=self.scanner._data.pos_w, ray_hits_w=self.scanner._data.ray_hits_w)
-        m.step(FM.PHASE_ALL)
+        if phases == FM.PHASE_ALL:
+            m.step(FM.PHASE_ALL)
+        else:
+            m.step(phases, hold_step_count=not (phases & FM.PHASE_OBSERVATION))
         return m.obs, m.reward_buf, m.terminated, m.time_outs

@@ -160,6 +160,36 @@ def test_generated_noise_and_samples_are_in_range_and_reproducible(dev):
     assert (cmd.abs() <= 1.0).all() and cmd.std() > 0.3
 
 
+@pytest.mark.parametrize("on_device", [False, True])
+def test_step_issued_as_two_launches_draws_like_one(dev, on_device):
+    """Decisions in one launch, observations in the next, the first holding the generator's step count: bit for bit the
+    outputs of the single launch, over several steps, with the count kept by the host or in device memory."""
+    from isaaclab_amd.envs import fused_mdp as FM
+    from isaaclab_amd.tasks import locomotion_velocity as LV
+
+    g = load_golden("managers_anymal")
+    s = {key: v[0] for key, v in g.items() if v.shape[:1] == (g["reward"].shape[0],)}
+    n = s["reward"].shape[0]
+    outs = []
+    for split in (False, True):
+        mdp = make_anymal_mdp(dev, n, command=dict(LV.VELOCITY_COMMAND, resampling_time_range=(0.02, 0.06)))
+        bind_state(mdp, s, dev)
+        mdp.count_steps_on_device(on_device)
+        trace = []
+        for _ in range(4):
+            if split:
+                mdp.step(FM.PHASE_ALL & ~FM.PHASE_OBSERVATION, hold_step_count=True)
+                mdp.step(FM.PHASE_OBSERVATION)
+            else:
+                mdp.step(FM.PHASE_ALL)
+            trace.append([t.cpu().clone() for t in (mdp.obs, mdp.command, mdp.time_left, mdp.reward_buf, mdp.episode_length_buf)])
+        outs.append(trace)
+    for one, two in zip(*outs):
+        for a, b in zip(one, two):
+            assert torch.equal(a, b)
+    assert not torch.equal(outs[0][0][0], outs[0][1][0]), "the noise changes from step to step"
+
+
 def test_pose_command_matches_reference(dev):
     """UniformPoseCommand through the fused kernel's COMMAND / RESET phases against the reference class."""
     from isaaclab_amd.envs import fused_mdp as FM

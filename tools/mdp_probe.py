@@ -18,15 +18,19 @@ torch.cuda.synchronize()
 blk = torch.randn(4096, 4096, device=dev)
 out = torch.empty_like(blk)
 
-def span(fn, reps=20):
+def span(fn, reps=100, rounds=7):
+    """Median over `rounds` of the mean time of `reps` queued launches."""
     for _ in range(3): fn()
-    torch.cuda.synchronize()
-    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    for _ in range(2): torch.mm(blk, blk, out=out)
-    a.record()
-    for _ in range(reps): fn()
-    b.record(); torch.cuda.synchronize()
-    return a.elapsed_time(b) / reps * 1e3
+    times = []
+    for _ in range(rounds):
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for _ in range(2): torch.mm(blk, blk, out=out)
+        a.record()
+        for _ in range(reps): fn()
+        b.record(); torch.cuda.synchronize()
+        times.append(a.elapsed_time(b) / reps * 1e3)
+    return sorted(times)[len(times) // 2]
 
 m = cfg.env.mdp
 print(f"{name} {envs} envs")
