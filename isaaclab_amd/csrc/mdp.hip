@@ -113,14 +113,18 @@ ILX_DEV __attribute__((address_space(1))) T* uni(T* p) {  // ... and a pointer, 
 // Element access as a uniform 64-bit base (scalar registers, advanced to the block's first env with scalar arithmetic)
 // plus a 32-bit per-lane byte offset: the address costs no vector instruction beyond forming the offset.
 template <typename T>
+ILX_DEV __attribute__((address_space(1))) char* scalar_base(T* base) {
+    uint64_t a = reinterpret_cast<uint64_t>(base);
+    asm volatile("" : "+s"(a));  // no instruction: pins the base to scalar registers, so that the compiler does not fold it into the lane's offset
+    return (__attribute__((address_space(1))) char*)a;
+}
+template <typename T>
 ILX_DEV T ld_at(const __attribute__((address_space(1))) T* base, uint32_t byte_off) {
-    return *reinterpret_cast<const __attribute__((address_space(1))) T*>(
-        reinterpret_cast<const __attribute__((address_space(1))) char*>(base) + byte_off);
+    return *reinterpret_cast<const __attribute__((address_space(1))) T*>(scalar_base(base) + byte_off);
 }
 template <typename T, typename V>
 ILX_DEV void st_at(__attribute__((address_space(1))) T* base, uint32_t byte_off, V v) {
-    *reinterpret_cast<__attribute__((address_space(1))) T*>(reinterpret_cast<__attribute__((address_space(1))) char*>(base) + byte_off) =
-        static_cast<T>(v);
+    *reinterpret_cast<__attribute__((address_space(1))) T*>(scalar_base(base) + byte_off) = static_cast<T>(v);
 }
 
 // The layout and the descriptor's most used scalars: a second, small kernel argument that the kernel reads in place (a
@@ -529,7 +533,7 @@ ILX_DEV void stage_segments(float* S, const uint4 rec, int count, int64_t env0, 
         for (int j = 0; j < count; ++j) {
             const uint32_t lo = __builtin_amdgcn_readlane(mine_lo, j), hi = __builtin_amdgcn_readlane(mine_hi, j),
                            a = __builtin_amdgcn_readlane(rec.z, j), b = __builtin_amdgcn_readlane(rec.w, j);
-            const uint64_t base = (static_cast<uint64_t>(hi) << 32) | lo;
+            const auto* base = scalar_base(reinterpret_cast<const char*>((static_cast<uint64_t>(hi) << 32) | lo));
             uint32_t* q = reinterpret_cast<uint32_t*>(S) + (b & 0xffffu);
             if (lane < ((a >> 16) & 127u)) {
                 if (a & (1u << 23)) __builtin_amdgcn_global_load_lds((GlobalPtr*)(base + lane16), (LdsPtr*)q, 16, 0, 0);
@@ -724,21 +728,19 @@ __global__ void __launch_bounds__(kBlock, 4) mdp_step_kernel(MdpDev args, const 
     }
     ILX_STAMP(1)
     if (threadIdx.x < 64) {
-        uint32_t lo = static_cast<uint32_t>(counted), hi = static_cast<uint32_t>(counted >> 32);
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {  // 64-bit sum over the wave
-            const uint32_t olo = __shfl_xor(lo, off, 64), ohi = __shfl_xor(hi, off, 64);
-            const uint64_t sum = ((static_cast<uint64_t>(hi) << 32) | lo) + ((static_cast<uint64_t>(ohi) << 32) | olo);
-            lo = static_cast<uint32_t>(sum), hi = static_cast<uint32_t>(sum >> 32);
-        }
+        // the sum of the counter's slots: every lane adds its own to the step word in LDS (one LDS instruction; the
+        // wavefront's LDS operations keep their order), then one lane turns the sum into the step
+        unsigned long long* word = reinterpret_cast<unsigned long long*>(S + L.gstep);
+        if (threadIdx.x == 0) *word = 0ull;
+        if (p_counter) atomicAdd(word, static_cast<unsigned long long>(counted));
         if (threadIdx.x == 0) {
             // sum / blocks with the sum below 2^52: the quotient of the doubles, corrected by its remainder (a 64-bit
             // integer division is a hundred instructions that the whole wavefront issues)
-            const uint64_t sum = (static_cast<uint64_t>(hi) << 32) | lo, blocks = gridDim.x;
+            const uint64_t sum = *word, blocks = gridDim.x;
             uint64_t quo = static_cast<uint64_t>(static_cast<double>(sum) / static_cast<double>(blocks));
             const int64_t rem = static_cast<int64_t>(sum - quo * blocks);
             quo = rem < 0 ? quo - 1 : (rem >= static_cast<int64_t>(blocks) ? quo + 1 : quo);
-            *reinterpret_cast<uint64_t*>(S + L.gstep) = step_arg + quo;
+            *word = step_arg + quo;
         }
     }
     __syncthreads();  // waits for this wave's copies (vmcnt(0)), then for every wave's

@@ -20,9 +20,10 @@ ILX_DEV u4 philox4(uint64_t seed, uint64_t step, uint64_t env, uint32_t elem) {
         const uint64_t p0 = static_cast<uint64_t>(0xD2511F53u) * c0, p1 = static_cast<uint64_t>(0xCD9E8D57u) * c2;
         const uint32_t hi0 = static_cast<uint32_t>(p0 >> 32), lo0 = static_cast<uint32_t>(p0);
         const uint32_t hi1 = static_cast<uint32_t>(p1 >> 32), lo1 = static_cast<uint32_t>(p1);
-        c0 = hi1 ^ c1 ^ k0;
+        // three-way exclusive or in one instruction (v_bitop3_b32, truth table 0x96)
+        c0 = __builtin_amdgcn_bitop3_b32(hi1, c1, k0, 0x96);
         c1 = lo1;
-        c2 = hi0 ^ c3 ^ k1;
+        c2 = __builtin_amdgcn_bitop3_b32(hi0, c3, k1, 0x96);
         c3 = lo0;
         k0 += 0x9E3779B9u;
         k1 += 0xBB67AE85u;
