@@ -43,7 +43,7 @@ struct Layout {
     int terms, ids;
     int q, qd, qdd, tau_a, tau_c, q0, qd0, vlim, lim;  // joints (lim: 2 per joint)
     int act, pact;                                     // action columns
-    int air, last_air, contact_t, fpeak;               // sensor bodies
+    int air, last_air, contact_t;                      // sensor bodies
     int fraw;                                          // force history [env][history][body][3] as it lies in memory
     int bvx, bvy, bacc;                                // asset bodies
     int cmd, root;                                     // command row, 13-wide root state
@@ -90,7 +90,7 @@ struct alignas(16) MdpDev {
     int any_noise;            // some observation term draws noise
     uint32_t noisy_terms;     // bit i: observation term i draws noise (kMaxTerms = 32)
     Layout L;
-    uint32_t inv_sensor_bodies, inv_rewards;  // ceil(2^32 / n): i / n == umulhi(i, inv) for the i < 2^16 of a block
+    uint32_t inv_rewards;     // ceil(2^32 / n): i / n == umulhi(i, inv) for the i < 2^16 of a block
     int num_segs;             // STAGE work list, see stage_segments
     uint4 segs[kMaxSegs];
 };
@@ -133,7 +133,7 @@ struct Hot {
     Layout L;
     int num_joints, num_bodies, num_sensor_bodies, command_dim, action_dim, num_rays, command_kind;
     int num_terminations, num_rewards, obs_dim, history_len, num_segs;
-    uint32_t phases, need, inv_sensor_bodies, inv_rewards;
+    uint32_t phases, need, inv_rewards;
     float step_dt, gravity[3];
     int64_t num_envs;
     uint64_t seed, step_index;
@@ -162,6 +162,16 @@ struct Env {
     ILX_DEV float joint(int off, int j) const { return S[off + e * h.num_joints + j]; }
     ILX_DEV float sbody(int off, int b) const { return S[off + e * h.num_sensor_bodies + b]; }
     ILX_DEV float abody(int off, int b) const { return S[off + e * h.num_bodies + b]; }
+    // max over the history of |F| of one sensor body (rewards.py:266 / terminations.py:157), from the force history as
+    // it lies in memory: the largest sum of squares, then one square root (the root is monotonic and correctly
+    // rounded, so this is the largest norm, bit for bit)
+    ILX_DEV float force_peak(int b) const {
+        const int H = h.history_len, CB = h.num_sensor_bodies;
+        const float* f = S + h.L.fraw + 3 * (e * H * CB + b);
+        float mx = -1.0f;
+        for (int k = 0; k < H; ++k, f += 3 * CB) mx = fmaxf(mx, fmaf_(f[2], f[2], fmaf_(f[1], f[1], f[0] * f[0])));
+        return mx < 0.0f ? -__builtin_inff() : sqrt_(mx);
+    }
     ILX_DEV float cmd(int k) const { return S[h.L.cmd + e * h.command_dim + k]; }
     template <typename F>
     ILX_DEV float joint_sum(const ilx_term& t, F f) const {
@@ -215,7 +225,7 @@ ILX_DEV bool eval_termination(const Env& e, const ilx_term& t, int64_t ep_len) {
         case ILX_TERM_ILLEGAL_CONTACT: {  // :150-158
             const int n = e.bcount_sensor(t);
             bool hit = false;
-            for (int k = 0; k < n; ++k) hit = hit | (e.sbody(L.fpeak, e.id(t, k)) > t.p[0]);
+            for (int k = 0; k < n; ++k) hit = hit | (e.force_peak(e.id(t, k)) > t.p[0]);
             return hit;
         }
     }
@@ -291,13 +301,13 @@ ILX_DEV float eval_reward(const Env& e, const ilx_term& t, bool terminated, bool
         case ILX_REW_UNDESIRED_CONTACTS: {  // :260-268 (count of bodies above the threshold)
             const int n = e.bcount_sensor(t);
             float acc = 0.0f;
-            for (int k = 0; k < n; ++k) acc += (e.sbody(L.fpeak, e.id(t, k)) > t.p[0]) ? 1.0f : 0.0f;
+            for (int k = 0; k < n; ++k) acc += (e.force_peak(e.id(t, k)) > t.p[0]) ? 1.0f : 0.0f;
             return acc;
         }
         case ILX_REW_CONTACT_FORCES: {  // :271-279
             const int n = e.bcount_sensor(t);
             float acc = 0.0f;
-            for (int k = 0; k < n; ++k) acc += fmaxf(e.sbody(L.fpeak, e.id(t, k)) - t.p[0], 0.0f);
+            for (int k = 0; k < n; ++k) acc += fmaxf(e.force_peak(e.id(t, k)) - t.p[0], 0.0f);
             return acc;
         }
         case ILX_REW_TRACK_LIN_VEL_XY_EXP: {  // :287-298
@@ -337,7 +347,7 @@ ILX_DEV float eval_reward(const Env& e, const ilx_term& t, bool terminated, bool
             const int n = e.bcount_sensor(t);
             float acc = 0.0f;
             for (int k = 0; k < n; ++k) {
-                const bool contact = e.sbody(L.fpeak, e.id(t, k)) > 1.0f;
+                const bool contact = e.force_peak(e.id(t, k)) > 1.0f;
                 const int ab = e.id2(t, k);
                 acc += norm2(e.abody(L.bvx, ab), e.abody(L.bvy, ab)) * (contact ? 1.0f : 0.0f);
             }
@@ -602,7 +612,7 @@ __global__ void __launch_bounds__(kBlock, 4) mdp_step_kernel(MdpDev args, const 
     const int64_t N = hot.num_envs;
     const int64_t env0 = static_cast<int64_t>(blockIdx.x) * kE;
     const int ne = static_cast<int>(N - env0 < kE ? N - env0 : kE);
-    const int B = hot.num_bodies, CB = hot.num_sensor_bodies, CD = hot.command_dim;
+    const int B = hot.num_bodies, CD = hot.command_dim;
     const int tid = threadIdx.x;
     const uint32_t phases = hot.phases, need = hot.need;
     const bool ph_term = phases & ILX_PHASE_TERMINATION, ph_rew = phases & ILX_PHASE_REWARD,
@@ -746,24 +756,6 @@ __global__ void __launch_bounds__(kBlock, 4) mdp_step_kernel(MdpDev args, const 
     __syncthreads();  // waits for this wave's copies (vmcnt(0)), then for every wave's
     const uint64_t gen_step = uni(*reinterpret_cast<const uint64_t*>(S + L.gstep));
     ILX_STAMP(2)
-    if (need & kNeedForces) {  // max over the history of |F| per (env, body): rewards.py:266 / terminations.py:157
-        const int H = hot.history_len;
-        const uint32_t inv = hot.inv_sensor_bodies;
-        for (int i = tid; i < ne * CB; i += kBlock) {
-            const int ee = CB > 1 ? static_cast<int>(__umulhi(static_cast<uint32_t>(i), inv)) : i;  // i / CB
-            const int b = i - ee * CB;
-            // the largest sum of squares, then one square root: the root is monotonic and correctly rounded, so this is
-            // the largest norm, bit for bit
-            float mx = -1.0f;
-            const float* f = S + L.fraw + 3 * (ee * H * CB + b);
-#pragma unroll 4
-            for (int h = 0; h < H; ++h, f += 3 * CB) mx = fmaxf(mx, fmaf_(f[2], f[2], fmaf_(f[1], f[1], f[0] * f[0])));
-            S[L.fpeak + i] = mx < 0.0f ? -__builtin_inff() : sqrt_(mx);
-        }
-        __syncthreads();
-    }
-
-    ILX_STAMP(3)
     // ================= DECIDE: one lane per env; the four waves split the reward terms =================
     Env en{m, hot, S, ids, e, env};
     const float dt = hot.step_dt;
@@ -1432,7 +1424,7 @@ extern "C" int ilx_mdp_step(ilx_mdp_plan_t plan, const ilx_mdp* desc, void* stre
     m.any_noise = plan->any_noise;
     m.noisy_terms = plan->noisy_terms;
     auto inverse = [](int n) { return n > 1 ? static_cast<uint32_t>((0x100000000ull + n - 1) / n) : 0xffffffffu; };
-    m.inv_sensor_bodies = inverse(d.num_sensor_bodies), m.inv_rewards = inverse(d.num_rewards);
+    m.inv_rewards = inverse(d.num_rewards);
     m.need = 0;
     if ((pt && plan->t_joint) || (pr && plan->r_joint) || (po && plan->o_joint)) m.need |= kNeedJoint;
     if ((pt && plan->t_contact) || (pr && plan->r_contact)) m.need |= kNeedForces;
@@ -1456,7 +1448,6 @@ extern "C" int ilx_mdp_step(ilx_mdp_plan_t plan, const ilx_mdp* desc, void* stre
     L.act = take(na ? kE * A : 0), L.pact = take(na ? kE * A : 0);
     const bool ntm = m.need & kNeedTimers;
     L.air = take(ntm ? kE * CB : 0), L.last_air = take(ntm ? kE * CB : 0), L.contact_t = take(ntm ? kE * CB : 0);
-    L.fpeak = take((m.need & kNeedForces) ? kE * CB : 0);
     L.fraw = take((m.need & kNeedForces) ? kE * 3 * d.history_len * CB : 0);
     L.bvx = take((m.need & kNeedBodyVel) ? kE * B : 0), L.bvy = take((m.need & kNeedBodyVel) ? kE * B : 0);
     L.bacc = take((m.need & kNeedBodyAcc) ? kE * B : 0);
@@ -1527,7 +1518,7 @@ extern "C" int ilx_mdp_step(ilx_mdp_plan_t plan, const ilx_mdp* desc, void* stre
     hot.num_terminations = plan->nt, hot.num_rewards = plan->nr, hot.obs_dim = plan->obs_dim;
     hot.history_len = d.history_len, hot.num_segs = m.num_segs;
     hot.phases = d.phases, hot.need = m.need;
-    hot.inv_sensor_bodies = m.inv_sensor_bodies, hot.inv_rewards = m.inv_rewards;
+    hot.inv_rewards = m.inv_rewards;
     hot.step_dt = d.step_dt;
     for (int k = 0; k < 3; ++k) hot.gravity[k] = d.gravity_dir[k];
     hot.num_envs = d.num_envs, hot.seed = d.seed, hot.step_index = d.step_index;

@@ -22,11 +22,11 @@ buf = (ctypes.c_ulonglong * (16 * 2048))()
 assert _abi.lib.ilx_debug_mdp_stamps(buf, 16 * 2048) == 0
 t = np.frombuffer(buf, dtype=np.uint64).reshape(2048, 16)[:blocks, :16].astype(np.int64)
 t0 = t[:, 0].min()
-labels = ["entry", "stage issued", "stage landed", "force peaks", "terminations", "rewards", "barrier", "reset+command", "barrier",
+labels = ["entry", "stage issued", "stage landed", "-", "terminations", "rewards", "barrier", "reset+command", "barrier",
           "sums/flags out", "observations out"]
 print(f"{name} {envs} envs, {blocks} blocks; ticks of 10 ns; per stamp: mean since kernel start, mean since previous stamp")
 labels += ["  obs: lane set up", "  obs: loads issued (env 0)", "  obs: noise drawn", "stage: work list reached", "arguments in LDS"]
-order = [0, 15, 14, 1, 2, 3, 4, 5, 6, 7, 8, 9, 11, 12, 13, 10]
+order = [0, 15, 14, 1, 2, 4, 5, 6, 7, 8, 9, 11, 12, 13, 10]
 prev = t[:, 0]
 for k in order:
     lab = labels[k]
