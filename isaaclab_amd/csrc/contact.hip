@@ -59,11 +59,24 @@ ILX_DEV void write_clock(float* ts, float* ts_last, uint8_t* outdated, int64_t e
     }
 }
 
+// What a refresh of one (env, body) reads besides the history: loaded ahead of the decision whether the env refreshes,
+// so that these loads and the clock's travel together.
+struct BodyIn {
+    f3 f;
+    float cur_air, cur_contact;
+};
+ILX_DEV BodyIn load_body(const ContactArgs& a, int64_t env, int body) {
+    const int64_t eb = env * a.b + body;
+    BodyIn in{load3(a.in + 3 * eb), 0.0f, 0.0f};
+    if (a.cur_air) in.cur_air = a.cur_air[eb], in.cur_contact = a.cur_contact[eb];
+    return in;
+}
+
 // contact_sensor.py:324-373 for one (env, body).
 // `slot`: ring mode, the history slot this refresh writes.
-ILX_DEV void contact_body(const ContactArgs& a, int64_t env, int body, float elapsed, int slot) {
+ILX_DEV void contact_body(const ContactArgs& a, int64_t env, int body, float elapsed, int slot, const BodyIn& in) {
     const int64_t eb = env * a.b + body;
-    const f3 f = load3(a.in + 3 * eb);
+    const f3 f = in.f;
     store3(a.net + 3 * eb, f);  // contact_sensor.py:324
     if (a.hist && a.head) {     // the same history as below, kept as a ring: one row written instead of h rows moved
         store3(a.hist + 3 * ((env * a.h + slot) * a.b + body), f);
@@ -80,7 +93,7 @@ ILX_DEV void contact_body(const ContactArgs& a, int64_t env, int body, float ela
     }
     if (a.cur_air) {  // contact_sensor.py:346-373
         const bool contact = norm3(f) > a.thr;
-        const float ca = a.cur_air[eb], cc = a.cur_contact[eb];
+        const float ca = in.cur_air, cc = in.cur_contact;
         const bool first_contact = (ca > 0.0f) && contact;
         const bool first_detached = (cc > 0.0f) && !contact;
         if (first_contact) a.last_air[eb] = ca + elapsed;
@@ -88,6 +101,9 @@ ILX_DEV void contact_body(const ContactArgs& a, int64_t env, int body, float ela
         if (first_detached) a.last_contact[eb] = cc + elapsed;
         a.cur_contact[eb] = contact ? cc + elapsed : 0.0f;
     }
+}
+ILX_DEV void contact_body(const ContactArgs& a, int64_t env, int body, float elapsed, int slot) {
+    contact_body(a, env, body, elapsed, slot, load_body(a, env, body));
 }
 
 __global__ void __launch_bounds__(256) contact_update_kernel(ContactArgs a) {
@@ -130,21 +146,30 @@ struct SceneArgs {
     uint8_t* ray_outdated;
     float ray_period;
     int width;
+    uint32_t inv_width;     // ceil(2^32 / width): t / width == umulhi(t, inv_width) for the t < 256 of a block
 };
 
 __global__ void __launch_bounds__(256) scene_update_kernel(SceneArgs s) {
     const ContactArgs& a = s.c;
     const int t = threadIdx.x;
-    const int le = t / s.width;
+    const int le = s.width > 1 ? static_cast<int>(__umulhi(static_cast<uint32_t>(t), s.inv_width)) : t;  // t / width
     const int k0 = t - le * s.width;
     const int64_t env = static_cast<int64_t>(blockIdx.x) * a.envs_per_block + le;
     const bool active = le < a.envs_per_block && env < a.n;
     const bool has_contact = a.in != nullptr;
 
+    // Everything the thread may read goes out before the barrier, in one trip to memory: the clock, and the inputs of
+    // the first body / joint the thread owns (read whether or not the env turns out to refresh).
     Clock c{0.0f, 0.0f, false};
     int slot = 0;
+    const bool body_ahead = active && has_contact && !s.contact_lazy && k0 < a.b;
+    const bool joint_ahead = active && s.joint_vel && k0 < s.j;
+    BodyIn first_body{};
+    float first_v = 0.0f, first_prev = 0.0f;
     if (active && has_contact) c = read_clock(a.ts, a.ts_last, a.outdated, env, 1, a.dt, a.period);
     if (active && has_contact && a.head) slot = next_slot(a.head[env], a.h);
+    if (body_ahead) first_body = load_body(a, env, k0);
+    if (joint_ahead) first_v = s.joint_vel[env * s.j + k0], first_prev = s.prev_joint_vel[env * s.j + k0];
     __syncthreads();
     if (!active) return;
     if (k0 == 0) {
@@ -158,14 +183,16 @@ __global__ void __launch_bounds__(256) scene_update_kernel(SceneArgs s) {
     if (s.joint_vel) {
         for (int j = k0; j < s.j; j += s.width) {
             const int64_t i = env * s.j + j;
-            const float v = s.joint_vel[i];
-            s.joint_acc[i] = div_(v - s.prev_joint_vel[i], s.joint_elapsed);
+            const float v = j == k0 ? first_v : s.joint_vel[i];
+            const float prev = j == k0 ? first_prev : s.prev_joint_vel[i];
+            s.joint_acc[i] = div_(v - prev, s.joint_elapsed);
             s.prev_joint_vel[i] = v;
         }
     }
     if (has_contact && c.refresh && !s.contact_lazy) {
         const float elapsed = c.ts_new - c.last;
-        for (int body = k0; body < a.b; body += s.width) contact_body(a, env, body, elapsed, slot);
+        for (int body = k0; body < a.b; body += s.width)
+            contact_body(a, env, body, elapsed, slot, body == k0 ? first_body : load_body(a, env, body));
     }
 }
 
@@ -243,6 +270,7 @@ extern "C" int ilx_scene_update(const ilx_scene* scene, void* stream) {
     }
     if (width > 256) width = 256;
     s.width = width;
+    s.inv_width = static_cast<uint32_t>((0x100000000ull + width - 1) / width);
     a.envs_per_block = 256 / width;
     const unsigned blocks = static_cast<unsigned>((d.num_envs + a.envs_per_block - 1) / a.envs_per_block);
     hipLaunchKernelGGL(scene_update_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), s);
