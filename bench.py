@@ -86,16 +86,23 @@ def capture_step(cfg, reducer):
             cfg.step()
     side.synchronize()
     graphs = []
+    # the statistics vector starts every replay at zero: the step clears it itself where it can (behind its fork, so that
+    # neither chain waits for the clearing launch), else the clearing is recorded ahead of the step
+    own_clear = reducer is not None and hasattr(cfg.env, "clear_log_sums")
+    if own_clear:
+        cfg.env.clear_log_sums = True
     for i in range(2 if reducer is not None else 1):
         if reducer is not None:
             cfg.bind_log_sums(reducer.buffer(i))
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph, stream=side):
-            if reducer is not None:
-                reducer.buffer(i).zero_()    # recorded: the vector starts every replay at zero
+            if reducer is not None and not own_clear:
+                reducer.buffer(i).zero_()
             cfg.step()
         graphs.append(graph)
     torch.cuda.synchronize()
+    if own_clear:
+        cfg.env.clear_log_sums = False
     if overlap:
         cfg.env.concurrent_chains = False
     return graphs

@@ -101,6 +101,8 @@ class LocomotionVelocityStep:
         # see step(): worth it when the step is replayed from a HIP graph and the actuator chain is long (network
         # actuators); issued launch by launch, the fork and join cost the host more than the overlap returns
         self.concurrent_chains = False
+        # the managers add the done envs' statistics to mdp.log_sums; set, every step starts the vector at zero itself
+        self.clear_log_sums = False
         self._side_stream = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
 
     def _bind(self):
@@ -159,6 +161,8 @@ class LocomotionVelocityStep:
             side.wait_stream(main)
         with torch.cuda.stream(side):
             self.step_sensors()
+        if self.clear_log_sums:   # at the head of chain (A), behind the fork: recorded in a graph, (B) then waits for nothing
+            self.mdp.log_sums.zero_()
         self.step_actuators(raw_action)
         if side is not main:
             main.wait_stream(side)
