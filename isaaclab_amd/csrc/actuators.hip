@@ -12,6 +12,7 @@
 #include "common.h"
 #include "math_dev.h"
 #include "mlp_net.h"
+#include "uniform_access.h"
 
 #include <algorithm>
 #include <vector>
@@ -160,6 +161,7 @@ struct NetArgs {
     float* applied;
     int64_t rows;  // N * J
     int j;
+    float inv_j;   // 1.0f / j
 };
 
 // Reads the row's inputs, forms the network input features, and hands back the old history values.
@@ -188,6 +190,19 @@ ILX_DEV RowAt<I> row_at(const NetArgs& a, I row) {
     return {row, env * static_cast<I>(a.hist_len) * static_cast<I>(a.j) + joint, a.per_env ? row : joint};
 }
 
+// Element `idx` of an array whose pointer is a kernel argument.  With 32-bit indices (the tile kernels: the host has
+// checked that every byte offset fits) the address is the scalar base plus the lane's 32-bit byte offset.
+template <class I>
+ILX_DEV float rd(const float* p, I idx) {
+    if constexpr (sizeof(I) == 4) return ld_at(as_global(p), 4u * static_cast<uint32_t>(idx));
+    else return p[idx];
+}
+template <class I>
+ILX_DEV void wr(float* p, I idx, float v) {
+    if constexpr (sizeof(I) == 4) st_at(as_global(p), 4u * static_cast<uint32_t>(idx), v);
+    else p[idx] = v;
+}
+
 // Row inputs as they come from memory; issue_row only issues the loads (nothing consumes them), so a caller can
 // put a tile's worth of compute between issue_row and finish_row.
 template <int H>
@@ -202,15 +217,15 @@ ILX_DEV void issue_row(const NetArgs& a, const RowAt<I>& at, bool valid, RowRawT
     w.q_des = w.q = w.qd = 0.0f;
     w.vel_limit = w.effort_limit = 1.0f;
     if (valid) {
-        w.q_des = a.q_des[at.row], w.q = a.q[at.row], w.qd = a.qd[at.row];
-        w.vel_limit = a.vel_limit[at.pidx], w.effort_limit = a.effort_limit[at.pidx];
+        w.q_des = rd(a.q_des, at.row), w.q = rd(a.q, at.row), w.qd = rd(a.qd, at.row);
+        w.vel_limit = rd(a.vel_limit, at.pidx), w.effort_limit = rd(a.effort_limit, at.pidx);
     }
 #pragma unroll
     for (int k = 0; k < H - 1; ++k) {
         w.pe_old[k] = w.v_old[k] = 0.0f;
         if (valid && k < a.hist_len - 1) {
-            w.pe_old[k] = a.pe_hist[at.hbase + static_cast<I>(k * a.j)];
-            w.v_old[k] = a.v_hist[at.hbase + static_cast<I>(k * a.j)];
+            w.pe_old[k] = rd(a.pe_hist, at.hbase + static_cast<I>(k * a.j));
+            w.v_old[k] = rd(a.v_hist, at.hbase + static_cast<I>(k * a.j));
         }
     }
     // which history slot feeds feature f is the same for all rows (resolved on the host): one more (cached) read
@@ -218,7 +233,7 @@ ILX_DEV void issue_row(const NetArgs& a, const RowAt<I>& at, bool valid, RowRawT
     for (int f = 0; f < 2 * H; ++f) {
         w.slot[f] = 0.0f;
         if (f < a.n_feat && a.feat_slot[f] > 0 && valid)
-            w.slot[f] = (((a.feat_is_pos >> f) & 1) ? a.pe_hist : a.v_hist)[at.hbase + static_cast<I>((a.feat_slot[f] - 1) * a.j)];
+            w.slot[f] = rd(((a.feat_is_pos >> f) & 1) ? a.pe_hist : a.v_hist, at.hbase + static_cast<I>((a.feat_slot[f] - 1) * a.j));
     }
 }
 
@@ -251,14 +266,14 @@ ILX_DEV void load_row(const NetArgs& a, const RowAt<I>& at, bool valid, RowInT<H
 // actuator_net.py:150-156: roll both histories by one slot and write the newest sample into slot 0.
 template <int H, class I>
 ILX_DEV void store_history(const NetArgs& a, const RowAt<I>& at, const RowInT<H>& r, bool do_pos, bool do_vel) {
-    if (do_pos) a.pe_hist[at.hbase] = r.pe_new0;
-    if (do_vel) a.v_hist[at.hbase] = r.vel;
+    if (do_pos) wr(a.pe_hist, at.hbase, r.pe_new0);
+    if (do_vel) wr(a.v_hist, at.hbase, r.vel);
 #pragma unroll
     for (int k = 0; k < H - 1; ++k) {
         if (k < a.hist_len - 1) {
             const I o = at.hbase + static_cast<I>((k + 1) * a.j);
-            if (do_pos) a.pe_hist[o] = r.pe_old[k];
-            if (do_vel) a.v_hist[o] = r.v_old[k];
+            if (do_pos) wr(a.pe_hist, o, r.pe_old[k]);
+            if (do_vel) wr(a.v_hist, o, r.v_old[k]);
         }
     }
 }
@@ -266,8 +281,8 @@ ILX_DEV void store_history(const NetArgs& a, const RowAt<I>& at, const RowInT<H>
 template <int H, class I>
 ILX_DEV void store_torque(const NetArgs& a, const RowAt<I>& at, float net_out, const RowInT<H>& r) {
     const float tau = net_out * a.torque_scale;  // actuator_net.py:179
-    a.computed[at.row] = tau;
-    a.applied[at.row] = dc_motor_clip(tau, r.vel, a.sat, r.vel_limit, r.effort_limit);
+    wr(a.computed, at.row, tau);
+    wr(a.applied, at.row, dc_motor_clip(tau, r.vel, a.sat, r.vel_limit, r.effort_limit));
 }
 
 // ---- generic path ------------------------------------------------------------------------------
@@ -416,7 +431,7 @@ __global__ void __launch_bounds__(256, 8) mlp_mfma_tile_kernel(NetArgs a) {
     const uint32_t row0 = static_cast<uint32_t>(live ? tile : 0) * 32u;
     const uint32_t env0 = row0 / j, joint0 = row0 - env0 * j;
     const uint32_t x = joint0 + (lane & 31);  // < j + 32
-    uint32_t q = static_cast<uint32_t>(static_cast<float>(x) * (1.0f / static_cast<float>(j)));  // exact up to +-1 for x < 2^22
+    uint32_t q = static_cast<uint32_t>(static_cast<float>(x) * a.inv_j);  // exact up to +-1 for x < 2^22
     q = (q * j > x) ? q - 1 : q;
     q = ((q + 1) * j <= x) ? q + 1 : q;
     const uint32_t env = env0 + q, joint = x - q * j, row = row0 + (lane & 31);
@@ -513,7 +528,7 @@ __global__ void __launch_bounds__(256, 8) mlp_mfma_split_kernel(NetArgs a) {
     const uint32_t row0 = static_cast<uint32_t>(live ? tile : 0) * 32u;
     const uint32_t env0 = row0 / j, joint0 = row0 - env0 * j;
     const uint32_t x = joint0 + (lane & 31);  // < j + 32
-    uint32_t q = static_cast<uint32_t>(static_cast<float>(x) * (1.0f / static_cast<float>(j)));  // exact up to +-1 for x < 2^22
+    uint32_t q = static_cast<uint32_t>(static_cast<float>(x) * a.inv_j);  // exact up to +-1 for x < 2^22
     q = (q * j > x) ? q - 1 : q;
     q = ((q + 1) * j <= x) ? q + 1 : q;
     const uint32_t env = env0 + q, joint = x - q * j, row = row0 + (lane & 31);
@@ -749,7 +764,7 @@ static void launch_mlp(const NetArgs& a, bool force_generic, bool exact_f32, hip
         const int nhid = a.net.num_layers - 1;
         // the tile kernels index with 32 bits
         const bool small = a.hist_len <= kResidentHist && a.n_feat <= 2 * kResidentHist && a.j < (1 << 20) &&
-                           a.rows * a.hist_len < (int64_t(1) << 31);
+                           a.rows * a.hist_len < (int64_t(1) << 30);  // byte offsets of the history below 2^32
         const unsigned tile_blocks = static_cast<unsigned>((tiles + 3) / 4);
         const bool split = a.net.image16 && !exact_f32;
         if (nhid == 3 && small && split)
@@ -802,7 +817,7 @@ extern "C" int ilx_actuator_net_mlp(ilx_mlp_t net, const float* q_des, const flo
     a.pos_scale = pos_scale, a.vel_scale = vel_scale, a.torque_scale = torque_scale;
     a.effort_limit = effort_limit, a.vel_limit = velocity_limit, a.per_env = params_per_env, a.sat = saturation_effort;
     a.computed = computed, a.applied = applied;
-    a.rows = n * j, a.j = j;
+    a.rows = n * j, a.j = j, a.inv_j = 1.0f / static_cast<float>(j);
     if (a.rows == 0) return ILX_OK;
     hipStream_t s = as_stream(stream);
     const bool generic = (flags & ILX_MLP_FORCE_GENERIC) != 0, exact = (flags & ILX_MLP_EXACT_F32) != 0;

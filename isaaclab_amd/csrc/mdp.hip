@@ -17,6 +17,7 @@
 #include "common.h"
 #include "math_dev.h"
 #include "philox.h"
+#include "uniform_access.h"
 
 #include "../../include/isaaclab_amd_mdp.h"
 
@@ -76,11 +77,6 @@ struct alignas(16) TermHead {
     float weight, p0, p1, p2, p3, aux;
 };
 static_assert(sizeof(ilx_term) == 48 && offsetof(ilx_term, aux) == 28, "TermHead mirrors the head of ilx_term");
-template <typename T>
-ILX_DEV __attribute__((address_space(1))) T* as_global(T* p) {  // pointers read back from LDS have lost their address space
-    return (__attribute__((address_space(1))) T*)p;
-}
-
 struct alignas(16) MdpDev {
     ilx_mdp d;                // by-value copy; the HOST pointers inside are nulled
     const ilx_term* terms;    // device: [terminations | rewards | observations]
@@ -94,38 +90,6 @@ struct alignas(16) MdpDev {
     int num_segs;             // STAGE work list, see stage_segments
     uint4 segs[kMaxSegs];
 };
-
-// A value that is the same in every lane, moved into scalar registers.  What the kernel reads from its LDS copy of the
-// arguments is such a value, but the compiler cannot know: left alone it keeps the value in a vector register, or reads
-// it again (one LDS load and one wait) wherever it is used, since nothing says that this part of LDS never changes.
-ILX_DEV int32_t uni(int32_t v) { return __builtin_amdgcn_readfirstlane(v); }
-ILX_DEV uint32_t uni(uint32_t v) { return static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int32_t>(v))); }
-ILX_DEV float uni(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int32_t, v))); }
-ILX_DEV uint64_t uni(uint64_t v) {
-    return (static_cast<uint64_t>(uni(static_cast<uint32_t>(v >> 32))) << 32) | uni(static_cast<uint32_t>(v));
-}
-ILX_DEV int64_t uni(int64_t v) { return static_cast<int64_t>(uni(static_cast<uint64_t>(v))); }
-template <typename T>
-ILX_DEV __attribute__((address_space(1))) T* uni(T* p) {  // ... and a pointer, as a global-memory one
-    return (__attribute__((address_space(1))) T*)uni(reinterpret_cast<uint64_t>(p));
-}
-
-// Element access as a uniform 64-bit base (scalar registers, advanced to the block's first env with scalar arithmetic)
-// plus a 32-bit per-lane byte offset: the address costs no vector instruction beyond forming the offset.
-template <typename T>
-ILX_DEV __attribute__((address_space(1))) char* scalar_base(T* base) {
-    uint64_t a = reinterpret_cast<uint64_t>(base);
-    asm volatile("" : "+s"(a));  // no instruction: pins the base to scalar registers, so that the compiler does not fold it into the lane's offset
-    return (__attribute__((address_space(1))) char*)a;
-}
-template <typename T>
-ILX_DEV T ld_at(const __attribute__((address_space(1))) T* base, uint32_t byte_off) {
-    return *reinterpret_cast<const __attribute__((address_space(1))) T*>(scalar_base(base) + byte_off);
-}
-template <typename T, typename V>
-ILX_DEV void st_at(__attribute__((address_space(1))) T* base, uint32_t byte_off, V v) {
-    *reinterpret_cast<__attribute__((address_space(1))) T*>(scalar_base(base) + byte_off) = static_cast<T>(v);
-}
 
 // The layout and the descriptor's most used scalars: a second, small kernel argument that the kernel reads in place (a
 // few scalar loads at its start, straight into scalar registers).

@@ -1,0 +1,44 @@
+// Device helpers for values and addresses that are the same in every lane of a wavefront.
+#pragma once
+
+#include <cstdint>
+
+#include "math_dev.h"
+
+namespace ilx {
+
+// A value that is the same in every lane, moved into scalar registers.
+ILX_DEV int32_t uni(int32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+ILX_DEV uint32_t uni(uint32_t v) { return static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int32_t>(v))); }
+ILX_DEV float uni(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int32_t, v))); }
+ILX_DEV uint64_t uni(uint64_t v) {
+    return (static_cast<uint64_t>(uni(static_cast<uint32_t>(v >> 32))) << 32) | uni(static_cast<uint32_t>(v));
+}
+ILX_DEV int64_t uni(int64_t v) { return static_cast<int64_t>(uni(static_cast<uint64_t>(v))); }
+template <typename T>
+ILX_DEV __attribute__((address_space(1))) T* uni(T* p) {  // ... and a pointer, as a global-memory one
+    return (__attribute__((address_space(1))) T*)uni(reinterpret_cast<uint64_t>(p));
+}
+template <typename T>
+ILX_DEV __attribute__((address_space(1))) T* as_global(T* p) {  // a generic pointer known to point to global memory
+    return (__attribute__((address_space(1))) T*)p;
+}
+
+// Element access as a uniform 64-bit base (scalar registers; advance it to a block's first element with scalar
+// arithmetic) plus a 32-bit per-lane byte offset: the address costs no vector instruction beyond forming the offset.
+template <typename T>
+ILX_DEV __attribute__((address_space(1))) char* scalar_base(T* base) {
+    uint64_t a = reinterpret_cast<uint64_t>(base);
+    asm volatile("" : "+s"(a));  // no instruction: pins the base to scalar registers, so that the compiler does not fold it into the lane's offset
+    return (__attribute__((address_space(1))) char*)a;
+}
+template <typename T>
+ILX_DEV T ld_at(const __attribute__((address_space(1))) T* base, uint32_t byte_off) {
+    return *reinterpret_cast<const __attribute__((address_space(1))) T*>(scalar_base(base) + byte_off);
+}
+template <typename T, typename V>
+ILX_DEV void st_at(__attribute__((address_space(1))) T* base, uint32_t byte_off, V v) {
+    *reinterpret_cast<__attribute__((address_space(1))) T*>(scalar_base(base) + byte_off) = static_cast<T>(v);
+}
+
+}  // namespace ilx
