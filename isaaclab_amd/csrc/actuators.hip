@@ -514,10 +514,19 @@ ILX_DEV void split_f16(const f32x16& x, h8 (&hi)[2], h8 (&lo)[2]) {
     }
 }
 
+#ifdef ILX_MLP_STAMPS  // diagnostics build only: wall-clock stamps (10 ns ticks) of the first wavefront of the first blocks
+__device__ unsigned long long g_mlp_stamps[8 * 2048];
+#define ILX_MLP_STAMP(k) \
+    if (threadIdx.x == 0 && blockIdx.x < 2048) g_mlp_stamps[blockIdx.x * 8 + (k)] = wall_clock64();
+#else
+#define ILX_MLP_STAMP(k)
+#endif
+
 template <int ACT, int NHID>
 __global__ void __launch_bounds__(256, 8) mlp_mfma_split_kernel(NetArgs a) {
     constexpr int kHiddenWords = (NHID - 1) * 1024;  // 4 fragments x 64 lanes x 16 bytes per hidden layer
     __shared__ __attribute__((aligned(16))) float img[kResidentHist * 64 + kHiddenWords + NHID * 32 + 32 + 4];
+    ILX_MLP_STAMP(0)
     const int lane = threadIdx.x & 63;
     const int half = lane >> 5;
     const int64_t tiles = (a.rows + 31) / 32;
@@ -537,6 +546,7 @@ __global__ void __launch_bounds__(256, 8) mlp_mfma_split_kernel(NetArgs a) {
                                 valid ? (a.per_env ? row : joint) : 0u};
     RowRawT<kResidentHist> raw;
     issue_row(a, at, valid, raw);
+    ILX_MLP_STAMP(1)
     // the image is padded to whole 16-byte words
     {
         const float4* src = reinterpret_cast<const float4*>(a.net.image16);
@@ -544,6 +554,7 @@ __global__ void __launch_bounds__(256, 8) mlp_mfma_split_kernel(NetArgs a) {
         for (int i = threadIdx.x; i < a.net.image16_floats / 4; i += 256) dst[i] = src[i];
     }
     __syncthreads();
+    ILX_MLP_STAMP(2)
     if (!live) return;
     RowInT<kResidentHist> cur;
     finish_row(a, raw, cur);
@@ -565,7 +576,9 @@ __global__ void __launch_bounds__(256, 8) mlp_mfma_split_kernel(NetArgs a) {
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w0[s * 64], bop, acc, 0, 0, 0);
         }
     }
+    ILX_MLP_STAMP(3)
     acc = activate16<ACT>(acc);
+    ILX_MLP_STAMP(4)
 #pragma unroll
     for (int l = 1; l < NHID; ++l) {
         h8 xh[2], xl[2];
@@ -583,6 +596,7 @@ __global__ void __launch_bounds__(256, 8) mlp_mfma_split_kernel(NetArgs a) {
         for (int s = 0; s < 2; ++s) y = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[s * 64], xh[s], y, 0, 0, 0);
         acc = activate16<ACT>(y);
     }
+    ILX_MLP_STAMP(5)
     float part = 0.0f;
 #pragma unroll
     for (int k = 0; k < 16; ++k) part = fmaf_(wo[acc_unit(k, 0)], acc[k], part);
@@ -592,11 +606,18 @@ __global__ void __launch_bounds__(256, 8) mlp_mfma_split_kernel(NetArgs a) {
         if (half == 0) store_torque(a, at, out, cur);
         store_history(a, at, cur, half == 0, half == 1);
     }
+    ILX_MLP_STAMP(6)
 }
 
 }  // namespace ilx
 
 using namespace ilx;
+
+#ifdef ILX_MLP_STAMPS
+extern "C" int ilx_debug_mlp_stamps(unsigned long long* out, int count) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(ilx::g_mlp_stamps), sizeof(unsigned long long) * count) == hipSuccess ? 0 : 1;
+}
+#endif
 
 extern "C" int ilx_mlp_create(int num_layers, const int32_t* dims, int activation, const float* const* weights_host,
                               const float* const* biases_host, ilx_mlp_t* out) {
