@@ -74,7 +74,9 @@ def capture_step(cfg, reducer):
     launch keeps its generator's step count in device memory, advanced inside the graph, so replays draw fresh numbers;
     sensor clocks and histories live in device memory anyway."""
     mdp = getattr(cfg.env, "mdp", None)
-    if mdp is not None:
+    if hasattr(cfg.env, "count_steps_on_device"):
+        cfg.env.count_steps_on_device()
+    elif mdp is not None:
         mdp.count_steps_on_device()
     overlap = getattr(cfg, "overlap_in_graph", False)
     if overlap:

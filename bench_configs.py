@@ -118,7 +118,7 @@ def build_locomotion(device, envs, seed, robot="anymal_c", actuator="mlp", stati
                                              _abi.stream()))
 
     launches = {act_kernel: (actuate, LV.DECIMATION), "scene_update": (lambda: env.scene.update(LV.PHYSICS_DT), LV.DECIMATION),
-                "raycaster_refresh": ((rays, rays_overhead), 1), "mdp_step": (lambda: env.mdp.step(FM.PHASE_ALL), 1),
+                "raycaster_refresh": ((rays, rays_overhead), 1), "mdp_step": (lambda: env.mdp.step(FM.PHASE_ALL, hold_step_count=True), 1),
                 "joint_action_process": (action, 1)}
     r = env.scanner.num_rays
     n_rewards = int(env.mdp.step_reward.shape[1])
@@ -160,7 +160,7 @@ def build_cartpole(device, envs, seed):
     raw = (torch.rand(n, 1, generator=g) * 2 - 1).to(device)
     launches = {"joint_action_process": (lambda: env.process_action(raw), 1), "actuator_pd": (env.apply_action, CP.DECIMATION),
                 "scene_update": (lambda: env.scene.update(CP.PHYSICS_DT), CP.DECIMATION),
-                "mdp_step": (lambda: env.mdp.step(FM.PHASE_ALL), 1)}
+                "mdp_step": (lambda: env.mdp.step(FM.PHASE_ALL, hold_step_count=True), 1)}
     nb = {
         "joint_action_process": 4 + 8 + 4,          # read raw; write action, previous action; write the scaled effort
         # effort target of the cart 4 + read q_des, qd_des, tau_ff, q, qd (5 x 8); write computed, applied (2 x 8)
@@ -208,7 +208,7 @@ def build_reach(device, envs, seed):
     raw = (torch.rand(n, 7, generator=g) * 2 - 1).to(device)
     launches = {"joint_action_process": (lambda: env.process_action(raw), 1), "actuator_pd": (env.apply_action, RE.DECIMATION),
                 "scene_update": (lambda: env.scene.update(RE.PHYSICS_DT), RE.DECIMATION),
-                "mdp_step": (lambda: env.mdp.step(FM.PHASE_ALL), 1)}
+                "mdp_step": (lambda: env.mdp.step(FM.PHASE_ALL, hold_step_count=True), 1)}
     nb = {
         "joint_action_process": 5 * 28,             # read raw, default; write action, previous action, arm target (7 joints)
         # arm target into the 9-joint target 28 + read q_des, qd_des, tau_ff, q, qd (5 x 36); write computed, applied (2 x 36)

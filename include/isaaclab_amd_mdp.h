@@ -129,11 +129,6 @@ typedef struct ilx_term {
 #define ILX_PHASE_COMMAND 8
 #define ILX_PHASE_OBSERVATION 16
 #define ILX_PHASE_ALL 31
-/* Not a phase: with a device-side step count (step_index_device below), this launch draws with the count as it is and
- * leaves it there.  An env step issued as several launches sets it on all but the last, so that every launch of the
- * step draws with the same step word and the count still advances once per env step. */
-#define ILX_PHASE_HOLD_STEP_COUNT 256
-
 typedef struct ilx_mdp {
     /* sizes */
     int64_t num_envs;
@@ -224,13 +219,11 @@ typedef struct ilx_mdp {
     /* buffers read by ILX_OBS_EXTERNAL terms: slot s is (n, external_obs_dim[s]) float32, dense */
     const float* external_obs[ILX_MAX_EXTERNAL_OBS];
     int32_t external_obs_dim[ILX_MAX_EXTERNAL_OBS];
-    /* generator, continued: when not NULL, a device counter that makes the step word advance without the host: an array
-     * of ILX_MDP_STEP_COUNTER_WORDS uint64 (zero it at set-up; the count is spread over 64 words on cache lines of their
-     * own so that the blocks' additions do not queue on one address).  Every block of a launch adds one when it is done,
-     * and the launch draws with step_index + (sum of the array) / blocks, blocks = ceil(num_envs / 16) -- constant over
-     * a launch, one more at the next.  A launch recorded in a HIP graph replays its arguments; with the count in
-     * device memory every replay still draws fresh numbers.  Keep num_envs fixed while a counter is in use. */
-    uint64_t* step_index_device;
+    /* generator, continued: when not NULL, one uint64 in device memory that the launch adds to step_index.  The caller
+     * advances it between launches (a one-word add on the stream).  A launch recorded in a HIP graph replays its
+     * arguments; with the count in device memory and its advance recorded in the same graph, every replay still draws
+     * fresh numbers.  The launches of one env step (phases issued separately) read the same value. */
+    const uint64_t* step_index_device;
     /* (n, num_rays) or NULL: the height scan as ilx_raycaster_refresh writes it (`height_scan` there, computed with
      * `height_offset` = the observation term's offset): sensor height - hit height - offset.  When given, the
      * height_scan observation columns are read from it instead of being formed from ray_hits_w / sensor_pos_w -- the
@@ -238,7 +231,6 @@ typedef struct ilx_mdp {
     const float* height_scan;
 } ilx_mdp;
 
-#define ILX_MDP_STEP_COUNTER_WORDS 1024 /* 64 slots, 128 bytes apart */
 
 /* Opaque prepared plan: term tables and id lists copied to the device once. */
 typedef struct ilx_mdp_plan_s* ilx_mdp_plan_t;

@@ -56,7 +56,6 @@ struct Layout {
     int coldesc;                                       // observation columns: one 16-byte ColDesc each
     int zero;                                          // one word of 0.0f (the subtrahend of columns that subtract nothing)
     int total;
-    int gstep;                                         // the generator's step word of this launch (two words)
 };
 constexpr int kDerived = 10;  // lin_b(3) ang_b(3) grav_b(3) sensor_z
 static_assert(offsetof(Layout, total) < 32 * 4, "ColDesc names a Layout field (all those before `total`) with 5 bits");
@@ -102,6 +101,7 @@ struct Hot {
     int64_t num_envs;
     uint64_t seed, step_index;
     const ilx_term* terms;  // the plan's table in device memory: [terminations | rewards | observations]
+    const uint64_t* step_index_device;
 };
 
 // One environment as seen by its lane in the DECIDE stage.
@@ -562,7 +562,6 @@ __global__ void __launch_bounds__(kBlock, 4) mdp_step_kernel(MdpDev args, const 
         }
         __syncthreads();
     }
-    ILX_STAMP(15)
 #ifdef ILX_MDP_STAMPS
     if ((threadIdx.x & 63) == 0 && blockIdx.x < 2048) {
         g_mdp_hwid[blockIdx.x * 8 + (threadIdx.x >> 6)] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
@@ -587,14 +586,13 @@ __global__ void __launch_bounds__(kBlock, 4) mdp_step_kernel(MdpDev args, const 
     const int num_segs = hot.num_segs;
     const ilx_term* terms = reinterpret_cast<const ilx_term*>(S + L.terms);
     const int32_t* ids = reinterpret_cast<const int32_t*>(S + L.ids);
-    // The generator's step word: the argument, plus the caller's device-side count when there is one (finished blocks of
-    // all earlier launches / blocks per launch: every block of this launch reads the counter before the last one has
-    // added to it, so all of them see the same quotient).  One thread divides; the others read the word from LDS after
-    // the staging barrier.
-    uint64_t counted = 0;  // wave 0: this lane's slot of the counter (the load travels while the staging is issued)
-    auto* p_counter = uni(d.step_index_device);
-    const uint64_t step_arg = hot.step_index, seed = hot.seed;
-    if (threadIdx.x < 64 && p_counter) counted = p_counter[16 * threadIdx.x];
+    // The generator's step word: the argument plus the caller's device-side count when there is one (a scalar load; the
+    // caller advances the word between launches, so it is constant over this one).
+    const uint64_t seed = hot.seed;
+    uint64_t gen_step = hot.step_index;
+    if (hot.step_index_device)
+        gen_step += *reinterpret_cast<const __attribute__((address_space(4))) uint64_t*>(
+            (const __attribute__((address_space(4))) char*)hot.step_index_device);
 
     ILX_STAMP(0)
     // ================= STAGE =================
@@ -701,24 +699,7 @@ __global__ void __launch_bounds__(kBlock, 4) mdp_step_kernel(MdpDev args, const 
         }
     }
     ILX_STAMP(1)
-    if (threadIdx.x < 64) {
-        // the sum of the counter's slots: every lane adds its own to the step word in LDS (one LDS instruction; the
-        // wavefront's LDS operations keep their order), then one lane turns the sum into the step
-        unsigned long long* word = reinterpret_cast<unsigned long long*>(S + L.gstep);
-        if (threadIdx.x == 0) *word = 0ull;
-        if (p_counter) atomicAdd(word, static_cast<unsigned long long>(counted));
-        if (threadIdx.x == 0) {
-            // sum / blocks with the sum below 2^52: the quotient of the doubles, corrected by its remainder (a 64-bit
-            // integer division is a hundred instructions that the whole wavefront issues)
-            const uint64_t sum = *word, blocks = gridDim.x;
-            uint64_t quo = static_cast<uint64_t>(static_cast<double>(sum) / static_cast<double>(blocks));
-            const int64_t rem = static_cast<int64_t>(sum - quo * blocks);
-            quo = rem < 0 ? quo - 1 : (rem >= static_cast<int64_t>(blocks) ? quo + 1 : quo);
-            *word = step_arg + quo;
-        }
-    }
     __syncthreads();  // waits for this wave's copies (vmcnt(0)), then for every wave's
-    const uint64_t gen_step = uni(*reinterpret_cast<const uint64_t*>(S + L.gstep));
     ILX_STAMP(2)
     // ================= DECIDE: one lane per env; the four waves split the reward terms =================
     Env en{m, hot, S, ids, e, env};
@@ -957,6 +938,11 @@ __global__ void __launch_bounds__(kBlock, 4) mdp_step_kernel(MdpDev args, const 
         auto* o_obs = uni(d.obs);
         const int R = hot.num_rays;
         const bool generate = !noise_in;
+        // memory: the block's rows as uniform bases
+        auto* rows = o_obs + env0 * O;
+        const auto* noise_rows = noise_in + env0 * O;
+        const auto* hit_rows = hits + (dense_scan ? 1 : 3) * (env0 * R);
+        const uint32_t hit_env_bytes = 4u * static_cast<uint32_t>((dense_scan ? 1 : 3) * R);
         for (int g = g_in; g < G; g += 64) {
             // The lane's four columns.  Every read below is unconditional and the reads of one step are independent, so
             // each step costs one LDS latency: descriptors; then the terms' flags and the rows' offsets.
@@ -1007,11 +993,7 @@ __global__ void __launch_bounds__(kBlock, 4) mdp_step_kernel(MdpDev args, const 
             }
             const char* lds = reinterpret_cast<const char*>(S);
             ILX_STAMP(11)
-            // memory: the block's rows as uniform bases, the lane's place in them as running 32-bit byte offsets
-            auto* rows = o_obs + env0 * O;
-            const auto* noise_rows = noise_in + env0 * O;
-            const auto* hit_rows = hits + (dense_scan ? 1 : 3) * (env0 * R);
-            const uint32_t hit_env_bytes = 4u * static_cast<uint32_t>((dense_scan ? 1 : 3) * R);
+            // memory: the lane's place in the block's rows as running 32-bit byte offsets
             uint32_t row_at = 4u * (ee0 * static_cast<uint32_t>(O) + 4u * static_cast<uint32_t>(g));  // column 4 g of the lane's env
             uint32_t hit_at = ee0 * hit_env_bytes;
             const uint32_t row_step = 4u * estep * static_cast<uint32_t>(O), hit_step = estep * hit_env_bytes;
@@ -1075,9 +1057,6 @@ __global__ void __launch_bounds__(kBlock, 4) mdp_step_kernel(MdpDev args, const 
         }
     }
     ILX_STAMP(10)
-    // the device-side count: one more finished block (no return value: nothing waits for it)
-    if (p_counter && tid == 0 && !(phases & ILX_PHASE_HOLD_STEP_COUNT))
-        __hip_atomic_fetch_add(p_counter + 16 * (blockIdx.x & 63), 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 }  // namespace ilx
@@ -1421,7 +1400,6 @@ extern "C" int ilx_mdp_step(ilx_mdp_plan_t plan, const ilx_mdp* desc, void* stre
     L.logp = take(plan->nr + plan->nt + 3);
     L.coldesc = take(po ? plan->obs_dim * static_cast<int>(sizeof(ColDesc) / 4) : 0);
     L.zero = take(1);
-    L.gstep = take(2);
     L.total = w;
     const size_t lds_bytes = static_cast<size_t>(w) * 4;
     ILX_REQUIRE(lds_bytes <= kMaxLdsBytes, ILX_ESHAPE,
@@ -1486,7 +1464,7 @@ extern "C" int ilx_mdp_step(ilx_mdp_plan_t plan, const ilx_mdp* desc, void* stre
     hot.step_dt = d.step_dt;
     for (int k = 0; k < 3; ++k) hot.gravity[k] = d.gravity_dir[k];
     hot.num_envs = d.num_envs, hot.seed = d.seed, hot.step_index = d.step_index;
-    hot.terms = plan->d_terms;
+    hot.terms = plan->d_terms, hot.step_index_device = d.step_index_device;
     hipLaunchKernelGGL(mdp_step_kernel, dim3(blocks), dim3(kBlock), lds_bytes, as_stream(stream), m, hot);
     ILX_LAUNCH_CHECK("ilx_mdp_step");
     return ILX_OK;

@@ -36,7 +36,6 @@ MAX_EXTERNAL_OBS = 4
 OBS_NOISE, OBS_CLIP, OBS_SCALE, OBS_QUAT_UNIQUE = 1, 2, 4, 8
 CMD_NONE, CMD_VELOCITY, CMD_POSE = 0, 1, 2
 PHASE_TERMINATION, PHASE_REWARD, PHASE_RESET, PHASE_COMMAND, PHASE_OBSERVATION, PHASE_ALL = 1, 2, 4, 8, 16, 31
-PHASE_HOLD_STEP_COUNT = 256   # not a phase: this launch leaves the generator's step count as it is
 
 
 class Term(ctypes.Structure):
@@ -263,23 +262,34 @@ class FusedMdp:
         self.desc.external_obs[slot] = t.data_ptr()
 
     def step(self, phases: int = PHASE_ALL, step_index: int | None = None, hold_step_count: bool = False):
-        """One launch of the given phases.  An env step issued as several launches passes ``hold_step_count=True`` on
-        all but the last: every launch of the step then draws with the same step word (host- or device-side count)."""
-        self.desc.phases = phases | (PHASE_HOLD_STEP_COUNT if hold_step_count else 0)
+        """One launch of the given phases; afterwards the generator's step count advances by one (on the host, or -- see
+        :meth:`count_steps_on_device` -- by a one-word add on the stream).  An env step issued as several launches
+        passes ``hold_step_count=True`` on all but the last, so that every launch of the step draws with the same
+        step word; a caller that advances the device-side count itself (:meth:`advance_step_count`) passes it always."""
+        self.desc.phases = phases
         if step_index is not None:
             self.desc.step_index = step_index
         elif not self._own_generator and not self._holding:
             self.desc.seed, self.desc.step_index = _rng.seed(), _rng.next_draw("fused_mdp")
         _abi.check(_abi.lib.ilx_mdp_step(self.plan, ctypes.byref(self.desc), _abi.stream()), "ilx_mdp_step")
         self._holding = hold_step_count
-        if self._step_counter is None and not hold_step_count:   # otherwise the launch has advanced the device-side count itself
-            self.desc.step_index += 1
+        if not hold_step_count:
+            self.advance_step_count()
 
-    def count_steps_on_device(self, enable: bool = True):
-        """Keep the generator's step count in device memory (every launch advances it) instead of on the host, so that a
-        step recorded in a HIP graph draws fresh random numbers at every replay."""
+    def advance_step_count(self):
+        """The generator's step count, one further: a host integer, or the device word's add on the current stream."""
+        if self._step_counter is None:
+            self.desc.step_index += 1
+        else:
+            self._step_counter.add_(1)
+
+    def count_steps_on_device(self, enable: bool = True, start: int = 0):
+        """Keep the generator's step count in device memory instead of on the host: the launch adds the device word to
+        its step argument and the advance is a one-word add on the stream, so a step recorded in a HIP graph draws
+        fresh random numbers at every replay.  ``start``: the word's first value (-1 for a caller that advances the
+        count before the step's launches instead of after them)."""
         if enable and self._step_counter is None:
-            self._step_counter = torch.zeros(1024, dtype=torch.int64, device=self.device)   # ILX_MDP_STEP_COUNTER_WORDS
+            self._step_counter = torch.full((1,), start, dtype=torch.int64, device=self.device)
             self.desc.step_index_device = self._step_counter.data_ptr()
         elif not enable:
             self._step_counter = None

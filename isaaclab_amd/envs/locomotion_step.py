@@ -103,6 +103,7 @@ class LocomotionVelocityStep:
         self.concurrent_chains = False
         # the managers add the done envs' statistics to mdp.log_sums; set, every step starts the vector at zero itself
         self.clear_log_sums = False
+        self._advance_count_first = False   # see count_steps_on_device
         self._side_stream = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
 
     def _bind(self):
@@ -161,12 +162,22 @@ class LocomotionVelocityStep:
             side.wait_stream(main)
         with torch.cuda.stream(side):
             self.step_sensors()
-        if self.clear_log_sums:   # at the head of chain (A), behind the fork: recorded in a graph, (B) then waits for nothing
+        # at the head of chain (A), behind the fork: recorded in a graph, (B) then waits for neither of these small launches
+        if self.clear_log_sums:
             self.mdp.log_sums.zero_()
+        if self._advance_count_first:
+            self.mdp.advance_step_count()
         self.step_actuators(raw_action)
         if side is not main:
             main.wait_stream(side)
         return self.step_managers(noise_u, command_samples, reset_command_samples)
+
+    def count_steps_on_device(self):
+        """Keep the managers' generator step count in device memory (for a step recorded in a HIP graph).  The step then
+        advances the count itself, ahead of its launches at the head of chain (A), where the small add is off the
+        step's critical path; the numbers drawn are those of the host-side count."""
+        self.mdp.count_steps_on_device(start=-1)
+        self._advance_count_first = True
 
     def step_sensors(self):
         """Chain (B): per substep ``scene.update`` (joint_acc, contact sensor, sensor clocks: one launch), then the
@@ -212,8 +223,5 @@ class LocomotionVelocityStep:
         m.bind(root_state_w=d.root_state_w, joint_pos=d.joint_pos, joint_vel=d.joint_vel, noise_u=noise_u,
                command_samples=command_samples, reset_command_samples=reset_command_samples,
                sensor_pos_w=self.scanner._data.pos_w, ray_hits_w=self.scanner._data.ray_hits_w)
-        if phases == FM.PHASE_ALL:
-            m.step(FM.PHASE_ALL)
-        else:
-            m.step(phases, hold_step_count=not (phases & FM.PHASE_OBSERVATION))
+        m.step(phases, hold_step_count=self._advance_count_first or not (phases & FM.PHASE_OBSERVATION))
         return m.obs, m.reward_buf, m.terminated, m.time_outs

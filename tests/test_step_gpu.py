@@ -170,7 +170,8 @@ def test_step_replayed_from_a_graph_equals_eager(dev):
     for graph in (False, True):
         env, _, state = build(dev, n, seed=31)
         raw = state["raw_action"].to(dev)
-        env.mdp.count_steps_on_device()      # both envs draw with the same (seed, step) keys
+        if graph:
+            env.count_steps_on_device()      # the same (seed, step) keys as the host-side count of the eager env
         env.concurrent_chains = graph
         env.step(raw)                        # first step eagerly in both: per-stream workspaces come into being here
         steps = []

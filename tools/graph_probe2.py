@@ -10,7 +10,7 @@ dev = torch.device("cuda:0")
 cfg = BC.build("anymal", dev, 16384, 3000)
 env = cfg.env
 raw = cfg.state["raw_action"].to(dev)
-env.mdp.count_steps_on_device()
+env.count_steps_on_device()
 s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
 
 def scenes():

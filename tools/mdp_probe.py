@@ -1,6 +1,6 @@
 """GPU probe: time the fused MDP kernel by phase subset (diagnostics, not a test).
 
-    python tools/mdp_probe.py [config] [envs]
+    python tools/mdp_probe.py [config] [envs] [device-count]
 Launches are queued behind a long-running blocker so that the device, not the host, paces them."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -33,8 +33,10 @@ def span(fn, reps=100, rounds=7):
     return sorted(times)[len(times) // 2]
 
 m = cfg.env.mdp
-print(f"{name} {envs} envs")
+if len(sys.argv) > 3 and sys.argv[3] == "device-count":
+    m.count_steps_on_device()
+print(f"{name} {envs} envs" + (" (step count kept on the device)" if len(sys.argv) > 3 else ""))
 for label, ph in (("all", FM.PHASE_ALL), ("termination", FM.PHASE_TERMINATION), ("term+reward", FM.PHASE_TERMINATION | FM.PHASE_REWARD),
                   ("term+reward+reset", 7), ("command", FM.PHASE_COMMAND), ("observation", FM.PHASE_OBSERVATION),
                   ("all but observation", 15)):
-    print(f"{label:20s} {span(lambda: m.step(ph)):8.1f} us")
+    print(f"{label:20s} {span(lambda: m.step(ph, hold_step_count=True)):8.1f} us")

@@ -26,7 +26,7 @@ labels = ["entry", "stage issued", "stage landed", "-", "terminations", "rewards
           "sums/flags out", "observations out"]
 print(f"{name} {envs} envs, {blocks} blocks; ticks of 10 ns; per stamp: mean since kernel start, mean since previous stamp")
 labels += ["  obs: lane set up", "  obs: loads issued (env 0)", "  obs: noise drawn", "stage: work list reached", "arguments in LDS"]
-order = [0, 15, 14, 1, 2, 4, 5, 6, 7, 8, 9, 11, 12, 13, 10]
+order = [0, 14, 1, 2, 4, 5, 6, 7, 8, 9, 11, 12, 13, 10]
 prev = t[:, 0]
 for k in order:
     lab = labels[k]
