@@ -591,6 +591,16 @@ constexpr int kPatchBins = 64;
 __global__ void __launch_bounds__(256) raycaster_prepare_kernel(ScanArgs a, LatEnvRec* __restrict__ recs, float4* __restrict__ pattern) {
     __shared__ float box_s[4][4];
     const float inf = __builtin_inff();
+    // the env's inputs go out first: they travel while the block reduces the pattern's box
+    const int64_t env = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+    const bool due = env < a.n && (!a.env_mask || a.env_mask[env]);
+    f3 pos{0.0f, 0.0f, 0.0f}, dr{0.0f, 0.0f, 0.0f};
+    f4 q{1.0f, 0.0f, 0.0f, 0.0f};
+    if (due) {
+        pos = load3(a.pos_w + a.pos_stride * env);
+        q = load4u(a.quat_w + a.quat_stride * env);
+        if (a.drift) dr = load3(a.drift + 3 * env);
+    }
     float bx0 = inf, bx1 = -inf, by0 = inf, by1 = -inf;  // xy box of the z-parallel pattern entries
     for (int ray = threadIdx.x; ray < a.r; ray += 256) {
         const f3 l = load3(a.ray_starts + 3 * ray), d = load3(a.ray_dirs + 3 * ray);
@@ -614,18 +624,12 @@ __global__ void __launch_bounds__(256) raycaster_prepare_kernel(ScanArgs a, LatE
         bx0 = fminf(bx0, box_s[w][0]), bx1 = fmaxf(bx1, box_s[w][1]);
         by0 = fminf(by0, box_s[w][2]), by1 = fmaxf(by1, box_s[w][3]);
     }
-    const int64_t env = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
     if (env >= a.n) return;
     LatEnvRec le{};
     le.sel = kLatNotDue;
-    if (!a.env_mask || a.env_mask[env]) {
+    if (due) {
         le.sel = -1;
-        f3 pos = load3(a.pos_w + a.pos_stride * env);
-        const f4 q = load4u(a.quat_w + a.quat_stride * env);
-        if (a.drift) {  // ray_caster.py:233-240
-            const f3 dr = load3(a.drift + 3 * env);
-            pos = {pos.x + dr.x, pos.y + dr.y, pos.z + dr.z};
-        }
+        if (a.drift) pos = {pos.x + dr.x, pos.y + dr.y, pos.z + dr.z};  // ray_caster.py:233-240
         if (a.pos_out) {
             store3(a.pos_out + 3 * env, pos);
             float* qo = a.quat_out + 4 * env;
@@ -654,24 +658,28 @@ __global__ void __launch_bounds__(256) raycaster_prepare_kernel(ScanArgs a, LatE
             // the patch whose extent holds the rectangle (any such patch will do: where patches overlap, the cells are
             // not simple)
             int sel = -1;
-            auto holds = [&](int p) {
-                const float4 ext = *reinterpret_cast<const float4*>(&a.mesh.patches[p].x0);  // x0, y0, x1, y1
-                return mnx >= ext.x && mxx <= ext.z && mny >= ext.y && mxy <= ext.w;
-            };
-            // a patch that holds the rectangle overlaps the bin of its centre: at most four candidates, tested together
+            LatticePatch P{};
+            auto holds = [&](const LatticePatch& c) { return mnx >= c.x0 && mxx <= c.x1 && mny >= c.y0 && mxy <= c.y1; };
+            // a patch that holds the rectangle overlaps the bin of its centre: at most four candidates, whose whole
+            // descriptors are fetched together (one trip to memory for the test and for the fields of the chosen one)
             const int bx = max(0, min(kPatchBins - 1, static_cast<int>((0.5f * (mnx + mxx) - a.mesh.pb_x0) * a.mesh.pb_inv_x)));
             const int by = max(0, min(kPatchBins - 1, static_cast<int>((0.5f * (mny + mxy) - a.mesh.pb_y0) * a.mesh.pb_inv_y)));
             const short4 cand = a.mesh.patch_bins[by * kPatchBins + bx];
             if (cand.x == -2) {
-                for (int p = 0; p < a.mesh.num_patches && sel < 0; ++p)
-                    if (holds(p)) sel = p;
+                for (int p = 0; p < a.mesh.num_patches && sel < 0; ++p) {
+                    P = a.mesh.patches[p];
+                    if (holds(P)) sel = p;
+                }
             } else {
-                const bool h0 = cand.x >= 0 && holds(max(0, static_cast<int>(cand.x))), h1 = cand.y >= 0 && holds(max(0, static_cast<int>(cand.y))),
-                           h2 = cand.z >= 0 && holds(max(0, static_cast<int>(cand.z))), h3 = cand.w >= 0 && holds(max(0, static_cast<int>(cand.w)));
-                sel = h0 ? cand.x : h1 ? cand.y : h2 ? cand.z : h3 ? cand.w : -1;
+                const int ids[4] = {cand.x, cand.y, cand.z, cand.w};
+                LatticePatch c[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) c[k] = a.mesh.patches[max(0, ids[k])];
+#pragma unroll
+                for (int k = 3; k >= 0; --k)   // the first candidate that holds it wins
+                    if (ids[k] >= 0 && holds(c[k])) sel = ids[k], P = c[k];
             }
             if (sel >= 0) {
-                const LatticePatch P = a.mesh.patches[sel];
                 const int gx0 = lattice_guess(mnx, P.x0, P.inv_dx), gx1 = lattice_guess(mxx, P.x0, P.inv_dx);
                 const int gy0 = lattice_guess(mny, P.y0, P.inv_dy), gy1 = lattice_guess(mxy, P.y0, P.inv_dy);
                 le.i_lo = max(0, min(gx0 - 1, P.nx - 2));
