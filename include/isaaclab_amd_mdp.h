@@ -238,6 +238,10 @@ int ilx_mdp_plan_create(const ilx_mdp* desc, ilx_mdp_plan_t* out);
 void ilx_mdp_plan_destroy(ilx_mdp_plan_t plan);
 /* Re-read the pointer / scalar fields of `desc` (term tables are fixed at creation) and launch `phases`. */
 int ilx_mdp_step(ilx_mdp_plan_t plan, const ilx_mdp* desc, void* stream);
+/* What a caller does between the launches of two env steps, as one small launch: clears `log_sums` (`count` floats, or
+ * NULL: the reference's managers rebuild their `extras["log"]` entries at every reset, reward_manager.py:100-126) and
+ * adds one to `step_index_device` (or NULL).  For steps recorded in a HIP graph, where each extra node costs. */
+int ilx_mdp_begin_step(float* log_sums, int32_t count, uint64_t* step_index_device, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1298,6 +1298,19 @@ extern "C" int ilx_debug_mdp_stamps(unsigned long long* out, int count) {
 }
 #endif
 
+__global__ void mdp_begin_step_kernel(float* log_sums, int count, uint64_t* step_index_device) {
+    for (int i = threadIdx.x; i < count; i += blockDim.x) log_sums[i] = 0.0f;
+    if (step_index_device && threadIdx.x == 0) *step_index_device += 1;
+}
+
+extern "C" int ilx_mdp_begin_step(float* log_sums, int32_t count, uint64_t* step_index_device, void* stream) {
+    ILX_REQUIRE(count >= 0 && (count == 0 || log_sums), ILX_EINVAL, "ilx_mdp_begin_step: %d floats at a NULL pointer", count);
+    if (count == 0 && !step_index_device) return ILX_OK;
+    hipLaunchKernelGGL(mdp_begin_step_kernel, dim3(1), dim3(64), 0, as_stream(stream), log_sums, log_sums ? count : 0, step_index_device);
+    ILX_LAUNCH_CHECK("ilx_mdp_begin_step");
+    return ILX_OK;
+}
+
 extern "C" int ilx_mdp_step(ilx_mdp_plan_t plan, const ilx_mdp* desc, void* stream) {
     ILX_REQUIRE(plan && desc, ILX_EINVAL, "ilx_mdp_step: NULL argument");
     const ilx_mdp& d = *desc;

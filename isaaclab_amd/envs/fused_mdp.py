@@ -85,6 +85,8 @@ _abi.lib.ilx_mdp_plan_destroy.argtypes = [c_void_p]
 _abi.lib.ilx_mdp_plan_destroy.restype = None
 _abi.lib.ilx_mdp_step.argtypes = [c_void_p, POINTER(MdpDesc), c_void_p]
 _abi.lib.ilx_mdp_step.restype = ctypes.c_int
+_abi.lib.ilx_mdp_begin_step.argtypes = [c_void_p, ctypes.c_int32, c_void_p, c_void_p]
+_abi.lib.ilx_mdp_begin_step.restype = ctypes.c_int
 
 
 class TermSpec:
@@ -275,6 +277,18 @@ class FusedMdp:
         self._holding = hold_step_count
         if not hold_step_count:
             self.advance_step_count()
+
+    def begin_step(self, clear_log_sums: bool = True, advance_step_count: bool = True):
+        """The statistics vector cleared and the device-side step count advanced, in one launch (``ilx_mdp_begin_step``);
+        a host-side count just advances."""
+        counter = self._step_counter if advance_step_count else None
+        if advance_step_count and counter is None:
+            self.desc.step_index += 1
+        log = self.log_sums if clear_log_sums else None
+        if log is None and counter is None:
+            return
+        _abi.check(_abi.lib.ilx_mdp_begin_step(_abi.ptr(log) if log is not None else None, 0 if log is None else log.numel(),
+                                               _abi.ptr(counter) if counter is not None else None, _abi.stream()), "ilx_mdp_begin_step")
 
     def advance_step_count(self):
         """The generator's step count, one further: a host integer, or the device word's add on the current stream."""

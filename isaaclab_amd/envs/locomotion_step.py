@@ -163,10 +163,8 @@ class LocomotionVelocityStep:
         with torch.cuda.stream(side):
             self.step_sensors()
         # at the head of chain (A), behind the fork: recorded in a graph, (B) then waits for neither of these small launches
-        if self.clear_log_sums:
-            self.mdp.log_sums.zero_()
-        if self._advance_count_first:
-            self.mdp.advance_step_count()
+        if self.clear_log_sums or self._advance_count_first:
+            self.mdp.begin_step(clear_log_sums=self.clear_log_sums, advance_step_count=self._advance_count_first)
         self.step_actuators(raw_action)
         if side is not main:
             main.wait_stream(side)

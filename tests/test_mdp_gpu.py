@@ -190,6 +190,25 @@ def test_step_issued_as_two_launches_draws_like_one(dev, on_device):
     assert not torch.equal(outs[0][0][0], outs[0][1][0]), "the noise changes from step to step"
 
 
+def test_begin_step_clears_the_statistics_and_advances_the_count(dev):
+    """ilx_mdp_begin_step: one launch for the two things a caller does between env steps."""
+    from isaaclab_amd.envs import fused_mdp as FM
+
+    g = load_golden("managers_anymal")
+    n = g["reward"].shape[0]
+    mdp = make_anymal_mdp(dev, n)
+    mdp.log_sums.fill_(3.0)
+    mdp.begin_step()                       # host-side count: only the vector is touched on the device
+    assert mdp.log_sums.abs().max().item() == 0.0 and mdp.desc.step_index == 1
+    mdp.count_steps_on_device(start=-1)
+    mdp.log_sums.fill_(2.0)
+    mdp.begin_step(clear_log_sums=False)
+    mdp.begin_step(clear_log_sums=False)
+    assert mdp._step_counter.item() == 1 and mdp.log_sums.min().item() == 2.0 and mdp.desc.step_index == 1
+    mdp.begin_step()
+    assert mdp._step_counter.item() == 2 and mdp.log_sums.abs().max().item() == 0.0
+
+
 def test_pose_command_matches_reference(dev):
     """UniformPoseCommand through the fused kernel's COMMAND / RESET phases against the reference class."""
     from isaaclab_amd.envs import fused_mdp as FM
