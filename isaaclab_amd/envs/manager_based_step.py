@@ -78,6 +78,16 @@ class ManagerBasedStep:
                                command_dim=command_dim, step_dt=step_dt, max_episode_length=max_episode_length, command=command,
                                seed=seed, **terms)
         self.physics = None
+        # the managers add the done envs' statistics to mdp.log_sums; set, every step starts the vector at zero itself
+        self.clear_log_sums = False
+        self._advance_count_first = False   # see count_steps_on_device
+
+    def count_steps_on_device(self):
+        """Keep the managers' generator step count in device memory (for a step recorded in a HIP graph); the step then
+        advances the count itself, in the one launch that also clears the statistics vector.  The numbers drawn are
+        those of the host-side count."""
+        self.mdp.count_steps_on_device(start=-1)
+        self._advance_count_first = True
 
     def load_physics(self, physics: dict):
         """Synthetic simulator output of one env step: ``joint_pos`` / ``joint_vel`` (decimation, N, J) per substep,
@@ -93,6 +103,8 @@ class ManagerBasedStep:
 
     def step(self, raw_action: torch.Tensor, noise_u=None, command_samples=None, reset_command_samples=None):
         d, ph = self.data, self.physics
+        if self.clear_log_sums or self._advance_count_first:
+            self.mdp.begin_step(clear_log_sums=self.clear_log_sums, advance_step_count=self._advance_count_first)
         self.process_action(raw_action)
         for k in range(self.decimation):
             self.apply_action()                              # action terms' apply_actions + write_data_to_sim (actuators)
@@ -106,7 +118,7 @@ class ManagerBasedStep:
                soft_joint_vel_limits=d.soft_joint_vel_limits, body_state_w=d.body_state_w, action=self.action,
                prev_action=self.prev_action, noise_u=noise_u, command_samples=command_samples,
                reset_command_samples=reset_command_samples)
-        m.step(FM.PHASE_ALL)
+        m.step(FM.PHASE_ALL, hold_step_count=self._advance_count_first)
         return m.obs, m.reward_buf, m.terminated, m.time_outs
 
     def _actuate(self, actuators):
