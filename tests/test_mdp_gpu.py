@@ -66,6 +66,38 @@ def test_anymal_managers_match_reference(dev):
         assert (mdp.episode_length_buf.cpu()[s["dones"]] == 0).all()
 
 
+@pytest.mark.parametrize("n", [1, 15, 17, 150])
+def test_ragged_env_counts_match_the_full_fixture_rows(dev, n):
+    """Env counts that are not a multiple of the 16 envs a block owns (a last block with fewer envs, a launch of one
+    partial block): every per-env output equals, bit for bit, the same rows of the launch over the whole fixture, and
+    the logging sums are those of the first n envs."""
+    from isaaclab_amd.envs import fused_mdp as FM
+
+    g = load_golden("managers_anymal")
+    steps, full = g["reward"].shape
+    s = {key: v[0] for key, v in g.items() if v.shape[:1] == (steps,)}
+    outs = []
+    for count in (full, n):
+        mdp = make_anymal_mdp(dev, count, command=None)
+        rows = {k: (v[:count] if v.shape[:1] == (full,) else v) for k, v in s.items()}
+        bind_state(mdp, rows, dev)
+        mdp.bind(command=rows["command"].to(dev).contiguous(), noise_u=rows["noise_u"].to(dev).contiguous())
+        mdp.episode_length_buf.copy_((rows["episode_length_buf"] - 1).to(dev))
+        # let some envs of every block time out, so that the reset path of the partial block runs too
+        mdp.episode_length_buf[::3] = 10 ** 6
+        mdp.log_sums.zero_()
+        mdp.step(FM.PHASE_ALL)
+        outs.append({k: getattr(mdp, k).cpu().clone() for k in ("obs", "reward_buf", "terminated", "time_outs", "reset_buf",
+                                                                 "episode_length_buf", "step_reward")}
+                    | {"term_dones": mdp.term_dones.cpu().clone(), "episode_sums": mdp.episode_sums.cpu().clone(),
+                       "log": mdp.log_sums.cpu().clone(), "action": mdp.action.cpu().clone()})
+    whole, part = outs
+    for k in ("obs", "reward_buf", "terminated", "time_outs", "reset_buf", "episode_length_buf", "step_reward", "action"):
+        assert torch.equal(part[k], whole[k][:n]), k
+    assert torch.equal(part["term_dones"], whole["term_dones"][:, :n]) and torch.equal(part["episode_sums"], whole["episode_sums"][:, :n])
+    assert part["log"][-1].item() == int(whole["reset_buf"][:n].sum()) > 0
+
+
 def test_velocity_command_matches_reference(dev):
     from isaaclab_amd.envs import fused_mdp as FM
     from isaaclab_amd.tasks import locomotion_velocity as LV
