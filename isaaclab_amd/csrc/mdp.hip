@@ -56,6 +56,7 @@ struct Layout {
     int coldesc;                                       // observation columns: one 16-byte ColDesc each
     int zero;                                          // one word of 0.0f (the subtrahend of columns that subtract nothing)
     int total;
+    int colrec;                                        // observation columns resolved for this launch: two 16-byte words each (ColRec)
 };
 constexpr int kDerived = 10;  // lin_b(3) ang_b(3) grav_b(3) sensor_z
 static_assert(offsetof(Layout, total) < 32 * 4, "ColDesc names a Layout field (all those before `total`) with 5 bits");
@@ -76,6 +77,16 @@ struct alignas(16) TermHead {
     float weight, p0, p1, p2, p3, aux;
 };
 static_assert(sizeof(ilx_term) == 48 && offsetof(ilx_term, aux) == 28, "TermHead mirrors the head of ilx_term");
+// A column as the EMIT stage's env loop wants it, resolved once per block (by the wavefronts that wait while the first one
+// runs the command term) from the column's descriptor, its term's parameters and the launch's layout.
+struct alignas(16) ColRec {
+    uint32_t base;     // LDS byte address of the value for the block's first env | that of the subtrahend << 16
+    uint32_t stride;   // bytes per env of the value's row | of the subtrahend's << 16
+    float n_off, n_rng;         // noise: x + u * n_rng + n_off (0, 0: none)
+    float c_lo, c_hi;           // clip bounds (-inf, +inf: none)
+    float scale;                // 1: none
+    uint32_t meta;     // ColMode | draws noise << 2 | observation term << 3 | byte offset into the env's ray hits << 11
+};
 struct alignas(16) MdpDev {
     ilx_mdp d;                // by-value copy; the HOST pointers inside are nulled
     const ilx_term* terms;    // device: [terminations | rewards | observations]
@@ -95,7 +106,7 @@ struct alignas(16) MdpDev {
 struct Hot {
     Layout L;
     int num_joints, num_bodies, num_sensor_bodies, command_dim, action_dim, num_rays, command_kind;
-    int num_terminations, num_rewards, obs_dim, history_len, num_segs;
+    int num_terminations, num_rewards, obs_dim, history_len, num_segs, dense_scan;
     uint32_t phases, need, inv_rewards;
     float step_dt, gravity[3];
     int64_t num_envs;
@@ -743,6 +754,37 @@ __global__ void __launch_bounds__(kBlock, 4) mdp_step_kernel(MdpDev args, const 
     }
     ILX_STAMP(5)
     __syncthreads();
+    // The observation columns of this launch, resolved once per block by the wavefronts that have little to do until the
+    // first one is through with the command term: descriptor -> LDS addresses under this launch's layout, the term's
+    // pipeline parameters made neutral where a step is off (x + u * 0 + 0, clip to +-inf, x * 1: the env loop then runs
+    // without branches or selects on them).  The records may lie over the force history (no reader is left).
+    if (ph_obs && wave != 0) {
+        const int O = hot.obs_dim;
+        const ColDesc* cdesc = reinterpret_cast<const ColDesc*>(S + L.coldesc);
+        const ilx_term* oterms = terms + NT + hot.num_rewards;
+        const int32_t* ltab = reinterpret_cast<const int32_t*>(&m.L);   // the layout, as words (its LDS copy: indexed per lane)
+        ColRec* recs = reinterpret_cast<ColRec*>(S + L.colrec);
+        for (int col = (wave - 1) * 64 + lane; col < O; col += 64 * (kWaves - 1)) {
+            const ColDesc cd = cdesc[col];
+            const uint32_t term = cd.mode_term >> 8, mode = cd.mode_term & 255u;
+            const TermHead th = *reinterpret_cast<const TermHead*>(oterms + term);
+            const uint32_t flags = static_cast<uint32_t>(th.flags);
+            const uint32_t a = static_cast<uint32_t>(ltab[(cd.src >> 16) & 31u]), b = static_cast<uint32_t>(ltab[(cd.sub >> 16) & 31u]);
+            const bool affine = mode == kColAffine, noisy = flags & ILX_OBS_FLAG_NOISE, clip = flags & ILX_OBS_FLAG_CLIP;
+            ColRec r;
+            // value and subtrahend of the other kinds: the zero word
+            r.base = affine ? ((4u * (a + (cd.src & 0xffffu))) | ((4u * (b + (cd.sub & 0xffffu))) << 16)) : 4u * static_cast<uint32_t>(L.zero) * 0x10001u;
+            r.stride = affine ? ((4u * (cd.stride & 0xffffu)) | ((4u * (cd.stride >> 16)) << 16)) : 0u;
+            r.n_off = noisy ? th.p0 : 0.0f, r.n_rng = noisy ? th.p1 : 0.0f;
+            // clip as one median-of-three; bounds given the wrong way round clip to the upper one, as torch.clip does
+            r.c_hi = clip ? th.p3 : __builtin_inff();
+            r.c_lo = clip ? fminf(th.p2, th.p3) : -__builtin_inff();
+            r.scale = (flags & ILX_OBS_FLAG_SCALE) ? th.weight : 1.0f;
+            const uint32_t zoff = mode == kColScan ? (hot.dense_scan ? 4u * cd.src : 12u * cd.src + 8u) : 0u;  // bytes into the env's hits
+            r.meta = mode | (noisy ? 4u : 0u) | (term << 3) | (zoff << 11);
+            recs[col] = r;
+        }
+    }
     // Reset bookkeeping that needs nothing but the env's done flag runs beside wave 0's command work: wave 1 adds the
     // episode sums of the done envs to the logging partials (reward_manager.py:115-121, termination_manager.py:142-144),
     // wave 2 restarts their action history (action_manager.py:309-311: the observations of this launch already see
@@ -928,7 +970,6 @@ __global__ void __launch_bounds__(kBlock, 4) mdp_step_kernel(MdpDev args, const 
         while (gp < G && gp < 64) gp <<= 1;
         const int per = 64 / gp, g_in = lane & (gp - 1), esub = lane / gp;
         const ilx_term* oterms = terms + NT + NR;
-        const int32_t* ltab = reinterpret_cast<const int32_t*>(&m.L);   // the layout, as words (its LDS copy: indexed per lane)
         const ColDesc* cdesc = reinterpret_cast<const ColDesc*>(S + L.coldesc);
         const auto* p_scan = uni(d.height_scan);
         const auto* p_hits = uni(d.ray_hits_w);
@@ -943,53 +984,30 @@ __global__ void __launch_bounds__(kBlock, 4) mdp_step_kernel(MdpDev args, const 
         const auto* noise_rows = noise_in + env0 * O;
         const auto* hit_rows = hits + (dense_scan ? 1 : 3) * (env0 * R);
         const uint32_t hit_env_bytes = 4u * static_cast<uint32_t>((dense_scan ? 1 : 3) * R);
+        const ColRec* recs = reinterpret_cast<const ColRec*>(S + L.colrec);
         for (int g = g_in; g < G; g += 64) {
-            // The lane's four columns.  Every read below is unconditional and the reads of one step are independent, so
-            // each step costs one LDS latency: descriptors; then the terms' flags and the rows' offsets.
-            ColDesc cd[4];
+            // The lane's four columns: their records (independent reads, one LDS latency), then the lane's own start in
+            // the rows.  Past the row's end: like the last column, not stored.
+            ColRec rec[4];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) cd[c] = cdesc[4 * g + c < O ? 4 * g + c : O - 1];  // past the row: like the last column, not stored
-            uint32_t what[4], where[4], stride[4];  // mode | term << 8 | flags << 16;  LDS words of value | subtrahend << 16
-            uint32_t all_flags = 0, all_modes = 0;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const uint32_t flags = static_cast<uint32_t>(oterms[cd[c].mode_term >> 8].flags);
-                const uint32_t a = static_cast<uint32_t>(ltab[(cd[c].src >> 16) & 31u]), b = static_cast<uint32_t>(ltab[(cd[c].sub >> 16) & 31u]);
-                const bool affine = (cd[c].mode_term & 255u) == kColAffine;
-                what[c] = cd[c].mode_term | (flags << 16);
-                // value and subtrahend of the other kinds: the zero word
-                where[c] = affine ? ((a + (cd[c].src & 0xffffu)) | ((b + (cd[c].sub & 0xffffu)) << 16)) : static_cast<uint32_t>(L.zero) * 0x10001u;
-                stride[c] = affine ? cd[c].stride : 0u;
-                all_flags |= flags, all_modes |= cd[c].mode_term & 255u;
-            }
-            // the terms' pipeline parameters, neutral where a step is switched off: the env loop then runs without
-            // branches or selects on them (x + u * 0 + 0 and x * 1 leave x as it is)
-            float n_off[4], n_rng[4], c_lo[4], c_hi[4], scl[4], hgt[4];
-            uint32_t zoff[4];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const TermHead th = *reinterpret_cast<const TermHead*>(oterms + ((what[c] >> 8) & 255u));
-                const uint32_t flags = what[c] >> 16;
-                n_off[c] = (flags & ILX_OBS_FLAG_NOISE) ? th.p0 : 0.0f, n_rng[c] = (flags & ILX_OBS_FLAG_NOISE) ? th.p1 : 0.0f;
-                // clip as one median-of-three: no bounds when switched off; bounds given the wrong way round clip to the
-                // upper one, as torch.clip does
-                const bool clip = flags & ILX_OBS_FLAG_CLIP;
-                c_hi[c] = clip ? th.p3 : __builtin_inff();
-                c_lo[c] = clip ? fminf(th.p2, th.p3) : -__builtin_inff();
-                scl[c] = (flags & ILX_OBS_FLAG_SCALE) ? th.weight : 1.0f;
-                hgt[c] = th.aux;
-                zoff[c] = (what[c] & 255u) == kColScan ? (dense_scan ? 4u * cd[c].src : 12u * cd[c].src + 8u) : 0u;  // bytes into the env's hits
-            }
-            const bool any_noise = all_flags & ILX_OBS_FLAG_NOISE, any_scan = all_modes & kColScan;
+            for (int c = 0; c < 4; ++c) rec[c] = recs[4 * g + c < O ? 4 * g + c : O - 1];
             // LDS byte addresses of value (low half) and subtrahend (high half) for the lane's first env, and what one
-            // trip of the env loop adds to them
+            // trip of the env loop adds to them (the halves never carry: every address is below 64 KB)
             const uint32_t ee0 = static_cast<uint32_t>(wave * per + esub), estep = static_cast<uint32_t>(kWaves * per);
-            uint32_t addr[4], astep[4];
+            uint32_t addr[4], astep[4], meta[4], zoff[4], all_meta = 0;
+            float n_off[4], n_rng[4], c_lo[4], c_hi[4], scl[4], hgt[4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                const uint32_t sv = stride[c] & 0xffffu, ss = stride[c] >> 16;
-                addr[c] = (4u * ((where[c] & 0xffffu) + ee0 * sv)) | ((4u * ((where[c] >> 16) + ee0 * ss)) << 16);
-                astep[c] = (4u * estep * sv) | ((4u * estep * ss) << 16);
+                addr[c] = rec[c].base + ee0 * rec[c].stride, astep[c] = estep * rec[c].stride;
+                n_off[c] = rec[c].n_off, n_rng[c] = rec[c].n_rng, c_lo[c] = rec[c].c_lo, c_hi[c] = rec[c].c_hi, scl[c] = rec[c].scale;
+                meta[c] = rec[c].meta, zoff[c] = rec[c].meta >> 11, all_meta |= rec[c].meta;
+                hgt[c] = 0.0f;
+            }
+            const uint32_t all_modes = all_meta & 3u;
+            const bool any_noise = all_meta & 4u, any_scan = all_modes & kColScan;
+            if (any_scan && !dense_scan) {  // the term's offset, for hits read as records
+#pragma unroll
+                for (int c = 0; c < 4; ++c) hgt[c] = oterms[(meta[c] >> 3) & 255u].aux;
             }
             const char* lds = reinterpret_cast<const char*>(S);
             ILX_STAMP(11)
@@ -1029,7 +1047,7 @@ __global__ void __launch_bounds__(kBlock, 4) mdp_step_kernel(MdpDev args, const 
                 }
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    const uint32_t mode = what[c] & 255u;
+                    const uint32_t mode = meta[c] & 3u;
                     float v = mode == kColScan ? zv[c] : val[c];
                     v = v + u[c] * n_rng[c] + n_off[c];                                          // noise_model.py:63-64
                     v = __builtin_amdgcn_fmed3f(v, c_lo[c], c_hi[c]);                            // observation_manager.py:315-316
@@ -1041,11 +1059,11 @@ __global__ void __launch_bounds__(kBlock, 4) mdp_step_kernel(MdpDev args, const 
                 if (all_modes & kColGeneric) {
 #pragma unroll 1
                     for (int c = 0; c < 4; ++c) {
-                        const uint32_t w = c == 0 ? what[0] : c == 1 ? what[1] : c == 2 ? what[2] : what[3];
-                        if ((w & 255u) != kColGeneric || 4 * g + c >= O) continue;
+                        const uint32_t w = c == 0 ? meta[0] : c == 1 ? meta[1] : c == 2 ? meta[2] : meta[3];
+                        if ((w & 3u) != kColGeneric || 4 * g + c >= O) continue;
                         const uint32_t k = cdesc[4 * g + c].src;
                         const float uc = c == 0 ? u[0] : c == 1 ? u[1] : c == 2 ? u[2] : u[3];
-                        const ilx_term& t = oterms[(w >> 8) & 255u];
+                        const ilx_term& t = oterms[(w >> 3) & 255u];
                         float v = eval_obs(m, hot, S, ids, ee, oenv, t, static_cast<int>(k));
                         if (t.flags & ILX_OBS_FLAG_NOISE) v = v + uc * t.p[1] + t.p[0];
                         if (t.flags & ILX_OBS_FLAG_CLIP) v = fminf(fmaxf(v, t.p[2]), t.p[3]);
@@ -1413,6 +1431,11 @@ extern "C" int ilx_mdp_step(ilx_mdp_plan_t plan, const ilx_mdp* desc, void* stre
     L.logp = take(plan->nr + plan->nt + 3);
     L.coldesc = take(po ? plan->obs_dim * static_cast<int>(sizeof(ColDesc) / 4) : 0);
     L.zero = take(1);
+    {   // the resolved column records: over the force history when it is large enough (nothing reads it by then)
+        const int rec_words = po ? plan->obs_dim * static_cast<int>(sizeof(ColRec) / 4) : 0;
+        const int fraw_words = (m.need & kNeedForces) ? kE * 3 * d.history_len * CB : 0;
+        L.colrec = (rec_words > 0 && fraw_words >= rec_words) ? L.fraw : take(rec_words);
+    }
     L.total = w;
     const size_t lds_bytes = static_cast<size_t>(w) * 4;
     ILX_REQUIRE(lds_bytes <= kMaxLdsBytes, ILX_ESHAPE,
@@ -1471,7 +1494,7 @@ extern "C" int ilx_mdp_step(ilx_mdp_plan_t plan, const ilx_mdp* desc, void* stre
     hot.num_joints = J, hot.num_bodies = B, hot.num_sensor_bodies = CB, hot.command_dim = CD, hot.action_dim = A;
     hot.num_rays = d.num_rays, hot.command_kind = d.command_kind;
     hot.num_terminations = plan->nt, hot.num_rewards = plan->nr, hot.obs_dim = plan->obs_dim;
-    hot.history_len = d.history_len, hot.num_segs = m.num_segs;
+    hot.history_len = d.history_len, hot.num_segs = m.num_segs, hot.dense_scan = d.height_scan != nullptr;
     hot.phases = d.phases, hot.need = m.need;
     hot.inv_rewards = m.inv_rewards;
     hot.step_dt = d.step_dt;
