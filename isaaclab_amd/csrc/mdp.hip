@@ -751,6 +751,10 @@ __global__ void __launch_bounds__(kBlock, 4) mdp_step_kernel(MdpDev args, const 
             }
             S[L.ptotal + wave * kE + e] = partial;
         }
+        if (wave == 0) {  // the decisions, for the wavefronts that write them out
+            reinterpret_cast<uint32_t*>(S + L.bits)[e] = term_bits;
+            reinterpret_cast<uint32_t*>(S + L.bits)[kE + e] = (terminated || time_out) ? 1u : 0u;
+        }
     }
     ILX_STAMP(5)
     __syncthreads();
@@ -785,30 +789,61 @@ __global__ void __launch_bounds__(kBlock, 4) mdp_step_kernel(MdpDev args, const 
             recs[col] = r;
         }
     }
-    // Reset bookkeeping that needs nothing but the env's done flag runs beside wave 0's command work: wave 1 adds the
-    // episode sums of the done envs to the logging partials (reward_manager.py:115-121, termination_manager.py:142-144),
-    // wave 2 restarts their action history (action_manager.py:309-311: the observations of this launch already see
-    // zeros; the rewards above used the step's own actions).
-    if (decide && ph_reset && (terminated || time_out) && wave == (1 % kWaves) && wave != 0) {
-        float* logp = S + L.logp;
-        for (int i = 0; i < NR; ++i) {
-            atomicAdd(logp + i, S[L.eps + i * kE + e]);  // per-block partials in LDS (ds_add_f32), one global atomic per entry and block
-            S[L.eps + i * kE + e] = 0.0f;
+    // What needs nothing but the decisions runs beside wave 0's command work.  Wave 1 adds the episode sums of the done
+    // envs to the logging partials (reward_manager.py:115-121, termination_manager.py:142-144) and writes the sums out;
+    // wave 2 restarts the done envs' action history (action_manager.py:309-311: the observations of this launch already
+    // see zeros; the rewards above used the step's own actions) and writes the per-term rewards out; wave 3 writes the
+    // termination terms' flags.
+    static_assert(kWaves == 4, "the reset bookkeeping and the write-out of the decisions are dealt to wavefronts 1, 2 and 3");
+    const uint32_t* bits = reinterpret_cast<const uint32_t*>(S + L.bits);
+    if (wave == 1) {
+        if (decide && ph_reset && (terminated || time_out)) {
+            float* logp = S + L.logp;
+            for (int i = 0; i < NR; ++i) {
+                atomicAdd(logp + i, S[L.eps + i * kE + e]);  // per-block partials in LDS (ds_add_f32), one global atomic per entry and block
+                S[L.eps + i * kE + e] = 0.0f;
+            }
+            for (int i = 0; i < NT; ++i)
+                if (term_bits & (1u << i)) atomicAdd(logp + NR + i, 1.0f);
+            atomicAdd(logp + NR + NT + 2, 1.0f);
         }
-        for (int i = 0; i < NT; ++i)
-            if (term_bits & (1u << i)) atomicAdd(logp + NR + i, 1.0f);
-        atomicAdd(logp + NR + NT + 2, 1.0f);
+        if (ph_rew || ph_reset) {  // the episode sums go out as they are after that (the wavefront's LDS operations keep their order)
+            auto* o_sums = uni(d.episode_sums);
+            for (int i = lane; i < NR * kE; i += 64) {
+                const int term = i / kE, ee = i - term * kE;
+                if (ee >= ne) continue;
+                const bool active = ph_rew && terms[NT + term].weight != 0.0f;
+                if (active || (ph_reset && bits[kE + ee])) o_sums[static_cast<int64_t>(term) * N + env0 + ee] = S[L.eps + i];
+            }
+        }
     }
-    if (decide && ph_reset && (terminated || time_out) && wave == (2 % kWaves) && wave != 0) {
-        auto* act = p_action;
-        auto* pact = p_prev_action;
-        const int A = hot.action_dim;
-        for (int k = 0; k < A; ++k) {
-            const uint32_t at = 4u * (static_cast<uint32_t>(e) * static_cast<uint32_t>(A) + k);
-            if (act) st_at(act + env0 * A, at, 0.0f);
-            if (pact) st_at(pact + env0 * A, at, 0.0f);
-            if (sa) S[L.act + e * A + k] = 0.0f;
-            if (spa) S[L.pact + e * A + k] = 0.0f;
+    if (wave == 2) {
+        if (decide && ph_reset && (terminated || time_out)) {
+            auto* act = p_action;
+            auto* pact = p_prev_action;
+            const int A = hot.action_dim;
+            for (int k = 0; k < A; ++k) {
+                const uint32_t at = 4u * (static_cast<uint32_t>(e) * static_cast<uint32_t>(A) + k);
+                if (act) st_at(act + env0 * A, at, 0.0f);
+                if (pact) st_at(pact + env0 * A, at, 0.0f);
+                if (sa) S[L.act + e * A + k] = 0.0f;
+                if (spa) S[L.pact + e * A + k] = 0.0f;
+            }
+        }
+        if (ph_rew) {
+            auto* o_step_reward = uni(d.step_reward);
+            const uint32_t inv = hot.inv_rewards;
+            for (int i = lane; i < ne * NR; i += 64) {
+                const int term = NR > 1 ? i - static_cast<int>(__umulhi(static_cast<uint32_t>(i), inv)) * NR : 0;  // i % NR
+                if (terms[NT + term].weight != 0.0f) st_at(o_step_reward + env0 * NR, 4u * i, S[L.srew + i]);
+            }
+        }
+    }
+    if (wave == 3 && ph_term) {
+        auto* o_dones = uni(d.term_dones);
+        for (int i = lane; i < NT * kE; i += 64) {
+            const int term = i / kE, ee = i - term * kE;
+            if (ee < ne) o_dones[static_cast<int64_t>(term) * N + env0 + ee] = (bits[ee] >> term) & 1u;
         }
     }
     if (wave == 0) {
@@ -846,8 +881,6 @@ __global__ void __launch_bounds__(kBlock, 4) mdp_step_kernel(MdpDev args, const 
             for (int w = 1; w < kWaves; ++w) total += S[L.ptotal + w * kE + e];
             st_at(o_reward + env0, 4u * ue, total);
         }
-        reinterpret_cast<uint32_t*>(S + L.bits)[e] = term_bits;
-        reinterpret_cast<uint32_t*>(S + L.bits)[kE + e] = done ? 1u : 0u;
         if (has_cmd_term) {
 #pragma unroll
             for (int k = 0; k < 7; ++k)
@@ -925,37 +958,10 @@ __global__ void __launch_bounds__(kBlock, 4) mdp_step_kernel(MdpDev args, const 
 
     ILX_STAMP(8)
     // ================= EMIT =================
-    const uint32_t* bits = reinterpret_cast<const uint32_t*>(S + L.bits);
-    {
-        auto* o_dones = uni(d.term_dones);
-        auto* o_sums = uni(d.episode_sums);
-        auto* o_step_reward = uni(d.step_reward);
+    if (ph_reset && tid < NR + NT + 3) {
         auto* o_log = uni(d.log_sums);
-        const uint32_t inv = hot.inv_rewards;
-        if (ph_term) {
-            for (int i = tid; i < NT * kE; i += kBlock) {
-                const int term = i / kE, ee = i - term * kE;
-                if (ee < ne) o_dones[static_cast<int64_t>(term) * N + env0 + ee] = (bits[ee] >> term) & 1u;
-            }
-        }
-        if (ph_rew || ph_reset) {
-            for (int i = tid; i < NR * kE; i += kBlock) {
-                const int term = i / kE, ee = i - term * kE;
-                if (ee >= ne) continue;
-                const bool active = ph_rew && terms[NT + term].weight != 0.0f;
-                if (active || (ph_reset && bits[kE + ee])) o_sums[static_cast<int64_t>(term) * N + env0 + ee] = S[L.eps + i];
-            }
-            if (ph_rew) {
-                for (int i = tid; i < ne * NR; i += kBlock) {
-                    const int term = NR > 1 ? i - static_cast<int>(__umulhi(static_cast<uint32_t>(i), inv)) * NR : 0;  // i % NR
-                    if (terms[NT + term].weight != 0.0f) st_at(o_step_reward + env0 * NR, 4u * i, S[L.srew + i]);
-                }
-            }
-        }
-        if (ph_reset && o_log && tid < NR + NT + 3) {
-            const float v = S[L.logp + tid];
-            if (v != 0.0f) unsafeAtomicAdd((float*)(o_log + tid), v);  // hardware float add at L2, no return value
-        }
+        const float v = S[L.logp + tid];
+        if (o_log && v != 0.0f) unsafeAtomicAdd((float*)(o_log + tid), v);  // hardware float add at L2, no return value
     }
     ILX_STAMP(9)
     // ---- observations (observation_manager.py:260-335).  The concatenated row is cut into groups of 4 columns (a
