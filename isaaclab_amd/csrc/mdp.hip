@@ -22,6 +22,7 @@
 #include "../../include/isaaclab_amd_mdp.h"
 
 #include <cstring>
+#include <algorithm>
 #include <vector>
 
 namespace ilx {
@@ -113,6 +114,7 @@ struct Hot {
     uint64_t seed, step_index;
     const ilx_term* terms;  // the plan's table in device memory: [terminations | rewards | observations]
     const uint64_t* step_index_device;
+    uint64_t reward_owner;  // two bits per reward term: the wavefront that evaluates it
 };
 
 // One environment as seen by its lane in the DECIDE stage.
@@ -712,7 +714,7 @@ __global__ void __launch_bounds__(kBlock, 4) mdp_step_kernel(MdpDev args, const 
     ILX_STAMP(1)
     __syncthreads();  // waits for this wave's copies (vmcnt(0)), then for every wave's
     ILX_STAMP(2)
-    // ================= DECIDE: one lane per env; the four waves split the reward terms =================
+    // ================= DECIDE: one lane per env; the four waves split the reward terms (dealt by cost at plan creation) =================
     Env en{m, hot, S, ids, e, env};
     const float dt = hot.step_dt;
     const f3 gravity = {hot.gravity[0], hot.gravity[1], hot.gravity[2]};
@@ -741,7 +743,8 @@ __global__ void __launch_bounds__(kBlock, 4) mdp_step_kernel(MdpDev args, const 
         // ---- rewards (reward_manager.py:128-157): this wave's share of the terms
         if (ph_rew) {
             float partial = 0.0f;
-            for (int i = wave; i < NR; i += kWaves) {
+            for (int i = 0; i < NR; ++i) {
+                if (static_cast<int>((hot.reward_owner >> (2 * i)) & 3u) != wave) continue;
                 const ilx_term t = uniform_term(hot.terms, NT + i);
                 if (t.weight == 0.0f) continue;  // :145-146 (episode sums and step_reward keep their values)
                 const float value = eval_reward(en, t, terminated, time_out, term_bits) * t.weight * dt;
@@ -1094,6 +1097,7 @@ struct ilx_mdp_plan_s {
     int dims[3] = {0, 0, 0};     // num_joints, action_dim, command_dim the column descriptors were made for
     bool any_noise = false;
     uint32_t noisy_terms = 0;
+    uint64_t reward_owner = 0;   // two bits per reward term: the wavefront that evaluates it
     int nt = 0, nr = 0, no = 0, nids = 0;
     int obs_dim = 0;
     // data the term tables read, per phase group (checked against NULL at every step)
@@ -1213,6 +1217,35 @@ extern "C" int ilx_mdp_plan_create(const ilx_mdp* desc, ilx_mdp_plan_t* out) {
         p->r_rays |= k == ILX_REW_BASE_HEIGHT_L2 && (d.rewards[i].flags & 1);
         p->r_command |= (k >= ILX_REW_TRACK_LIN_VEL_XY_EXP && k <= ILX_REW_FEET_AIR_TIME_POSITIVE_BIPED) ||
                         (k >= ILX_REW_TRACK_LIN_VEL_XY_YAW_FRAME_EXP && k <= ILX_REW_ORIENTATION_COMMAND_ERROR);
+    }
+    {   // The block's four wavefronts split the reward terms; the stage lasts as long as its most loaded wavefront, so the
+        // terms are dealt by a rough count of the LDS reads each makes, heaviest first, to the least loaded wavefront.
+        auto cost = [&](const ilx_term& t) {
+            if (t.weight == 0.0f) return 0;
+            const int k = t.kind;
+            const int nj = t.ids_cnt < 0 ? d.num_joints : t.ids_cnt, nb = t.ids_cnt < 0 ? d.num_sensor_bodies : t.ids_cnt;
+            if ((k >= ILX_REW_JOINT_TORQUES_L2 && k <= ILX_REW_APPLIED_TORQUE_LIMITS) || k == ILX_REW_JOINT_POS_TARGET_L2) return 10 + 3 * nj;
+            if (k == ILX_REW_ACTION_RATE_L2 || k == ILX_REW_ACTION_L2) return 10 + 3 * d.action_dim;
+            if (k == ILX_REW_UNDESIRED_CONTACTS || k == ILX_REW_CONTACT_FORCES || k == ILX_REW_FEET_SLIDE)
+                return 10 + (4 + 4 * d.history_len) * nb;
+            if (k == ILX_REW_FEET_AIR_TIME || k == ILX_REW_FEET_AIR_TIME_POSITIVE_BIPED) return 15 + 5 * nb;
+            if (k == ILX_REW_BODY_LIN_ACC_L2) return 10 + 2 * (t.ids_cnt < 0 ? d.num_bodies : t.ids_cnt);
+            if (k == ILX_REW_BASE_HEIGHT_L2 && (t.flags & 1)) return 10 + 4 * d.num_rays;
+            if (k >= ILX_REW_TRACK_LIN_VEL_XY_EXP && k <= ILX_REW_TRACK_ANG_VEL_Z_EXP) return 25;
+            if (k >= ILX_REW_TRACK_LIN_VEL_XY_YAW_FRAME_EXP) return 40;
+            return 8;
+        };
+        std::vector<int> order(static_cast<size_t>(d.num_rewards));
+        for (int i = 0; i < d.num_rewards; ++i) order[i] = i;
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cost(d.rewards[a]) > cost(d.rewards[b]); });
+        int load[kWaves] = {0, 0, 0, 0};
+        for (int i : order) {
+            int w = 0;
+            for (int k = 1; k < kWaves; ++k)
+                if (load[k] < load[w]) w = k;
+            load[w] += cost(d.rewards[i]) + 12;   // + the fixed part of a term: its record, the dispatch, the sums it updates
+            p->reward_owner |= static_cast<uint64_t>(w) << (2 * i);
+        }
     }
     for (int i = 0; i < d.num_observations; ++i) {
         const int k = d.observations[i].kind;
@@ -1506,7 +1539,7 @@ extern "C" int ilx_mdp_step(ilx_mdp_plan_t plan, const ilx_mdp* desc, void* stre
     hot.step_dt = d.step_dt;
     for (int k = 0; k < 3; ++k) hot.gravity[k] = d.gravity_dir[k];
     hot.num_envs = d.num_envs, hot.seed = d.seed, hot.step_index = d.step_index;
-    hot.terms = plan->d_terms, hot.step_index_device = d.step_index_device;
+    hot.terms = plan->d_terms, hot.step_index_device = d.step_index_device, hot.reward_owner = plan->reward_owner;
     hipLaunchKernelGGL(mdp_step_kernel, dim3(blocks), dim3(kBlock), lds_bytes, as_stream(stream), m, hot);
     ILX_LAUNCH_CHECK("ilx_mdp_step");
     return ILX_OK;
