@@ -710,6 +710,14 @@ ILX_DEV bool lattice_cell(const float* l, int n, float x, float x0, float inv, i
 // (uniform: scalar registers), copies the window of the height grid into LDS and intersects its rays there; a
 // wavefront's own LDS traffic is ordered.  Rays that are not strictly inside a simple cell use the column grid (or
 // are left to the tree launch that follows).
+#ifdef ILX_RAY_STAMPS  // diagnostics build only: wall-clock stamps (10 ns ticks) of the first wavefront of the first blocks
+__device__ unsigned long long g_ray_stamps[8 * 4096];
+#define ILX_RAY_STAMP(k) \
+    if (threadIdx.x == 0 && blockIdx.x < 4096) g_ray_stamps[blockIdx.x * 8 + (k)] = wall_clock64();
+#else
+#define ILX_RAY_STAMP(k)
+#endif
+
 __global__ void __launch_bounds__(64 * kLatWaves) raycaster_update_lattice_kernel(ScanArgs a, const LatEnvRec* __restrict__ recs,
                                                                                    const float4* __restrict__ pattern) {
     __shared__ LatStage stage_s[kLatWaves];
@@ -717,6 +725,7 @@ __global__ void __launch_bounds__(64 * kLatWaves) raycaster_update_lattice_kerne
     const float inf = __builtin_inff();
     const int64_t env = static_cast<int64_t>(xcd_block(blockIdx.x, gridDim.x)) * kLatWaves + wave;
     if (env >= a.n) return;
+    ILX_RAY_STAMP(0)
     const LatEnvRec E = recs[env];
 
     // pattern entries of the lane: local start, z of the direction (NaN: not z-parallel)
@@ -730,6 +739,7 @@ __global__ void __launch_bounds__(64 * kLatWaves) raycaster_update_lattice_kerne
     if (sel == kLatNotDue) return;
     LatStage& st = stage_s[wave];
     const int w0 = j_lo >> 5;
+    ILX_RAY_STAMP(1)
     if (sel >= 0) {
         // a wavefront load takes two window rows (lanes 0-31 and 32-63): row-contiguous runs of the height grid, no
         // index arithmetic, and the LDS address of load k is 64 k + lane
@@ -762,6 +772,7 @@ __global__ void __launch_bounds__(64 * kLatWaves) raycaster_update_lattice_kerne
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     }
+    ILX_RAY_STAMP(2)
 
     const f3 pos = {E.px, E.py, E.pz};
     const f4 rot = {E.rw, E.rx, E.ry, E.rz};
@@ -827,7 +838,9 @@ __global__ void __launch_bounds__(64 * kLatWaves) raycaster_update_lattice_kerne
         const int ray = lane + 64 * r;
         const bool zp = kp[r].w == kp[r].w;
         if (ray < a.r && !(sel >= 0 && zp && serve(world_start(f3{kp[r].x, kp[r].y, kp[r].z}), kp[r].w, ray))) pending |= 1u << r;
+        if (r == 0) { ILX_RAY_STAMP(3) }
     }
+    ILX_RAY_STAMP(4)
     for (int ray = lane + 64 * kLatKeep, round = kLatKeep; ray < a.r; ray += 64, ++round) {
         const float4 e = pattern[ray];
         if (!(sel >= 0 && e.w == e.w && serve(world_start(f3{e.x, e.y, e.z}), e.w, ray))) pending |= 1u << round;
@@ -847,6 +860,7 @@ __global__ void __launch_bounds__(64 * kLatWaves) raycaster_update_lattice_kerne
         const Hit h = trace_column<false>(a.mesh, o, d, a.max_dist);
         write_scan(a, h, o, d, pos.z, i);
     }
+    ILX_RAY_STAMP(5)
 }
 
 // RayCasterCamera._update_buffers_impl (ray_caster_camera.py:257-318): one thread per (env, pixel) of the refreshed
@@ -1716,6 +1730,12 @@ extern "C" int ilx_raycaster_update(ilx_mesh_t mesh, const float* pos_w, const f
     ILX_LAUNCH_CHECK("ilx_raycaster_update");
     return ILX_OK;
 }
+
+#ifdef ILX_RAY_STAMPS
+extern "C" int ilx_debug_ray_stamps(unsigned long long* out, int count) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(ilx::g_ray_stamps), sizeof(unsigned long long) * count) == hipSuccess ? 0 : 1;
+}
+#endif
 
 extern "C" int ilx_raycaster_refresh(const ilx_raycaster* rc, void* stream) {
     ILX_REQUIRE(rc, ILX_EINVAL, "ilx_raycaster_refresh: descriptor is NULL");

@@ -1,0 +1,33 @@
+"""GPU probe (diagnostics build: CXXFLAGS+=-DILX_RAY_STAMPS): where a wavefront of the height-field cast spends its time.
+    python tools/ray_stamps.py [envs]"""
+import ctypes, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+import bench_configs as BC
+from isaaclab_amd import _abi
+
+envs = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
+cfg = BC.build("anymal", torch.device("cuda:0"), envs, 3000)
+for _ in range(3):
+    cfg.step()
+torch.cuda.synchronize()
+fn = cfg.launches["raycaster_refresh"][0]
+fn = fn[0] if isinstance(fn, tuple) else fn
+for _ in range(5):
+    fn()
+torch.cuda.synchronize()
+blocks = min(4096, (envs + 3) // 4)
+buf = (ctypes.c_ulonglong * (8 * 4096))()
+assert _abi.lib.ilx_debug_ray_stamps(buf, 8 * 4096) == 0
+t = np.frombuffer(buf, dtype=np.uint64).reshape(4096, 8)[:blocks].astype(np.int64)
+t0 = t[:, 0].min()
+labels = ["entry", "record and pattern requested", "window in LDS", "first 64 rays served", "all rays served", "exit"]
+prev = t[:, 0]
+for k, lab in enumerate(labels):
+    print(f"{k} {lab:30s} {(t[:, k] - t0).mean() / 100:8.2f} us   +{(t[:, k] - prev).mean() / 100:6.2f}   (max +{(t[:, k] - prev).max() / 100:6.2f})")
+    prev = t[:, k]
+life = (t[:, 5] - t[:, 0]) / 100.0
+print("entry: " + "  ".join(f"p{q}={np.percentile((t[:, 0] - t0) / 100.0, q):.2f}" for q in (0, 10, 50, 90, 100)))
+print("exit:  " + "  ".join(f"p{q}={np.percentile((t[:, 5] - t0) / 100.0, q):.2f}" for q in (0, 10, 50, 90, 100)))
+print("life of a wavefront: " + "  ".join(f"p{q}={np.percentile(life, q):.2f}" for q in (0, 10, 50, 90, 100)))
