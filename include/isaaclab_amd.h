@@ -670,7 +670,13 @@ enum ilx_ray_hint {
      * directions, ray_caster.py:247): a PROMISE that the caller has checked every pattern direction to be (0, 0, +-z).
      * The launch that would pick up other rays is then not queued; a ray that breaks the promise is left with a NaN in
      * ray_hits_w[..., 0] instead of a result. */
-    ILX_RAYS_Z_PARALLEL_CHECKED = 2
+    ILX_RAYS_Z_PARALLEL_CHECKED = 2,
+    /* For ilx_raycaster_refresh: a PROMISE that ray_starts_local / ray_directions_local hold what they held at the
+     * previous refresh issued for this mesh on this stream (a sensor's pattern is fixed once it is initialised,
+     * ray_caster.py:190-212).  The refresh then reuses the packed pattern and its bounding box that that refresh left in
+     * the stream's workspace instead of reading and reducing the pattern again.  It has no effect when there was no
+     * such refresh (first call, other arrays or ray count, workspace regrown). */
+    ILX_RAYS_PATTERN_STATIC = 4
 };
 int ilx_raycast_mesh(ilx_mesh_t mesh, const float* ray_starts, const float* ray_directions, int64_t num_rays,
                      float max_dist, float* ray_hits, float* ray_distance, float* ray_normal, int32_t* ray_face_id,

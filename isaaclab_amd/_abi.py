@@ -108,6 +108,7 @@ mesh_lattice_counter = _sig("ilx_mesh_lattice_counter", P, c_int, P)
 mesh_lattice_probe = _sig("ilx_mesh_lattice_probe", P, c_int64, P, c_int64, P)
 RAYS_Z_PARALLEL = 1
 RAYS_Z_PARALLEL_CHECKED = 2
+RAYS_PATTERN_STATIC = 4
 raycast_mesh = _sig("ilx_raycast_mesh", P, P, P, c_int64, c_float, P, P, P, P, c_int, P)
 raycaster_update = _sig("ilx_raycaster_update", P, P, P, P, P, P, c_int, c_float, P, P, c_float, c_int64, c_int, c_int, P)
 joint_action_process = _sig("ilx_joint_action_process", P, P, P, P, c_float, P, c_float, P, P, c_int64, c_int, P)

@@ -582,15 +582,30 @@ ILX_DEV float wave_max(float v) {
     return v;
 }
 
+#ifdef ILX_RAY_STAMPS  // diagnostics build only: wall-clock stamps (10 ns ticks) of the first wavefront of the first blocks
+__device__ unsigned long long g_ray_stamps[8 * 4096];
+__device__ unsigned long long g_prep_stamps[8 * 256];
+#define ILX_PREP_STAMP(k) \
+    if (threadIdx.x == 0 && blockIdx.x < 256) g_prep_stamps[blockIdx.x * 8 + (k)] = wall_clock64();
+#define ILX_RAY_STAMP(k) \
+    if (threadIdx.x == 0 && blockIdx.x < 4096) g_ray_stamps[blockIdx.x * 8 + (k)] = wall_clock64();
+#else
+#define ILX_RAY_STAMP(k)
+#define ILX_PREP_STAMP(k)
+#endif
+
 // Preparation launch of the height-field refresh: one thread per env (yaw-only sensors, ray_caster.py:243-247).
 //   pos_w / quat_w of RayCasterData, the sensor clocks (sensor_base.py:284-293), the yaw quaternion, the rectangle
 //   that the rotated scan pattern covers, the patch that holds it and the window of lattice lines -> LatEnvRec.
 // The pattern's xy box is reduced by every workgroup for itself (a few loads per thread).
 constexpr int kPatchBins = 64;
 
-__global__ void __launch_bounds__(256) raycaster_prepare_kernel(ScanArgs a, LatEnvRec* __restrict__ recs, float4* __restrict__ pattern) {
+// `box_cache` (or null): four floats that keep the pattern's box; `reuse`: they and `pattern` are those of this pattern.
+__global__ void __launch_bounds__(256) raycaster_prepare_kernel(ScanArgs a, LatEnvRec* __restrict__ recs, float4* __restrict__ pattern,
+                                                                float* __restrict__ box_cache, int reuse) {
     __shared__ float box_s[4][4];
     const float inf = __builtin_inff();
+    ILX_PREP_STAMP(0)
     // the env's inputs go out first: they travel while the block reduces the pattern's box
     const int64_t env = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
     const bool due = env < a.n && (!a.env_mask || a.env_mask[env]);
@@ -602,28 +617,34 @@ __global__ void __launch_bounds__(256) raycaster_prepare_kernel(ScanArgs a, LatE
         if (a.drift) dr = load3(a.drift + 3 * env);
     }
     float bx0 = inf, bx1 = -inf, by0 = inf, by1 = -inf;  // xy box of the z-parallel pattern entries
-    for (int ray = threadIdx.x; ray < a.r; ray += 256) {
-        const f3 l = load3(a.ray_starts + 3 * ray), d = load3(a.ray_dirs + 3 * ray);
-        const bool zp = z_parallel(d);
-        if (zp) {
-            bx0 = fminf(bx0, l.x), bx1 = fmaxf(bx1, l.x);
-            by0 = fminf(by0, l.y), by1 = fmaxf(by1, l.y);
+    if (reuse) {
+        bx0 = box_cache[0], bx1 = box_cache[1], by0 = box_cache[2], by1 = box_cache[3];
+    } else {
+        for (int ray = threadIdx.x; ray < a.r; ray += 256) {
+            const f3 l = load3(a.ray_starts + 3 * ray), d = load3(a.ray_dirs + 3 * ray);
+            const bool zp = z_parallel(d);
+            if (zp) {
+                bx0 = fminf(bx0, l.x), bx1 = fmaxf(bx1, l.x);
+                by0 = fminf(by0, l.y), by1 = fmaxf(by1, l.y);
+            }
+            // the pattern as the cast wants it: one 16-byte word per ray, local start and z of the direction -- NaN when
+            // the direction is not z-parallel (such a ray never takes the height-grid path)
+            if (blockIdx.x == 0) pattern[ray] = make_float4(l.x, l.y, l.z, zp ? d.z : __builtin_nanf(""));
         }
-        // the pattern as the cast wants it: one 16-byte word per ray, local start and z of the direction -- NaN when
-        // the direction is not z-parallel (such a ray never takes the height-grid path)
-        if (blockIdx.x == 0) pattern[ray] = make_float4(l.x, l.y, l.z, zp ? d.z : __builtin_nanf(""));
-    }
-    bx0 = wave_min(bx0), bx1 = wave_max(bx1), by0 = wave_min(by0), by1 = wave_max(by1);
-    if ((threadIdx.x & 63) == 0) {
-        float* b = box_s[threadIdx.x >> 6];
-        b[0] = bx0, b[1] = bx1, b[2] = by0, b[3] = by1;
-    }
-    __syncthreads();
+        bx0 = wave_min(bx0), bx1 = wave_max(bx1), by0 = wave_min(by0), by1 = wave_max(by1);
+        if ((threadIdx.x & 63) == 0) {
+            float* b = box_s[threadIdx.x >> 6];
+            b[0] = bx0, b[1] = bx1, b[2] = by0, b[3] = by1;
+        }
+        __syncthreads();
 #pragma unroll
-    for (int w = 0; w < 4; ++w) {
-        bx0 = fminf(bx0, box_s[w][0]), bx1 = fmaxf(bx1, box_s[w][1]);
-        by0 = fminf(by0, box_s[w][2]), by1 = fmaxf(by1, box_s[w][3]);
+        for (int w = 0; w < 4; ++w) {
+            bx0 = fminf(bx0, box_s[w][0]), bx1 = fmaxf(bx1, box_s[w][1]);
+            by0 = fminf(by0, box_s[w][2]), by1 = fmaxf(by1, box_s[w][3]);
+        }
+        if (box_cache && blockIdx.x == 0 && threadIdx.x == 0) box_cache[0] = bx0, box_cache[1] = bx1, box_cache[2] = by0, box_cache[3] = by1;
     }
+    ILX_PREP_STAMP(1)
     if (env >= a.n) return;
     LatEnvRec le{};
     le.sel = kLatNotDue;
@@ -657,6 +678,7 @@ __global__ void __launch_bounds__(256) raycaster_prepare_kernel(ScanArgs a, LatE
             mny = mny + pos.y - pad, mxy = mxy + pos.y + pad;
             // the patch whose extent holds the rectangle (any such patch will do: where patches overlap, the cells are
             // not simple)
+            ILX_PREP_STAMP(2)
             int sel = -1;
             LatticePatch P{};
             auto holds = [&](const LatticePatch& c) { return mnx >= c.x0 && mxx <= c.x1 && mny >= c.y0 && mxy <= c.y1; };
@@ -679,6 +701,7 @@ __global__ void __launch_bounds__(256) raycaster_prepare_kernel(ScanArgs a, LatE
                 for (int k = 3; k >= 0; --k)   // the first candidate that holds it wins
                     if (ids[k] >= 0 && holds(c[k])) sel = ids[k], P = c[k];
             }
+            ILX_PREP_STAMP(3)
             if (sel >= 0) {
                 const int gx0 = lattice_guess(mnx, P.x0, P.inv_dx), gx1 = lattice_guess(mxx, P.x0, P.inv_dx);
                 const int gy0 = lattice_guess(mny, P.y0, P.inv_dy), gy1 = lattice_guess(mxy, P.y0, P.inv_dy);
@@ -694,6 +717,7 @@ __global__ void __launch_bounds__(256) raycaster_prepare_kernel(ScanArgs a, LatE
         }
     }
     recs[env] = le;
+    ILX_PREP_STAMP(4)
 }
 
 // The staged lattice cell that the index estimate names for coordinate x (line l[k] is line lo_abs + k of the patch):
@@ -710,14 +734,6 @@ ILX_DEV bool lattice_cell(const float* l, int n, float x, float x0, float inv, i
 // (uniform: scalar registers), copies the window of the height grid into LDS and intersects its rays there; a
 // wavefront's own LDS traffic is ordered.  Rays that are not strictly inside a simple cell use the column grid (or
 // are left to the tree launch that follows).
-#ifdef ILX_RAY_STAMPS  // diagnostics build only: wall-clock stamps (10 ns ticks) of the first wavefront of the first blocks
-__device__ unsigned long long g_ray_stamps[8 * 4096];
-#define ILX_RAY_STAMP(k) \
-    if (threadIdx.x == 0 && blockIdx.x < 4096) g_ray_stamps[blockIdx.x * 8 + (k)] = wall_clock64();
-#else
-#define ILX_RAY_STAMP(k)
-#endif
-
 __global__ void __launch_bounds__(64 * kLatWaves) raycaster_update_lattice_kernel(ScanArgs a, const LatEnvRec* __restrict__ recs,
                                                                                    const float4* __restrict__ pattern) {
     __shared__ LatStage stage_s[kLatWaves];
@@ -1040,7 +1056,14 @@ struct MeshHost {
     // are ordered, so they can share it), grown on demand; outgrown buffers are kept until the mesh is destroyed because
     // work that uses them may still be queued.
     std::mutex ws_lock;
-    std::unordered_map<void*, std::pair<void*, size_t>> ws_by_stream;
+    struct Workspace {
+        void* first = nullptr;   // device memory
+        size_t second = 0;       // its size; the last 16 bytes hold the bounding box of the pattern named below
+        const void* starts = nullptr;  // the scan pattern that the last refresh on this stream packed into it
+        const void* dirs = nullptr;
+        int rays = 0;
+    };
+    std::unordered_map<void*, Workspace> ws_by_stream;
     std::vector<void*> ws_retired;
     int32_t* d_off_grid = nullptr;  // kFlagSlots flags, one raised by a column kernel for the tree kernel launched after it
     std::atomic<uint32_t> calls{0}; // hinted casts so far: call c uses slot c % kFlagSlots and the ticket c + 1
@@ -1644,10 +1667,12 @@ static size_t lattice_workspace_bytes(int64_t n, int r) {
 // broke the z-parallel hint -- it only looks at the flag unless there are such rays, and it is left out altogether when
 // the caller has checked the pattern (ILX_RAYS_Z_PARALLEL_CHECKED) and the mesh has a column grid for the rays that
 // leave the height-grid path.
-static void launch_lattice(ilx_mesh_t mesh, ScanArgs a, int hints, void* ws, void* stream) {
+// `box` (or null) / `reuse`: see lattice_workspace.
+static void launch_lattice(ilx_mesh_t mesh, ScanArgs a, int hints, void* ws, float* box, bool reuse, void* stream) {
     float4* pattern = static_cast<float4*>(ws);
     LatEnvRec* recs = reinterpret_cast<LatEnvRec*>(static_cast<char*>(ws) + lattice_workspace_bytes(0, a.r));
-    hipLaunchKernelGGL(raycaster_prepare_kernel, dim3(blocks_for(a.n)), dim3(256), 0, as_stream(stream), a, recs, pattern);
+    hipLaunchKernelGGL(raycaster_prepare_kernel, dim3(blocks_for(a.n)), dim3(256), 0, as_stream(stream), a, recs, pattern, box,
+                       (box && reuse) ? 1 : 0);
     hipLaunchKernelGGL(raycaster_update_lattice_kernel, dim3(static_cast<unsigned>((a.n + kLatWaves - 1) / kLatWaves)),
                        dim3(64 * kLatWaves), 0, as_stream(stream), a, recs, pattern);
     if ((hints & ILX_RAYS_Z_PARALLEL_CHECKED) && mesh->h.d_cells) return;
@@ -1655,20 +1680,25 @@ static void launch_lattice(ilx_mesh_t mesh, ScanArgs a, int hints, void* ws, voi
     hipLaunchKernelGGL(raycaster_update_kernel, dim3(std::min(ray_grid(a.n * a.r), 256u)), dim3(kRayBlock), 0, as_stream(stream), a);
 }
 
-// The workspace of `stream` with room for `bytes`.
-static int lattice_workspace(ilx_mesh_t mesh, void* stream, size_t bytes, void** out) {
+// The workspace of `stream` with room for `bytes`, and the four floats behind it that keep the scan pattern's bounding
+// box from one refresh to the next.  `reuse`: the workspace still holds the packed pattern and the box of exactly this
+// pattern (same arrays, same length) from the previous refresh on the stream.
+static int lattice_workspace(ilx_mesh_t mesh, void* stream, size_t bytes, const ScanArgs& a, void** out, float** box, bool* reuse) {
     MeshHost& h = mesh->h;
     std::lock_guard<std::mutex> guard(h.ws_lock);
     auto& slot = h.ws_by_stream[stream];
-    if (slot.second < bytes) {
+    if (slot.second < bytes + 16) {
         void* fresh = nullptr;
-        const size_t cap = std::max<size_t>(bytes + bytes / 4, size_t(1) << 16);
+        const size_t cap = (std::max<size_t>(bytes + bytes / 4, size_t(1) << 16) + 31) & ~size_t(15);
         const int rc = check_hip(hipMalloc(&fresh, cap), "ilx_raycaster: hipMalloc(workspace)");
         if (rc != ILX_OK) return rc;
         if (slot.first) h.ws_retired.push_back(slot.first);
-        slot = {fresh, cap};
+        slot = MeshHost::Workspace{fresh, cap, nullptr, nullptr, 0};
     }
     *out = slot.first;
+    *box = reinterpret_cast<float*>(static_cast<char*>(slot.first) + slot.second - 16);
+    *reuse = slot.starts == a.ray_starts && slot.dirs == a.ray_dirs && slot.rays == a.r;
+    slot.starts = a.ray_starts, slot.dirs = a.ray_dirs, slot.rays = a.r;
     return ILX_OK;
 }
 
@@ -1732,6 +1762,9 @@ extern "C" int ilx_raycaster_update(ilx_mesh_t mesh, const float* pos_w, const f
 }
 
 #ifdef ILX_RAY_STAMPS
+extern "C" int ilx_debug_prepare_stamps(unsigned long long* out, int count) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(ilx::g_prep_stamps), sizeof(unsigned long long) * count) == hipSuccess ? 0 : 1;
+}
 extern "C" int ilx_debug_ray_stamps(unsigned long long* out, int count) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(ilx::g_ray_stamps), sizeof(unsigned long long) * count) == hipSuccess ? 0 : 1;
 }
@@ -1818,17 +1851,19 @@ static int launch_scan(ilx_mesh_t mesh, ScanArgs a, int hints, void* stream, voi
         // height-field patches: a preparation launch (one thread per env; it also advances the sensor clocks), the cast
         // (one wavefront per env), and the tree launch, which only looks at the flag: it has work when rays broke the hint
         void* ws = fixed_ws;
+        float* box = nullptr;   // the built-in buffer keeps nothing from call to call
+        bool same_pattern = false;
         if (fixed_ws) {
             ILX_REQUIRE(lattice_workspace_bytes(a.n, a.r) <= fixed_bytes, ILX_ESHAPE,
                         "ilx_raycaster_refresh_static: %lld envs x %d rays need %zu bytes between the launches, the built-in "
                         "buffer holds %zu (at most %d envs at %d rays); use ilx_raycaster_refresh",
                         (long long)a.n, a.r, lattice_workspace_bytes(a.n, a.r), fixed_bytes, kStaticEnvs, kLatMaxRays);
         } else {
-            const int rc = lattice_workspace(mesh, stream, lattice_workspace_bytes(a.n, a.r), &ws);
+            const int rc = lattice_workspace(mesh, stream, lattice_workspace_bytes(a.n, a.r), a, &ws, &box, &same_pattern);
             if (rc != ILX_OK) return rc;
         }
         take_ticket(mesh, a.ticket, a.off_grid);
-        launch_lattice(mesh, a, hints, ws, stream);
+        launch_lattice(mesh, a, hints, ws, box, same_pattern && (hints & ILX_RAYS_PATTERN_STATIC), stream);
         return ILX_OK;
     }
     if ((hints & ILX_RAYS_Z_PARALLEL) && mesh->h.d_cells) {

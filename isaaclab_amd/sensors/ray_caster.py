@@ -77,6 +77,9 @@ class RayCaster:
         if cfg.attach_yaw_only and bool((self.ray_directions[:, :2] == 0).all()):
             # ... and the check just made is the promise that lets the library drop the launch for other rays
             self._hints = _abi.RAYS_Z_PARALLEL | _abi.RAYS_Z_PARALLEL_CHECKED
+        # the pattern tensors are never written in place after this point (a new pattern means new tensors): the library
+        # may keep the packed pattern and its bounding box from one refresh to the next
+        self._hints |= _abi.RAYS_PATTERN_STATIC
         self.drift = torch.zeros(n, 3, device=dev)
         self._has_drift = cfg.drift_range[0] != 0.0 or cfg.drift_range[1] != 0.0
         self._data = RayCasterData(pos_w=torch.zeros(n, 3, device=dev), quat_w=torch.zeros(n, 4, device=dev),

@@ -212,3 +212,43 @@ def test_sensor_envs_masks_clocks_and_long_patterns(dev):
         assert_exact(torch.isinf(h[keep][..., 0]), ~got_hit[keep], "hit / miss pattern")
         assert_exact(hits[keep][got_hit[keep]], h[keep][got_hit[keep]], f"hits, pattern {size} @ {res}")
         assert (~got_hit[1]).all() and (size[0] > 1.7 or got_hit[2].all())
+
+
+def test_kept_pattern_is_reused_only_for_the_same_pattern(dev):
+    """ILX_RAYS_PATTERN_STATIC: the packed pattern and its box stay in the stream's workspace between refreshes.  Two
+    sensors with different patterns that take turns on one mesh and stream, and a sensor that refreshes several times in a
+    row, give what a sensor gives on its first refresh."""
+    from isaaclab_amd import _abi
+    from isaaclab_amd.sensors.patterns import GridPatternCfg
+    from isaaclab_amd.sensors.ray_caster import OffsetCfg, RayCaster, RayCasterCfg
+    from isaaclab_amd.utils.mesh import convert_to_mesh
+
+    v, t, rows, cols = hf_case(rows=81, cols=97, seed=22, origin=(10.0, 20.0))
+    mesh = convert_to_mesh(v, t, str(dev))
+    gen = torch.Generator().manual_seed(5)
+    n = 64
+    pos = torch.cat([torch.rand(n, 1, generator=gen) * 6.0 + 11.0, torch.rand(n, 1, generator=gen) * 7.0 + 21.0,
+                     torch.rand(n, 1, generator=gen) + 0.5], -1).to(dev)
+    yaw = torch.rand(n, generator=gen) * 6.28 - 3.14
+    quat = torch.stack([torch.cos(yaw / 2), torch.zeros(n), torch.zeros(n), torch.sin(yaw / 2)], -1).to(dev)
+
+    def sensor(size, res):
+        cfg = RayCasterCfg(offset=OffsetCfg(pos=(0.0, 0.0, 20.0)), attach_yaw_only=True,
+                           pattern_cfg=GridPatternCfg(resolution=res, size=size), update_period=0.02)
+        rc = RayCaster(cfg, n, mesh, dev)
+        assert rc._hints & _abi.RAYS_PATTERN_STATIC
+        rc.set_pose(pos, quat)
+        return rc
+
+    def refresh(rc):
+        rc._is_outdated[:] = True
+        return rc.data.ray_hits_w.clone()
+
+    first = {}
+    for key, size, res in (("a", (1.6, 1.0), 0.1), ("b", (1.0, 1.4), 0.2)):   # fresh mesh workspace state for neither: just first use
+        first[key] = refresh(sensor(size, res))
+    a, b = sensor((1.6, 1.0), 0.1), sensor((1.0, 1.4), 0.2)
+    for _ in range(2):
+        assert torch.equal(refresh(a), first["a"]) and torch.equal(refresh(a), first["a"])   # second one reuses
+        assert torch.equal(refresh(b), first["b"])                                           # other pattern: packed anew
+    assert torch.equal(refresh(a), first["a"])

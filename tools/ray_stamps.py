@@ -31,3 +31,14 @@ life = (t[:, 5] - t[:, 0]) / 100.0
 print("entry: " + "  ".join(f"p{q}={np.percentile((t[:, 0] - t0) / 100.0, q):.2f}" for q in (0, 10, 50, 90, 100)))
 print("exit:  " + "  ".join(f"p{q}={np.percentile((t[:, 5] - t0) / 100.0, q):.2f}" for q in (0, 10, 50, 90, 100)))
 print("life of a wavefront: " + "  ".join(f"p{q}={np.percentile(life, q):.2f}" for q in (0, 10, 50, 90, 100)))
+
+pbuf = (ctypes.c_ulonglong * (8 * 256))()
+if hasattr(_abi.lib, "ilx_debug_prepare_stamps") and _abi.lib.ilx_debug_prepare_stamps(pbuf, 8 * 256) == 0:
+    pblocks = min(256, (envs + 255) // 256)
+    p = np.frombuffer(pbuf, dtype=np.uint64).reshape(256, 8)[:pblocks].astype(np.int64)
+    p0 = p[:, 0].min()
+    print("preparation launch (one thread per env):")
+    prev = p[:, 0]
+    for k, lab in enumerate(["entry", "pattern box reduced", "pose -> yaw frame -> rectangle", "patch found", "record stored"]):
+        print(f"{k} {lab:32s} {(p[:, k] - p0).mean() / 100:8.2f} us   +{(p[:, k] - prev).mean() / 100:6.2f}   (max +{(p[:, k] - prev).max() / 100:6.2f})")
+        prev = p[:, k]
