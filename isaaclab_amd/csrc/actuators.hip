@@ -507,7 +507,13 @@ ILX_DEV void split_f16(const f32x16& x, h8 (&hi)[2], h8 (&lo)[2]) {
         for (int jj = 0; jj < 8; jj += 2) {
             const float a = x[8 * s + jj], b = x[8 * s + jj + 1];
             const h2 h = __builtin_amdgcn_cvt_pkrtz(a, b);  // truncation: the remainder is exact in f32
-            const h2 l = __builtin_amdgcn_cvt_pkrtz(a - static_cast<float>(h[0]), b - static_cast<float>(h[1]));
+            // a - float(h), b - float(h'): one mixed-precision fused multiply-add each, which reads the f16 half as it is
+            // (no conversion instruction); h * -1 + a is a - h exactly
+            const uint32_t hp = __builtin_bit_cast(uint32_t, h);
+            float ra, rb;
+            asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(ra) : "v"(hp), "v"(a));
+            asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(rb) : "v"(hp), "v"(b));
+            const h2 l = __builtin_amdgcn_cvt_pkrtz(ra, rb);
             hi[s][jj] = static_cast<_Float16>(h[0]), hi[s][jj + 1] = static_cast<_Float16>(h[1]);
             lo[s][jj] = static_cast<_Float16>(l[0]), lo[s][jj + 1] = static_cast<_Float16>(l[1]);
         }
