@@ -213,7 +213,7 @@ struct RowRawT {
 };
 
 template <int H, class I>
-ILX_DEV void issue_row(const NetArgs& a, const RowAt<I>& at, bool valid, RowRawT<H>& w) {
+ILX_DEV void issue_row(const NetArgs& a, const RowAt<I>& at, bool valid, RowRawT<H>& w, bool feature_slots = true) {
     w.q_des = w.q = w.qd = 0.0f;
     w.vel_limit = w.effort_limit = 1.0f;
     if (valid) {
@@ -232,7 +232,7 @@ ILX_DEV void issue_row(const NetArgs& a, const RowAt<I>& at, bool valid, RowRawT
 #pragma unroll
     for (int f = 0; f < 2 * H; ++f) {
         w.slot[f] = 0.0f;
-        if (f < a.n_feat && a.feat_slot[f] > 0 && valid)
+        if (feature_slots && f < a.n_feat && a.feat_slot[f] > 0 && valid)
             w.slot[f] = rd(((a.feat_is_pos >> f) & 1) ? a.pe_hist : a.v_hist, at.hbase + static_cast<I>((a.feat_slot[f] - 1) * a.j));
     }
 }
@@ -253,6 +253,26 @@ ILX_DEV void finish_row(const NetArgs& a, const RowRawT<H>& w, RowInT<H>& r) {
             val = v * (pos ? a.pos_scale : a.vel_scale);
         }
         r.feat[f] = val;
+    }
+}
+
+// finish_row for the usual feature list -- position errors of samples 0 .. K-1, then velocities of samples 0 .. K-1
+// (input_idx = range(K), "pos_vel" order: actuator_net.py:160-171) -- where every feature is a known register: no
+// per-feature selects on the host's tables.
+template <int H, int K>
+ILX_DEV void finish_row_pos_vel(const NetArgs& a, const RowRawT<H>& w, RowInT<H>& r) {
+    static_assert(K >= 1 && K <= H, "history length of the specialisation");
+    r.pe_new0 = w.q_des - w.q;
+    r.vel = w.qd;
+    r.vel_limit = w.vel_limit, r.effort_limit = w.effort_limit;
+#pragma unroll
+    for (int k = 0; k < H - 1; ++k) r.pe_old[k] = w.pe_old[k], r.v_old[k] = w.v_old[k];
+#pragma unroll
+    for (int f = 0; f < 2 * H; ++f) r.feat[f] = 0.0f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        r.feat[k] = (k == 0 ? r.pe_new0 : w.pe_old[k > 0 ? k - 1 : 0]) * a.pos_scale;
+        r.feat[K + k] = (k == 0 ? r.vel : w.v_old[k > 0 ? k - 1 : 0]) * a.vel_scale;
     }
 }
 
@@ -528,7 +548,8 @@ __device__ unsigned long long g_mlp_stamps[8 * 2048];
 #define ILX_MLP_STAMP(k)
 #endif
 
-template <int ACT, int NHID>
+// POS_VEL: 0, or the history length K of a launch whose feature list is the usual one (see finish_row_pos_vel).
+template <int ACT, int NHID, int POS_VEL>
 __global__ void __launch_bounds__(256, 8) mlp_mfma_split_kernel(NetArgs a) {
     constexpr int kHiddenWords = (NHID - 1) * 1024;  // 4 fragments x 64 lanes x 16 bytes per hidden layer
     __shared__ __attribute__((aligned(16))) float img[kResidentHist * 64 + kHiddenWords + NHID * 32 + 32 + 4];
@@ -551,7 +572,7 @@ __global__ void __launch_bounds__(256, 8) mlp_mfma_split_kernel(NetArgs a) {
     const RowAt<uint32_t> at = {valid ? row : 0u, valid ? env * static_cast<uint32_t>(a.hist_len) * j + joint : 0u,
                                 valid ? (a.per_env ? row : joint) : 0u};
     RowRawT<kResidentHist> raw;
-    issue_row(a, at, valid, raw);
+    issue_row(a, at, valid, raw, POS_VEL == 0);
     ILX_MLP_STAMP(1)
     // the image is padded to whole 16-byte words
     {
@@ -563,7 +584,8 @@ __global__ void __launch_bounds__(256, 8) mlp_mfma_split_kernel(NetArgs a) {
     ILX_MLP_STAMP(2)
     if (!live) return;
     RowInT<kResidentHist> cur;
-    finish_row(a, raw, cur);
+    if constexpr (POS_VEL > 0) finish_row_pos_vel<kResidentHist, POS_VEL>(a, raw, cur);
+    else finish_row(a, raw, cur);
 
     const int ks0 = a.net.ks0;
     const float* w0 = img + lane;
@@ -794,10 +816,16 @@ static void launch_mlp(const NetArgs& a, bool force_generic, bool exact_f32, hip
                            a.rows * a.hist_len < (int64_t(1) << 30);  // byte offsets of the history below 2^32
         const unsigned tile_blocks = static_cast<unsigned>((tiles + 3) / 4);
         const bool split = a.net.image16 && !exact_f32;
-        if (nhid == 3 && small && split)
-            hipLaunchKernelGGL((mlp_mfma_split_kernel<ACT, 3>), dim3(tile_blocks), dim3(256), 0, s, a);
+        // the usual feature list: position errors of samples 0 .. K-1, then the velocities of the same samples
+        bool pos_vel = a.n_feat == 2 * a.hist_len;
+        for (int f = 0; f < a.n_feat && pos_vel; ++f)
+            pos_vel = a.feat_slot[f] == f % a.hist_len && (((a.feat_is_pos >> f) & 1u) != 0) == (f < a.hist_len);
+        if (nhid == 3 && small && split && pos_vel && a.hist_len == 3)   // the ANYdrive network's shape: three samples
+            hipLaunchKernelGGL((mlp_mfma_split_kernel<ACT, 3, 3>), dim3(tile_blocks), dim3(256), 0, s, a);
+        else if (nhid == 3 && small && split)
+            hipLaunchKernelGGL((mlp_mfma_split_kernel<ACT, 3, 0>), dim3(tile_blocks), dim3(256), 0, s, a);
         else if (nhid == 2 && small && split)
-            hipLaunchKernelGGL((mlp_mfma_split_kernel<ACT, 2>), dim3(tile_blocks), dim3(256), 0, s, a);
+            hipLaunchKernelGGL((mlp_mfma_split_kernel<ACT, 2, 0>), dim3(tile_blocks), dim3(256), 0, s, a);
         else if (nhid == 3 && small)
             hipLaunchKernelGGL((mlp_mfma_tile_kernel<ACT, 3>), dim3(tile_blocks), dim3(256), 0, s, a);
         else if (nhid == 2 && small)
