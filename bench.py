@@ -212,7 +212,11 @@ def main():
         if reducer is not None:
             reducer.end_step()
 
+    restart_clocks = getattr(cfg, "restart_sensor_clocks", None)
+
     def timed(one_step):
+        if restart_clocks is not None:   # the sensors' clocks start every timed region where an env reset leaves them
+            restart_clocks()
         for _ in range(args.warmup):
             one_step()
         if dist is not None:
@@ -242,6 +246,24 @@ def main():
         if world == 1 and args.config != "shadow":
             graphs = capture_step(cfg, reducer)
             other_s = timed(graph_step)
+    # The same run of steps once more, untimed, with a look at the sensor clocks after every step: on how many steps did
+    # every env's contact sensor and height scanner refresh (a step on which the clocks skip the refresh does less work).
+    refresh_check = None
+    if restart_clocks is not None:
+        restart_clocks()
+        one_step = graph_step if use_graph else eager_step
+        total = args.warmup + args.steps
+        full = 0
+        for _ in range(total):
+            one_step()
+            torch.cuda.synchronize()
+            full += bool(cfg.sensors_refreshed())
+        if reducer is not None:
+            reducer.finish()
+        refresh_check = {"steps": total, "steps_with_every_sensor_refreshed": full}
+        if full != total:
+            print(f"bench.py: the sensors skipped refreshes on {total - full} of {total} steps: the timed region did less "
+                  "than the full step's work (run fewer steps per timed region)", file=sys.stderr)
     if reducer is not None:
         cfg.bind_log_sums(cfg.log_sums)
     # what the collective group saw: the number of ranks that took part (a sum of ones over RCCL) and the spread of the
@@ -305,6 +327,8 @@ def main():
             "mfma_frac": mfma_frac,
             "rccl_ranks": rccl_ranks, "ms_per_step_min_rank": rank_ms[0], "ms_per_step_max_rank": rank_ms[1],
         }
+        if refresh_check is not None:
+            line["sensor_refresh_check"] = refresh_check
         if args.config == "anymal":
             line["env_term_steps_per_s"] = value * TERM_EVALS_PER_ENV_STEP
         line["launch_mode"] = ("hip-graph replay: the step's launches recorded once per statistics vector, replayed per step"

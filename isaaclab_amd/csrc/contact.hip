@@ -170,15 +170,16 @@ __global__ void __launch_bounds__(256) scene_update_kernel(SceneArgs s) {
     if (active && has_contact && a.head) slot = next_slot(a.head[env], a.h);
     if (body_ahead) first_body = load_body(a, env, k0);
     if (joint_ahead) first_v = s.joint_vel[env * s.j + k0], first_prev = s.prev_joint_vel[env * s.j + k0];
+    // the ray caster's clock belongs to the env's first thread alone: read in the same trip
+    const bool ray_clock = active && k0 == 0 && s.ray_ts;
+    Clock r{0.0f, 0.0f, false};
+    if (ray_clock) r = read_clock(s.ray_ts, s.ray_ts_last, s.ray_outdated, env, 1, a.dt, s.ray_period);
     __syncthreads();
     if (!active) return;
     if (k0 == 0) {
         if (has_contact) write_clock(a.ts, a.ts_last, a.outdated, env, c, s.contact_lazy != 0);
         if (has_contact && a.head && c.refresh && !s.contact_lazy) a.head[env] = slot;
-        if (s.ray_ts) {
-            const Clock r = read_clock(s.ray_ts, s.ray_ts_last, s.ray_outdated, env, 1, a.dt, s.ray_period);
-            write_clock(s.ray_ts, s.ray_ts_last, s.ray_outdated, env, r, true);
-        }
+        if (ray_clock) write_clock(s.ray_ts, s.ray_ts_last, s.ray_outdated, env, r, true);
     }
     if (s.joint_vel) {
         for (int j = k0; j < s.j; j += s.width) {

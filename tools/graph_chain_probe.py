@@ -1,0 +1,95 @@
+"""GPU probe (diagnostics): which chain of the two-branch step graph is the critical one.  Replays the headline step with
+shortened chains (fewer actuator launches, fewer scene updates, no scanner refresh, no managers) and prints the time per
+replay of each variant."""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench_configs as BC
+from isaaclab_amd import _abi
+from isaaclab_amd.tasks import locomotion_velocity as LV
+from isaaclab_amd.utils.types import ArticulationActions
+
+dev = torch.device("cuda:0")
+cfg = BC.build("anymal", dev, 16384, seed=3000)
+env = cfg.env
+env.count_steps_on_device()
+raw = cfg.state["raw_action"].to(dev)
+
+
+def sensors(n_su, refresh):
+    d = env.data
+    for k in range(n_su):
+        d.joint_pos, d.joint_vel = env.physics["joint_pos"][k], env.physics["joint_vel"][k]
+        env.contact.set_net_contact_forces(env.physics["net_forces"][k])
+        env.scene.update(LV.PHYSICS_DT)
+    d.set_sim_state(root_state_w=env.physics["root_state_w"])
+    env.scanner.set_pose(d.root_state_w[:, :3], d.root_state_w[:, 3:7])
+    if refresh:
+        env.scanner._update_outdated_buffers(height_out=env.height_scan, height_offset=env.height_scan_offset)
+
+
+def actuators(n_mlp, small):
+    d = env.data
+    if small:
+        env.mdp.begin_step(clear_log_sums=True, advance_step_count=True)
+        _abi.check(_abi.joint_action_process(_abi.ptr(raw), _abi.ptr(env.action), _abi.ptr(env.prev_action), None,
+                                             env.action_scale, _abi.ptr(d.default_joint_pos), 0.0, None,
+                                             _abi.ptr(d.joint_pos_target), env.n, d._j, _abi.stream()), "ja")
+    for k in range(n_mlp):
+        d.joint_pos, d.joint_vel = env.physics["joint_pos"][k], env.physics["joint_vel"][k]
+        ca = ArticulationActions(joint_positions=d.joint_pos_target, joint_velocities=d.joint_vel_target,
+                                 joint_efforts=d.joint_effort_target, joint_indices=slice(None))
+        env.actuator.compute(ca, d.joint_pos, d.joint_vel)
+
+
+def step(n_su, refresh, n_mlp, small, managers, branches, a_first=False, a_on_side=False):
+    main = torch.cuda.current_stream()
+    side = env._side_stream if branches else main
+    if side is not main:
+        side.wait_stream(main)
+    sa, sb = (side, main) if a_on_side else (main, side)
+    if a_first:
+        with torch.cuda.stream(sa):
+            actuators(n_mlp, small)
+    with torch.cuda.stream(sb):
+        sensors(n_su, refresh)
+    if not a_first:
+        with torch.cuda.stream(sa):
+            actuators(n_mlp, small)
+    if side is not main:
+        main.wait_stream(side)
+    if managers:
+        env.step_managers(None, None, None)
+
+
+def measure(label, cap_priority=0, **kw):
+    cfg.restart_sensor_clocks()   # every variant runs over the same range of the sensors' clocks (full refreshes)
+    cap = torch.cuda.Stream(priority=cap_priority)
+    cap.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(cap):
+        for _ in range(3):
+            step(**kw)
+    cap.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=cap):
+        step(**kw)
+    for _ in range(30):
+        g.replay()
+    torch.cuda.synchronize()
+    K = 300
+    t0 = time.perf_counter()
+    for _ in range(K):
+        g.replay()
+    torch.cuda.synchronize()
+    print(f"{label:60s} {1e6 * (time.perf_counter() - t0) / K:6.1f} us per replay", flush=True)
+
+
+full = dict(n_su=4, refresh=True, n_mlp=4, small=True, managers=True, branches=True)
+for rep in range(2):
+    measure("full step, two branches", **full)
+    measure("full step, one chain", **dict(full, branches=False))
+    measure("no managers", **dict(full, managers=False))
