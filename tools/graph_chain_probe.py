@@ -46,7 +46,7 @@ def actuators(n_mlp, small):
         env.actuator.compute(ca, d.joint_pos, d.joint_vel)
 
 
-def step(n_su, refresh, n_mlp, small, managers, branches, a_first=False, a_on_side=False):
+def step(n_su, refresh, n_mlp, small, managers, branches, a_first=False, a_on_side=False, late_join=False):
     main = torch.cuda.current_stream()
     side = env._side_stream if branches else main
     if side is not main:
@@ -60,6 +60,11 @@ def step(n_su, refresh, n_mlp, small, managers, branches, a_first=False, a_on_si
     if not a_first:
         with torch.cuda.stream(sa):
             actuators(n_mlp, small)
+    if late_join:   # (not a valid step: the managers do not wait for the actuator chain) what the join ahead of them costs
+        with torch.cuda.stream(sb):
+            env.step_managers(None, None, None)
+        main.wait_stream(side)
+        return
     if side is not main:
         main.wait_stream(side)
     if managers:
@@ -91,5 +96,5 @@ def measure(label, cap_priority=0, **kw):
 full = dict(n_su=4, refresh=True, n_mlp=4, small=True, managers=True, branches=True)
 for rep in range(2):
     measure("full step, two branches", **full)
-    measure("full step, one chain", **dict(full, branches=False))
-    measure("no managers", **dict(full, managers=False))
+    measure("managers behind the sensor chain, join after them", **dict(full, late_join=True))
+    measure("same, sensor chain on the capture stream", **dict(full, late_join=True, a_on_side=True))
