@@ -541,6 +541,9 @@ constexpr int kLatKeep = 3;         // rays per lane whose pattern entry stays i
 constexpr int kLatMaxRays = 1024;   // longest scan pattern served per env; longer ones use the per-ray kernels
 constexpr float kLatMargin = 1.0f / 32768.0f;   // of the cell width; the barycentric slack is 1e-6 of a face
 constexpr float kLatDiagonal = 1.0f / 16384.0f; // of the cell area: closer to the diagonal than this, both faces are tested
+#ifndef ILX_CAST_ATTR
+#define ILX_CAST_ATTR __attribute__((amdgpu_waves_per_eu(8, 8), amdgpu_num_sgpr(80)))
+#endif
 constexpr int kLatNotDue = -2;      // LatEnvRec::sel of an env that this refresh leaves alone
 
 // Per env, written by the preparation launch and read (as scalars) by the env's wavefront in the cast launch.  The
@@ -734,8 +737,12 @@ ILX_DEV bool lattice_cell(const float* l, int n, float x, float x0, float inv, i
 // (uniform: scalar registers), copies the window of the height grid into LDS and intersects its rays there; a
 // wavefront's own LDS traffic is ordered.  Rays that are not strictly inside a simple cell use the column grid (or
 // are left to the tree launch that follows).
-__global__ void __launch_bounds__(64 * kLatWaves) raycaster_update_lattice_kernel(ScanArgs a, const LatEnvRec* __restrict__ recs,
-                                                                                   const float4* __restrict__ pattern) {
+// Registers: a CU admits floor(800 / (scalar registers rounded up to 16, + 16)) workgroups of 256 threads, eight at most.
+// Left alone the compiler takes 98 scalar and 70 vector registers: six workgroups per CU, 2.7 rounds of wavefronts for
+// 16 384 envs.  Held to 80 scalar registers (the surplus lives in lanes of a vector register) and eight wavefronts per
+// SIMD (64 vector registers), eight workgroups fit -- and their LDS, 8 x 18 KB: two rounds.
+__global__ void __launch_bounds__(64 * kLatWaves) ILX_CAST_ATTR
+raycaster_update_lattice_kernel(ScanArgs a, const LatEnvRec* __restrict__ recs, const float4* __restrict__ pattern) {
     __shared__ LatStage stage_s[kLatWaves];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const float inf = __builtin_inff();
@@ -843,7 +850,14 @@ __global__ void __launch_bounds__(64 * kLatWaves) raycaster_update_lattice_kerne
             t = h.t, ok = h.face >= 0;
         }
         const float hz = o.z + t * dz;  // kernels.py:69: start + t * dir; x and y are exact for a z-parallel ray
-        store3(hits_env + 3 * ray, ok ? f3{o.x, o.y, hz} : f3{inf, inf, inf});
+        // streaming stores for the hit records: nothing on the step reads them again (the managers read the height
+        // scan, which is stored the usual way and waits for them in the caches), and written the usual way they would
+        // push the height grid out of the L2 that the other envs' windows are read from
+        const f3 hit = ok ? f3{o.x, o.y, hz} : f3{inf, inf, inf};
+        float* const hp = hits_env + 3 * ray;
+        __builtin_nontemporal_store(hit.x, hp);
+        __builtin_nontemporal_store(hit.y, hp + 1);
+        __builtin_nontemporal_store(hit.z, hp + 2);
         if (height_env) height_env[ray] = pos.z - (ok ? hz : inf) - a.height_offset;
         if (a.mesh.lat_served) atomicAdd(a.mesh.lat_served, 1ull);
         return true;

@@ -96,5 +96,6 @@ def measure(label, cap_priority=0, **kw):
 full = dict(n_su=4, refresh=True, n_mlp=4, small=True, managers=True, branches=True)
 for rep in range(2):
     measure("full step, two branches", **full)
-    measure("managers behind the sensor chain, join after them", **dict(full, late_join=True))
-    measure("same, sensor chain on the capture stream", **dict(full, late_join=True, a_on_side=True))
+    measure("full step, one chain", **dict(full, branches=False))
+    measure("no managers", **dict(full, managers=False))
+    measure("actuator chain without the network launches", **dict(full, n_mlp=0))

@@ -28,8 +28,11 @@ for k, lab in enumerate(labels):
     print(f"{k} {lab:30s} {(t[:, k] - t0).mean() / 100:8.2f} us   +{(t[:, k] - prev).mean() / 100:6.2f}   (max +{(t[:, k] - prev).max() / 100:6.2f})")
     prev = t[:, k]
 life = (t[:, 5] - t[:, 0]) / 100.0
-print("entry: " + "  ".join(f"p{q}={np.percentile((t[:, 0] - t0) / 100.0, q):.2f}" for q in (0, 10, 50, 90, 100)))
-print("exit:  " + "  ".join(f"p{q}={np.percentile((t[:, 5] - t0) / 100.0, q):.2f}" for q in (0, 10, 50, 90, 100)))
+qs = (0, 5, 10, 20, 30, 40, 50, 60, 70, 80, 90, 100)
+print("entry: " + "  ".join(f"p{q}={np.percentile((t[:, 0] - t0) / 100.0, q):.2f}" for q in qs))
+print("exit:  " + "  ".join(f"p{q}={np.percentile((t[:, 5] - t0) / 100.0, q):.2f}" for q in qs))
+resident = [(int(((t[:, 0] - t0) <= 100 * us).sum()) - int(((t[:, 5] - t0) <= 100 * us).sum())) for us in range(0, 28, 2)]
+print("workgroups resident at 0, 2, 4 ... us: " + " ".join(str(r) for r in resident))
 print("life of a wavefront: " + "  ".join(f"p{q}={np.percentile(life, q):.2f}" for q in (0, 10, 50, 90, 100)))
 
 pbuf = (ctypes.c_ulonglong * (8 * 256))()
