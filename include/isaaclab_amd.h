@@ -119,6 +119,14 @@ int ilx_sample(int kind, const float* a, int64_t a_row_stride, int64_t a_col_str
 int ilx_joint_action_process(const float* raw_action, float* action, float* prev_action, const float* scale,
                              float scale_scalar, const float* offset, float offset_scalar, const float* clip,
                              float* processed, int64_t n, int a, void* stream);
+/* The same launch, which also opens the env step for the fused managers (what ilx_mdp_begin_step of isaaclab_amd_mdp.h
+ * does as a launch of its own): clears `log_sums` (`log_count` floats, or NULL) and adds one to `step_index_device` (or
+ * NULL).  process_action is the first call of ManagerBasedRLEnv.step (envs/manager_based_rl_env.py:172), so a step
+ * recorded in a HIP graph is one node shorter.  n > 0. */
+int ilx_joint_action_process_begin(const float* raw_action, float* action, float* prev_action, const float* scale,
+                                   float scale_scalar, const float* offset, float offset_scalar, const float* clip,
+                                   float* processed, int64_t n, int a, float* log_sums, int32_t log_count,
+                                   uint64_t* step_index_device, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Actuators — source/isaaclab/isaaclab/actuators/

@@ -112,6 +112,8 @@ RAYS_PATTERN_STATIC = 4
 raycast_mesh = _sig("ilx_raycast_mesh", P, P, P, c_int64, c_float, P, P, P, P, c_int, P)
 raycaster_update = _sig("ilx_raycaster_update", P, P, P, P, P, P, c_int, c_float, P, P, c_float, c_int64, c_int, c_int, P)
 joint_action_process = _sig("ilx_joint_action_process", P, P, P, P, c_float, P, c_float, P, P, c_int64, c_int, P)
+joint_action_process_begin = _sig("ilx_joint_action_process_begin", P, P, P, P, c_float, P, c_float, P, P, c_int64, c_int, P,
+                                  ctypes.c_int32, P, P)
 joint_action_to_limits = _sig("ilx_joint_action_to_limits", P, P, c_float, P, c_int, P, P, c_int, P, c_float, P, P, c_int64, c_int, P)
 binary_joint_action = _sig("ilx_binary_joint_action", P, P, P, P, P, P, c_int64, c_int, P)
 non_holonomic_action_apply = _sig("ilx_non_holonomic_action_apply", P, c_int64, P, P, c_int64, P)

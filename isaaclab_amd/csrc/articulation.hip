@@ -51,7 +51,14 @@ joint_acc_kernel(const float* __restrict__ vel, float* __restrict__ prev, float*
 __global__ void __launch_bounds__(256)
 joint_action_kernel(const float* __restrict__ raw, float* __restrict__ action, float* __restrict__ prev_action,
                     const float* __restrict__ scale, float scale_scalar, const float* __restrict__ offset,
-                    float offset_scalar, const float* __restrict__ clip, float* __restrict__ processed, int64_t total) {
+                    float offset_scalar, const float* __restrict__ clip, float* __restrict__ processed, int64_t total,
+                    float* __restrict__ log_sums, int log_count, uint64_t* __restrict__ step_index_device) {
+    // the opening of an env step rides on its first launch (ilx_joint_action_process_begin): the managers' statistics
+    // vector cleared and their device-side step count advanced, by the first workgroup
+    if (blockIdx.x == 0) {
+        for (int k = threadIdx.x; k < log_count; k += blockDim.x) log_sums[k] = 0.0f;
+        if (step_index_device && threadIdx.x == 0) *step_index_device += 1;
+    }
     const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (i >= total) return;
     const float r = raw[i];
@@ -75,8 +82,25 @@ extern "C" int ilx_joint_action_process(const float* raw_action, float* action, 
     ILX_REQUIRE(!prev_action || action, ILX_EINVAL, "ilx_joint_action_process: prev_action needs action");
     const int64_t total = n * a;
     hipLaunchKernelGGL(joint_action_kernel, dim3(blocks_for(total)), dim3(256), 0, as_stream(stream), raw_action, action,
-                       prev_action, scale, scale_scalar, offset, offset_scalar, clip, processed, total);
+                       prev_action, scale, scale_scalar, offset, offset_scalar, clip, processed, total, nullptr, 0, nullptr);
     ILX_LAUNCH_CHECK("ilx_joint_action_process");
+    return ILX_OK;
+}
+
+extern "C" int ilx_joint_action_process_begin(const float* raw_action, float* action, float* prev_action, const float* scale,
+                                              float scale_scalar, const float* offset, float offset_scalar, const float* clip,
+                                              float* processed, int64_t n, int a, float* log_sums, int32_t log_count,
+                                              uint64_t* step_index_device, void* stream) {
+    ILX_REQUIRE(n > 0 && a > 0, ILX_EINVAL, "ilx_joint_action_process_begin: bad shape (%lld, %d)", (long long)n, a);
+    ILX_REQUIRE(raw_action && processed, ILX_EINVAL, "ilx_joint_action_process_begin: NULL operand");
+    ILX_REQUIRE(!prev_action || action, ILX_EINVAL, "ilx_joint_action_process_begin: prev_action needs action");
+    ILX_REQUIRE(log_count >= 0 && (log_count == 0 || log_sums), ILX_EINVAL,
+                "ilx_joint_action_process_begin: %d floats at a NULL pointer", log_count);
+    const int64_t total = n * a;
+    hipLaunchKernelGGL(joint_action_kernel, dim3(blocks_for(total)), dim3(256), 0, as_stream(stream), raw_action, action,
+                       prev_action, scale, scale_scalar, offset, offset_scalar, clip, processed, total, log_sums,
+                       log_sums ? log_count : 0, step_index_device);
+    ILX_LAUNCH_CHECK("ilx_joint_action_process_begin");
     return ILX_OK;
 }
 

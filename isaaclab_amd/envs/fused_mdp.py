@@ -290,6 +290,17 @@ class FusedMdp:
         _abi.check(_abi.lib.ilx_mdp_begin_step(_abi.ptr(log) if log is not None else None, 0 if log is None else log.numel(),
                                                _abi.ptr(counter) if counter is not None else None, _abi.stream()), "ilx_mdp_begin_step")
 
+    def begin_step_args(self, clear_log_sums: bool = True, advance_step_count: bool = True):
+        """:meth:`begin_step` for a caller whose first launch of the step can do it on the side
+        (``ilx_joint_action_process_begin``): the (log_sums, count, step counter) arguments of that launch.  A host-side
+        step count advances here."""
+        counter = self._step_counter if advance_step_count else None
+        if advance_step_count and counter is None:
+            self.desc.step_index += 1
+        log = self.log_sums if clear_log_sums else None
+        return (_abi.ptr(log) if log is not None else None, 0 if log is None else log.numel(),
+                _abi.ptr(counter) if counter is not None else None)
+
     def advance_step_count(self):
         """The generator's step count, one further: a host integer, or the device word's add on the current stream."""
         if self._step_counter is None:

@@ -162,10 +162,12 @@ class LocomotionVelocityStep:
             side.wait_stream(main)
         with torch.cuda.stream(side):
             self.step_sensors()
-        # at the head of chain (A), behind the fork: recorded in a graph, (B) then waits for neither of these small launches
+        # the step's opening (statistics vector cleared, device-side step count advanced) rides on the first launch of
+        # chain (A), behind the fork: recorded in a graph, (B) waits for neither
+        begin = None
         if self.clear_log_sums or self._advance_count_first:
-            self.mdp.begin_step(clear_log_sums=self.clear_log_sums, advance_step_count=self._advance_count_first)
-        self.step_actuators(raw_action)
+            begin = self.mdp.begin_step_args(self.clear_log_sums, self._advance_count_first)
+        self.step_actuators(raw_action, begin)
         if side is not main:
             main.wait_stream(side)
         return self.step_managers(noise_u, command_samples, reset_command_samples)
@@ -195,14 +197,17 @@ class LocomotionVelocityStep:
         # the refresh also writes the height scan the observation term reads (sensor height - hit height - offset)
         self.scanner._update_outdated_buffers(height_out=self.height_scan, height_offset=self.height_scan_offset)
 
-    def step_actuators(self, raw_action: torch.Tensor):
+    def step_actuators(self, raw_action: torch.Tensor, begin=None):
         """Chain (A): process_action (manager_based_rl_env.py:172), then the actuator model of every substep
-        (write_data_to_sim)."""
+        (write_data_to_sim).  ``begin``: ``FusedMdp.begin_step_args`` -- the launch then also opens the step."""
         d = self.data
         n, j = self.n, d._j
-        _abi.check(_abi.joint_action_process(_abi.ptr(raw_action), _abi.ptr(self.action), _abi.ptr(self.prev_action), None,
-                                             self.action_scale, _abi.ptr(d.default_joint_pos), 0.0, None,
-                                             _abi.ptr(d.joint_pos_target), n, j, _abi.stream()), "ilx_joint_action_process")
+        args = (_abi.ptr(raw_action), _abi.ptr(self.action), _abi.ptr(self.prev_action), None, self.action_scale,
+                _abi.ptr(d.default_joint_pos), 0.0, None, _abi.ptr(d.joint_pos_target), n, j)
+        if begin is not None:
+            _abi.check(_abi.joint_action_process_begin(*args, *begin, _abi.stream()), "ilx_joint_action_process_begin")
+        else:
+            _abi.check(_abi.joint_action_process(*args, _abi.stream()), "ilx_joint_action_process")
         for k in range(LV.DECIMATION):
             d.joint_pos, d.joint_vel = self.physics["joint_pos"][k], self.physics["joint_vel"][k]
             ca = ArticulationActions(joint_positions=d.joint_pos_target, joint_velocities=d.joint_vel_target,

@@ -95,17 +95,37 @@ class ManagerBasedStep:
         dev = self.device
         self.physics = {k: v.to(dev).contiguous() for k, v in physics.items()}
 
+    opens_with_joint_action = False   # process_action is one ilx_joint_action_process launch (see _joint_action)
+    _begin = None
+
     def process_action(self, raw):
         raise NotImplementedError
+
+    def _joint_action(self, raw, scale, offset, processed, width):
+        """JointAction.process_actions + the ActionManager's bookkeeping as one launch; inside :meth:`step` the launch
+        also opens the step (``ilx_joint_action_process_begin``)."""
+        args = (_abi.ptr(raw), _abi.ptr(self.action), _abi.ptr(self.prev_action), None, scale,
+                _abi.ptr(offset) if offset is not None else None, 0.0, None, _abi.ptr(processed), self.n, width)
+        if self._begin is not None:
+            _abi.check(_abi.joint_action_process_begin(*args, *self._begin, _abi.stream()), "ilx_joint_action_process_begin")
+        else:
+            _abi.check(_abi.joint_action_process(*args, _abi.stream()), "ilx_joint_action_process")
 
     def apply_action(self):
         raise NotImplementedError
 
     def step(self, raw_action: torch.Tensor, noise_u=None, command_samples=None, reset_command_samples=None):
         d, ph = self.data, self.physics
+        # the step's opening (statistics vector cleared, device-side step count advanced) rides on the first launch where
+        # that is the joint action's, else it is a small launch of its own
+        self._begin = None
         if self.clear_log_sums or self._advance_count_first:
-            self.mdp.begin_step(clear_log_sums=self.clear_log_sums, advance_step_count=self._advance_count_first)
+            if self.opens_with_joint_action:
+                self._begin = self.mdp.begin_step_args(self.clear_log_sums, self._advance_count_first)
+            else:
+                self.mdp.begin_step(clear_log_sums=self.clear_log_sums, advance_step_count=self._advance_count_first)
         self.process_action(raw_action)
+        self._begin = None
         for k in range(self.decimation):
             self.apply_action()                              # action terms' apply_actions + write_data_to_sim (actuators)
             d.joint_pos, d.joint_vel = ph["joint_pos"][k], ph["joint_vel"][k]   # <sim.step>
@@ -137,6 +157,8 @@ class CartpoleStep(ManagerBasedStep):
     """Isaac-Cartpole-v0 (cartpole_env_cfg.py): JointEffortAction on the cart (scale 100), implicit actuators
     (isaaclab_assets/robots/cartpole.py:39-50), five rewards, two terminations, 4-wide observation."""
 
+    opens_with_joint_action = True
+
     def __init__(self, num_envs: int, device, seed: int = 0):
         super().__init__(num_envs, device, CP.JOINTS, CP.BODIES, CP.cartpole_terms(), action_dim=1, step_dt=CP.STEP_DT,
                          physics_dt=CP.PHYSICS_DT, decimation=CP.DECIMATION, max_episode_length=CP.MAX_EPISODE_LENGTH, seed=seed)
@@ -146,9 +168,7 @@ class CartpoleStep(ManagerBasedStep):
         self._effort = torch.zeros(num_envs, 1, device=self.device)
 
     def process_action(self, raw):  # joint_actions.py:130-139, 214-225 (JointEffortAction, no offset)
-        _abi.check(_abi.joint_action_process(_abi.ptr(_abi.f32c(raw)), _abi.ptr(self.action), _abi.ptr(self.prev_action), None,
-                                             CP.ACTION_SCALE, None, 0.0, None, _abi.ptr(self._effort), self.n, 1, _abi.stream()),
-                   "ilx_joint_action_process")
+        self._joint_action(_abi.f32c(raw), CP.ACTION_SCALE, None, self._effort, 1)
 
     def apply_action(self):
         d = self.data
@@ -188,6 +208,7 @@ class ReachStep(ManagerBasedStep):
         self._arm_target = torch.zeros(n, 7, device=dev)
         self._arm_default = torch.zeros(n, 7, device=dev)
         self.ik = None
+        self.opens_with_joint_action = arm_action == "joint_pos"
         if arm_action != "joint_pos":
             env = types.SimpleNamespace(num_envs=n, device=dev, scene={"robot": self.asset})
             ik_cfg = DifferentialInverseKinematicsActionCfg(
@@ -210,9 +231,7 @@ class ReachStep(ManagerBasedStep):
     def process_action(self, raw):
         raw = _abi.f32c(raw)
         if self.ik is None:  # JointPositionAction: processed = raw * 0.5 + default (joint_actions.py:145-160)
-            _abi.check(_abi.joint_action_process(_abi.ptr(raw), _abi.ptr(self.action), _abi.ptr(self.prev_action), None,
-                                                 RE.ARM_ACTION_SCALE, _abi.ptr(self._arm_default), 0.0, None,
-                                                 _abi.ptr(self._arm_target), self.n, 7, _abi.stream()), "ilx_joint_action_process")
+            self._joint_action(raw, RE.ARM_ACTION_SCALE, self._arm_default, self._arm_target, 7)
         else:  # ActionManager bookkeeping (action_manager.py:331-332), then the term
             self.prev_action.copy_(self.action)
             self.action.copy_(raw)

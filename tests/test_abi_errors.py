@@ -32,6 +32,12 @@ def test_math_and_articulation_arguments():
     fails(_abi.root_frame_derive(NULL, 0.0, 0.0, -1.0, FAKE, FAKE, FAKE, FAKE, 4, NULL), EINVAL, "ilx_root_frame_derive")
     fails(_abi.joint_action_process(NULL, FAKE, FAKE, NULL, 1.0, NULL, 0.0, NULL, FAKE, 4, 2, NULL), EINVAL,
           "ilx_joint_action_process")
+    fails(_abi.joint_action_process_begin(NULL, FAKE, FAKE, NULL, 1.0, NULL, 0.0, NULL, FAKE, 4, 2, NULL, 0, NULL, NULL), EINVAL,
+          "ilx_joint_action_process_begin")
+    fails(_abi.joint_action_process_begin(FAKE, FAKE, FAKE, NULL, 1.0, NULL, 0.0, NULL, FAKE, 4, 2, NULL, 3, NULL, NULL), EINVAL,
+          "NULL pointer")
+    fails(_abi.joint_action_process_begin(FAKE, FAKE, FAKE, NULL, 1.0, NULL, 0.0, NULL, FAKE, 0, 2, NULL, 0, NULL, NULL), EINVAL,
+          "bad shape")
 
 
 def test_actuator_arguments():

@@ -241,6 +241,37 @@ def test_begin_step_clears_the_statistics_and_advances_the_count(dev):
     assert mdp._step_counter.item() == 2 and mdp.log_sums.abs().max().item() == 0.0
 
 
+def test_joint_action_launch_opens_the_step(dev):
+    """ilx_joint_action_process_begin = ilx_joint_action_process + ilx_mdp_begin_step in one launch: same action buffers,
+    statistics vector cleared, device-side count advanced; ragged sizes (the opening belongs to the first workgroup)."""
+    from isaaclab_amd import _abi
+
+    for n, a in ((1, 1), (5, 3), (300, 12), (4096, 7)):
+        gen = torch.Generator().manual_seed(n)
+        raw, act, default = (torch.randn(n, a, generator=gen).to(dev) for _ in range(3))
+        outs = []
+        for fused in (False, True):
+            action, prev, target = act.clone(), torch.zeros(n, a, device=dev), torch.zeros(n, a, device=dev)
+            log = torch.full((17,), 5.0, device=dev)
+            count = torch.full((1,), 41, dtype=torch.int64, device=dev)
+            args = (_abi.ptr(raw), _abi.ptr(action), _abi.ptr(prev), None, 0.5, _abi.ptr(default), 0.0, None, _abi.ptr(target), n, a)
+            if fused:
+                _abi.check(_abi.joint_action_process_begin(*args, _abi.ptr(log), 17, _abi.ptr(count), _abi.stream()), "begin")
+            else:
+                _abi.check(_abi.joint_action_process(*args, _abi.stream()), "ilx_joint_action_process")
+                _abi.check(_abi.lib.ilx_mdp_begin_step(_abi.ptr(log), 17, _abi.ptr(count), _abi.stream()), "ilx_mdp_begin_step")
+            outs.append([t.cpu() for t in (action, prev, target, log, count)])
+        for x, y in zip(*outs):
+            assert torch.equal(x, y)
+        assert outs[1][3].abs().max().item() == 0.0 and outs[1][4].item() == 42
+        assert torch.equal(outs[1][1], act.cpu()) and torch.equal(outs[1][0], raw.cpu())
+    # the opening alone can be left out: no vector, no count
+    action, prev, target = act.clone(), torch.zeros_like(act), torch.zeros_like(act)
+    _abi.check(_abi.joint_action_process_begin(_abi.ptr(raw), _abi.ptr(action), _abi.ptr(prev), None, 0.5, _abi.ptr(default), 0.0, None,
+                                               _abi.ptr(target), n, a, None, 0, None, _abi.stream()), "begin")
+    assert torch.equal(target.cpu(), outs[1][2])
+
+
 def test_pose_command_matches_reference(dev):
     """UniformPoseCommand through the fused kernel's COMMAND / RESET phases against the reference class."""
     from isaaclab_amd.envs import fused_mdp as FM
