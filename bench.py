@@ -110,7 +110,7 @@ def capture_step(cfg, reducer):
     return graphs
 
 
-def cpu_baseline(seed, envs=NUM_ENVS, warmup=2, steps=10):
+def cpu_baseline(seed, envs=NUM_ENVS, warmup=2, steps=10, root_scatter="origins"):
     """The oracle step (unfused PyTorch CPU ops + C ray cast) at the workload's full env count on the host's cores:
     `warmup` untimed steps, then `steps` timed ones between perf_counter reads -- the step-loop timing of
     scripts/benchmarks/benchmark_non_rl.py:154-179 without the simulator inside the step."""
@@ -131,8 +131,9 @@ def cpu_baseline(seed, envs=NUM_ENVS, warmup=2, steps=10):
     idx, _, vals = resolve_matching_names_values(LV.ANYMAL_DEFAULT_JOINT_POS, LV.ANYMAL_JOINTS)
     default = torch.zeros(12)
     default[idx] = torch.tensor(vals)
+    origins = synth.curriculum_env_origins(sample_envs, seed) if root_scatter == "origins" else None   # as the GPU leg
     state = synth.locomotion_state(sample_envs, seed, num_joints=12, num_bodies=17, default_joint_pos=default,
-                                   feet_ids=[13, 14, 15, 16], height_at=height_at)
+                                   feet_ids=[13, 14, 15, 16], height_at=height_at, env_origins=origins)
     cm = RC.CMesh(verts, tris)
     cm.bvh()
     o = AnymalRoughOracle(sample_envs, state, ws, bs, default, cm)
@@ -167,6 +168,9 @@ def main():
     ap.add_argument("--actuator", choices=("mlp", "lstm"), default="mlp",
                     help="anymal only -- actuator network: the headline 6-32-32-32-1 MLP, or the ANYdrive-shaped LSTM(2, 8, 2) + "
                          "head (no CPU baseline, reported as a side measurement)")
+    ap.add_argument("--root-scatter", choices=("origins", "uniform"), default="origins",
+                    help="anymal / h1 -- where the robots stand: within 0.5 m of the env origins that the reference's terrain "
+                         "importer deals (default), or uniformly over the whole terrain (no two envs near each other)")
     args = ap.parse_args()
     args.envs = args.envs or BC.ENVS[args.config]
 
@@ -186,7 +190,8 @@ def main():
     from isaaclab_amd.distributed import OverlappedLogReducer
 
     cfg_id = list(BC.ENVS).index(args.config) + 1
-    cfg = BC.build(args.config, device, args.envs, seed=cfg_id * 1000 + rank, actuator=args.actuator)
+    cfg = BC.build(args.config, device, args.envs, seed=cfg_id * 1000 + rank, actuator=args.actuator,
+                   root_scatter=args.root_scatter)
 
     # episode statistics of the done envs: the only cross-rank exchange of the path, one all-reduce per step, started
     # after the step and completed beside the next two (nothing in the step consumes it).  The in-hand env reduces its two
@@ -340,7 +345,7 @@ def main():
                 "ms_per_step": other_s / args.steps * 1e3, "value": args.envs * world * args.steps / other_s,
                 "note": "the same step " + ("issued launch by launch from the host" if use_graph else "replayed from a captured graph")}
         if not args.no_cpu_baseline and world == 1 and args.config == "anymal" and args.actuator == "mlp":
-            line["cpu_baseline"] = cpu_baseline(3000, envs=args.envs)
+            line["cpu_baseline"] = cpu_baseline(3000, envs=args.envs, root_scatter=args.root_scatter)
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line))

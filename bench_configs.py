@@ -66,7 +66,7 @@ def _locomotion_bytes(j, b, r, obs_dim, n_rewards, actuator):
     return out
 
 
-def build_locomotion(device, envs, seed, robot="anymal_c", actuator="mlp", static_scan=False):
+def build_locomotion(device, envs, seed, robot="anymal_c", actuator="mlp", static_scan=False, root_scatter="origins"):
     from isaaclab_amd import synth
     from isaaclab_amd.envs import fused_mdp as FM
     from isaaclab_amd.envs.locomotion_step import LocomotionVelocityStep
@@ -92,8 +92,13 @@ def build_locomotion(device, envs, seed, robot="anymal_c", actuator="mlp", stati
     idx, _, vals = resolve_matching_names_values(default_cfg, joints)
     default = torch.zeros(j)
     default[idx] = torch.tensor(vals)
+    # where the robots stand: around the env origins that the reference's terrain importer deals for this terrain (env
+    # blocks per terrain column, random start level; each robot within the reset event's +-0.5 m of its origin), or
+    # ("uniform") anywhere on the terrain, every env somewhere else: no two envs near each other, the worst case for
+    # the caches under the height scan
+    origins = synth.curriculum_env_origins(envs, seed) if root_scatter == "origins" else None
     state = synth.locomotion_state(envs, seed, num_joints=j, num_bodies=b, default_joint_pos=default, feet_ids=feet,
-                                   height_at=height_at, with_bodies=robot == "h1")
+                                   height_at=height_at, with_bodies=robot == "h1", env_origins=origins)
     env = LocomotionVelocityStep(envs, device, mesh, robot, actuator_net=net, seed=seed)
     env.load_state(state)
     env.scanner.static_workspace = static_scan
@@ -122,7 +127,9 @@ def build_locomotion(device, envs, seed, robot="anymal_c", actuator="mlp", stati
                 "joint_action_process": (action, 1)}
     r = env.scanner.num_rays
     n_rewards = int(env.mdp.step_reward.shape[1])
-    info = {"decimation": LV.DECIMATION, "joints": j, "bodies": b, "rays": r, "obs_dim": int(env.mdp.obs_dim),
+    info = {"root_positions": ("env origins of the curriculum terrain (terrain_importer.py) + U(-0.5, 0.5) m" if origins is not None
+                               else "uniform over the terrain"),
+            "decimation": LV.DECIMATION, "joints": j, "bodies": b, "rays": r, "obs_dim": int(env.mdp.obs_dim),
             "terrain_triangles": int(env.scanner.meshes["/World/ground"].num_triangles)}
     if robot == "anymal_c":
         info["actuator"] = ("ActuatorNetMLP 6-32-32-32-1 softsign (f32 first layer, hidden layers as split-f16 MFMA)" if actuator == "mlp" else
@@ -280,12 +287,12 @@ def build_shadow(device, envs, seed):
     return cfg
 
 
-def build(name, device, envs=None, seed=0, actuator="mlp", static_scan=False):
+def build(name, device, envs=None, seed=0, actuator="mlp", static_scan=False, root_scatter="origins"):
     envs = envs or ENVS[name]
     if name == "anymal":
-        return build_locomotion(device, envs, seed, "anymal_c", actuator, static_scan)
+        return build_locomotion(device, envs, seed, "anymal_c", actuator, static_scan, root_scatter)
     if name == "h1":
-        return build_locomotion(device, envs, seed, "h1", static_scan=static_scan)
+        return build_locomotion(device, envs, seed, "h1", static_scan=static_scan, root_scatter=root_scatter)
     if name == "cartpole":
         return build_cartpole(device, envs, seed)
     if name == "reach":

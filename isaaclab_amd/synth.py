@@ -81,6 +81,17 @@ def rough_terrain_mesh(seed: int = 0, rows: int = 10, cols: int = 20, tile: floa
     return verts, tris, height_at
 
 
+def curriculum_env_origins(n: int, seed: int, rows: int = 10, cols: int = 20, tile: float = 8.0, max_init_level: int = 5):
+    """Env origins as the reference's terrain importer deals them for a curriculum terrain
+    (terrains/terrain_importer.py:_compute_env_origins_curriculum): env i belongs to terrain type (column)
+    floor(i / (n / cols)) and starts at a random level (row) up to ``max_init_level`` (rough_env_cfg: 5); its origin is
+    the centre of that tile.  (n, 2) for the tile layout of :func:`rough_terrain_mesh`."""
+    g = torch.Generator().manual_seed(seed)
+    levels = torch.randint(0, min(max_init_level, rows - 1) + 1, (n,), generator=g)
+    types = torch.div(torch.arange(n), n / cols, rounding_mode="floor").to(torch.long).clamp_(max=cols - 1)
+    return torch.stack([(levels.float() + 0.5) * tile, (types.float() + 0.5) * tile], dim=-1)
+
+
 def _quat_from_rpy(roll, pitch, yaw):
     cy, sy = torch.cos(yaw * 0.5), torch.sin(yaw * 0.5)
     cr, sr = torch.cos(roll * 0.5), torch.sin(roll * 0.5)
@@ -92,8 +103,13 @@ def _quat_from_rpy(roll, pitch, yaw):
 
 def locomotion_state(n: int, seed: int, *, num_joints: int, num_bodies: int, default_joint_pos: torch.Tensor,
                      feet_ids, decimation: int = 4, height_at=None, extent=(80.0, 160.0), history_len: int = 3,
-                     max_episode_length: int = 1000, joint_vel_std: float = 2.0, with_bodies: bool = False):
+                     max_episode_length: int = 1000, joint_vel_std: float = 2.0, with_bodies: bool = False,
+                     env_origins: torch.Tensor | None = None):
     """Seeded stand-in for what PhysX hands the rollout step of a legged robot on rough terrain.
+
+    Root positions: uniform over ``extent``, or -- with ``env_origins`` (n, >=2), e.g. :func:`curriculum_env_origins` --
+    each env's origin + U(-0.5, 0.5) in x and y, where the task's reset event puts a robot
+    (velocity_env_cfg.py: ``reset_base`` pose_range).
 
     Per physics substep k < decimation: joint positions / velocities and net contact forces; once per step: root
     state.  Plus the persistent buffers a running env would hold (previous actions, contact history / timers,
@@ -103,7 +119,11 @@ def locomotion_state(n: int, seed: int, *, num_joints: int, num_bodies: int, def
     g = torch.Generator().manual_seed(seed)
     j, b, d = num_joints, num_bodies, decimation
     s = {}
-    xy = torch.rand(n, 2, generator=g) * torch.tensor([extent[0] - 2.0, extent[1] - 2.0]) + 1.0
+    xy = torch.rand(n, 2, generator=g)
+    if env_origins is None:
+        xy = xy * torch.tensor([extent[0] - 2.0, extent[1] - 2.0]) + 1.0
+    else:
+        xy = env_origins[:, :2].float().cpu() + (xy - 0.5)
     z0 = torch.zeros(n) if height_at is None else torch.from_numpy(np.asarray(height_at(xy[:, 0].numpy(), xy[:, 1].numpy())))
     pos = torch.cat([xy, (z0 + 0.6 + (torch.rand(n, generator=g) - 0.5) * 0.1).unsqueeze(-1)], dim=-1).float()
     yaw = (torch.rand(n, generator=g) * 2 - 1) * np.pi
