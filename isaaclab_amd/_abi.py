@@ -63,8 +63,13 @@ def ptr(t: torch.Tensor | None) -> int | None:
     return t.data_ptr()
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream() -> int:
-    """The current torch stream as a raw hipStream_t."""
+    """The current torch stream (of the current device) as a raw hipStream_t."""
+    if _raw_stream is not None:   # the same handle without building a torch.cuda.Stream object per launch (~3 us each)
+        return _raw_stream(-1)
     return torch.cuda.current_stream().cuda_stream
 
 
