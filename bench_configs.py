@@ -41,10 +41,10 @@ class Config:
 def _locomotion_bytes(j, b, r, obs_dim, n_rewards, actuator):
     f = 4 * j           # one fp32 per joint
     out = {
-        # InteractiveScene.update in one launch -- contact: read net forces, write net_forces_w, write one history row
-        # (ring) + head 8, read+write 4 timers, clock 18; joint_acc: read vel, read+write previous vel, write acc;
-        # scanner clock 18
-        "scene_update": 3 * 12 * b + 8 + 8 * 4 * b + 18 + 4 * f + 18,
+        # InteractiveScene.update in one launch -- contact: read net forces, write one history row (ring; net_forces_w
+        # is its newest entry and not written apart) + head 8, read+write 4 timers, clock 18; joint_acc: read vel,
+        # read+write previous vel, write acc; scanner clock 18
+        "scene_update": 2 * 12 * b + 8 + 8 * 4 * b + 18 + 4 * f + 18,
         # read pose 28 + clock 9, write pose 28, ray hits R*12, height scan R*4, clock 5
         "raycaster_refresh": 28 + 9 + 28 + r * 12 + r * 4 + 5,
         # read root 52, joints (pos, vel, acc, torque, default) 5f, actions 2f, contact history 3*B*12, timers 2*4B,

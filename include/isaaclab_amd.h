@@ -587,7 +587,10 @@ int ilx_frame_transformer_update(const ilx_frame_transformer* sensor, void* stre
  * entry and a push moves every row one slot up.  With history_head (n,) int32 the same entries are kept as a ring per
  * env: the entry of age k sits at slot (history_head[env] + k) % h and a push writes one row and moves the head (the
  * terms that read the history take a maximum over it, rewards.py:266 / terminations.py:157, so they need no order;
- * a reader that does reorders by the head).  Zero-filled heads and history are a valid initial / reset state. */
+ * a reader that does reorders by the head).  Zero-filled heads and history are a valid initial / reset state.
+ * net_forces_w may be NULL when there is a history: its newest entry holds the same values at all times (both are
+ * written by the same refresh and zeroed by the same reset), so a caller whose step reads only the history can leave the
+ * copy out and hand out the newest entry as net_forces_w when somebody asks. */
 int ilx_contact_update(const float* net_forces_in, float* net_forces_w, float* history, int32_t* history_head,
                        float* current_air_time,
                        float* last_air_time, float* current_contact_time, float* last_contact_time,
@@ -614,7 +617,7 @@ typedef struct ilx_scene {
     float joint_acc_elapsed;
     /* contact sensor: same meaning as the arguments of ilx_contact_update */
     const float* net_forces_in;      /* (n,b,3) */
-    float* net_forces_w;
+    float* net_forces_w;             /* (n,b,3), or NULL with a history */
     float* net_forces_w_history;     /* (n,h,b,3) or NULL */
     float* current_air_time;
     float* last_air_time;

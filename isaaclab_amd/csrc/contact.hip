@@ -77,7 +77,7 @@ ILX_DEV BodyIn load_body(const ContactArgs& a, int64_t env, int body) {
 ILX_DEV void contact_body(const ContactArgs& a, int64_t env, int body, float elapsed, int slot, const BodyIn& in) {
     const int64_t eb = env * a.b + body;
     const f3 f = in.f;
-    store3(a.net + 3 * eb, f);  // contact_sensor.py:324
+    if (a.net) store3(a.net + 3 * eb, f);  // contact_sensor.py:324 (null: the newest history entry stands for it)
     if (a.hist && a.head) {     // the same history as below, kept as a ring: one row written instead of h rows moved
         store3(a.hist + 3 * ((env * a.h + slot) * a.b + body), f);
     } else if (a.hist) {        // contact_sensor.py:326-328
@@ -210,8 +210,9 @@ extern "C" int ilx_contact_update(const float* net_forces_in, float* net_forces_
                 b, h);
     ILX_REQUIRE(h <= kMaxContactHistory, ILX_ESHAPE, "ilx_contact_update: history length %d (max %d)", h,
                 kMaxContactHistory);
-    ILX_REQUIRE(net_forces_in && net_forces_w && timestamp && timestamp_last_update && is_outdated, ILX_EINVAL,
+    ILX_REQUIRE(net_forces_in && timestamp && timestamp_last_update && is_outdated, ILX_EINVAL,
                 "ilx_contact_update: NULL operand");
+    ILX_REQUIRE(net_forces_w || history, ILX_EINVAL, "ilx_contact_update: net_forces_w may be NULL only with a history");
     ILX_REQUIRE((h == 0) == (history == nullptr), ILX_EINVAL, "ilx_contact_update: history must be NULL iff h == 0");
     ILX_REQUIRE(history || !history_head, ILX_EINVAL, "ilx_contact_update: history_head without a history");
     const int timers = (current_air_time != nullptr) + (last_air_time != nullptr) + (current_contact_time != nullptr) +
@@ -248,8 +249,10 @@ extern "C" int ilx_scene_update(const ilx_scene* scene, void* stream) {
         const int b = d.num_bodies, h = d.history_length;
         ILX_REQUIRE(b > 0 && h >= 0, ILX_EINVAL, "ilx_scene_update: bad contact shape (b=%d, h=%d)", b, h);
         ILX_REQUIRE(h <= kMaxContactHistory, ILX_ESHAPE, "ilx_scene_update: history length %d (max %d)", h, kMaxContactHistory);
-        ILX_REQUIRE(d.net_forces_w && d.contact_timestamp && d.contact_timestamp_last_update && d.contact_is_outdated,
+        ILX_REQUIRE(d.contact_timestamp && d.contact_timestamp_last_update && d.contact_is_outdated,
                     ILX_EINVAL, "ilx_scene_update: NULL contact operand");
+        ILX_REQUIRE(d.net_forces_w || d.net_forces_w_history, ILX_EINVAL,
+                    "ilx_scene_update: net_forces_w may be NULL only with a history");
         ILX_REQUIRE((h == 0) == (d.net_forces_w_history == nullptr), ILX_EINVAL,
                     "ilx_scene_update: history must be NULL iff history_length == 0");
         const int timers = (d.current_air_time != nullptr) + (d.last_air_time != nullptr) +

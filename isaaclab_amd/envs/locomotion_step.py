@@ -77,6 +77,7 @@ class LocomotionVelocityStep:
         self.data.soft_joint_vel_limits[:] = self.actuator.velocity_limit
         # sensors
         self.contact = ContactSensor(ContactSensorCfg(**LV.CONTACT_SENSOR), n, bodies, dev)
+        self.contact.net_forces_from_history = True   # every term of these tasks reads the force history
         hs = LV.HEIGHT_SCAN
         self.scanner = RayCaster(RayCasterCfg(offset=OffsetCfg(pos=(0.0, 0.0, hs["offset_z"])), attach_yaw_only=True,
                                               pattern_cfg=GridPatternCfg(resolution=hs["resolution"], size=hs["size"]),

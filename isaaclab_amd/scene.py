@@ -72,7 +72,7 @@ class InteractiveScene:
         if contacts:
             c = contacts[0]
             cd, h, t = c._data, c.cfg.history_length, c.cfg.track_air_time
-            sc.net_forces_in, sc.net_forces_w = _abi.ptr(c._forces_in), _abi.ptr(cd.net_forces_w)
+            sc.net_forces_in, sc.net_forces_w = _abi.ptr(c._forces_in), (None if c._skip_net() else _abi.ptr(cd.net_forces_w))
             sc.net_forces_w_history = _abi.ptr(cd.net_forces_w_history) if h > 0 else None
             sc.contact_history_head = None if c._history_head is None else c._history_head.data_ptr()
             if t:

@@ -74,6 +74,11 @@ class ContactSensor:
             self._data.last_contact_time = torch.zeros(n, b, device=self._device)
             self._data.current_contact_time = torch.zeros(n, b, device=self._device)
         self._forces_in = torch.zeros(n, b, 3, device=self._device)
+        # With a history, its newest entry and net_forces_w hold the same values at all times (contact_sensor.py:324-328:
+        # one refresh writes both, one reset zeroes both).  True: a refresh leaves the copy into net_forces_w out and
+        # `data.net_forces_w` hands out the newest entry -- for steps that read only the history (a seventh of the
+        # bytes of a scene update).  `raw_data.net_forces_w` is then stale.
+        self.net_forces_from_history = False
 
     # -- properties (contact_sensor.py:80-130)
     @property
@@ -95,11 +100,16 @@ class ContactSensor:
     @property
     def data(self) -> ContactSensorData:
         self._update_outdated_buffers()
-        if self._history_head is None:
+        if self._history_head is None and not self._skip_net():
             return self._data
         d = copy.copy(self._data)
         d.net_forces_w_history = self.ordered_history()
+        if self._skip_net():
+            d.net_forces_w = d.net_forces_w_history[:, 0]
         return d
+
+    def _skip_net(self) -> bool:
+        return self.net_forces_from_history and self.cfg.history_length > 0
 
     @property
     def raw_data(self) -> ContactSensorData:
@@ -160,7 +170,8 @@ class ContactSensor:
         d, h = self._data, self.cfg.history_length
         t = self.cfg.track_air_time
         _abi.check(_abi.contact_update(
-            _abi.ptr(self._forces_in), _abi.ptr(d.net_forces_w), _abi.ptr(d.net_forces_w_history) if h > 0 else None,
+            _abi.ptr(self._forces_in), None if self._skip_net() else _abi.ptr(d.net_forces_w),
+            _abi.ptr(d.net_forces_w_history) if h > 0 else None,
             None if self._history_head is None else self._history_head.data_ptr(), _abi.ptr(d.current_air_time) if t else None, _abi.ptr(d.last_air_time) if t else None,
             _abi.ptr(d.current_contact_time) if t else None, _abi.ptr(d.last_contact_time) if t else None,
             _abi.ptr(self._timestamp), _abi.ptr(self._timestamp_last_update), self._is_outdated.data_ptr(),

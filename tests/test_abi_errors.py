@@ -76,6 +76,8 @@ def test_actuator_arguments():
 def test_sensor_arguments():
     fails(_abi.contact_update(NULL, FAKE, NULL, NULL, NULL, NULL, NULL, NULL, FAKE, FAKE, FAKE, 1, 0.005, 0.0, 1.0, 4, 2, 0, NULL), EINVAL,
           "ilx_contact_update")
+    fails(_abi.contact_update(FAKE, NULL, NULL, NULL, NULL, NULL, NULL, NULL, FAKE, FAKE, FAKE, 1, 0.005, 0.0, 1.0, 4, 2, 0, NULL), EINVAL,
+          "only with a history")
     fails(_abi.contact_update(FAKE, FAKE, NULL, FAKE, NULL, NULL, NULL, NULL, FAKE, FAKE, FAKE, 1, 0.005, 0.0, 1.0, 4, 2, 0, NULL), EINVAL,
           "history_head without a history")
     sc = _abi.Scene()

@@ -297,6 +297,25 @@ def test_contact_sensor(dev):
         assert_exact(s.compute_first_air(0.02), g["first_air"][k], f"first_air step {k}")
 
 
+def test_contact_sensor_net_forces_from_history(dev):
+    """A sensor that leaves the copy into net_forces_w out (net_forces_w = NULL at the C ABI) hands out the same
+    net_forces_w -- the newest history entry -- and the same everything else as the reference class, reset included."""
+    g = load_golden("contact_sensor")
+    for period, net_key, hist_key in ((0.005, "net", "hist"),):
+        for k, s in _drive_contact(dev, g, period, int(g["reset_step"]), g["reset_ids"].tolist()):
+            s.net_forces_from_history = True
+            if k == 0:
+                s._data.net_forces_w.fill_(123.0)        # never written from here on
+            d = s.data
+            for key, val in ((net_key, d.net_forces_w), (hist_key, d.net_forces_w_history), ("cur_air", d.current_air_time),
+                             ("last_air", d.last_air_time), ("cur_contact", d.current_contact_time),
+                             ("last_contact", d.last_contact_time), ("ts", s._timestamp), ("ts_last", s._timestamp_last_update)):
+                assert_exact(val, g[key][k], f"{key} step {k}")
+        reset_ids = g["reset_ids"].tolist()
+        keep = [i for i in range(s._data.net_forces_w.shape[0]) if i not in reset_ids]
+        assert (s._data.net_forces_w[keep] == 123.0).all()
+
+
 def test_contact_sensor_slow_period(dev):
     g = load_golden("contact_sensor")
     for k, s in _drive_contact(dev, g, 0.02):
