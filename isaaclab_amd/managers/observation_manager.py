@@ -19,6 +19,58 @@ from ._base import iter_terms, resolve_term
 from .manager_term_cfg import ObservationGroupCfg, ObservationTermCfg, UniformNoiseCfg
 
 
+class _CompositeObservationPlan:
+    """The row of an observation group whose terms read different articulations / sensor sets
+    (observation_manager.py:260-335 concatenates whatever its terms return): one fused plan per set of bindings, each
+    launched on its own buffers, its terms' columns then copied to their places in the group's row.  Offers what the
+    manager uses of a single plan: ``obs``, ``obs_dim``, ``observations`` / ``_obs_dim`` (the terms in the group's order
+    and their widths), ``bind(noise_u=...)``."""
+
+    class _Term:
+        def __init__(self, width):
+            self.width = width
+
+    def __init__(self, env, specs, posts, groups):
+        self._env = env
+        self._parts = []
+        where = [None] * len(specs)   # term -> (part, first column in the part's row, width)
+        for bindings, idx in groups:
+            sub_specs = [specs[i] for i in idx]
+            mdp = F.make_plan(env, "observation", sub_specs, posts=[posts[i] for i in idx], bindings=bindings)
+            col = 0
+            for i, spec in zip(idx, mdp.observations):
+                width = mdp._obs_dim(spec)
+                where[i] = (len(self._parts), col, width)
+                col += width
+            self._parts.append((bindings, sub_specs, mdp))
+        self.observations = [self._Term(w[2]) for w in where]
+        self.obs_dim = sum(w[2] for w in where)
+        self.obs = torch.zeros(env.num_envs, self.obs_dim, device=env.device)
+        self._moves, col = [], 0      # (part, source column, row column, width) per term, in the group's order
+        for part, src, width in where:
+            self._moves.append((part, src, col, width))
+            col += width
+
+    @staticmethod
+    def _obs_dim(term) -> int:
+        return term.width
+
+    def bind(self, noise_u=None):
+        """``noise_u``: (num_envs, obs_dim) draws for the group's row, dealt to the plans by column, or None."""
+        for k, (_, _, mdp) in enumerate(self._parts):
+            if noise_u is None:
+                mdp.bind(noise_u=None)
+            else:
+                cols = [noise_u[:, dst:dst + w] for part, _, dst, w in self._moves if part == k]
+                mdp.bind(noise_u=torch.cat(cols, dim=1).contiguous())
+
+    def run(self):
+        for bindings, sub_specs, mdp in self._parts:
+            F.run_plan(mdp, self._env, "observation", sub_specs, bindings)
+        for part, src, dst, width in self._moves:
+            self.obs[:, dst:dst + width].copy_(self._parts[part][2].obs[:, src:src + width])
+
+
 class ObservationManager:
     def __init__(self, cfg, env):
         self.cfg, self._env = cfg, env
@@ -98,13 +150,14 @@ class ObservationManager:
         if plan is None:
             specs, cfgs = self._group_specs[group], self._group_obs_term_cfgs[group]
             groups = F.group_specs(specs)
-            if len(groups) != 1:
-                raise NotImplementedError("an observation group must read one articulation / sensor set")
             corrupt = self._flag(group, "enable_corruption", False)
             posts = [dict(noise=None, clip=None, scale=None) if self._needs_post(c) else
                      dict(noise=(c.noise.n_min, c.noise.n_max) if (c.noise is not None and corrupt) else None, clip=c.clip,
                           scale=c.scale) for c in cfgs]
-            mdp = F.make_plan(self._env, "observation", specs, posts=posts, bindings=groups[0][0])
+            if len(groups) == 1:
+                mdp = F.make_plan(self._env, "observation", specs, posts=posts, bindings=groups[0][0])
+            else:   # terms of several articulations / sensor sets (a robot and an object, say): one fused plan per set
+                mdp = _CompositeObservationPlan(self._env, specs, posts, groups)
             plan = self._plans[group] = (groups[0][0], None, specs, mdp)
             post, col = [], 0
             for name, c, spec in zip(self._group_obs_term_names[group], cfgs, mdp.observations):
@@ -177,7 +230,10 @@ class ObservationManager:
                              f" Available groups are: {list(self._group_specs)}")
         bindings, _, specs, mdp = self._plan(group_name)
         mdp.bind(noise_u=noise_u)
-        F.run_plan(mdp, self._env, "observation", specs, bindings)
+        if isinstance(mdp, _CompositeObservationPlan):
+            mdp.run()
+        else:
+            F.run_plan(mdp, self._env, "observation", specs, bindings)
         for c0, c1, cfg, noisy in self._post[group_name]:
             cols = mdp.obs[:, c0:c1]
             obs = cols

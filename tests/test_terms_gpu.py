@@ -257,3 +257,50 @@ def test_manager_classes_match_reference_managers(dev):
         RewardManager(dict(custom=RewTerm(lambda env: torch.zeros(n), {}, 1.0)), env)
     with pytest.raises(TypeError):
         RewardManager(dict(bad=RewTerm(mdp.action_l2, {}, "1.0")), env)
+
+
+def test_observation_group_over_two_articulations(dev):
+    """A group whose terms read different articulations (observation_manager.py:260-335 concatenates whatever its terms
+    return): one fused plan per articulation, columns in the group's order, noise and clip per term -- against the same
+    terms computed one group each."""
+    from isaaclab_amd.envs import mdp
+    from isaaclab_amd.managers import ObservationManager, ObservationTermCfg as ObsTerm, SceneEntityCfg as E, UniformNoiseCfg as Unoise
+
+    g = load_golden("managers_anymal")
+    steps = g["reward"].shape[0]
+    s0 = {k: v[0] for k, v in g.items() if v.shape[:1] == (steps,)}
+    s1 = {k: v[min(1, steps - 1)] for k, v in g.items() if v.shape[:1] == (steps,)}
+    n = s0["joint_pos"].shape[0]
+    env = make_env(s0, dev)
+    other = make_env(s1, dev).scene["robot"]
+    other.data.joint_pos = other.data.joint_pos + 0.25          # a second articulation with a state of its own
+    other.data.root_state_w = other.data.root_state_w.flip(0).contiguous()
+    env.scene["object"] = other
+    terms = dict(
+        base_lin_vel=ObsTerm(mdp.base_lin_vel, {}, noise=Unoise(-0.1, 0.1)),
+        object_joint_pos=ObsTerm(mdp.joint_pos_rel, dict(asset_cfg=E("object")), noise=Unoise(-0.01, 0.01), clip=(-0.2, 0.2)),
+        joint_vel=ObsTerm(mdp.joint_vel_rel, {}, noise=Unoise(-1.5, 1.5), scale=0.5),
+        object_lin_vel=ObsTerm(mdp.base_lin_vel, dict(asset_cfg=E("object"))),
+        actions=ObsTerm(mdp.last_action, {}),
+        projected_gravity=ObsTerm(mdp.projected_gravity, dict(asset_cfg=E("object")), noise=Unoise(-0.05, 0.05)),
+    )
+    om = ObservationManager(dict(policy=dict(terms, enable_corruption=True, concatenate_terms=True)), env)
+    widths = [3, 12, 12, 3, 12, 3]
+    total = sum(widths)
+    assert om.group_obs_dim["policy"] == (total,)
+    noise = torch.rand(n, total, generator=torch.Generator().manual_seed(3)).to(dev)
+    for rep in range(2):   # the plans are built once and launched again
+        row = om.compute_group("policy", noise_u=noise)
+        assert row.shape == (n, total)
+        col = 0
+        for (name, cfg), w in zip(terms.items(), widths):
+            single = ObservationManager(dict(one=dict({name: cfg}, enable_corruption=True, concatenate_terms=True)), env)
+            ref = single.compute_group("one", noise_u=noise[:, col:col + w].contiguous())
+            assert_exact(row[:, col:col + w], ref, f"{name} (columns {col}..{col + w})")
+            col += w
+    # the two articulations really differ, and un-concatenated groups hand the same columns out by name
+    assert not torch.equal(row[:, 0:3], row[:, 27:30])
+    om2 = ObservationManager(dict(policy=dict(terms, enable_corruption=True, concatenate_terms=False)), env)
+    parts = om2.compute_group("policy", noise_u=noise)
+    assert list(parts) == list(terms)
+    assert_exact(torch.cat(list(parts.values()), dim=1), row, "un-concatenated terms")
