@@ -139,10 +139,11 @@ def subset_state(state, ids):
     return out
 
 
-def test_anymal_step_at_benchmark_size(dev):
-    """16,384 envs (the benchmark's shard): catches index-width and grid-size errors that 512 envs cannot.  The oracle
-    runs on 512 of the envs -- the first and last 64 and random ones; every per-env buffer of those rows is compared."""
-    n = 16384
+@pytest.mark.parametrize("n", [16384, 131072, 1048576])
+def test_anymal_step_at_benchmark_size(dev, n):
+    """16,384 envs (the benchmark's shard) and eight times that (what one GPU holds when it takes a whole node's envs):
+    catches index-width and grid-size errors that 512 envs cannot.  The oracle runs on 512 of the envs -- the first and
+    last 64 and random ones; every per-env buffer of those rows is compared."""
     env, make_oracle, state = build(dev, n, seed=5, rows=3, cols=3)
     gen = torch.Generator().manual_seed(17)
     ids = torch.cat([torch.arange(64), torch.arange(n - 64, n), torch.randperm(n - 128, generator=gen)[:384] + 64]).sort().values
