@@ -687,7 +687,12 @@ enum ilx_ray_hint {
      * ray_caster.py:190-212).  The refresh then reuses the packed pattern and its bounding box that that refresh left in
      * the stream's workspace instead of reading and reducing the pattern again.  It has no effect when there was no
      * such refresh (first call, other arrays or ray count, workspace regrown). */
-    ILX_RAYS_PATTERN_STATIC = 4
+    ILX_RAYS_PATTERN_STATIC = 4,
+    /* For ilx_raycaster_refresh: the refresh's preparation launch was issued by ilx_scene_update_prepare_raycaster for
+     * this descriptor, on this stream, with nothing that touches the sensor in between; only the cast is launched.
+     * Where a refresh has no preparation launch (no height-field patches, a pattern above 1 024 rays, no vertical-ray
+     * hint) the hint changes nothing. */
+    ILX_RAYS_PREPARED = 8
 };
 int ilx_raycast_mesh(ilx_mesh_t mesh, const float* ray_starts, const float* ray_directions, int64_t num_rays,
                      float max_dist, float* ray_hits, float* ray_distance, float* ray_normal, int32_t* ray_face_id,
@@ -735,6 +740,15 @@ typedef struct ilx_raycaster {
     uint8_t* is_outdated;
 } ilx_raycaster;
 int ilx_raycaster_refresh(const ilx_raycaster* rc, void* stream);
+/* ilx_scene_update (declared above) for the last scene update before the scanner is read, which also issues the
+ * preparation of the refresh that follows -- ilx_raycaster_refresh(rc with hints | ILX_RAYS_PREPARED) on the same stream
+ * -- as part of the same launch: the thread that advances an env's sensor clocks (sensor_base.py:197-205) also turns the
+ * sensor pose into the env's record once it knows whether the scanner is due.  One launch and its latency fewer on the
+ * path to the ray hits.  `scene`'s ray-caster clock must be `rc`'s clock (ILX_EINVAL otherwise); the pose in `rc` must be
+ * the one the refresh will see.  The first call for a pattern on a stream, and sensors whose refresh has no preparation
+ * launch, are served by separate launches with the same results.  The two calls together leave every buffer as
+ * ilx_scene_update followed by ilx_raycaster_refresh does. */
+int ilx_scene_update_prepare_raycaster(const ilx_scene* scene, const ilx_raycaster* rc, void* stream);
 /* ilx_raycaster_refresh for callers that cannot allocate (no counterpart in the reference): code under HIP graph
  * capture, tight serving loops, harnesses that forbid hipMalloc.  Same arguments, same results.  Where
  * ilx_raycaster_refresh keeps the scan pattern and one record per env between its launches in a per-stream workspace that

@@ -114,6 +114,7 @@ mesh_lattice_probe = _sig("ilx_mesh_lattice_probe", P, c_int64, P, c_int64, P)
 RAYS_Z_PARALLEL = 1
 RAYS_Z_PARALLEL_CHECKED = 2
 RAYS_PATTERN_STATIC = 4
+RAYS_PREPARED = 8
 raycast_mesh = _sig("ilx_raycast_mesh", P, P, P, c_int64, c_float, P, P, P, P, c_int, P)
 raycaster_update = _sig("ilx_raycaster_update", P, P, P, P, P, P, c_int, c_float, P, P, c_float, c_int64, c_int, c_int, P)
 joint_action_process = _sig("ilx_joint_action_process", P, P, P, P, c_float, P, c_float, P, P, c_int64, c_int, P)
@@ -189,6 +190,7 @@ raycaster_camera_refresh = _sig("ilx_raycaster_camera_refresh", ctypes.POINTER(R
 scene_update = _sig("ilx_scene_update", ctypes.POINTER(Scene), P)
 raycaster_refresh = _sig("ilx_raycaster_refresh", ctypes.POINTER(RayCasterDesc), P)
 raycaster_refresh_static = _sig("ilx_raycaster_refresh_static", ctypes.POINTER(RayCasterDesc), P)
+scene_update_prepare_raycaster = _sig("ilx_scene_update_prepare_raycaster", ctypes.POINTER(Scene), ctypes.POINTER(RayCasterDesc), P)
 
 
 def row_view(t: torch.Tensor, width: int):

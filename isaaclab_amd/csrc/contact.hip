@@ -4,107 +4,10 @@
 // One launch = one ContactSensor.update(dt).  A 256-thread block owns whole environments (floor(256 / B)
 // of them) with one thread per (env, body), so the per-env clock words are read by every thread of the env
 // before the barrier and written by the body-0 thread after it.  All traffic is contiguous per env:
-// forces/history rows are B*3 floats, timer rows B floats.
-#include "common.h"
-#include "math_dev.h"
+// forces/history rows are B*3 floats, timer rows B floats.  The device code is in scene_update_dev.h.
+#include "scene_update_dev.h"
 
 namespace ilx {
-
-constexpr int kMaxContactHistory = 8;
-
-struct ContactArgs {
-    const float* in;
-    float* net;
-    float* hist;
-    int32_t* head;  // (n) ring mode: slot of the newest history entry per env; null: slot 0 is always the newest
-    float* cur_air;
-    float* last_air;
-    float* cur_contact;
-    float* last_contact;
-    float* ts;
-    float* ts_last;
-    uint8_t* outdated;
-    float dt, period, thr;
-    int tick;
-    int64_t n;
-    int b, h;
-    int envs_per_block;
-};
-
-// Sensor clock of one env (sensor_base.py:197-205): returns whether the env is refreshed in this launch.
-// tick: advance the clock by dt; lazy: only flag outdated envs, refresh nothing.
-struct Clock {
-    float ts_new, last;
-    bool refresh;
-};
-ILX_DEV Clock read_clock(const float* ts, const float* ts_last, const uint8_t* outdated, int64_t env, int tick, float dt,
-                         float period) {
-    Clock c{ts[env], ts_last[env], outdated[env] != 0};
-    if (tick) {
-        c.ts_new = c.ts_new + dt;                                              // sensor_base.py:199
-        c.refresh = c.refresh || ((c.ts_new - c.last + 1e-6f) >= period);      // sensor_base.py:200
-    }
-    return c;
-}
-// Ring mode: the newest entry moves one slot down (mod h), so that age k sits at slot (head + k) % h.
-ILX_DEV int next_slot(int head, int h) { return (head <= 0 || head >= h ? h : head) - 1; }
-
-ILX_DEV void write_clock(float* ts, float* ts_last, uint8_t* outdated, int64_t env, const Clock& c, bool lazy) {
-    ts[env] = c.ts_new;
-    if (lazy) {
-        outdated[env] = c.refresh;
-    } else {
-        if (c.refresh) ts_last[env] = c.ts_new;  // sensor_base.py:291
-        outdated[env] = 0;                       // refreshed now, or it was not outdated to begin with
-    }
-}
-
-// What a refresh of one (env, body) reads besides the history: loaded ahead of the decision whether the env refreshes,
-// so that these loads and the clock's travel together.
-struct BodyIn {
-    f3 f;
-    float cur_air, cur_contact;
-};
-ILX_DEV BodyIn load_body(const ContactArgs& a, int64_t env, int body) {
-    const int64_t eb = env * a.b + body;
-    BodyIn in{load3(a.in + 3 * eb), 0.0f, 0.0f};
-    if (a.cur_air) in.cur_air = a.cur_air[eb], in.cur_contact = a.cur_contact[eb];
-    return in;
-}
-
-// contact_sensor.py:324-373 for one (env, body).
-// `slot`: ring mode, the history slot this refresh writes.
-ILX_DEV void contact_body(const ContactArgs& a, int64_t env, int body, float elapsed, int slot, const BodyIn& in) {
-    const int64_t eb = env * a.b + body;
-    const f3 f = in.f;
-    if (a.net) store3(a.net + 3 * eb, f);  // contact_sensor.py:324 (null: the newest history entry stands for it)
-    if (a.hist && a.head) {     // the same history as below, kept as a ring: one row written instead of h rows moved
-        store3(a.hist + 3 * ((env * a.h + slot) * a.b + body), f);
-    } else if (a.hist) {        // contact_sensor.py:326-328
-        const int64_t hb = (env * a.h) * a.b + body;
-        f3 old[kMaxContactHistory - 1];
-#pragma unroll
-        for (int k = 0; k < kMaxContactHistory - 1; ++k)
-            if (k < a.h - 1) old[k] = load3(a.hist + 3 * (hb + static_cast<int64_t>(k) * a.b));
-        store3(a.hist + 3 * hb, f);
-#pragma unroll
-        for (int k = 0; k < kMaxContactHistory - 1; ++k)
-            if (k < a.h - 1) store3(a.hist + 3 * (hb + static_cast<int64_t>(k + 1) * a.b), old[k]);
-    }
-    if (a.cur_air) {  // contact_sensor.py:346-373
-        const bool contact = norm3(f) > a.thr;
-        const float ca = in.cur_air, cc = in.cur_contact;
-        const bool first_contact = (ca > 0.0f) && contact;
-        const bool first_detached = (cc > 0.0f) && !contact;
-        if (first_contact) a.last_air[eb] = ca + elapsed;
-        a.cur_air[eb] = contact ? 0.0f : ca + elapsed;
-        if (first_detached) a.last_contact[eb] = cc + elapsed;
-        a.cur_contact[eb] = contact ? cc + elapsed : 0.0f;
-    }
-}
-ILX_DEV void contact_body(const ContactArgs& a, int64_t env, int body, float elapsed, int slot) {
-    contact_body(a, env, body, elapsed, slot, load_body(a, env, body));
-}
 
 __global__ void __launch_bounds__(256) contact_update_kernel(ContactArgs a) {
     const int t = threadIdx.x;
@@ -129,73 +32,7 @@ __global__ void __launch_bounds__(256) contact_update_kernel(ContactArgs a) {
     }
 }
 
-// InteractiveScene.update(dt) for the usual locomotion scene in ONE launch (scene/interactive_scene.py:496-513):
-// articulation -> joint_acc (articulation_data.py:77-82, 445-455); contact sensor -> clock + bookkeeping;
-// ray caster -> clock only (its buffers refresh lazily, on the next read).  Thread layout as above: a block owns
-// whole envs, `width` threads per env.
-struct SceneArgs {
-    ContactArgs c;          // c.in == nullptr: no contact sensor
-    int contact_lazy;       // history_length == 0 and lazy updates: flag, do not refresh
-    const float* joint_vel; // nullptr: no articulation
-    float* prev_joint_vel;
-    float* joint_acc;
-    int j;
-    float joint_elapsed;
-    float* ray_ts;          // nullptr: no ray caster
-    float* ray_ts_last;
-    uint8_t* ray_outdated;
-    float ray_period;
-    int width;
-    uint32_t inv_width;     // ceil(2^32 / width): t / width == umulhi(t, inv_width) for the t < 256 of a block
-};
-
-__global__ void __launch_bounds__(256) scene_update_kernel(SceneArgs s) {
-    const ContactArgs& a = s.c;
-    const int t = threadIdx.x;
-    const int le = s.width > 1 ? static_cast<int>(__umulhi(static_cast<uint32_t>(t), s.inv_width)) : t;  // t / width
-    const int k0 = t - le * s.width;
-    const int64_t env = static_cast<int64_t>(blockIdx.x) * a.envs_per_block + le;
-    const bool active = le < a.envs_per_block && env < a.n;
-    const bool has_contact = a.in != nullptr;
-
-    // Everything the thread may read goes out before the barrier, in one trip to memory: the clock, and the inputs of
-    // the first body / joint the thread owns (read whether or not the env turns out to refresh).
-    Clock c{0.0f, 0.0f, false};
-    int slot = 0;
-    const bool body_ahead = active && has_contact && !s.contact_lazy && k0 < a.b;
-    const bool joint_ahead = active && s.joint_vel && k0 < s.j;
-    BodyIn first_body{};
-    float first_v = 0.0f, first_prev = 0.0f;
-    if (active && has_contact) c = read_clock(a.ts, a.ts_last, a.outdated, env, 1, a.dt, a.period);
-    if (active && has_contact && a.head) slot = next_slot(a.head[env], a.h);
-    if (body_ahead) first_body = load_body(a, env, k0);
-    if (joint_ahead) first_v = s.joint_vel[env * s.j + k0], first_prev = s.prev_joint_vel[env * s.j + k0];
-    // the ray caster's clock belongs to the env's first thread alone: read in the same trip
-    const bool ray_clock = active && k0 == 0 && s.ray_ts;
-    Clock r{0.0f, 0.0f, false};
-    if (ray_clock) r = read_clock(s.ray_ts, s.ray_ts_last, s.ray_outdated, env, 1, a.dt, s.ray_period);
-    __syncthreads();
-    if (!active) return;
-    if (k0 == 0) {
-        if (has_contact) write_clock(a.ts, a.ts_last, a.outdated, env, c, s.contact_lazy != 0);
-        if (has_contact && a.head && c.refresh && !s.contact_lazy) a.head[env] = slot;
-        if (ray_clock) write_clock(s.ray_ts, s.ray_ts_last, s.ray_outdated, env, r, true);
-    }
-    if (s.joint_vel) {
-        for (int j = k0; j < s.j; j += s.width) {
-            const int64_t i = env * s.j + j;
-            const float v = j == k0 ? first_v : s.joint_vel[i];
-            const float prev = j == k0 ? first_prev : s.prev_joint_vel[i];
-            s.joint_acc[i] = div_(v - prev, s.joint_elapsed);
-            s.prev_joint_vel[i] = v;
-        }
-    }
-    if (has_contact && c.refresh && !s.contact_lazy) {
-        const float elapsed = c.ts_new - c.last;
-        for (int body = k0; body < a.b; body += s.width)
-            contact_body(a, env, body, elapsed, slot, body == k0 ? first_body : load_body(a, env, body));
-    }
-}
+__global__ void __launch_bounds__(256) scene_update_kernel(SceneArgs s) { scene_update_thread(s, blockIdx.x); }
 
 }  // namespace ilx
 
@@ -234,49 +71,9 @@ extern "C" int ilx_scene_update(const ilx_scene* scene, void* stream) {
     ILX_REQUIRE(d.num_envs >= 0, ILX_EINVAL, "ilx_scene_update: negative env count");
     if (d.num_envs == 0) return ILX_OK;
     SceneArgs s{};
-    int width = 1;
-    if (d.joint_vel) {
-        ILX_REQUIRE(d.previous_joint_vel && d.joint_acc && d.num_joints > 0, ILX_EINVAL,
-                    "ilx_scene_update: articulation needs previous_joint_vel, joint_acc and num_joints > 0");
-        ILX_REQUIRE(d.joint_acc_elapsed > 0.0f, ILX_EINVAL, "ilx_scene_update: joint_acc_elapsed must be positive");
-        s.joint_vel = d.joint_vel, s.prev_joint_vel = d.previous_joint_vel, s.joint_acc = d.joint_acc;
-        s.j = d.num_joints, s.joint_elapsed = d.joint_acc_elapsed;
-        width = d.num_joints;
-    }
-    ContactArgs& a = s.c;
-    a.n = d.num_envs, a.dt = d.dt;
-    if (d.net_forces_in) {
-        const int b = d.num_bodies, h = d.history_length;
-        ILX_REQUIRE(b > 0 && h >= 0, ILX_EINVAL, "ilx_scene_update: bad contact shape (b=%d, h=%d)", b, h);
-        ILX_REQUIRE(h <= kMaxContactHistory, ILX_ESHAPE, "ilx_scene_update: history length %d (max %d)", h, kMaxContactHistory);
-        ILX_REQUIRE(d.contact_timestamp && d.contact_timestamp_last_update && d.contact_is_outdated,
-                    ILX_EINVAL, "ilx_scene_update: NULL contact operand");
-        ILX_REQUIRE(d.net_forces_w || d.net_forces_w_history, ILX_EINVAL,
-                    "ilx_scene_update: net_forces_w may be NULL only with a history");
-        ILX_REQUIRE((h == 0) == (d.net_forces_w_history == nullptr), ILX_EINVAL,
-                    "ilx_scene_update: history must be NULL iff history_length == 0");
-        const int timers = (d.current_air_time != nullptr) + (d.last_air_time != nullptr) +
-                           (d.current_contact_time != nullptr) + (d.last_contact_time != nullptr);
-        ILX_REQUIRE(timers == 0 || timers == 4, ILX_EINVAL, "ilx_scene_update: pass all four timers or none");
-        ILX_REQUIRE(d.net_forces_w_history || !d.contact_history_head, ILX_EINVAL, "ilx_scene_update: history head without a history");
-        a.in = d.net_forces_in, a.net = d.net_forces_w, a.hist = d.net_forces_w_history, a.head = d.contact_history_head;
-        a.cur_air = d.current_air_time, a.last_air = d.last_air_time, a.cur_contact = d.current_contact_time;
-        a.last_contact = d.last_contact_time;
-        a.ts = d.contact_timestamp, a.ts_last = d.contact_timestamp_last_update, a.outdated = d.contact_is_outdated;
-        a.period = d.contact_update_period, a.thr = d.force_threshold, a.tick = 1, a.b = b, a.h = h;
-        s.contact_lazy = d.contact_lazy;
-        width = b;
-    }
-    if (d.ray_timestamp) {
-        ILX_REQUIRE(d.ray_timestamp_last_update && d.ray_is_outdated, ILX_EINVAL, "ilx_scene_update: NULL ray caster clock");
-        s.ray_ts = d.ray_timestamp, s.ray_ts_last = d.ray_timestamp_last_update, s.ray_outdated = d.ray_is_outdated;
-        s.ray_period = d.ray_update_period;
-    }
-    if (width > 256) width = 256;
-    s.width = width;
-    s.inv_width = static_cast<uint32_t>((0x100000000ull + width - 1) / width);
-    a.envs_per_block = 256 / width;
-    const unsigned blocks = static_cast<unsigned>((d.num_envs + a.envs_per_block - 1) / a.envs_per_block);
+    unsigned blocks = 0;
+    const int rc = scene_args_from(d, s, blocks);
+    if (rc != ILX_OK) return rc;
     hipLaunchKernelGGL(scene_update_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), s);
     ILX_LAUNCH_CHECK("ilx_scene_update");
     return ILX_OK;

@@ -23,6 +23,7 @@
 #include "common.h"
 #include "lattice.h"
 #include "raytri.h"
+#include "scene_update_dev.h"
 
 #include <algorithm>
 #include <atomic>
@@ -603,52 +604,12 @@ __device__ unsigned long long g_prep_stamps[8 * 256];
 // The pattern's xy box is reduced by every workgroup for itself (a few loads per thread).
 constexpr int kPatchBins = 64;
 
-// `box_cache` (or null): four floats that keep the pattern's box; `reuse`: they and `pattern` are those of this pattern.
-__global__ void __launch_bounds__(256) raycaster_prepare_kernel(ScanArgs a, LatEnvRec* __restrict__ recs, float4* __restrict__ pattern,
-                                                                float* __restrict__ box_cache, int reuse) {
-    __shared__ float box_s[4][4];
+// The per-env part of the preparation: the record of env `env` from its pose (already loaded: `pos`, `q`, drift `dr`)
+// and the pattern's box; for a due env also RayCasterData.pos_w / quat_w and the refresh time.  `now` (or null): the
+// env's clock value when the caller has it in a register (else it is read from clock_now).
+ILX_DEV void prepare_env(const ScanArgs& a, int64_t env, bool due, f3 pos, f4 q, f3 dr, float bx0, float bx1, float by0, float by1,
+                         LatEnvRec* __restrict__ recs, const float* now = nullptr) {
     const float inf = __builtin_inff();
-    ILX_PREP_STAMP(0)
-    // the env's inputs go out first: they travel while the block reduces the pattern's box
-    const int64_t env = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
-    const bool due = env < a.n && (!a.env_mask || a.env_mask[env]);
-    f3 pos{0.0f, 0.0f, 0.0f}, dr{0.0f, 0.0f, 0.0f};
-    f4 q{1.0f, 0.0f, 0.0f, 0.0f};
-    if (due) {
-        pos = load3(a.pos_w + a.pos_stride * env);
-        q = load4u(a.quat_w + a.quat_stride * env);
-        if (a.drift) dr = load3(a.drift + 3 * env);
-    }
-    float bx0 = inf, bx1 = -inf, by0 = inf, by1 = -inf;  // xy box of the z-parallel pattern entries
-    if (reuse) {
-        bx0 = box_cache[0], bx1 = box_cache[1], by0 = box_cache[2], by1 = box_cache[3];
-    } else {
-        for (int ray = threadIdx.x; ray < a.r; ray += 256) {
-            const f3 l = load3(a.ray_starts + 3 * ray), d = load3(a.ray_dirs + 3 * ray);
-            const bool zp = z_parallel(d);
-            if (zp) {
-                bx0 = fminf(bx0, l.x), bx1 = fmaxf(bx1, l.x);
-                by0 = fminf(by0, l.y), by1 = fmaxf(by1, l.y);
-            }
-            // the pattern as the cast wants it: one 16-byte word per ray, local start and z of the direction -- NaN when
-            // the direction is not z-parallel (such a ray never takes the height-grid path)
-            if (blockIdx.x == 0) pattern[ray] = make_float4(l.x, l.y, l.z, zp ? d.z : __builtin_nanf(""));
-        }
-        bx0 = wave_min(bx0), bx1 = wave_max(bx1), by0 = wave_min(by0), by1 = wave_max(by1);
-        if ((threadIdx.x & 63) == 0) {
-            float* b = box_s[threadIdx.x >> 6];
-            b[0] = bx0, b[1] = bx1, b[2] = by0, b[3] = by1;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            bx0 = fminf(bx0, box_s[w][0]), bx1 = fmaxf(bx1, box_s[w][1]);
-            by0 = fminf(by0, box_s[w][2]), by1 = fmaxf(by1, box_s[w][3]);
-        }
-        if (box_cache && blockIdx.x == 0 && threadIdx.x == 0) box_cache[0] = bx0, box_cache[1] = bx1, box_cache[2] = by0, box_cache[3] = by1;
-    }
-    ILX_PREP_STAMP(1)
-    if (env >= a.n) return;
     LatEnvRec le{};
     le.sel = kLatNotDue;
     if (due) {
@@ -660,7 +621,7 @@ __global__ void __launch_bounds__(256) raycaster_prepare_kernel(ScanArgs a, LatE
             qo[0] = q.w, qo[1] = q.x, qo[2] = q.y, qo[3] = q.z;
         }
         if (a.outdated) {  // the refreshed env records the time
-            a.clock_last[env] = a.clock_now[env];
+            a.clock_last[env] = now ? *now : a.clock_now[env];
             a.outdated[env] = 0;
         }
         const f4 rot = yaw_quat(q);
@@ -720,7 +681,81 @@ __global__ void __launch_bounds__(256) raycaster_prepare_kernel(ScanArgs a, LatE
         }
     }
     recs[env] = le;
+}
+
+// `box_cache` (or null): four floats that keep the pattern's box; `reuse`: they and `pattern` are those of this pattern.
+__global__ void __launch_bounds__(256) raycaster_prepare_kernel(ScanArgs a, LatEnvRec* __restrict__ recs, float4* __restrict__ pattern,
+                                                                float* __restrict__ box_cache, int reuse) {
+    __shared__ float box_s[4][4];
+    const float inf = __builtin_inff();
+    ILX_PREP_STAMP(0)
+    // the env's inputs go out first: they travel while the block reduces the pattern's box
+    const int64_t env = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+    const bool due = env < a.n && (!a.env_mask || a.env_mask[env]);
+    f3 pos{0.0f, 0.0f, 0.0f}, dr{0.0f, 0.0f, 0.0f};
+    f4 q{1.0f, 0.0f, 0.0f, 0.0f};
+    if (due) {
+        pos = load3(a.pos_w + a.pos_stride * env);
+        q = load4u(a.quat_w + a.quat_stride * env);
+        if (a.drift) dr = load3(a.drift + 3 * env);
+    }
+    float bx0 = inf, bx1 = -inf, by0 = inf, by1 = -inf;  // xy box of the z-parallel pattern entries
+    if (reuse) {
+        bx0 = box_cache[0], bx1 = box_cache[1], by0 = box_cache[2], by1 = box_cache[3];
+    } else {
+        for (int ray = threadIdx.x; ray < a.r; ray += 256) {
+            const f3 l = load3(a.ray_starts + 3 * ray), d = load3(a.ray_dirs + 3 * ray);
+            const bool zp = z_parallel(d);
+            if (zp) {
+                bx0 = fminf(bx0, l.x), bx1 = fmaxf(bx1, l.x);
+                by0 = fminf(by0, l.y), by1 = fmaxf(by1, l.y);
+            }
+            // the pattern as the cast wants it: one 16-byte word per ray, local start and z of the direction -- NaN when
+            // the direction is not z-parallel (such a ray never takes the height-grid path)
+            if (blockIdx.x == 0) pattern[ray] = make_float4(l.x, l.y, l.z, zp ? d.z : __builtin_nanf(""));
+        }
+        bx0 = wave_min(bx0), bx1 = wave_max(bx1), by0 = wave_min(by0), by1 = wave_max(by1);
+        if ((threadIdx.x & 63) == 0) {
+            float* b = box_s[threadIdx.x >> 6];
+            b[0] = bx0, b[1] = bx1, b[2] = by0, b[3] = by1;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            bx0 = fminf(bx0, box_s[w][0]), bx1 = fmaxf(bx1, box_s[w][1]);
+            by0 = fminf(by0, box_s[w][2]), by1 = fmaxf(by1, box_s[w][3]);
+        }
+        if (box_cache && blockIdx.x == 0 && threadIdx.x == 0) box_cache[0] = bx0, box_cache[1] = bx1, box_cache[2] = by0, box_cache[3] = by1;
+    }
+    ILX_PREP_STAMP(1)
+    if (env >= a.n) return;
+    prepare_env(a, env, due, pos, q, dr, bx0, bx1, by0, by1, recs);
     ILX_PREP_STAMP(4)
+}
+
+// InteractiveScene.update and the preparation launch of the height scanner's refresh as one launch (the last scene
+// update before the scanner is read).  The two share no data but the scanner's clock, so they are dealt to different
+// workgroups of one grid: the first `prep_blocks` workgroups own the scanner's clock -- one thread per env advances it
+// and flags the env (sensor_base.py:197-205), then, knowing whether the env is due, turns the sensor pose into the
+// env's record as raycaster_prepare_kernel does; the other workgroups are the scene update without that clock.  (The
+// preparation as extra work of the update's own clock threads -- a few lanes per wavefront -- took 16 us: every
+// wavefront of the update then runs the preparation's instruction stream.)  The pattern's box is the cached one.
+__global__ void __launch_bounds__(256) scene_update_prepare_kernel(SceneArgs s, ScanArgs a, LatEnvRec* __restrict__ recs,
+                                                                   const float* __restrict__ box_cache, unsigned prep_blocks) {
+    if (blockIdx.x >= prep_blocks) {
+        scene_update_thread(s, blockIdx.x - prep_blocks, false);
+        return;
+    }
+    const int64_t env = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+    if (env >= a.n) return;
+    // every load of the thread goes out at once: the clock, the pose, the pattern's box
+    const Clock r = read_clock(s.ray_ts, s.ray_ts_last, s.ray_outdated, env, 1, s.c.dt, s.ray_period);
+    const f3 pos = load3(a.pos_w + a.pos_stride * env);
+    const f4 q = load4u(a.quat_w + a.quat_stride * env);
+    const f3 dr = a.drift ? load3(a.drift + 3 * env) : f3{0.0f, 0.0f, 0.0f};
+    const float bx0 = box_cache[0], bx1 = box_cache[1], by0 = box_cache[2], by1 = box_cache[3];
+    write_clock(s.ray_ts, s.ray_ts_last, s.ray_outdated, env, r, true);
+    prepare_env(a, env, r.refresh, pos, q, dr, bx0, bx1, by0, by1, recs, &r.ts_new);
 }
 
 // The staged lattice cell that the index estimate names for coordinate x (line l[k] is line lo_abs + k of the patch):
@@ -1685,8 +1720,9 @@ static size_t lattice_workspace_bytes(int64_t n, int r) {
 static void launch_lattice(ilx_mesh_t mesh, ScanArgs a, int hints, void* ws, float* box, bool reuse, void* stream) {
     float4* pattern = static_cast<float4*>(ws);
     LatEnvRec* recs = reinterpret_cast<LatEnvRec*>(static_cast<char*>(ws) + lattice_workspace_bytes(0, a.r));
-    hipLaunchKernelGGL(raycaster_prepare_kernel, dim3(blocks_for(a.n)), dim3(256), 0, as_stream(stream), a, recs, pattern, box,
-                       (box && reuse) ? 1 : 0);
+    if (!(hints & ILX_RAYS_PREPARED))
+        hipLaunchKernelGGL(raycaster_prepare_kernel, dim3(blocks_for(a.n)), dim3(256), 0, as_stream(stream), a, recs, pattern, box,
+                           (box && reuse) ? 1 : 0);
     hipLaunchKernelGGL(raycaster_update_lattice_kernel, dim3(static_cast<unsigned>((a.n + kLatWaves - 1) / kLatWaves)),
                        dim3(64 * kLatWaves), 0, as_stream(stream), a, recs, pattern);
     if ((hints & ILX_RAYS_Z_PARALLEL_CHECKED) && mesh->h.d_cells) return;
@@ -1805,6 +1841,61 @@ extern "C" int ilx_raycaster_refresh(const ilx_raycaster* rc, void* stream) {
     return ILX_OK;
 }
 
+// Whether a refresh described by `a` goes over the height-field patches (preparation + cast launches).
+static bool lattice_refresh(ilx_mesh_t mesh, const ScanArgs& a, int hints) {
+    return (hints & ILX_RAYS_Z_PARALLEL) && a.yaw_only && mesh->h.dev.num_patches > 0 && a.r <= kLatMaxRays && a.n < (int64_t(1) << 31);
+}
+
+extern "C" int ilx_scene_update_prepare_raycaster(const ilx_scene* scene, const ilx_raycaster* rc, void* stream) {
+    ILX_REQUIRE(scene && rc, ILX_EINVAL, "ilx_scene_update_prepare_raycaster: NULL descriptor");
+    const ilx_raycaster& d = *rc;
+    ILX_REQUIRE(d.mesh, ILX_EINVAL, "ilx_scene_update_prepare_raycaster: mesh is NULL");
+    ILX_REQUIRE(d.num_envs == scene->num_envs && d.num_rays > 0, ILX_EINVAL,
+                "ilx_scene_update_prepare_raycaster: scene and sensor differ in their env count (%lld, %lld) or the sensor has no rays",
+                (long long)scene->num_envs, (long long)d.num_envs);
+    ILX_REQUIRE(d.pose_pos && d.pose_quat && d.ray_starts_local && d.ray_directions_local && d.pos_w && d.quat_w &&
+                    d.ray_hits_w && d.timestamp && d.timestamp_last_update && d.is_outdated,
+                ILX_EINVAL, "ilx_scene_update_prepare_raycaster: NULL operand");
+    ILX_REQUIRE(d.pose_pos_stride >= 3 && d.pose_quat_stride >= 4, ILX_EINVAL, "ilx_scene_update_prepare_raycaster: bad pose strides");
+    ILX_REQUIRE(scene->ray_timestamp == d.timestamp && scene->ray_timestamp_last_update == d.timestamp_last_update &&
+                    scene->ray_is_outdated == d.is_outdated,
+                ILX_EINVAL, "ilx_scene_update_prepare_raycaster: the scene's ray-caster clock is not this sensor's");
+    ILX_REQUIRE(!(d.hints & ILX_RAYS_PREPARED), ILX_EINVAL, "ilx_scene_update_prepare_raycaster: ILX_RAYS_PREPARED is for the refresh that follows");
+    if (d.num_envs == 0) return ILX_OK;
+    ScanArgs a{d.mesh->h.dev, d.pose_pos, d.pose_quat, d.pose_pos_stride, d.pose_quat_stride, d.drift, d.pos_w, d.quat_w,
+               d.ray_starts_local, d.ray_directions_local, d.is_outdated, d.attach_yaw_only, d.max_distance, d.ray_hits_w,
+               d.height_scan, d.height_offset, d.num_envs, d.num_rays, 0, nullptr, d.timestamp, d.timestamp_last_update,
+               d.is_outdated};
+    if (lattice_refresh(d.mesh, a, d.hints)) {
+        void* ws = nullptr;
+        float* box = nullptr;
+        bool same_pattern = false;
+        int status = lattice_workspace(d.mesh, stream, lattice_workspace_bytes(a.n, a.r), a, &ws, &box, &same_pattern);
+        if (status != ILX_OK) return status;
+        LatEnvRec* recs = reinterpret_cast<LatEnvRec*>(static_cast<char*>(ws) + lattice_workspace_bytes(0, a.r));
+        if (same_pattern && (d.hints & ILX_RAYS_PATTERN_STATIC)) {   // the packed pattern and its box are in the workspace: one launch
+            SceneArgs s{};
+            unsigned blocks = 0;
+            status = scene_args_from(*scene, s, blocks);
+            if (status != ILX_OK) return status;
+            const unsigned prep_blocks = blocks_for(a.n);
+            hipLaunchKernelGGL(scene_update_prepare_kernel, dim3(prep_blocks + blocks), dim3(256), 0, as_stream(stream), s, a, recs,
+                               box, prep_blocks);
+            ILX_LAUNCH_CHECK("ilx_scene_update_prepare_raycaster");
+            return ILX_OK;
+        }
+        // first use of this pattern on this stream: the update, then the preparation launch proper (it packs the pattern)
+        status = ilx_scene_update(scene, stream);
+        if (status != ILX_OK) return status;
+        hipLaunchKernelGGL(raycaster_prepare_kernel, dim3(blocks_for(a.n)), dim3(256), 0, as_stream(stream), a, recs,
+                           static_cast<float4*>(ws), box, 0);
+        ILX_LAUNCH_CHECK("ilx_scene_update_prepare_raycaster");
+        return ILX_OK;
+    }
+    // no preparation launch in this refresh: the update alone; the refresh that follows does everything
+    return ilx_scene_update(scene, stream);
+}
+
 // ilx_raycaster_refresh for callers that must not allocate.  What ilx_raycaster_refresh keeps between its launches in
 // a workspace grown with hipMalloc lives here in one array of the code object, per GPU: every call on a GPU shares it.
 // Nothing in it has to start at zero: the preparation launch writes the pattern and every env record before the cast
@@ -1861,7 +1952,7 @@ extern "C" int ilx_raycaster_refresh_static(const ilx_raycaster* rc, void* strea
 // no-op when there are none), or the tree kernel alone followed by the clock update.
 static int launch_scan(ilx_mesh_t mesh, ScanArgs a, int hints, void* stream, void* fixed_ws, size_t fixed_bytes) {
     const int64_t rays = a.n * a.r;
-    if ((hints & ILX_RAYS_Z_PARALLEL) && a.yaw_only && mesh->h.dev.num_patches > 0 && a.r <= kLatMaxRays && a.n < (int64_t(1) << 31)) {
+    if (lattice_refresh(mesh, a, hints)) {
         // height-field patches: a preparation launch (one thread per env; it also advances the sensor clocks), the cast
         // (one wavefront per env), and the tree launch, which only looks at the flag: it has work when rays broke the hint
         void* ws = fixed_ws;

@@ -106,6 +106,8 @@ class LocomotionVelocityStep:
         self.clear_log_sums = False
         self._advance_count_first = False   # see count_steps_on_device
         self._side_stream = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
+        # the last scene update of a step also issues the preparation of the scanner's refresh (see step_sensors)
+        self.fuse_scanner_preparation = True
 
     def _bind(self):
         d, c = self.data, self.contact._data
@@ -184,19 +186,29 @@ class LocomotionVelocityStep:
         """Chain (B): per substep ``scene.update`` (joint_acc, contact sensor, sensor clocks: one launch), then the
         height scanner's refresh (once per env step: update_period = step_dt; lazy in the reference)."""
         d = self.data
+        prepared = False
         for k in range(LV.DECIMATION):
             # <sim.step would run here; its results for this substep are self.physics[...][k]>
             d.joint_pos, d.joint_vel = self.physics["joint_pos"][k], self.physics["joint_vel"][k]
             self.contact.set_net_contact_forces(self.physics["net_forces"][k])
-            self.scene.update(LV.PHYSICS_DT)
+            if k == LV.DECIMATION - 1:
+                # the last physics step has left the pose the scanner will see: the update's launch also prepares the
+                # scanner's refresh (one launch fewer between the last physics step and the ray hits)
+                self._bind_scanner_pose()
+                prepared = self.scene.update(LV.PHYSICS_DT, prepare_scanner=self.fuse_scanner_preparation)
+            else:
+                self.scene.update(LV.PHYSICS_DT)
+        # the refresh also writes the height scan the observation term reads (sensor height - hit height - offset)
+        self.scanner._update_outdated_buffers(height_out=self.height_scan, height_offset=self.height_scan_offset, prepared=prepared)
+
+    def _bind_scanner_pose(self):
+        d = self.data
         d.set_sim_state(root_state_w=self.physics["root_state_w"])
         if self.scanner_body is None:
             self.scanner.set_pose(d.root_state_w[:, :3], d.root_state_w[:, 3:7])
         else:  # strided views of the body's rows: the kernel reads them in place
             pose = d.body_state_w[:, self.scanner_body]
             self.scanner.set_pose(pose[:, :3], pose[:, 3:7])
-        # the refresh also writes the height scan the observation term reads (sensor height - hit height - offset)
-        self.scanner._update_outdated_buffers(height_out=self.height_scan, height_offset=self.height_scan_offset)
 
     def step_actuators(self, raw_action: torch.Tensor, begin=None):
         """Chain (A): process_action (manager_based_rl_env.py:172), then the actuator model of every substep

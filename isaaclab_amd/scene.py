@@ -49,7 +49,11 @@ class InteractiveScene:
             if hasattr(a, "write_data_to_sim"):
                 a.write_data_to_sim()
 
-    def update(self, dt: float) -> None:
+    def update(self, dt: float, prepare_scanner: bool = False) -> bool:
+        """interactive_scene.py:496-513.  ``prepare_scanner`` (no counterpart in the reference): this is the last update
+        before the height scanner is read, and the scanner's pose is final (``set_pose``): the launch also issues the
+        preparation of the scanner's refresh.  Returns whether it did -- then the refresh that follows on this stream is
+        ``scanner._update_outdated_buffers(..., prepared=True)``."""
         arts = list(self.articulations.values())
         contacts = [s for s in self.sensors.values() if isinstance(s, ContactSensor)]
         rays = [s for s in self.sensors.values() if isinstance(s, RayCaster)]
@@ -59,7 +63,7 @@ class InteractiveScene:
                 a.update(dt)
             for s in self.sensors.values():
                 s.update(dt, force_recompute=not self.lazy_sensor_update)
-            return
+            return False
         force = not self.lazy_sensor_update
         sc = _abi.Scene(num_envs=self.num_envs, dt=float(dt))
         if arts:
@@ -87,6 +91,13 @@ class InteractiveScene:
             r = rays[0]
             sc.ray_timestamp, sc.ray_timestamp_last_update = _abi.ptr(r._timestamp), _abi.ptr(r._timestamp_last_update)
             sc.ray_is_outdated, sc.ray_update_period = r._is_outdated.data_ptr(), float(r.cfg.update_period)
+        eager_rays = bool(rays) and (force or rays[0].cfg.history_length > 0)
+        if prepare_scanner and rays and not eager_rays and not rays[0].static_workspace:
+            rc = rays[0]._descriptor()
+            _abi.check(_abi.scene_update_prepare_raycaster(ctypes.byref(sc), ctypes.byref(rc), _abi.stream()),
+                       "ilx_scene_update_prepare_raycaster")
+            return True
         _abi.check(_abi.scene_update(ctypes.byref(sc), _abi.stream()), "ilx_scene_update")
-        if rays and (force or rays[0].cfg.history_length > 0):
+        if eager_rays:
             rays[0]._update_outdated_buffers()
+        return False

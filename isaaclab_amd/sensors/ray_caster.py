@@ -135,21 +135,27 @@ class RayCaster:
         if force_recompute or self.cfg.history_length > 0:
             self._update_outdated_buffers()
 
-    def _update_outdated_buffers(self, height_out: torch.Tensor | None = None, height_offset: float = 0.0):
-        """sensor_base.py:284-293 + ray_caster.py:220-260: the flagged envs take the new pose (+ drift), cast their
-        rays and record the refresh time -- two launches, the env subset is the ``_is_outdated`` mask on the device."""
+    def _descriptor(self, height_out: torch.Tensor | None = None, height_offset: float = 0.0, hints: int = 0):
+        """The refresh's arguments at the C ABI (``ilx_raycaster``) for the pose set last."""
         d = self._data
         mesh = self.meshes[self.cfg.mesh_prim_paths[0]]
         pp, ps = _abi.row_view(self._pose_pos, 3)
         qp, qs = _abi.row_view(self._pose_quat, 4)
-        rc = _abi.RayCasterDesc(
+        return _abi.RayCasterDesc(
             mesh=mesh.handle, num_envs=self._num_envs, num_rays=self.num_rays, attach_yaw_only=int(self.cfg.attach_yaw_only),
-            hints=self._hints, max_distance=float(self.cfg.max_distance), pose_pos=pp, pose_quat=qp, pose_pos_stride=ps,
+            hints=self._hints | hints, max_distance=float(self.cfg.max_distance), pose_pos=pp, pose_quat=qp, pose_pos_stride=ps,
             pose_quat_stride=qs, drift=_abi.ptr(self.drift),
             ray_starts_local=_abi.ptr(self.ray_starts), ray_directions_local=_abi.ptr(self.ray_directions),
             pos_w=_abi.ptr(d.pos_w), quat_w=_abi.ptr(d.quat_w), ray_hits_w=_abi.ptr(d.ray_hits_w),
             height_scan=_abi.ptr(height_out), height_offset=float(height_offset), timestamp=_abi.ptr(self._timestamp),
             timestamp_last_update=_abi.ptr(self._timestamp_last_update), is_outdated=self._is_outdated.data_ptr())
+
+    def _update_outdated_buffers(self, height_out: torch.Tensor | None = None, height_offset: float = 0.0, prepared: bool = False):
+        """sensor_base.py:284-293 + ray_caster.py:220-260: the flagged envs take the new pose (+ drift), cast their
+        rays and record the refresh time -- two launches, the env subset is the ``_is_outdated`` mask on the device.
+        ``prepared``: the scene update just before issued the refresh's preparation with its own launch
+        (``InteractiveScene.update(dt, prepare_scanner=True)``, same stream, same pose); only the cast follows."""
+        rc = self._descriptor(height_out, height_offset, _abi.RAYS_PREPARED if (prepared and not self.static_workspace) else 0)
         if self.static_workspace:
             _abi.check(_abi.raycaster_refresh_static(ctypes.byref(rc), _abi.stream()), "ilx_raycaster_refresh_static")
         else:

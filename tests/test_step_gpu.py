@@ -199,3 +199,41 @@ def test_step_replayed_from_a_graph_equals_eager(dev):
         for name, a, b in zip(names, outs[0][k], outs[1][k]):
             assert_exact(b, a, f"{name}, step {k}: graph replay vs eager")
     assert not torch.equal(outs[1][0][0], outs[1][1][0]), "a replay draws new observation noise"
+
+
+@pytest.mark.parametrize("robot", ["anymal_c", "h1"])
+def test_scene_update_that_prepares_the_scanner_equals_separate_launches(dev, robot):
+    """ilx_scene_update_prepare_raycaster + ilx_raycaster_refresh(ILX_RAYS_PREPARED) against ilx_scene_update +
+    ilx_raycaster_refresh: every buffer of the step bit for bit over several steps -- including the first step (the pattern
+    is not packed yet: separate launches inside), a scanner that is due only every other step (envs that are not due keep
+    their hits and clocks), clocks restarted for some envs in between, and the H1's scanner on a body (strided pose)."""
+    n = 333
+    outs = []
+    for fused in (False, True):
+        env, _, state = build(dev, n, seed=31, robot=robot)
+        env.fuse_scanner_preparation = fused
+        env.scanner.cfg.update_period = 0.04            # due every other env step ...
+        env.scanner._timestamp[: n // 2] = 0.02         # ... half of the envs on odd steps, half on even ones
+        gen = torch.Generator().manual_seed(7)
+        j = state["raw_action"].shape[1]
+        trace = []
+        for step in range(5):
+            if step == 3:   # what a reset of some envs does to the scanner's clocks (sensor_base.py:182-195)
+                env.scanner.reset(torch.arange(0, n, 7, device=dev))
+            raw = torch.rand(n, j, generator=gen) * 2 - 1
+            noise_u, samples, reset_samples = draws(gen, n, env.mdp.obs_dim)
+            out = env.step(raw.to(dev), noise_u.to(dev), samples.to(dev), reset_samples.to(dev))
+            sc, c = env.scanner, env.contact
+            trace.append([t.cpu().clone() for t in (*out, sc._data.ray_hits_w, sc._data.pos_w, sc._data.quat_w, env.height_scan,
+                                                    sc._timestamp, sc._timestamp_last_update, sc._is_outdated,
+                                                    c._timestamp, c._timestamp_last_update, c.ordered_history(),
+                                                    c._data.current_air_time, c._data.last_contact_time, env.data.joint_acc)])
+        outs.append(trace)
+    names = ("obs", "reward", "terminated", "time_outs", "ray hits", "pos_w", "quat_w", "height scan", "scanner clock",
+             "scanner last update", "scanner flags", "contact clock", "contact last update", "contact history", "air time",
+             "last contact time", "joint_acc")
+    for step, (one, two) in enumerate(zip(*outs)):
+        for name, a, b in zip(names, one, two):
+            assert_exact(b, a, f"{name}, step {step}")
+    last = outs[1][-1]
+    assert 0 < int((last[8] == last[9]).sum()) < n, "some envs refreshed on the last step, some did not"
