@@ -334,8 +334,9 @@ def main():
         }
         if refresh_check is not None:
             line["sensor_refresh_check"] = refresh_check
-        if "raycaster_refresh" in kern and "rays" in cfg.info:   # the height scanner's rate: rays of one refresh / its duration
-            line["raycast_mrays_per_s"] = round(args.envs * cfg.info["rays"] / kern["raycaster_refresh"], 1)
+        cast = "raycaster_cast" if "raycaster_cast" in kern else "raycaster_refresh"
+        if cast in kern and "rays" in cfg.info:   # the height scanner's rate: rays of one refresh / its (cast's) duration
+            line["raycast_mrays_per_s"] = round(args.envs * cfg.info["rays"] / kern[cast], 1)
         if args.config == "anymal":
             line["env_term_steps_per_s"] = value * TERM_EVALS_PER_ENV_STEP
         line["launch_mode"] = ("hip-graph replay: the step's launches recorded once per statistics vector, replayed per step"

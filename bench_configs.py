@@ -122,9 +122,26 @@ def build_locomotion(device, envs, seed, robot="anymal_c", actuator="mlp", stati
                                              _abi.ptr(d.default_joint_pos), 0.0, None, _abi.ptr(d.joint_pos_target), env.n, j,
                                              _abi.stream()))
 
-    launches = {act_kernel: (actuate, LV.DECIMATION), "scene_update": (lambda: env.scene.update(LV.PHYSICS_DT), LV.DECIMATION),
-                "raycaster_refresh": ((rays, rays_overhead), 1), "mdp_step": (lambda: env.mdp.step(FM.PHASE_ALL, hold_step_count=True), 1),
-                "joint_action_process": (action, 1)}
+    def update_and_prepare():   # the step's last scene update, which also prepares the scanner's refresh (every env due)
+        env.scanner._is_outdated.fill_(True)
+        env._bind_scanner_pose()
+        env.scene.update(LV.PHYSICS_DT, prepare_scanner=True)
+
+    def cast():                 # the refresh behind it: the cast alone, on the records of the last preparation
+        env.scanner._update_outdated_buffers(height_out=env.height_scan, height_offset=env.height_scan_offset, prepared=True)
+
+    fused = env.fuse_scanner_preparation and not static_scan
+    if fused:
+        for _ in range(2):      # the first preparation on a stream packs the pattern; every env's record marked due
+            update_and_prepare()
+        launches = {act_kernel: (actuate, LV.DECIMATION),
+                    "scene_update": (lambda: env.scene.update(LV.PHYSICS_DT), LV.DECIMATION - 1),
+                    "scene_update_prepare": ((update_and_prepare, rays_overhead), 1), "raycaster_cast": (cast, 1),
+                    "mdp_step": (lambda: env.mdp.step(FM.PHASE_ALL, hold_step_count=True), 1), "joint_action_process": (action, 1)}
+    else:
+        launches = {act_kernel: (actuate, LV.DECIMATION), "scene_update": (lambda: env.scene.update(LV.PHYSICS_DT), LV.DECIMATION),
+                    "raycaster_refresh": ((rays, rays_overhead), 1),
+                    "mdp_step": (lambda: env.mdp.step(FM.PHASE_ALL, hold_step_count=True), 1), "joint_action_process": (action, 1)}
     r = env.scanner.num_rays
     n_rewards = int(env.mdp.step_reward.shape[1])
     info = {"root_positions": ("env origins of the curriculum terrain (terrain_importer.py) + U(-0.5, 0.5) m" if origins is not None
@@ -136,8 +153,11 @@ def build_locomotion(device, envs, seed, robot="anymal_c", actuator="mlp", stati
                             "ActuatorNetLSTM LSTM(2, 8, 2 layers) + 8-32-1 softsign head")
     else:
         info["actuator"] = "DCMotor (PD + torque-speed envelope)"
-    cfg = Config("anymal" if robot == "anymal_c" else "h1", envs, lambda: env.step(raw), launches,
-                 _locomotion_bytes(j, b, r, int(env.mdp.obs_dim), n_rewards, act_kernel), info,
+    nbytes = _locomotion_bytes(j, b, r, int(env.mdp.obs_dim), n_rewards, act_kernel)
+    if fused:   # the refresh's bytes dealt to the two launches: pose in / out and clocks with the update, the results with the cast
+        nbytes["scene_update_prepare"] = nbytes["scene_update"] + 28 + 28 + 5
+        nbytes["raycaster_cast"] = nbytes.pop("raycaster_refresh") - (28 + 28 + 5)
+    cfg = Config("anymal" if robot == "anymal_c" else "h1", envs, lambda: env.step(raw), launches, nbytes, info,
                  env.mdp.log_sums, lambda buf: env.mdp.bind(log_sums=buf))
     cfg.env, cfg.state = env, state
 

@@ -12,8 +12,14 @@ cfg = BC.build("anymal", torch.device("cuda:0"), envs, 3000)
 for _ in range(3):
     cfg.step()
 torch.cuda.synchronize()
-fn = cfg.launches["raycaster_refresh"][0]
-fn = fn[0] if isinstance(fn, tuple) else fn
+env = cfg.env
+
+
+def fn():   # the whole refresh (preparation + cast) with every env due
+    env.scanner._is_outdated.fill_(True)
+    env.scanner._update_outdated_buffers(height_out=env.height_scan, height_offset=env.height_scan_offset)
+
+
 for _ in range(5):
     fn()
 torch.cuda.synchronize()

@@ -19,11 +19,13 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 KERNELS = {  # substring of the kernel symbol -> bench kernel name (launches of one bench kernel are summed per call)
     "joint_action_kernel": "joint_action_process", "mlp_mfma": "actuator_net_mlp", "actuator_lstm_kernel": "actuator_net_lstm", "scene_update_kernel": "scene_update",
-    "raycaster_update": "raycaster_refresh", "raycaster_prepare_kernel": "raycaster_refresh", "sensor_refreshed_kernel": "raycaster_refresh",
+    "raycaster_update": "raycaster_cast", "raycaster_prepare_kernel": "raycaster_prepare", "sensor_refreshed_kernel": "raycaster_cast",
+    "scene_update_prepare_kernel": "scene_update_prepare",
     "mdp_step_kernel": "mdp_step",
 }
 PRIMARY = {"actuator_net_lstm": "actuator_lstm_kernel", "joint_action_process": "joint_action_kernel", "actuator_net_mlp": "mlp_mfma", "scene_update": "scene_update_kernel",
-           "raycaster_refresh": "raycaster_update_lattice_kernel", "mdp_step": "mdp_step_kernel"}
+           "raycaster_cast": "raycaster_update_lattice_kernel", "raycaster_prepare": "raycaster_prepare_kernel",
+           "scene_update_prepare": "scene_update_prepare_kernel", "mdp_step": "mdp_step_kernel"}
 
 
 def counter_per_launch(path, counter):
