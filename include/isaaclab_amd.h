@@ -637,6 +637,21 @@ typedef struct ilx_scene {
     int32_t* contact_history_head;
 } ilx_scene;
 int ilx_scene_update(const ilx_scene* scene, void* stream);
+/* ilx_actuator_net_mlp (declared above) for physics substep k + 1 together with ilx_scene_update for substep k.  The two
+ * have no physics step between them (manager_based_rl_env.py:180-195: scene.update(dt) ends one pass of the decimation
+ * loop, action_manager.apply_action + write_data_to_sim open the next) and share no buffer: the scene update reads joint
+ * velocities and contact forces and writes joint_acc, the contact buffers and the sensor clocks; the actuator model writes
+ * torques and its histories.  For the three-sample 6-32-32-32-1-shaped networks served by the split-f16 kernel they are
+ * workgroups of one grid (one launch and its fixed cost fewer per substep, the memory-bound update beside the
+ * matrix-bound network); every other network is served by the two launches, the scene update first.  Results are those
+ * of the two calls. */
+int ilx_actuator_net_mlp_scene_update(ilx_mlp_t net, const float* q_des, const float* q, const float* qd,
+                                      float* pos_error_history, float* velocity_history, int history_length,
+                                      const int32_t* input_idx_host, int num_input_idx, int input_order, float pos_scale,
+                                      float vel_scale, float torque_scale, const float* effort_limit,
+                                      const float* velocity_limit, int params_per_env, float saturation_effort,
+                                      float* computed, float* applied, int64_t n, int j, int flags, const ilx_scene* scene,
+                                      void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Mesh ray casting — source/isaaclab/isaaclab/utils/warp/ops.py, utils/warp/kernels.py,

@@ -169,17 +169,22 @@ class ActuatorNetMLP(DCMotor):
         self._joint_pos_error_history[env_ids] = 0.0
         self._joint_vel_history[env_ids] = 0.0
 
-    def compute(self, control_action, joint_pos, joint_vel):
+    def compute(self, control_action, joint_pos, joint_vel, scene_update=None):
+        """actuator_net.py:147-188.  ``scene_update`` (no counterpart in the reference): the descriptor of the scene update
+        of the substep before (``InteractiveScene.describe_update``), which then travels with this launch."""
         q_des, q, qd = _abi.f32c(control_action.joint_positions), _abi.f32c(joint_pos), _abi.f32c(joint_vel)
         n, j = q.shape
         self._joint_vel = joint_vel
-        _abi.check(_abi.actuator_net_mlp(
-            self.network.handle, _abi.ptr(q_des), _abi.ptr(q), _abi.ptr(qd), _abi.ptr(self._joint_pos_error_history),
-            _abi.ptr(self._joint_vel_history), self._joint_pos_error_history.shape[1], self._idx, len(self.cfg.input_idx),
-            0 if self.cfg.input_order == "pos_vel" else 1, float(self.cfg.pos_scale), float(self.cfg.vel_scale),
-            float(self.cfg.torque_scale), _abi.ptr(self.effort_limit), _abi.ptr(self.velocity_limit), 1,
-            float(self._saturation_effort), _abi.ptr(self.computed_effort), _abi.ptr(self.applied_effort), n, j,
-            self._flags, _abi.stream()), "ilx_actuator_net_mlp")
+        args = (self.network.handle, _abi.ptr(q_des), _abi.ptr(q), _abi.ptr(qd), _abi.ptr(self._joint_pos_error_history),
+                _abi.ptr(self._joint_vel_history), self._joint_pos_error_history.shape[1], self._idx, len(self.cfg.input_idx),
+                0 if self.cfg.input_order == "pos_vel" else 1, float(self.cfg.pos_scale), float(self.cfg.vel_scale),
+                float(self.cfg.torque_scale), _abi.ptr(self.effort_limit), _abi.ptr(self.velocity_limit), 1,
+                float(self._saturation_effort), _abi.ptr(self.computed_effort), _abi.ptr(self.applied_effort), n, j, self._flags)
+        if scene_update is not None:
+            _abi.check(_abi.actuator_net_mlp_scene_update(*args, ctypes.byref(scene_update), _abi.stream()),
+                       "ilx_actuator_net_mlp_scene_update")
+        else:
+            _abi.check(_abi.actuator_net_mlp(*args, _abi.stream()), "ilx_actuator_net_mlp")
         control_action.joint_efforts = self.applied_effort
         control_action.joint_positions = None
         control_action.joint_velocities = None

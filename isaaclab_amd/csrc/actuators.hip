@@ -12,6 +12,7 @@
 #include "common.h"
 #include "math_dev.h"
 #include "mlp_net.h"
+#include "scene_update_dev.h"
 #include "uniform_access.h"
 
 #include <algorithm>
@@ -549,15 +550,16 @@ __device__ unsigned long long g_mlp_stamps[8 * 2048];
 #endif
 
 // POS_VEL: 0, or the history length K of a launch whose feature list is the usual one (see finish_row_pos_vel).
+// `block`: the workgroup's index among the network's workgroups (the launch may hold others: mlp_split_scene_kernel).
 template <int ACT, int NHID, int POS_VEL>
-__global__ void __launch_bounds__(256, 8) mlp_mfma_split_kernel(NetArgs a) {
+ILX_DEV void mlp_split_block(const NetArgs& a, unsigned block) {
     constexpr int kHiddenWords = (NHID - 1) * 1024;  // 4 fragments x 64 lanes x 16 bytes per hidden layer
     __shared__ __attribute__((aligned(16))) float img[kResidentHist * 64 + kHiddenWords + NHID * 32 + 32 + 4];
     ILX_MLP_STAMP(0)
     const int lane = threadIdx.x & 63;
     const int half = lane >> 5;
     const int64_t tiles = (a.rows + 31) / 32;
-    const int64_t tile = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+    const int64_t tile = static_cast<int64_t>(block) * 4 + (threadIdx.x >> 6);
     const bool live = tile < tiles;  // wave-uniform
 
     const uint32_t j = static_cast<uint32_t>(a.j);
@@ -635,6 +637,27 @@ __global__ void __launch_bounds__(256, 8) mlp_mfma_split_kernel(NetArgs a) {
         store_history(a, at, cur, half == 0, half == 1);
     }
     ILX_MLP_STAMP(6)
+}
+
+template <int ACT, int NHID, int POS_VEL>
+__global__ void __launch_bounds__(256, 8) mlp_mfma_split_kernel(NetArgs a) {
+    mlp_split_block<ACT, NHID, POS_VEL>(a, blockIdx.x);
+}
+
+// The actuator network of one physics substep and the scene update of the substep before it, which have no physics step
+// between them and share no buffer (articulation.py:1399-1436 writes torques and the network's histories;
+// interactive_scene.py:496-513 reads joint velocities and contact forces and writes joint_acc, the contact buffers and
+// the sensor clocks), as workgroups of one grid: the network's first -- it is the longer of the two and bound by the
+// vector and matrix pipes --, the update's, bound by memory, fill in beside them.  One launch and its fixed cost fewer
+// per substep, and the overlap of the two does not depend on how two queues happen to run.
+// Registers: seven wavefronts per SIMD (72 vector registers) -- held to eight (64) the two bodies in one function spill.
+// `mlp_first`, `su_first`: where each kind's workgroups start in the grid.
+template <int ACT>
+__global__ void __launch_bounds__(256, 7) mlp_split_scene_kernel(NetArgs a, SceneArgs s, unsigned mlp_first, unsigned mlp_blocks,
+                                                                 unsigned su_first) {
+    const unsigned b = blockIdx.x;
+    if (b >= mlp_first && b - mlp_first < mlp_blocks) mlp_split_block<ACT, 3, 3>(a, b - mlp_first);
+    else scene_update_thread(s, b - su_first);
 }
 
 }  // namespace ilx
@@ -806,8 +829,17 @@ extern "C" int ilx_actuator_pd(int model, const float* q_des, const float* qd_de
     return ILX_OK;
 }
 
+// `scene` (or null): the scene update that goes with this launch -- as workgroups of the same grid where the launch is
+// the three-sample split kernel's, else as a launch of its own ahead of it.
 template <int ACT>
-static void launch_mlp(const NetArgs& a, bool force_generic, bool exact_f32, hipStream_t s) {
+static int launch_mlp(const NetArgs& a, bool force_generic, bool exact_f32, hipStream_t s, const ilx_scene* scene = nullptr) {
+    SceneArgs sa{};
+    unsigned su_blocks = 0;
+    if (scene) {
+        const int rc = scene_args_from(*scene, sa, su_blocks);
+        if (rc != ILX_OK) return rc;
+    }
+    bool scene_inside = false;
     if (a.net.packed && !force_generic) {
         const int64_t tiles = (a.rows + 31) / 32;
         const int nhid = a.net.num_layers - 1;
@@ -820,7 +852,18 @@ static void launch_mlp(const NetArgs& a, bool force_generic, bool exact_f32, hip
         bool pos_vel = a.n_feat == 2 * a.hist_len;
         for (int f = 0; f < a.n_feat && pos_vel; ++f)
             pos_vel = a.feat_slot[f] == f % a.hist_len && (((a.feat_is_pos >> f) & 1u) != 0) == (f < a.hist_len);
-        if (nhid == 3 && small && split && pos_vel && a.hist_len == 3)   // the ANYdrive network's shape: three samples
+        scene_inside = scene && scene->num_envs > 0 && nhid == 3 && small && split && pos_vel && a.hist_len == 3;
+        if (scene && !scene_inside) {
+            const int rc = ilx_scene_update(scene, s);
+            if (rc != ILX_OK) return rc;
+        }
+        if (scene_inside)
+        {
+            static const bool su_first = getenv("ILX_FUSED_SU_FIRST") && atoi(getenv("ILX_FUSED_SU_FIRST")) != 0;
+            hipLaunchKernelGGL((mlp_split_scene_kernel<ACT>), dim3(tile_blocks + su_blocks), dim3(256), 0, s, a, sa,
+                               su_first ? su_blocks : 0u, tile_blocks, su_first ? 0u : tile_blocks);
+        }
+        else if (nhid == 3 && small && split && pos_vel && a.hist_len == 3)   // the ANYdrive network's shape: three samples
             hipLaunchKernelGGL((mlp_mfma_split_kernel<ACT, 3, 3>), dim3(tile_blocks), dim3(256), 0, s, a);
         else if (nhid == 3 && small && split)
             hipLaunchKernelGGL((mlp_mfma_split_kernel<ACT, 3, 0>), dim3(tile_blocks), dim3(256), 0, s, a);
@@ -833,16 +876,21 @@ static void launch_mlp(const NetArgs& a, bool force_generic, bool exact_f32, hip
         else
             hipLaunchKernelGGL(mlp_mfma_kernel<ACT>, dim3(static_cast<unsigned>((tiles + 3) / 4)), dim3(256), 0, s, a);
     } else {
+        if (scene) {
+            const int rc = ilx_scene_update(scene, s);
+            if (rc != ILX_OK) return rc;
+        }
         hipLaunchKernelGGL(mlp_generic_kernel<ACT>, dim3(blocks_for(a.rows, 128)), dim3(128), 0, s, a);
     }
+    return ILX_OK;
 }
 
-extern "C" int ilx_actuator_net_mlp(ilx_mlp_t net, const float* q_des, const float* q, const float* qd,
-                                    float* pos_error_history, float* velocity_history, int history_length,
-                                    const int32_t* input_idx_host, int num_input_idx, int input_order, float pos_scale,
-                                    float vel_scale, float torque_scale, const float* effort_limit,
-                                    const float* velocity_limit, int params_per_env, float saturation_effort,
-                                    float* computed, float* applied, int64_t n, int j, int flags, void* stream) {
+static int actuator_net_mlp(ilx_mlp_t net, const float* q_des, const float* q, const float* qd,
+                            float* pos_error_history, float* velocity_history, int history_length,
+                            const int32_t* input_idx_host, int num_input_idx, int input_order, float pos_scale,
+                            float vel_scale, float torque_scale, const float* effort_limit,
+                            const float* velocity_limit, int params_per_env, float saturation_effort,
+                            float* computed, float* applied, int64_t n, int j, int flags, const ilx_scene* scene, void* stream) {
     ILX_REQUIRE(net, ILX_EINVAL, "ilx_actuator_net_mlp: net is NULL");
     ILX_REQUIRE(n >= 0 && j > 0, ILX_EINVAL, "ilx_actuator_net_mlp: bad shape (%lld, %d)", (long long)n, j);
     ILX_REQUIRE(q_des && q && qd && pos_error_history && velocity_history && effort_limit && velocity_limit && computed &&
@@ -873,18 +921,44 @@ extern "C" int ilx_actuator_net_mlp(ilx_mlp_t net, const float* q_des, const flo
     a.effort_limit = effort_limit, a.vel_limit = velocity_limit, a.per_env = params_per_env, a.sat = saturation_effort;
     a.computed = computed, a.applied = applied;
     a.rows = n * j, a.j = j, a.inv_j = 1.0f / static_cast<float>(j);
-    if (a.rows == 0) return ILX_OK;
+    if (a.rows == 0) return scene ? ilx_scene_update(scene, stream) : ILX_OK;
     hipStream_t s = as_stream(stream);
     const bool generic = (flags & ILX_MLP_FORCE_GENERIC) != 0, exact = (flags & ILX_MLP_EXACT_F32) != 0;
+    int rc = ILX_OK;
     switch (a.net.act) {
-        case ILX_ACT_SOFTSIGN: launch_mlp<ILX_ACT_SOFTSIGN>(a, generic, exact, s); break;
-        case ILX_ACT_ELU: launch_mlp<ILX_ACT_ELU>(a, generic, exact, s); break;
-        case ILX_ACT_TANH: launch_mlp<ILX_ACT_TANH>(a, generic, exact, s); break;
-        case ILX_ACT_RELU: launch_mlp<ILX_ACT_RELU>(a, generic, exact, s); break;
-        default: launch_mlp<ILX_ACT_IDENTITY>(a, generic, exact, s); break;
+        case ILX_ACT_SOFTSIGN: rc = launch_mlp<ILX_ACT_SOFTSIGN>(a, generic, exact, s, scene); break;
+        case ILX_ACT_ELU: rc = launch_mlp<ILX_ACT_ELU>(a, generic, exact, s, scene); break;
+        case ILX_ACT_TANH: rc = launch_mlp<ILX_ACT_TANH>(a, generic, exact, s, scene); break;
+        case ILX_ACT_RELU: rc = launch_mlp<ILX_ACT_RELU>(a, generic, exact, s, scene); break;
+        default: rc = launch_mlp<ILX_ACT_IDENTITY>(a, generic, exact, s, scene); break;
     }
+    if (rc != ILX_OK) return rc;
     ILX_LAUNCH_CHECK("ilx_actuator_net_mlp");
     return ILX_OK;
+}
+
+extern "C" int ilx_actuator_net_mlp(ilx_mlp_t net, const float* q_des, const float* q, const float* qd,
+                                    float* pos_error_history, float* velocity_history, int history_length,
+                                    const int32_t* input_idx_host, int num_input_idx, int input_order, float pos_scale,
+                                    float vel_scale, float torque_scale, const float* effort_limit,
+                                    const float* velocity_limit, int params_per_env, float saturation_effort,
+                                    float* computed, float* applied, int64_t n, int j, int flags, void* stream) {
+    return actuator_net_mlp(net, q_des, q, qd, pos_error_history, velocity_history, history_length, input_idx_host, num_input_idx,
+                            input_order, pos_scale, vel_scale, torque_scale, effort_limit, velocity_limit, params_per_env,
+                            saturation_effort, computed, applied, n, j, flags, nullptr, stream);
+}
+
+extern "C" int ilx_actuator_net_mlp_scene_update(ilx_mlp_t net, const float* q_des, const float* q, const float* qd,
+                                                 float* pos_error_history, float* velocity_history, int history_length,
+                                                 const int32_t* input_idx_host, int num_input_idx, int input_order,
+                                                 float pos_scale, float vel_scale, float torque_scale,
+                                                 const float* effort_limit, const float* velocity_limit, int params_per_env,
+                                                 float saturation_effort, float* computed, float* applied, int64_t n, int j,
+                                                 int flags, const ilx_scene* scene, void* stream) {
+    ILX_REQUIRE(scene, ILX_EINVAL, "ilx_actuator_net_mlp_scene_update: scene is NULL");
+    return actuator_net_mlp(net, q_des, q, qd, pos_error_history, velocity_history, history_length, input_idx_host, num_input_idx,
+                            input_order, pos_scale, vel_scale, torque_scale, effort_limit, velocity_limit, params_per_env,
+                            saturation_effort, computed, applied, n, j, flags, scene, stream);
 }
 
 extern "C" int ilx_actuator_delayed_pd(const float* q_des, const float* qd_des, const float* tau_ff, const float* q,

@@ -108,6 +108,9 @@ class LocomotionVelocityStep:
         self._side_stream = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
         # the last scene update of a step also issues the preparation of the scanner's refresh (see step_sensors)
         self.fuse_scanner_preparation = True
+        # network actuators: the step as one chain with scene.update(k) and the actuator model of substep k + 1 as one
+        # launch (see _step_paired); concurrent_chains takes precedence
+        self.paired_substeps = True
 
     def _bind(self):
         d, c = self.data, self.contact._data
@@ -159,6 +162,8 @@ class LocomotionVelocityStep:
         a fork and a join, so the memory-bound sensor updates can run beside the compute-bound actuator network; a
         caller that replays the step from HIP graphs can also record the three parts separately and launch (A) and (B)
         on two streams of its own."""
+        if self.paired_substeps and isinstance(self.actuator, ActuatorNetMLP) and not self.concurrent_chains:
+            return self._step_paired(raw_action, noise_u, command_samples, reset_command_samples)
         main = torch.cuda.current_stream()
         side = self._side_stream if self.concurrent_chains else main
         if side is not main:
@@ -173,6 +178,43 @@ class LocomotionVelocityStep:
         self.step_actuators(raw_action, begin)
         if side is not main:
             main.wait_stream(side)
+        return self.step_managers(noise_u, command_samples, reset_command_samples)
+
+    def _step_paired(self, raw_action, noise_u, command_samples, reset_command_samples):
+        """The step as one chain in the reference's own order (manager_based_rl_env.py:172-195), with the launches that
+        have no physics step between them paired: process_action; actuator(0); <physics 0>; {scene.update(0), actuator(1)}
+        as one launch; <physics 1>; ... ; {scene.update(D-1), scanner preparation} as one launch; the scanner's cast; the
+        managers.  Eight launches instead of twelve, and nothing runs ahead of a physics step it would depend on."""
+        d, ph = self.data, self.physics
+        begin = None
+        if self.clear_log_sums or self._advance_count_first:
+            begin = self.mdp.begin_step_args(self.clear_log_sums, self._advance_count_first)
+        n, j = self.n, d._j
+        args = (_abi.ptr(raw_action), _abi.ptr(self.action), _abi.ptr(self.prev_action), None, self.action_scale,
+                _abi.ptr(d.default_joint_pos), 0.0, None, _abi.ptr(d.joint_pos_target), n, j)
+        if begin is not None:
+            _abi.check(_abi.joint_action_process_begin(*args, *begin, _abi.stream()), "ilx_joint_action_process_begin")
+        else:
+            _abi.check(_abi.joint_action_process(*args, _abi.stream()), "ilx_joint_action_process")
+        prepared = False
+        for k in range(LV.DECIMATION + 1):
+            update = None
+            if k > 0:   # the scene update of substep k - 1 (its physics results: ph[...][k - 1])
+                d.joint_pos, d.joint_vel = ph["joint_pos"][k - 1], ph["joint_vel"][k - 1]
+                self.contact.set_net_contact_forces(ph["net_forces"][k - 1])
+                if k == LV.DECIMATION:
+                    self._bind_scanner_pose()
+                    prepared = self.scene.update(LV.PHYSICS_DT, prepare_scanner=self.fuse_scanner_preparation)
+                    break
+                update = self.scene.describe_update(LV.PHYSICS_DT)
+                if update is None:
+                    self.scene.update(LV.PHYSICS_DT)
+            # the actuator model of substep k
+            d.joint_pos, d.joint_vel = ph["joint_pos"][k], ph["joint_vel"][k]
+            ca = ArticulationActions(joint_positions=d.joint_pos_target, joint_velocities=d.joint_vel_target,
+                                     joint_efforts=d.joint_effort_target, joint_indices=slice(None))
+            self.actuator.compute(ca, d.joint_pos, d.joint_vel, scene_update=update)
+        self.scanner._update_outdated_buffers(height_out=self.height_scan, height_offset=self.height_scan_offset, prepared=prepared)
         return self.step_managers(noise_u, command_samples, reset_command_samples)
 
     def count_steps_on_device(self):

@@ -49,21 +49,15 @@ class InteractiveScene:
             if hasattr(a, "write_data_to_sim"):
                 a.write_data_to_sim()
 
-    def update(self, dt: float, prepare_scanner: bool = False) -> bool:
-        """interactive_scene.py:496-513.  ``prepare_scanner`` (no counterpart in the reference): this is the last update
-        before the height scanner is read, and the scanner's pose is final (``set_pose``): the launch also issues the
-        preparation of the scanner's refresh.  Returns whether it did -- then the refresh that follows on this stream is
-        ``scanner._update_outdated_buffers(..., prepared=True)``."""
+    def _describe(self, dt: float):
+        """The one-launch update's descriptor (``ilx_scene``) for a scene of up to one articulation, one contact sensor and
+        one ray caster, with the host-side clocks advanced as ``update`` advances them; None for any other scene."""
         arts = list(self.articulations.values())
         contacts = [s for s in self.sensors.values() if isinstance(s, ContactSensor)]
         rays = [s for s in self.sensors.values() if isinstance(s, RayCaster)]
         fusable = len(arts) <= 1 and len(contacts) <= 1 and len(rays) <= 1 and len(contacts) + len(rays) == len(self.sensors)
         if not fusable:
-            for a in arts:
-                a.update(dt)
-            for s in self.sensors.values():
-                s.update(dt, force_recompute=not self.lazy_sensor_update)
-            return False
+            return None
         force = not self.lazy_sensor_update
         sc = _abi.Scene(num_envs=self.num_envs, dt=float(dt))
         if arts:
@@ -91,6 +85,33 @@ class InteractiveScene:
             r = rays[0]
             sc.ray_timestamp, sc.ray_timestamp_last_update = _abi.ptr(r._timestamp), _abi.ptr(r._timestamp_last_update)
             sc.ray_is_outdated, sc.ray_update_period = r._is_outdated.data_ptr(), float(r.cfg.update_period)
+        return sc, rays, force
+
+    def describe_update(self, dt: float):
+        """``update(dt)`` for a caller that issues the launch itself, together with another one
+        (``ActuatorNetMLP.compute(..., scene_update=...)``): the descriptor, or None when this scene's update is not one
+        launch (several assets, sensors that refresh eagerly) -- then call ``update``."""
+        desc = self._describe(dt)
+        if desc is None:
+            return None
+        sc, rays, force = desc
+        if rays and (force or rays[0].cfg.history_length > 0):
+            raise _abi.IlxError("describe_update: the ray caster of this scene refreshes with every update; use update()")
+        return sc
+
+    def update(self, dt: float, prepare_scanner: bool = False) -> bool:
+        """interactive_scene.py:496-513.  ``prepare_scanner`` (no counterpart in the reference): this is the last update
+        before the height scanner is read, and the scanner's pose is final (``set_pose``): the launch also issues the
+        preparation of the scanner's refresh.  Returns whether it did -- then the refresh that follows on this stream is
+        ``scanner._update_outdated_buffers(..., prepared=True)``."""
+        desc = self._describe(dt)
+        if desc is None:
+            for a in self.articulations.values():
+                a.update(dt)
+            for s in self.sensors.values():
+                s.update(dt, force_recompute=not self.lazy_sensor_update)
+            return False
+        sc, rays, force = desc
         eager_rays = bool(rays) and (force or rays[0].cfg.history_length > 0)
         if prepare_scanner and rays and not eager_rays and not rays[0].static_workspace:
             rc = rays[0]._descriptor()

@@ -94,8 +94,49 @@ def measure(label, cap_priority=0, **kw):
 
 
 full = dict(n_su=4, refresh=True, n_mlp=4, small=True, managers=True, branches=True)
+
+
+def measure_fn(label, fn):
+    cfg.restart_sensor_clocks()
+    cap = torch.cuda.Stream()
+    cap.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(cap):
+        for _ in range(3):
+            fn()
+    cap.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=cap):
+        fn()
+    for _ in range(30):
+        g.replay()
+    torch.cuda.synchronize()
+    K = 300
+    t0 = time.perf_counter()
+    for _ in range(K):
+        g.replay()
+    torch.cuda.synchronize()
+    print(f"{label:60s} {1e6 * (time.perf_counter() - t0) / K:6.1f} us per replay", flush=True)
+
+
+env.clear_log_sums = True
+
+
+def two_chains():
+    env.concurrent_chains, env.paired_substeps = True, False
+    env.step(raw)
+
+
+def one_chain():
+    env.concurrent_chains, env.paired_substeps = False, False
+    env.step(raw)
+
+
+def paired():
+    env.concurrent_chains, env.paired_substeps = False, True
+    env.step(raw)
+
+
 for rep in range(2):
-    measure("full step, two branches", **full)
-    measure("full step, one chain", **dict(full, branches=False))
-    measure("no managers", **dict(full, managers=False))
-    measure("actuator chain without the network launches", **dict(full, n_mlp=0))
+    measure_fn("two branches", two_chains)
+    measure_fn("one chain, separate launches", one_chain)
+    measure_fn("one chain, paired substeps", paired)
