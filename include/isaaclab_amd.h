@@ -645,6 +645,11 @@ int ilx_scene_update(const ilx_scene* scene, void* stream);
  * workgroups of one grid (one launch and its fixed cost fewer per substep, the memory-bound update beside the
  * matrix-bound network); every other network is served by the two launches, the scene update first.  Results are those
  * of the two calls. */
+/* The same pairing for the PD models (ilx_actuator_pd, declared above): always one launch. */
+int ilx_actuator_pd_scene_update(int model, const float* q_des, const float* qd_des, const float* tau_ff, const float* q,
+                                 const float* qd, const float* stiffness, const float* damping, const float* effort_limit,
+                                 const float* velocity_limit, int params_per_env, float saturation_effort, float* computed,
+                                 float* applied, int64_t n, int j, const ilx_scene* scene, void* stream);
 int ilx_actuator_net_mlp_scene_update(ilx_mlp_t net, const float* q_des, const float* q, const float* qd,
                                       float* pos_error_history, float* velocity_history, int history_length,
                                       const int32_t* input_idx_host, int num_input_idx, int input_order, float pos_scale,

@@ -7,6 +7,8 @@ from __future__ import annotations
 
 from collections.abc import Sequence
 
+import ctypes
+
 import torch
 
 from .. import _abi
@@ -16,17 +18,20 @@ from .actuator_base import ActuatorBase
 _IDEAL, _DC = 0, 1
 
 
-def _launch_pd(model, act, control_action, joint_pos, joint_vel, vel_limit, sat):
+def _launch_pd(model, act, control_action, joint_pos, joint_vel, vel_limit, sat, scene_update=None):
     q_des = _abi.f32c(control_action.joint_positions)
     qd_des = None if control_action.joint_velocities is None else _abi.f32c(control_action.joint_velocities)
     tau_ff = None if control_action.joint_efforts is None else _abi.f32c(control_action.joint_efforts)
     q, qd = _abi.f32c(joint_pos), _abi.f32c(joint_vel)
     n, j = q.shape
-    _abi.check(_abi.actuator_pd(
-        model, _abi.ptr(q_des), _abi.ptr(qd_des), _abi.ptr(tau_ff), _abi.ptr(q), _abi.ptr(qd),
-        _abi.ptr(act.stiffness), _abi.ptr(act.damping), _abi.ptr(act.effort_limit),
-        None if vel_limit is None else _abi.ptr(vel_limit), 1, float(sat), _abi.ptr(act.computed_effort),
-        _abi.ptr(act.applied_effort), n, j, _abi.stream()), "ilx_actuator_pd")
+    args = (model, _abi.ptr(q_des), _abi.ptr(qd_des), _abi.ptr(tau_ff), _abi.ptr(q), _abi.ptr(qd),
+            _abi.ptr(act.stiffness), _abi.ptr(act.damping), _abi.ptr(act.effort_limit),
+            None if vel_limit is None else _abi.ptr(vel_limit), 1, float(sat), _abi.ptr(act.computed_effort),
+            _abi.ptr(act.applied_effort), n, j)
+    if scene_update is not None:   # the scene update of the substep before travels with this launch
+        _abi.check(_abi.actuator_pd_scene_update(*args, ctypes.byref(scene_update), _abi.stream()), "ilx_actuator_pd_scene_update")
+    else:
+        _abi.check(_abi.actuator_pd(*args, _abi.stream()), "ilx_actuator_pd")
 
 
 class ImplicitActuator(ActuatorBase):
@@ -35,8 +40,8 @@ class ImplicitActuator(ActuatorBase):
     def reset(self, *args, **kwargs):
         pass
 
-    def compute(self, control_action, joint_pos, joint_vel):
-        _launch_pd(_IDEAL, self, control_action, joint_pos, joint_vel, None, 0.0)
+    def compute(self, control_action, joint_pos, joint_vel, scene_update=None):
+        _launch_pd(_IDEAL, self, control_action, joint_pos, joint_vel, None, 0.0, scene_update)
         return control_action
 
 
@@ -46,8 +51,10 @@ class IdealPDActuator(ActuatorBase):
     def reset(self, env_ids: Sequence[int]):
         pass
 
-    def compute(self, control_action, joint_pos, joint_vel):
-        _launch_pd(_IDEAL, self, control_action, joint_pos, joint_vel, None, 0.0)
+    def compute(self, control_action, joint_pos, joint_vel, scene_update=None):
+        """``scene_update`` (no counterpart in the reference): the descriptor of the scene update of the substep before
+        (``InteractiveScene.describe_update``), which then travels with this launch."""
+        _launch_pd(_IDEAL, self, control_action, joint_pos, joint_vel, None, 0.0, scene_update)
         control_action.joint_efforts = self.applied_effort
         control_action.joint_positions = None
         control_action.joint_velocities = None
@@ -64,9 +71,9 @@ class DCMotor(IdealPDActuator):
         if self.cfg.velocity_limit is None:
             raise ValueError("The velocity limit must be provided for the DC motor actuator model.")
 
-    def compute(self, control_action, joint_pos, joint_vel):
+    def compute(self, control_action, joint_pos, joint_vel, scene_update=None):
         self._joint_vel = joint_vel  # kept for API compatibility; the kernel reads joint_vel directly
-        _launch_pd(_DC, self, control_action, joint_pos, joint_vel, self.velocity_limit, self._saturation_effort)
+        _launch_pd(_DC, self, control_action, joint_pos, joint_vel, self.velocity_limit, self._saturation_effort, scene_update)
         control_action.joint_efforts = self.applied_effort
         control_action.joint_positions = None
         control_action.joint_velocities = None

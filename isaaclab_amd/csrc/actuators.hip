@@ -23,14 +23,14 @@ namespace ilx {
 // ------------------------------------------------------------------------------------------------
 // PD family
 // ------------------------------------------------------------------------------------------------
+// `block`: the workgroup's index among the actuator's workgroups (the launch may hold others: pd_scene_kernel).
 template <int MODEL>
-__global__ void __launch_bounds__(256)
-actuator_pd_kernel(const float* __restrict__ q_des, const float* __restrict__ qd_des, const float* __restrict__ tau_ff,
-                   const float* __restrict__ q, const float* __restrict__ qd, const float* __restrict__ kp,
-                   const float* __restrict__ kd, const float* __restrict__ effort_limit,
-                   const float* __restrict__ vel_limit, int per_env, float sat, float* __restrict__ computed,
-                   float* __restrict__ applied, int64_t total, int j) {
-    const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+ILX_DEV void actuator_pd_block(const float* __restrict__ q_des, const float* __restrict__ qd_des, const float* __restrict__ tau_ff,
+                               const float* __restrict__ q, const float* __restrict__ qd, const float* __restrict__ kp,
+                               const float* __restrict__ kd, const float* __restrict__ effort_limit,
+                               const float* __restrict__ vel_limit, int per_env, float sat, float* __restrict__ computed,
+                               float* __restrict__ applied, int64_t total, int j, unsigned block) {
+    const int64_t i = static_cast<int64_t>(block) * blockDim.x + threadIdx.x;
     if (i >= total) return;
     const int64_t pi = per_env ? i : (i % j);
     const float vel = qd[i];
@@ -47,6 +47,31 @@ actuator_pd_kernel(const float* __restrict__ q_des, const float* __restrict__ qd
     }
     computed[i] = tau;
     applied[i] = out;
+}
+
+template <int MODEL>
+__global__ void __launch_bounds__(256)
+actuator_pd_kernel(const float* __restrict__ q_des, const float* __restrict__ qd_des, const float* __restrict__ tau_ff,
+                   const float* __restrict__ q, const float* __restrict__ qd, const float* __restrict__ kp,
+                   const float* __restrict__ kd, const float* __restrict__ effort_limit,
+                   const float* __restrict__ vel_limit, int per_env, float sat, float* __restrict__ computed,
+                   float* __restrict__ applied, int64_t total, int j) {
+    actuator_pd_block<MODEL>(q_des, qd_des, tau_ff, q, qd, kp, kd, effort_limit, vel_limit, per_env, sat, computed, applied, total, j,
+                             blockIdx.x);
+}
+
+// The PD actuator model of one physics substep and the scene update of the substep before it as workgroups of one grid
+// (see mlp_split_scene_kernel below for why the two go together): both are short and bound by the launch's fixed cost.
+template <int MODEL>
+__global__ void __launch_bounds__(256)
+pd_scene_kernel(const float* __restrict__ q_des, const float* __restrict__ qd_des, const float* __restrict__ tau_ff,
+                const float* __restrict__ q, const float* __restrict__ qd, const float* __restrict__ kp,
+                const float* __restrict__ kd, const float* __restrict__ effort_limit, const float* __restrict__ vel_limit,
+                int per_env, float sat, float* __restrict__ computed, float* __restrict__ applied, int64_t total, int j,
+                SceneArgs s, unsigned su_blocks) {
+    if (blockIdx.x < su_blocks) scene_update_thread(s, blockIdx.x);
+    else actuator_pd_block<MODEL>(q_des, qd_des, tau_ff, q, qd, kp, kd, effort_limit, vel_limit, per_env, sat, computed, applied, total,
+                                  j, blockIdx.x - su_blocks);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -804,10 +829,10 @@ extern "C" void ilx_mlp_destroy(ilx_mlp_t net) {
     delete net;
 }
 
-extern "C" int ilx_actuator_pd(int model, const float* q_des, const float* qd_des, const float* tau_ff, const float* q,
-                               const float* qd, const float* stiffness, const float* damping, const float* effort_limit,
-                               const float* velocity_limit, int params_per_env, float saturation_effort, float* computed,
-                               float* applied, int64_t n, int j, void* stream) {
+static int actuator_pd(int model, const float* q_des, const float* qd_des, const float* tau_ff, const float* q,
+                       const float* qd, const float* stiffness, const float* damping, const float* effort_limit,
+                       const float* velocity_limit, int params_per_env, float saturation_effort, float* computed,
+                       float* applied, int64_t n, int j, const ilx_scene* scene, void* stream) {
     ILX_REQUIRE(model == ILX_ACTUATOR_IDEAL_PD || model == ILX_ACTUATOR_DC_MOTOR, ILX_EINVAL,
                 "ilx_actuator_pd: unknown model %d", model);
     ILX_REQUIRE(n >= 0 && j > 0, ILX_EINVAL, "ilx_actuator_pd: bad shape (%lld, %d)", (long long)n, j);
@@ -816,10 +841,22 @@ extern "C" int ilx_actuator_pd(int model, const float* q_des, const float* qd_de
     ILX_REQUIRE(model != ILX_ACTUATOR_DC_MOTOR || velocity_limit, ILX_EINVAL,
                 "ilx_actuator_pd: the DC motor model needs velocity_limit");
     const int64_t total = n * j;
-    if (total == 0) return ILX_OK;
+    if (total == 0) return scene ? ilx_scene_update(scene, stream) : ILX_OK;
     dim3 g(blocks_for(total)), b(256);
     hipStream_t s = as_stream(stream);
-    if (model == ILX_ACTUATOR_DC_MOTOR)
+    if (scene && scene->num_envs > 0) {   // the scene update's workgroups first, the actuator's behind them
+        SceneArgs sa{};
+        unsigned su_blocks = 0;
+        const int rc = scene_args_from(*scene, sa, su_blocks);
+        if (rc != ILX_OK) return rc;
+        dim3 both(g.x + su_blocks);
+        if (model == ILX_ACTUATOR_DC_MOTOR)
+            hipLaunchKernelGGL(pd_scene_kernel<1>, both, b, 0, s, q_des, qd_des, tau_ff, q, qd, stiffness, damping, effort_limit,
+                               velocity_limit, params_per_env, saturation_effort, computed, applied, total, j, sa, su_blocks);
+        else
+            hipLaunchKernelGGL(pd_scene_kernel<0>, both, b, 0, s, q_des, qd_des, tau_ff, q, qd, stiffness, damping, effort_limit,
+                               velocity_limit, params_per_env, saturation_effort, computed, applied, total, j, sa, su_blocks);
+    } else if (model == ILX_ACTUATOR_DC_MOTOR)
         hipLaunchKernelGGL(actuator_pd_kernel<1>, g, b, 0, s, q_des, qd_des, tau_ff, q, qd, stiffness, damping,
                            effort_limit, velocity_limit, params_per_env, saturation_effort, computed, applied, total, j);
     else
@@ -827,6 +864,24 @@ extern "C" int ilx_actuator_pd(int model, const float* q_des, const float* qd_de
                            effort_limit, velocity_limit, params_per_env, saturation_effort, computed, applied, total, j);
     ILX_LAUNCH_CHECK("ilx_actuator_pd");
     return ILX_OK;
+}
+
+extern "C" int ilx_actuator_pd(int model, const float* q_des, const float* qd_des, const float* tau_ff, const float* q,
+                               const float* qd, const float* stiffness, const float* damping, const float* effort_limit,
+                               const float* velocity_limit, int params_per_env, float saturation_effort, float* computed,
+                               float* applied, int64_t n, int j, void* stream) {
+    return actuator_pd(model, q_des, qd_des, tau_ff, q, qd, stiffness, damping, effort_limit, velocity_limit, params_per_env,
+                       saturation_effort, computed, applied, n, j, nullptr, stream);
+}
+
+extern "C" int ilx_actuator_pd_scene_update(int model, const float* q_des, const float* qd_des, const float* tau_ff, const float* q,
+                                            const float* qd, const float* stiffness, const float* damping,
+                                            const float* effort_limit, const float* velocity_limit, int params_per_env,
+                                            float saturation_effort, float* computed, float* applied, int64_t n, int j,
+                                            const ilx_scene* scene, void* stream) {
+    ILX_REQUIRE(scene, ILX_EINVAL, "ilx_actuator_pd_scene_update: scene is NULL");
+    return actuator_pd(model, q_des, qd_des, tau_ff, q, qd, stiffness, damping, effort_limit, velocity_limit, params_per_env,
+                       saturation_effort, computed, applied, n, j, scene, stream);
 }
 
 // `scene` (or null): the scene update that goes with this launch -- as workgroups of the same grid where the launch is

@@ -108,8 +108,8 @@ class LocomotionVelocityStep:
         self._side_stream = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
         # the last scene update of a step also issues the preparation of the scanner's refresh (see step_sensors)
         self.fuse_scanner_preparation = True
-        # network actuators: the step as one chain with scene.update(k) and the actuator model of substep k + 1 as one
-        # launch (see _step_paired); concurrent_chains takes precedence
+        # the step as one chain with scene.update(k) and the actuator model of substep k + 1 as one launch (see
+        # _step_paired; MLP and DC-motor actuators); concurrent_chains takes precedence
         self.paired_substeps = True
 
     def _bind(self):
@@ -162,7 +162,7 @@ class LocomotionVelocityStep:
         a fork and a join, so the memory-bound sensor updates can run beside the compute-bound actuator network; a
         caller that replays the step from HIP graphs can also record the three parts separately and launch (A) and (B)
         on two streams of its own."""
-        if self.paired_substeps and isinstance(self.actuator, ActuatorNetMLP) and not self.concurrent_chains:
+        if self.paired_substeps and isinstance(self.actuator, (ActuatorNetMLP, DCMotor)) and not self.concurrent_chains:
             return self._step_paired(raw_action, noise_u, command_samples, reset_command_samples)
         main = torch.cuda.current_stream()
         side = self._side_stream if self.concurrent_chains else main

@@ -13,6 +13,7 @@ The rough-terrain locomotion configs (contact sensor, ray caster, actuator net) 
 
 from __future__ import annotations
 
+import ctypes
 import types
 
 import torch
@@ -111,7 +112,9 @@ class ManagerBasedStep:
         else:
             _abi.check(_abi.joint_action_process(*args, _abi.stream()), "ilx_joint_action_process")
 
-    def apply_action(self):
+    paired_substeps = True   # see step()
+
+    def apply_action(self, scene_update=None):
         raise NotImplementedError
 
     def step(self, raw_action: torch.Tensor, noise_u=None, command_samples=None, reset_command_samples=None):
@@ -126,10 +129,15 @@ class ManagerBasedStep:
                 self.mdp.begin_step(clear_log_sums=self.clear_log_sums, advance_step_count=self._advance_count_first)
         self.process_action(raw_action)
         self._begin = None
+        update = None
         for k in range(self.decimation):
-            self.apply_action()                              # action terms' apply_actions + write_data_to_sim (actuators)
+            # action terms' apply_actions + write_data_to_sim (actuators); from the second substep on the launch of the
+            # actuator model also carries the scene update of the substep before (no physics step lies between them)
+            self.apply_action(update)
             d.joint_pos, d.joint_vel = ph["joint_pos"][k], ph["joint_vel"][k]   # <sim.step>
-            self.scene.update(self.physics_dt)
+            update = self.scene.describe_update(self.physics_dt) if (self.paired_substeps and k + 1 < self.decimation) else None
+            if update is None:
+                self.scene.update(self.physics_dt)
         d.set_sim_state(root_state_w=ph["root_state_w"], body_state_w=ph.get("body_state_w"))
         m = self.mdp
         m.bind(root_state_w=d.root_state_w, joint_pos=d.joint_pos, joint_vel=d.joint_vel, joint_acc=d._joint_acc,
@@ -170,12 +178,12 @@ class CartpoleStep(ManagerBasedStep):
     def process_action(self, raw):  # joint_actions.py:130-139, 214-225 (JointEffortAction, no offset)
         self._joint_action(_abi.f32c(raw), CP.ACTION_SCALE, None, self._effort, 1)
 
-    def apply_action(self):
+    def apply_action(self, scene_update=None):
         d = self.data
         d.joint_effort_target[:, 0:1] = self._effort          # set_joint_effort_target(processed, joint_ids=[cart])
         ca = ArticulationActions(joint_positions=d.joint_pos_target, joint_velocities=d.joint_vel_target,
                                  joint_efforts=d.joint_effort_target, joint_indices=slice(None))
-        self.actuator.compute(ca, d.joint_pos, d.joint_vel)
+        self.actuator.compute(ca, d.joint_pos, d.joint_vel, scene_update=scene_update)
 
 
 class ReachStep(ManagerBasedStep):
@@ -237,12 +245,15 @@ class ReachStep(ManagerBasedStep):
             self.action.copy_(raw)
             self.ik.process_actions(raw)
 
-    def apply_action(self):
+    def apply_action(self, scene_update=None):
         d = self.data
         if self.ik is None:
             d.joint_pos_target[:, self._arm_index] = self._arm_target
         else:
+            if scene_update is not None:   # the IK term reads what the update writes (joint state of the new substep): in order
+                _abi.check(_abi.scene_update(ctypes.byref(scene_update), _abi.stream()), "ilx_scene_update")
+                scene_update = None
             self.ik.apply_actions()
         ca = ArticulationActions(joint_positions=d.joint_pos_target, joint_velocities=d.joint_vel_target,
                                  joint_efforts=d.joint_effort_target, joint_indices=slice(None))
-        self.actuator.compute(ca, d.joint_pos, d.joint_vel)
+        self.actuator.compute(ca, d.joint_pos, d.joint_vel, scene_update=scene_update)

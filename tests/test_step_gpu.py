@@ -201,19 +201,20 @@ def test_step_replayed_from_a_graph_equals_eager(dev):
     assert not torch.equal(outs[1][0][0], outs[1][1][0]), "a replay draws new observation noise"
 
 
-def test_paired_substeps_equal_separate_launches(dev):
-    """The step as one chain with {scene.update(k), actuator network of substep k + 1} as one launch
-    (ilx_actuator_net_mlp_scene_update) against the step of separate launches: every buffer bit for bit over several
-    steps, at an env count that leaves ragged last workgroups in both halves of the grid."""
+@pytest.mark.parametrize("robot", ["anymal_c", "h1"])
+def test_paired_substeps_equal_separate_launches(dev, robot):
+    """The step as one chain with {scene.update(k), actuator model of substep k + 1} as one launch
+    (ilx_actuator_net_mlp_scene_update, ilx_actuator_pd_scene_update) against the step of separate launches: every buffer
+    bit for bit over several steps, at an env count that leaves ragged last workgroups in both halves of the grid."""
     n = 1237
     outs = []
     for paired in (False, True):
-        env, _, state = build(dev, n, seed=33)
+        env, _, state = build(dev, n, seed=33, robot=robot)
         env.paired_substeps = paired
         gen = torch.Generator().manual_seed(9)
         trace = []
         for step in range(4):
-            raw = torch.rand(n, 12, generator=gen) * 2 - 1
+            raw = torch.rand(n, state["raw_action"].shape[1], generator=gen) * 2 - 1
             noise_u, samples, reset_samples = draws(gen, n, env.mdp.obs_dim)
             out = env.step(raw.to(dev), noise_u.to(dev), samples.to(dev), reset_samples.to(dev))
             sc, c, a = env.scanner, env.contact, env.actuator
@@ -221,8 +222,8 @@ def test_paired_substeps_equal_separate_launches(dev):
                                                     c._timestamp, c._timestamp_last_update, c.ordered_history(), c._data.current_air_time,
                                                     c._data.last_air_time, c._data.current_contact_time, c._data.last_contact_time,
                                                     env.data.joint_acc, env.data._previous_joint_vel, env.data.computed_torque,
-                                                    env.data.applied_torque, a._joint_pos_error_history, a._joint_vel_history,
-                                                    env.mdp.episode_sums, env.mdp.command)])
+                                                    env.data.applied_torque, env.mdp.episode_sums, env.mdp.command,
+                                                    *((a._joint_pos_error_history, a._joint_vel_history) if robot == "anymal_c" else ()))])
         outs.append(trace)
     for step, (one, two) in enumerate(zip(*outs)):
         for k, (x, y) in enumerate(zip(one, two)):
