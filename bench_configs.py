@@ -201,7 +201,7 @@ def build_cartpole(device, envs, seed):
     env.load_physics(dict(joint_pos=torch.stack([q0 + 0.3 * torch.randn(n, 2, generator=g) for _ in range(CP.DECIMATION)]),
                           joint_vel=torch.stack([torch.randn(n, 2, generator=g) for _ in range(CP.DECIMATION)]), root_state_w=root))
     raw = (torch.rand(n, 1, generator=g) * 2 - 1).to(device)
-    launches = {"joint_action_process": (lambda: env.process_action(raw), 1), "actuator_pd": (env.apply_action, CP.DECIMATION),
+    launches = {"joint_action_process": (lambda: env.process_action(raw), 1), "actuator_pd": (lambda: env.apply_action(first=False), CP.DECIMATION),
                 "scene_update": (lambda: env.scene.update(CP.PHYSICS_DT), CP.DECIMATION),
                 "mdp_step": (lambda: env.mdp.step(FM.PHASE_ALL, hold_step_count=True), 1)}
     nb = {
@@ -249,7 +249,7 @@ def build_reach(device, envs, seed):
                           joint_vel=torch.stack([0.5 * torch.randn(n, 9, generator=g) for _ in range(RE.DECIMATION)]),
                           root_state_w=root, body_state_w=body))
     raw = (torch.rand(n, 7, generator=g) * 2 - 1).to(device)
-    launches = {"joint_action_process": (lambda: env.process_action(raw), 1), "actuator_pd": (env.apply_action, RE.DECIMATION),
+    launches = {"joint_action_process": (lambda: env.process_action(raw), 1), "actuator_pd": (lambda: env.apply_action(first=False), RE.DECIMATION),
                 "scene_update": (lambda: env.scene.update(RE.PHYSICS_DT), RE.DECIMATION),
                 "mdp_step": (lambda: env.mdp.step(FM.PHASE_ALL, hold_step_count=True), 1)}
     nb = {

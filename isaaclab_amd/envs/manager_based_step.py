@@ -114,7 +114,10 @@ class ManagerBasedStep:
 
     paired_substeps = True   # see step()
 
-    def apply_action(self, scene_update=None):
+    def apply_action(self, scene_update=None, first=True):
+        """``first``: the step's first substep.  The processed action does not change between the substeps of a step, so
+        the targets that an action term's apply_actions sets again in every substep (joint_actions.py:162-164) are
+        written once."""
         raise NotImplementedError
 
     def step(self, raw_action: torch.Tensor, noise_u=None, command_samples=None, reset_command_samples=None):
@@ -133,7 +136,7 @@ class ManagerBasedStep:
         for k in range(self.decimation):
             # action terms' apply_actions + write_data_to_sim (actuators); from the second substep on the launch of the
             # actuator model also carries the scene update of the substep before (no physics step lies between them)
-            self.apply_action(update)
+            self.apply_action(update, first=k == 0)
             d.joint_pos, d.joint_vel = ph["joint_pos"][k], ph["joint_vel"][k]   # <sim.step>
             update = self.scene.describe_update(self.physics_dt) if (self.paired_substeps and k + 1 < self.decimation) else None
             if update is None:
@@ -178,9 +181,10 @@ class CartpoleStep(ManagerBasedStep):
     def process_action(self, raw):  # joint_actions.py:130-139, 214-225 (JointEffortAction, no offset)
         self._joint_action(_abi.f32c(raw), CP.ACTION_SCALE, None, self._effort, 1)
 
-    def apply_action(self, scene_update=None):
+    def apply_action(self, scene_update=None, first=True):
         d = self.data
-        d.joint_effort_target[:, 0:1] = self._effort          # set_joint_effort_target(processed, joint_ids=[cart])
+        if first:
+            d.joint_effort_target[:, 0:1] = self._effort      # set_joint_effort_target(processed, joint_ids=[cart])
         ca = ArticulationActions(joint_positions=d.joint_pos_target, joint_velocities=d.joint_vel_target,
                                  joint_efforts=d.joint_effort_target, joint_indices=slice(None))
         self.actuator.compute(ca, d.joint_pos, d.joint_vel, scene_update=scene_update)
@@ -245,10 +249,11 @@ class ReachStep(ManagerBasedStep):
             self.action.copy_(raw)
             self.ik.process_actions(raw)
 
-    def apply_action(self, scene_update=None):
+    def apply_action(self, scene_update=None, first=True):
         d = self.data
         if self.ik is None:
-            d.joint_pos_target[:, self._arm_index] = self._arm_target
+            if first:
+                d.joint_pos_target[:, self._arm_index] = self._arm_target
         else:
             if scene_update is not None:   # the IK term reads what the update writes (joint state of the new substep): in order
                 _abi.check(_abi.scene_update(ctypes.byref(scene_update), _abi.stream()), "ilx_scene_update")
