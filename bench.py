@@ -251,6 +251,17 @@ def main():
         if world == 1 and args.config != "shadow":
             graphs = capture_step(cfg, reducer)
             other_s = timed(graph_step)
+    # The two-branch recording lets the sensor chain run ahead of actuator launches that, with a simulator between them,
+    # it would have to wait for.  Beside it: the step recorded as ONE chain in the reference's own order (scene update k
+    # and the actuator model of substep k + 1 paired in one launch), where nothing runs ahead of a physics step.
+    one_chain_s = None
+    if use_graph and getattr(cfg, "overlap_in_graph", False):
+        cfg.overlap_in_graph = False
+        branch_graphs = graphs
+        graphs = capture_step(cfg, reducer)
+        one_chain_s = timed(graph_step)
+        graphs = branch_graphs
+        cfg.overlap_in_graph = True
     # The same run of steps once more, untimed, with a look at the sensor clocks after every step: on how many steps did
     # every env's contact sensor and height scanner refresh (a step on which the clocks skip the refresh does less work).
     refresh_check = None
@@ -345,6 +356,11 @@ def main():
             line["eager" if use_graph else "hip_graph"] = {
                 "ms_per_step": other_s / args.steps * 1e3, "value": args.envs * world * args.steps / other_s,
                 "note": "the same step " + ("issued launch by launch from the host" if use_graph else "replayed from a captured graph")}
+        if one_chain_s is not None:
+            line["hip_graph_one_chain"] = {
+                "ms_per_step": one_chain_s / args.steps * 1e3, "value": args.envs * world * args.steps / one_chain_s,
+                "note": "the same step recorded as one chain in the reference's order (scene update k and the actuator model of "
+                        "substep k + 1 as one launch): no launch runs ahead of a physics step it would depend on"}
         if not args.no_cpu_baseline and world == 1 and args.config == "anymal" and args.actuator == "mlp":
             line["cpu_baseline"] = cpu_baseline(3000, envs=args.envs, root_scatter=args.root_scatter)
         else:
