@@ -19,7 +19,7 @@ def small_mesh(seed=0, n=21, size=2.0, amp=0.2):
     return verts, tris, xs
 
 
-def test_rays(seed=1, n=1500, size=2.0):
+def make_rays(seed=1, n=1500, size=2.0):
     """Vertical, oblique, edge-aligned and missing rays over the small mesh."""
     g = torch.Generator().manual_seed(seed)
     verts, tris, xs = small_mesh()
@@ -69,7 +69,7 @@ def test_world_rays_match_reference():
 
 
 def test_brute_force_c_and_bvh_agree():
-    verts, tris, starts, dirs = test_rays()
+    verts, tris, starts, dirs = make_rays()
     h1, t1, f1 = RC.raycast_brute(starts, dirs, verts, tris)
     mesh = RC.CMesh(verts.numpy(), tris.numpy())
     h2, t2, f2 = RC.raycast_c(starts, dirs, mesh, brute=True)

@@ -6,7 +6,7 @@ import torch
 
 from conftest import assert_close, assert_exact, load_golden
 from oracle import raycast as RC
-from test_oracle_raycast import small_mesh, test_rays as make_rays
+from test_oracle_raycast import make_rays, small_mesh
 
 pytestmark = pytest.mark.gpu
 
