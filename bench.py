@@ -239,8 +239,8 @@ def main():
 
     # The step is eleven short launches (2-40 us each): issued one by one from the host they are launch-bound, so the
     # measured mode records the step in a HIP graph and replays it.  The in-hand env (four launches, a collective between
-    # them on several GPUs) is measured eagerly.  The other mode is timed as well and reported beside the headline.
-    use_graph = not args.eager and args.config != "shadow"
+    # them on several GPUs) is measured eagerly (replayed from a graph it takes 30 us against 24; reported beside it on one GPU).  The other mode is timed as well and reported beside the headline.
+    use_graph = not args.eager and args.config != "shadow"   # four launches: a replay's fixed cost is above their host time
     other_s = None
     if use_graph:
         other_s = timed(eager_step)
@@ -248,7 +248,7 @@ def main():
         elapsed = timed(graph_step)
     else:
         elapsed = timed(eager_step)
-        if world == 1 and args.config != "shadow":
+        if world == 1:
             graphs = capture_step(cfg, reducer)
             other_s = timed(graph_step)
     # The two-branch recording lets the sensor chain run ahead of actuator launches that, with a simulator between them,

@@ -59,6 +59,9 @@ typedef struct ilx_inhand {
     const float* goal_samples;
     const float* reset_goal_samples;
     uint64_t seed, step_index;
+    /* NULL, or one word in device memory that is added to step_index and that ilx_inhand_finish advances by one: a step
+     * recorded in a HIP graph then draws fresh numbers at every replay (no counterpart in the reference). */
+    uint64_t* step_index_device;
 } ilx_inhand;
 
 int ilx_inhand_apply_action(const ilx_inhand* env, void* stream);

@@ -111,14 +111,15 @@ __global__ void __launch_bounds__(256) inhand_step_kernel(ilx_inhand d) {
             atomicAdd(&block_stats[1], successes);
         }
         // ---- goal resets (:168-171) then env resets (direct_rl_env.py:369-371, :200-247), simulator writes left out
+        const uint64_t gen_step = d.step_index + (d.step_index_device ? *d.step_index_device : 0ull);
         if (goal_reset) {
-            const float r0 = d.goal_samples ? d.goal_samples[2 * env] : 2.0f * inhand_uniform(d.seed, d.step_index, env, 0) - 1.0f;
-            const float r1 = d.goal_samples ? d.goal_samples[2 * env + 1] : 2.0f * inhand_uniform(d.seed, d.step_index, env, 1) - 1.0f;
+            const float r0 = d.goal_samples ? d.goal_samples[2 * env] : 2.0f * inhand_uniform(d.seed, gen_step, env, 0) - 1.0f;
+            const float r1 = d.goal_samples ? d.goal_samples[2 * env + 1] : 2.0f * inhand_uniform(d.seed, gen_step, env, 1) - 1.0f;
             goal = randomize_rotation(r0, r1);
         }
         if (reset) {
-            const float r0 = d.reset_goal_samples ? d.reset_goal_samples[2 * env] : 2.0f * inhand_uniform(d.seed, d.step_index, env, 2) - 1.0f;
-            const float r1 = d.reset_goal_samples ? d.reset_goal_samples[2 * env + 1] : 2.0f * inhand_uniform(d.seed, d.step_index, env, 3) - 1.0f;
+            const float r0 = d.reset_goal_samples ? d.reset_goal_samples[2 * env] : 2.0f * inhand_uniform(d.seed, gen_step, env, 2) - 1.0f;
+            const float r1 = d.reset_goal_samples ? d.reset_goal_samples[2 * env + 1] : 2.0f * inhand_uniform(d.seed, gen_step, env, 3) - 1.0f;
             goal = randomize_rotation(r0, r1);
             successes = 0.0f;
             ep = 0;
@@ -187,6 +188,7 @@ __global__ void inhand_finish_kernel(ilx_inhand d) {
     if (num_resets > 0.0f) d.consecutive_successes[0] = div_(d.av_factor * finished, num_resets) + d.one_minus_av_factor * prev;
     d.stats[0] = 0.0f;
     d.stats[1] = 0.0f;
+    if (d.step_index_device) *d.step_index_device += 1;   // the step's launches are behind this one on the stream
 }
 
 static int check_common(const ilx_inhand& d, const char* who) {

@@ -35,7 +35,7 @@ class InHandDesc(ctypes.Structure):
         ("reach_goal_bonus", c_f), ("fall_penalty", c_f), ("fall_dist", c_f), ("vel_obs_scale", c_f), ("success_tolerance", c_f),
         ("av_factor", c_f), ("one_minus_av_factor", c_f), ("act_moving_average", c_f), ("one_minus_act_moving_average", c_f),
         ("max_consecutive_success", c_i32), ("max_episode_length", c_i64),
-        ("goal_samples", P), ("reset_goal_samples", P), ("seed", c_u64), ("step_index", c_u64),
+        ("goal_samples", P), ("reset_goal_samples", P), ("seed", c_u64), ("step_index", c_u64), ("step_index_device", P),
     ]
 
 
@@ -97,6 +97,7 @@ class InHandManipulationStep:
         self.reset_terminated, self.reset_time_outs, self.reset_buf = (z(n, dtype=torch.bool) for _ in range(3))
         self.stats = z(2)
         self.joint_pos = self.joint_vel = self.body_state_w = self.object_state_w = None
+        self._step_counter = None   # see count_steps_on_device
         d = self.desc = InHandDesc(num_envs=n, num_joints=num_joints, num_bodies=num_bodies, num_actuated=a,
                                    num_fingertips=self.num_fingertips, seed=seed, step_index=0)
         for k in ("dist_reward_scale", "rot_reward_scale", "rot_eps", "action_penalty_scale", "reach_goal_bonus", "fall_penalty",
@@ -135,5 +136,14 @@ class InHandManipulationStep:
         _abi.check(_step(ref, s), "ilx_inhand_step")
         all_reduce_log_sums(self.stats)                        # no-op on one GPU
         _abi.check(_finish(ref, s), "ilx_inhand_finish")
-        self.desc.step_index += 1
+        if self._step_counter is None:
+            self.desc.step_index += 1
         return self.obs, self.reward, self.reset_terminated, self.reset_time_outs
+
+    def count_steps_on_device(self):
+        """Keep the generator's step count in device memory (``ilx_inhand_finish`` advances it): a step recorded in a HIP
+        graph then draws fresh goal rotations at every replay; the numbers are those of the host-side count."""
+        if self._step_counter is None:
+            self._step_counter = torch.full((1,), int(self.desc.step_index), dtype=torch.int64, device=self.device)
+            self.desc.step_index = 0
+            self.desc.step_index_device = self._step_counter.data_ptr()

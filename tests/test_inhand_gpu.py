@@ -104,3 +104,45 @@ def test_inhand_step_at_benchmark_size(dev):
         assert_close(obs, r["obs"], rtol=1e-5, atol=2e-6, what=f"obs step {step}")
         assert_close(env.consecutive_successes, o.s["consecutive_successes"], rtol=1e-5, what=f"consecutive successes step {step}")
         assert r["terminated"].sum() > 50 and (step > 0 or r["goal_resets"].sum() > 20)
+
+
+def test_inhand_step_replayed_from_a_graph_equals_eager(dev):
+    """The step recorded in a HIP graph with the generator's step count in device memory (ilx_inhand_finish advances it)
+    against the same steps issued launch by launch with the host-side count: every replay draws the numbers of its own
+    step -- goals, successes, rewards and observations bit for bit over several steps."""
+    g = load_golden("inhand")
+    s = load_case(g, "shadow_ema")
+    actions = s["actions"].to(dev)
+    outs = []
+    for graph in (False, True):
+        env = make_env(dev, s, 0.8, 50)
+        env.episode_length_buf[::3] = 598      # time-outs on the first steps: the reset draws run
+        trace = []
+        if graph:
+            env.count_steps_on_device()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            gr = torch.cuda.CUDAGraph()
+            state = [t.clone() for t in (env.cur_targets, env.prev_targets, env.goal_rot, env.successes, env.consecutive_successes,
+                                         env.episode_length_buf, env.reset_goal_buf, env._step_counter)]
+            with torch.cuda.stream(side):
+                env.step(actions)               # creates whatever is created lazily
+            side.synchronize()
+            for t, v in zip((env.cur_targets, env.prev_targets, env.goal_rot, env.successes, env.consecutive_successes,
+                             env.episode_length_buf, env.reset_goal_buf, env._step_counter), state):
+                t.copy_(v)                      # ... and is undone: the replays start from the same state as the eager run
+            with torch.cuda.graph(gr, stream=side):
+                env.step(actions)
+        for step in range(5):
+            if graph:
+                gr.replay()
+            else:
+                env.step(actions)
+            torch.cuda.synchronize()
+            trace.append([t.cpu().clone() for t in (env.obs, env.reward, env.goal_rot, env.successes, env.episode_length_buf,
+                                                    env.reset_terminated, env.reset_time_outs, env.consecutive_successes)])
+        outs.append(trace)
+    for step, (one, two) in enumerate(zip(*outs)):
+        for k, (x, y) in enumerate(zip(one, two)):
+            assert_exact(y, x, f"buffer {k}, step {step}")
+    assert not torch.equal(outs[1][0][2], outs[1][1][2]), "new goals are drawn from step to step"
