@@ -136,7 +136,50 @@ def paired():
     env.step(raw)
 
 
+def interleaved(order):
+    """Two branches, the launches of the two chains issued (= recorded) in turns: `order` is a string over 's' (next launch
+    of the sensor chain: 3 scene updates, the update that prepares the scanner, the cast) and 'a' (next launch of the
+    actuator chain: joint action, 4 network launches)."""
+    main = torch.cuda.current_stream()
+    side = env._side_stream
+    side.wait_stream(main)
+    d = env.data
+    begin = env.mdp.begin_step_args(True, True)
+    state = {"s": 0, "a": 0}
+
+    def sensor_launch(k):
+        with torch.cuda.stream(side):
+            if k < 4:
+                d.joint_pos, d.joint_vel = env.physics["joint_pos"][k], env.physics["joint_vel"][k]
+                env.contact.set_net_contact_forces(env.physics["net_forces"][k])
+                if k == 3:
+                    env._bind_scanner_pose()
+                    env.scene.update(LV.PHYSICS_DT, prepare_scanner=True)
+                else:
+                    env.scene.update(LV.PHYSICS_DT)
+            else:
+                env.scanner._update_outdated_buffers(height_out=env.height_scan, height_offset=env.height_scan_offset, prepared=True)
+
+    def actuator_launch(k):
+        if k == 0:
+            args = (_abi.ptr(raw), _abi.ptr(env.action), _abi.ptr(env.prev_action), None, env.action_scale,
+                    _abi.ptr(d.default_joint_pos), 0.0, None, _abi.ptr(d.joint_pos_target), env.n, d._j)
+            _abi.check(_abi.joint_action_process_begin(*args, *begin, _abi.stream()), "ja")
+        else:
+            d.joint_pos, d.joint_vel = env.physics["joint_pos"][k - 1], env.physics["joint_vel"][k - 1]
+            ca = ArticulationActions(joint_positions=d.joint_pos_target, joint_velocities=d.joint_vel_target,
+                                     joint_efforts=d.joint_effort_target, joint_indices=slice(None))
+            env.actuator.compute(ca, d.joint_pos, d.joint_vel)
+
+    for c in order:
+        (sensor_launch if c == "s" else actuator_launch)(state[c])
+        state[c] += 1
+    assert state == {"s": 5, "a": 5}
+    main.wait_stream(side)
+    env.step_managers(None, None, None)
+
+
 for rep in range(2):
     measure_fn("two branches", two_chains)
-    measure_fn("one chain, separate launches", one_chain)
-    measure_fn("one chain, paired substeps", paired)
+    for order in ("sssssaaaaa", "sasasasasa", "asasasasas", "ssasasasaa", "sssaasaasa", "aasssssaaa"):
+        measure_fn("issued " + order, lambda: interleaved(order))
