@@ -645,6 +645,21 @@ int ilx_scene_update(const ilx_scene* scene, void* stream);
  * workgroups of one grid (one launch and its fixed cost fewer per substep, the memory-bound update beside the
  * matrix-bound network); every other network is served by the two launches, the scene update first.  Results are those
  * of the two calls. */
+/* ilx_actuator_net_mlp for the FIRST physics substep of an env step, which also does what the launch just before it
+ * would do -- ilx_joint_action_process_begin (declared above): prev_action <- action <- raw_action,
+ * q_des <- raw_action * action_scale + action_offset (joint_actions.py:130-160 with a scalar scale and an (n,j) offset,
+ * e.g. the default joint positions), the statistics vector cleared and the step count advanced -- and runs the network on
+ * that q_des.  Here q_des is an OUTPUT (the articulation's joint position target; the later substeps read it).  For the
+ * three-sample networks of the split-f16 kernel this is one launch; every other network gets the two launches. */
+int ilx_actuator_net_mlp_joint_action(ilx_mlp_t net, const float* raw_action, float* action, float* prev_action,
+                                      float action_scale, const float* action_offset, float* q_des, const float* q,
+                                      const float* qd, float* pos_error_history, float* velocity_history,
+                                      int history_length, const int32_t* input_idx_host, int num_input_idx,
+                                      int input_order, float pos_scale, float vel_scale, float torque_scale,
+                                      const float* effort_limit, const float* velocity_limit, int params_per_env,
+                                      float saturation_effort, float* computed, float* applied, int64_t n, int j,
+                                      int flags, float* log_sums, int32_t log_count, uint64_t* step_index_device,
+                                      void* stream);
 /* The same pairing for the PD models (ilx_actuator_pd, declared above): always one launch. */
 int ilx_actuator_pd_scene_update(int model, const float* q_des, const float* qd_des, const float* tau_ff, const float* q,
                                  const float* qd, const float* stiffness, const float* damping, const float* effort_limit,

@@ -169,12 +169,30 @@ class ActuatorNetMLP(DCMotor):
         self._joint_pos_error_history[env_ids] = 0.0
         self._joint_vel_history[env_ids] = 0.0
 
-    def compute(self, control_action, joint_pos, joint_vel, scene_update=None):
+    def compute(self, control_action, joint_pos, joint_vel, scene_update=None, joint_action=None):
         """actuator_net.py:147-188.  ``scene_update`` (no counterpart in the reference): the descriptor of the scene update
-        of the substep before (``InteractiveScene.describe_update``), which then travels with this launch."""
+        of the substep before (``InteractiveScene.describe_update``), which then travels with this launch.
+        ``joint_action`` (likewise): the step's first substep -- ``(raw, action, prev_action, scale, offset, begin)`` of the
+        JointPositionAction whose processing this launch does on the way (``control_action.joint_positions`` is then its
+        output), ``begin`` = ``FusedMdp.begin_step_args()`` or None."""
         q_des, q, qd = _abi.f32c(control_action.joint_positions), _abi.f32c(joint_pos), _abi.f32c(joint_vel)
         n, j = q.shape
         self._joint_vel = joint_vel
+        if joint_action is not None:
+            raw, action, prev_action, scale, offset, begin = joint_action
+            begin = begin if begin is not None else (None, 0, None)
+            _abi.check(_abi.actuator_net_mlp_joint_action(
+                self.network.handle, _abi.ptr(raw), _abi.ptr(action), _abi.ptr(prev_action), float(scale), _abi.ptr(offset),
+                _abi.ptr(q_des), _abi.ptr(q), _abi.ptr(qd), _abi.ptr(self._joint_pos_error_history),
+                _abi.ptr(self._joint_vel_history), self._joint_pos_error_history.shape[1], self._idx, len(self.cfg.input_idx),
+                0 if self.cfg.input_order == "pos_vel" else 1, float(self.cfg.pos_scale), float(self.cfg.vel_scale),
+                float(self.cfg.torque_scale), _abi.ptr(self.effort_limit), _abi.ptr(self.velocity_limit), 1,
+                float(self._saturation_effort), _abi.ptr(self.computed_effort), _abi.ptr(self.applied_effort), n, j, self._flags,
+                *begin, _abi.stream()), "ilx_actuator_net_mlp_joint_action")
+            control_action.joint_efforts = self.applied_effort
+            control_action.joint_positions = None
+            control_action.joint_velocities = None
+            return control_action
         args = (self.network.handle, _abi.ptr(q_des), _abi.ptr(q), _abi.ptr(qd), _abi.ptr(self._joint_pos_error_history),
                 _abi.ptr(self._joint_vel_history), self._joint_pos_error_history.shape[1], self._idx, len(self.cfg.input_idx),
                 0 if self.cfg.input_order == "pos_vel" else 1, float(self.cfg.pos_scale), float(self.cfg.vel_scale),

@@ -188,6 +188,19 @@ struct NetArgs {
     int64_t rows;  // N * J
     int j;
     float inv_j;   // 1.0f / j
+    // The first actuator launch of an env step can do the joint action's processing on the way (process_action is the
+    // launch just before it, joint_actions.py:130-160 / action_manager.py:318-339): with ja_raw set, q_des is an OUTPUT --
+    // prev_action <- action <- raw, q_des <- raw * ja_scale + ja_offset -- and the network runs on that q_des.  The
+    // first workgroup also opens the step for the fused managers (begin_*: as ilx_joint_action_process_begin).
+    const float* ja_raw;
+    float* ja_action;
+    float* ja_prev_action;
+    const float* ja_offset;
+    float* ja_target;
+    float ja_scale;
+    float* begin_log;
+    int begin_count;
+    uint64_t* begin_counter;
 };
 
 // Reads the row's inputs, forms the network input features, and hands back the old history values.
@@ -576,7 +589,7 @@ __device__ unsigned long long g_mlp_stamps[8 * 2048];
 
 // POS_VEL: 0, or the history length K of a launch whose feature list is the usual one (see finish_row_pos_vel).
 // `block`: the workgroup's index among the network's workgroups (the launch may hold others: mlp_split_scene_kernel).
-template <int ACT, int NHID, int POS_VEL>
+template <int ACT, int NHID, int POS_VEL, bool JA = false>
 ILX_DEV void mlp_split_block(const NetArgs& a, unsigned block) {
     constexpr int kHiddenWords = (NHID - 1) * 1024;  // 4 fragments x 64 lanes x 16 bytes per hidden layer
     __shared__ __attribute__((aligned(16))) float img[kResidentHist * 64 + kHiddenWords + NHID * 32 + 32 + 4];
@@ -600,6 +613,17 @@ ILX_DEV void mlp_split_block(const NetArgs& a, unsigned block) {
                                 valid ? (a.per_env ? row : joint) : 0u};
     RowRawT<kResidentHist> raw;
     issue_row(a, at, valid, raw, POS_VEL == 0);
+    float ja_raw = 0.0f, ja_old = 0.0f;
+    if constexpr (JA) {
+        if (valid) {
+            ja_raw = rd(a.ja_raw, at.row), ja_old = rd(a.ja_action, at.row);
+            raw.q_des = rd(a.ja_offset, at.row);   // the offset for now; the processed action below
+        }
+        if (block == 0) {
+            for (int k = threadIdx.x; k < a.begin_count; k += 256) a.begin_log[k] = 0.0f;
+            if (a.begin_counter && threadIdx.x == 0) *a.begin_counter += 1;
+        }
+    }
     ILX_MLP_STAMP(1)
     // the image is padded to whole 16-byte words
     {
@@ -610,6 +634,14 @@ ILX_DEV void mlp_split_block(const NetArgs& a, unsigned block) {
     __syncthreads();
     ILX_MLP_STAMP(2)
     if (!live) return;
+    if constexpr (JA) {
+        raw.q_des = ja_raw * a.ja_scale + raw.q_des;   // joint_actions.py:133: raw * scale + offset
+        if (valid && half == 0) {                      // each row is held by a lane of either half: one of them writes
+            wr(a.ja_prev_action, at.row, ja_old);      // action_manager.py:331-332
+            wr(a.ja_action, at.row, ja_raw);
+            wr(a.ja_target, at.row, raw.q_des);
+        }
+    }
     RowInT<kResidentHist> cur;
     if constexpr (POS_VEL > 0) finish_row_pos_vel<kResidentHist, POS_VEL>(a, raw, cur);
     else finish_row(a, raw, cur);
@@ -667,6 +699,12 @@ ILX_DEV void mlp_split_block(const NetArgs& a, unsigned block) {
 template <int ACT, int NHID, int POS_VEL>
 __global__ void __launch_bounds__(256, 8) mlp_mfma_split_kernel(NetArgs a) {
     mlp_split_block<ACT, NHID, POS_VEL>(a, blockIdx.x);
+}
+
+// The three-sample launch that also processes the joint action and opens the step (NetArgs::ja_raw).
+template <int ACT>
+__global__ void __launch_bounds__(256, 8) mlp_split_joint_action_kernel(NetArgs a) {
+    mlp_split_block<ACT, 3, 3, true>(a, blockIdx.x);
 }
 
 // The actuator network of one physics substep and the scene update of the substep before it, which have no physics step
@@ -907,7 +945,12 @@ static int launch_mlp(const NetArgs& a, bool force_generic, bool exact_f32, hipS
         bool pos_vel = a.n_feat == 2 * a.hist_len;
         for (int f = 0; f < a.n_feat && pos_vel; ++f)
             pos_vel = a.feat_slot[f] == f % a.hist_len && (((a.feat_is_pos >> f) & 1u) != 0) == (f < a.hist_len);
-        scene_inside = scene && scene->num_envs > 0 && nhid == 3 && small && split && pos_vel && a.hist_len == 3;
+        const bool three = nhid == 3 && small && split && pos_vel && a.hist_len == 3;
+        if (a.ja_raw && three) {   // the step's first actuator launch: the joint action's processing rides on it
+            hipLaunchKernelGGL((mlp_split_joint_action_kernel<ACT>), dim3(tile_blocks), dim3(256), 0, s, a);
+            return ILX_OK;
+        }
+        scene_inside = scene && scene->num_envs > 0 && three;
         if (scene && !scene_inside) {
             const int rc = ilx_scene_update(scene, s);
             if (rc != ILX_OK) return rc;
@@ -940,12 +983,26 @@ static int launch_mlp(const NetArgs& a, bool force_generic, bool exact_f32, hipS
     return ILX_OK;
 }
 
+// What the step's first actuator launch does on the way (ilx_actuator_net_mlp_joint_action), or null.
+struct JointActionRide {
+    const float* raw;
+    float* action;
+    float* prev_action;
+    float scale;
+    const float* offset;
+    float* target;
+    float* log_sums;
+    int32_t log_count;
+    uint64_t* step_index_device;
+};
+
 static int actuator_net_mlp(ilx_mlp_t net, const float* q_des, const float* q, const float* qd,
                             float* pos_error_history, float* velocity_history, int history_length,
                             const int32_t* input_idx_host, int num_input_idx, int input_order, float pos_scale,
                             float vel_scale, float torque_scale, const float* effort_limit,
                             const float* velocity_limit, int params_per_env, float saturation_effort,
-                            float* computed, float* applied, int64_t n, int j, int flags, const ilx_scene* scene, void* stream) {
+                            float* computed, float* applied, int64_t n, int j, int flags, const ilx_scene* scene, void* stream,
+                            const JointActionRide* ride = nullptr) {
     ILX_REQUIRE(net, ILX_EINVAL, "ilx_actuator_net_mlp: net is NULL");
     ILX_REQUIRE(n >= 0 && j > 0, ILX_EINVAL, "ilx_actuator_net_mlp: bad shape (%lld, %d)", (long long)n, j);
     ILX_REQUIRE(q_des && q && qd && pos_error_history && velocity_history && effort_limit && velocity_limit && computed &&
@@ -958,7 +1015,7 @@ static int actuator_net_mlp(ilx_mlp_t net, const float* q_des, const float* q, c
     ILX_REQUIRE(2 * num_input_idx == net->h.dev.dims[0], ILX_ESHAPE,
                 "ilx_actuator_net_mlp: network input width %d != 2 * %d input indices", net->h.dev.dims[0], num_input_idx);
     ILX_REQUIRE(input_order == 0 || input_order == 1, ILX_EINVAL, "ilx_actuator_net_mlp: input_order must be 0 or 1");
-    NetArgs a;
+    NetArgs a{};
     a.net = net->h.dev;
     a.q_des = q_des, a.q = q, a.qd = qd;
     a.pe_hist = pos_error_history, a.v_hist = velocity_history;
@@ -979,6 +1036,27 @@ static int actuator_net_mlp(ilx_mlp_t net, const float* q_des, const float* q, c
     if (a.rows == 0) return scene ? ilx_scene_update(scene, stream) : ILX_OK;
     hipStream_t s = as_stream(stream);
     const bool generic = (flags & ILX_MLP_FORCE_GENERIC) != 0, exact = (flags & ILX_MLP_EXACT_F32) != 0;
+    if (ride) {
+        // the launch that can carry the ride is the three-sample split kernel's (as launch_mlp picks it); every other
+        // network gets the joint action's own launch ahead of it
+        const int nhid = a.net.num_layers - 1;
+        bool pos_vel = a.n_feat == 2 * a.hist_len;
+        for (int f = 0; f < a.n_feat && pos_vel; ++f)
+            pos_vel = a.feat_slot[f] == f % a.hist_len && (((a.feat_is_pos >> f) & 1u) != 0) == (f < a.hist_len);
+        const bool small = a.hist_len <= kResidentHist && a.n_feat <= 2 * kResidentHist && a.j < (1 << 20) &&
+                           a.rows * a.hist_len < (int64_t(1) << 30);
+        const bool carries = a.net.packed && !generic && a.net.image16 && !exact && nhid == 3 && small && pos_vel && a.hist_len == 3;
+        if (carries) {
+            a.ja_raw = ride->raw, a.ja_action = ride->action, a.ja_prev_action = ride->prev_action, a.ja_scale = ride->scale;
+            a.ja_offset = ride->offset, a.ja_target = ride->target;
+            a.begin_log = ride->log_sums, a.begin_count = ride->log_sums ? ride->log_count : 0, a.begin_counter = ride->step_index_device;
+        } else {
+            const int rc = ilx_joint_action_process_begin(ride->raw, ride->action, ride->prev_action, nullptr, ride->scale, ride->offset,
+                                                          0.0f, nullptr, ride->target, n, j, ride->log_sums, ride->log_count,
+                                                          ride->step_index_device, stream);
+            if (rc != ILX_OK) return rc;
+        }
+    }
     int rc = ILX_OK;
     switch (a.net.act) {
         case ILX_ACT_SOFTSIGN: rc = launch_mlp<ILX_ACT_SOFTSIGN>(a, generic, exact, s, scene); break;
@@ -1001,6 +1079,27 @@ extern "C" int ilx_actuator_net_mlp(ilx_mlp_t net, const float* q_des, const flo
     return actuator_net_mlp(net, q_des, q, qd, pos_error_history, velocity_history, history_length, input_idx_host, num_input_idx,
                             input_order, pos_scale, vel_scale, torque_scale, effort_limit, velocity_limit, params_per_env,
                             saturation_effort, computed, applied, n, j, flags, nullptr, stream);
+}
+
+extern "C" int ilx_actuator_net_mlp_joint_action(ilx_mlp_t net, const float* raw_action, float* action, float* prev_action,
+                                                 float action_scale, const float* action_offset, float* q_des, const float* q,
+                                                 const float* qd, float* pos_error_history, float* velocity_history,
+                                                 int history_length, const int32_t* input_idx_host, int num_input_idx,
+                                                 int input_order, float pos_scale, float vel_scale, float torque_scale,
+                                                 const float* effort_limit, const float* velocity_limit, int params_per_env,
+                                                 float saturation_effort, float* computed, float* applied, int64_t n, int j,
+                                                 int flags, float* log_sums, int32_t log_count, uint64_t* step_index_device,
+                                                 void* stream) {
+    ILX_REQUIRE(raw_action && action && prev_action && action_offset && q_des, ILX_EINVAL,
+                "ilx_actuator_net_mlp_joint_action: NULL operand");
+    ILX_REQUIRE(n > 0, ILX_EINVAL, "ilx_actuator_net_mlp_joint_action: no envs");
+    ILX_REQUIRE(log_count >= 0 && (log_count == 0 || log_sums), ILX_EINVAL,
+                "ilx_actuator_net_mlp_joint_action: %d floats at a NULL pointer", log_count);
+    const JointActionRide ride{raw_action, action, prev_action, action_scale, action_offset, q_des, log_sums, log_count,
+                               step_index_device};
+    return actuator_net_mlp(net, q_des, q, qd, pos_error_history, velocity_history, history_length, input_idx_host, num_input_idx,
+                            input_order, pos_scale, vel_scale, torque_scale, effort_limit, velocity_limit, params_per_env,
+                            saturation_effort, computed, applied, n, j, flags, nullptr, stream, &ride);
 }
 
 extern "C" int ilx_actuator_net_mlp_scene_update(ilx_mlp_t net, const float* q_des, const float* q, const float* qd,

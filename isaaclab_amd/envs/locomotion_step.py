@@ -111,6 +111,8 @@ class LocomotionVelocityStep:
         # the step as one chain with scene.update(k) and the actuator model of substep k + 1 as one launch (see
         # _step_paired; MLP and DC-motor actuators); concurrent_chains takes precedence
         self.paired_substeps = True
+        # network actuators: process_action is done by the step's first actuator launch (ilx_actuator_net_mlp_joint_action)
+        self.joint_action_rides = True
 
     def _bind(self):
         d, c = self.data, self.contact._data
@@ -189,13 +191,7 @@ class LocomotionVelocityStep:
         begin = None
         if self.clear_log_sums or self._advance_count_first:
             begin = self.mdp.begin_step_args(self.clear_log_sums, self._advance_count_first)
-        n, j = self.n, d._j
-        args = (_abi.ptr(raw_action), _abi.ptr(self.action), _abi.ptr(self.prev_action), None, self.action_scale,
-                _abi.ptr(d.default_joint_pos), 0.0, None, _abi.ptr(d.joint_pos_target), n, j)
-        if begin is not None:
-            _abi.check(_abi.joint_action_process_begin(*args, *begin, _abi.stream()), "ilx_joint_action_process_begin")
-        else:
-            _abi.check(_abi.joint_action_process(*args, _abi.stream()), "ilx_joint_action_process")
+        ride = self._process_action(raw_action, begin)
         prepared = False
         for k in range(LV.DECIMATION + 1):
             update = None
@@ -213,7 +209,10 @@ class LocomotionVelocityStep:
             d.joint_pos, d.joint_vel = ph["joint_pos"][k], ph["joint_vel"][k]
             ca = ArticulationActions(joint_positions=d.joint_pos_target, joint_velocities=d.joint_vel_target,
                                      joint_efforts=d.joint_effort_target, joint_indices=slice(None))
-            self.actuator.compute(ca, d.joint_pos, d.joint_vel, scene_update=update)
+            if k == 0 and ride is not None:
+                self.actuator.compute(ca, d.joint_pos, d.joint_vel, joint_action=ride)
+            else:
+                self.actuator.compute(ca, d.joint_pos, d.joint_vel, scene_update=update)
         self.scanner._update_outdated_buffers(height_out=self.height_scan, height_offset=self.height_scan_offset, prepared=prepared)
         return self.step_managers(noise_u, command_samples, reset_command_samples)
 
@@ -256,18 +255,29 @@ class LocomotionVelocityStep:
         """Chain (A): process_action (manager_based_rl_env.py:172), then the actuator model of every substep
         (write_data_to_sim).  ``begin``: ``FusedMdp.begin_step_args`` -- the launch then also opens the step."""
         d = self.data
-        n, j = self.n, d._j
-        args = (_abi.ptr(raw_action), _abi.ptr(self.action), _abi.ptr(self.prev_action), None, self.action_scale,
-                _abi.ptr(d.default_joint_pos), 0.0, None, _abi.ptr(d.joint_pos_target), n, j)
-        if begin is not None:
-            _abi.check(_abi.joint_action_process_begin(*args, *begin, _abi.stream()), "ilx_joint_action_process_begin")
-        else:
-            _abi.check(_abi.joint_action_process(*args, _abi.stream()), "ilx_joint_action_process")
+        ride = self._process_action(raw_action, begin)
         for k in range(LV.DECIMATION):
             d.joint_pos, d.joint_vel = self.physics["joint_pos"][k], self.physics["joint_vel"][k]
             ca = ArticulationActions(joint_positions=d.joint_pos_target, joint_velocities=d.joint_vel_target,
                                      joint_efforts=d.joint_effort_target, joint_indices=slice(None))
-            self.actuator.compute(ca, d.joint_pos, d.joint_vel)
+            if k == 0 and ride is not None:
+                self.actuator.compute(ca, d.joint_pos, d.joint_vel, joint_action=ride)
+            else:
+                self.actuator.compute(ca, d.joint_pos, d.joint_vel)
+
+    def _process_action(self, raw_action, begin):
+        """process_action (manager_based_rl_env.py:172) -- as a launch of its own, or, for the network actuators, as
+        arguments for the first actuator launch, which then does it on the way: returns those, or None when launched."""
+        d = self.data
+        if self.joint_action_rides and isinstance(self.actuator, ActuatorNetMLP):
+            return (raw_action, self.action, self.prev_action, self.action_scale, d.default_joint_pos, begin)
+        args = (_abi.ptr(raw_action), _abi.ptr(self.action), _abi.ptr(self.prev_action), None, self.action_scale,
+                _abi.ptr(d.default_joint_pos), 0.0, None, _abi.ptr(d.joint_pos_target), self.n, d._j)
+        if begin is not None:
+            _abi.check(_abi.joint_action_process_begin(*args, *begin, _abi.stream()), "ilx_joint_action_process_begin")
+        else:
+            _abi.check(_abi.joint_action_process(*args, _abi.stream()), "ilx_joint_action_process")
+        return None
 
     def step_managers(self, noise_u=None, command_samples=None, reset_command_samples=None, phases: int = FM.PHASE_ALL):
         """The post-physics managers in one launch: terminations, rewards, resets, command, observations -- or, with

@@ -266,3 +266,38 @@ def test_scene_update_that_prepares_the_scanner_equals_separate_launches(dev, ro
             assert_exact(b, a, f"{name}, step {step}")
     last = outs[1][-1]
     assert 0 < int((last[8] == last[9]).sum()) < n, "some envs refreshed on the last step, some did not"
+
+
+def test_joint_action_on_the_first_actuator_launch_equals_its_own_launch(dev):
+    """ilx_actuator_net_mlp_joint_action (process_action done by the step's first network launch, which also opens the step)
+    against ilx_joint_action_process_begin + ilx_actuator_net_mlp: every buffer of the step bit for bit over several steps,
+    with the statistics vector cleared and the device-side step count advanced by that launch."""
+    n = 1237
+    outs = []
+    for rides in (False, True):
+        env, _, state = build(dev, n, seed=35)
+        env.joint_action_rides = rides
+        env.clear_log_sums = True
+        env.count_steps_on_device()
+        gen = torch.Generator().manual_seed(11)
+        trace = []
+        for step in range(4):
+            raw = torch.rand(n, 12, generator=gen) * 2 - 1
+            noise_u, samples, reset_samples = draws(gen, n, env.mdp.obs_dim)
+            env.mdp.log_sums.fill_(7.0)     # the step must start it at zero itself
+            out = env.step(raw.to(dev), noise_u.to(dev), samples.to(dev), reset_samples.to(dev))
+            a = env.actuator
+            trace.append([t.cpu().clone() for t in (*out, env.action, env.prev_action, env.data.joint_pos_target, env.data.computed_torque,
+                                                    env.data.applied_torque, a._joint_pos_error_history, a._joint_vel_history,
+                                                    env.mdp.log_sums, env.mdp._step_counter, env.mdp.episode_sums)])
+        outs.append(trace)
+    for step, (one, two) in enumerate(zip(*outs)):
+        for k, (x, y) in enumerate(zip(one, two)):
+            if k == 11:   # the statistics vector: sums of atomic float adds, whose order is not fixed
+                assert_close(y, x, rtol=1e-5, atol=1e-6, what=f"log sums, step {step}")
+            else:
+                assert_exact(y, x, f"buffer {k}, step {step}")
+    assert outs[1][-1][12].item() == 3 and outs[1][-1][11][-1].item() > 0, "count advanced; this step's resets were logged"
+    prev1, act0 = outs[1][1][5], outs[1][0][4]
+    kept = prev1.abs().sum(1) > 0   # envs that the second step did not reset (a reset zeroes the action history)
+    assert kept.sum() > n // 2 and torch.equal(prev1[kept], act0[kept]), "prev_action of a step is the action of the step before"
