@@ -179,7 +179,50 @@ def interleaved(order):
     env.step_managers(None, None, None)
 
 
+def shortened(skip_s=(), skip_a=(), ride=True):
+    """The two-branch step with launches left out (not a valid step: what each launch costs the replay).  Sensor chain
+    launches 0-2: scene updates, 3: update + preparation, 4: cast; actuator chain 0: joint action (+ first network launch
+    when it rides on it), 1-4: network launches."""
+    main = torch.cuda.current_stream()
+    side = env._side_stream
+    side.wait_stream(main)
+    d = env.data
+    begin = env.mdp.begin_step_args(True, True)
+    with torch.cuda.stream(side):
+        for k in range(5):
+            if k in skip_s:
+                continue
+            if k < 4:
+                d.joint_pos, d.joint_vel = env.physics["joint_pos"][k], env.physics["joint_vel"][k]
+                env.contact.set_net_contact_forces(env.physics["net_forces"][k])
+                if k == 3:
+                    env._bind_scanner_pose()
+                    env.scene.update(LV.PHYSICS_DT, prepare_scanner=True)
+                else:
+                    env.scene.update(LV.PHYSICS_DT)
+            else:
+                env.scanner._update_outdated_buffers(height_out=env.height_scan, height_offset=env.height_scan_offset, prepared=True)
+    env.joint_action_rides = ride
+    r = env._process_action(raw, begin)
+    for k in range(4):
+        if (k + 1) in skip_a:
+            continue
+        d.joint_pos, d.joint_vel = env.physics["joint_pos"][k], env.physics["joint_vel"][k]
+        ca = ArticulationActions(joint_positions=d.joint_pos_target, joint_velocities=d.joint_vel_target,
+                                 joint_efforts=d.joint_effort_target, joint_indices=slice(None))
+        if k == 0 and r is not None:
+            env.actuator.compute(ca, d.joint_pos, d.joint_vel, joint_action=r)
+        else:
+            env.actuator.compute(ca, d.joint_pos, d.joint_vel)
+    main.wait_stream(side)
+    env.step_managers(None, None, None)
+
+
 for rep in range(2):
-    measure_fn("two branches", two_chains)
-    for order in ("sssssaaaaa", "sasasasasa", "asasasasas", "ssasasasaa", "sssaasaasa", "aasssssaaa"):
-        measure_fn("issued " + order, lambda: interleaved(order))
+    measure_fn("two branches, whole step", lambda: shortened())
+    measure_fn("  without network launch 4", lambda: shortened(skip_a=(4,)))
+    measure_fn("  without network launches 3, 4", lambda: shortened(skip_a=(3, 4)))
+    measure_fn("  without scene update 1", lambda: shortened(skip_s=(1,)))
+    measure_fn("  without scene updates 1, 2", lambda: shortened(skip_s=(1, 2)))
+    measure_fn("  without the cast", lambda: shortened(skip_s=(4,)))
+    measure_fn("  joint action as a launch of its own", lambda: shortened(ride=False))
