@@ -154,6 +154,18 @@ def build_locomotion(device, envs, seed, robot="anymal_c", actuator="mlp", stati
     else:
         info["actuator"] = "DCMotor (PD + torque-speed envelope)"
     nbytes = _locomotion_bytes(j, b, r, int(env.mdp.obs_dim), n_rewards, act_kernel)
+    if act_kernel == "actuator_net_mlp" and env.joint_action_rides:
+        # process_action is done by the step's first network launch: three plain network launches and one that carries it
+        def actuate_first():
+            ca = ArticulationActions(joint_positions=d.joint_pos_target, joint_velocities=d.joint_vel_target,
+                                     joint_efforts=d.joint_effort_target)
+            env.actuator.compute(ca, d.joint_pos, d.joint_vel,
+                                 joint_action=(raw, env.action, env.prev_action, env.action_scale, d.default_joint_pos, None))
+
+        launches[act_kernel] = (actuate, LV.DECIMATION - 1)
+        launches["actuator_net_mlp_joint_action"] = (actuate_first, 1)
+        del launches["joint_action_process"]
+        nbytes["actuator_net_mlp_joint_action"] = nbytes[act_kernel] + nbytes.pop("joint_action_process")
     if fused:   # the refresh's bytes dealt to the two launches: pose in / out and clocks with the update, the results with the cast
         nbytes["scene_update_prepare"] = nbytes["scene_update"] + 28 + 28 + 5
         nbytes["raycaster_cast"] = nbytes.pop("raycaster_refresh") - (28 + 28 + 5)

@@ -18,12 +18,13 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 KERNELS = {  # substring of the kernel symbol -> bench kernel name (launches of one bench kernel are summed per call)
+    "mlp_split_joint_action": "actuator_net_mlp_joint_action", "mlp_split_scene": "actuator_net_mlp+scene_update",
     "joint_action_kernel": "joint_action_process", "mlp_mfma": "actuator_net_mlp", "actuator_lstm_kernel": "actuator_net_lstm", "scene_update_kernel": "scene_update",
     "raycaster_update": "raycaster_cast", "raycaster_prepare_kernel": "raycaster_prepare", "sensor_refreshed_kernel": "raycaster_cast",
     "scene_update_prepare_kernel": "scene_update_prepare",
     "mdp_step_kernel": "mdp_step",
 }
-PRIMARY = {"actuator_net_lstm": "actuator_lstm_kernel", "joint_action_process": "joint_action_kernel", "actuator_net_mlp": "mlp_mfma", "scene_update": "scene_update_kernel",
+PRIMARY = {"actuator_net_mlp_joint_action": "mlp_split_joint_action", "actuator_net_mlp+scene_update": "mlp_split_scene", "actuator_net_lstm": "actuator_lstm_kernel", "joint_action_process": "joint_action_kernel", "actuator_net_mlp": "mlp_mfma", "scene_update": "scene_update_kernel",
            "raycaster_cast": "raycaster_update_lattice_kernel", "raycaster_prepare": "raycaster_prepare_kernel",
            "scene_update_prepare": "scene_update_prepare_kernel", "mdp_step": "mdp_step_kernel"}
 
@@ -36,10 +37,11 @@ def counter_per_launch(path, counter):
     for r in rows:
         if r["Counter_Name"] != counter:
             continue
-        for sub, name in KERNELS.items():
+        for sub, name in KERNELS.items():   # the first (most specific) entry that matches names the kernel
             if sub in r["Kernel_Name"]:
                 if PRIMARY[name] in r["Kernel_Name"]:
                     grid[name] = max(grid.get(name, 0), int(r["Grid_Size"]))
+                break
     for r in rows:
         if r["Counter_Name"] != counter:
             continue
@@ -47,10 +49,11 @@ def counter_per_launch(path, counter):
             if sub in r["Kernel_Name"]:
                 primary = PRIMARY[name] in r["Kernel_Name"]
                 if primary and int(r["Grid_Size"]) != grid[name]:
-                    continue  # smaller launches belong to the CPU-baseline-free set-up, not to the step
+                    break  # smaller launches belong to the set-up, not to the step
                 total[name] = total.get(name, 0.0) + float(r["Counter_Value"])
                 if primary:
                     calls[name] = calls.get(name, 0) + 1
+                break
     return {k: (total[k] / calls[k], calls[k]) for k in total if calls.get(k)}
 
 
