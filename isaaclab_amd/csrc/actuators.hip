@@ -710,8 +710,8 @@ __global__ void __launch_bounds__(512, 8) mlp_mfma_split8_kernel(NetArgs a) {
 
 // The three-sample launch that also processes the joint action and opens the step (NetArgs::ja_raw).
 template <int ACT>
-__global__ void __launch_bounds__(256, 8) mlp_split_joint_action_kernel(NetArgs a) {
-    mlp_split_block<ACT, 3, 3, true>(a, blockIdx.x);
+__global__ void __launch_bounds__(512, 8) mlp_split_joint_action_kernel(NetArgs a) {
+    mlp_split_block<ACT, 3, 3, true, 8>(a, blockIdx.x);
 }
 
 // The actuator network of one physics substep and the scene update of the substep before it, which have no physics step
@@ -954,7 +954,7 @@ static int launch_mlp(const NetArgs& a, bool force_generic, bool exact_f32, hipS
             pos_vel = a.feat_slot[f] == f % a.hist_len && (((a.feat_is_pos >> f) & 1u) != 0) == (f < a.hist_len);
         const bool three = nhid == 3 && small && split && pos_vel && a.hist_len == 3;
         if (a.ja_raw && three) {   // the step's first actuator launch: the joint action's processing rides on it
-            hipLaunchKernelGGL((mlp_split_joint_action_kernel<ACT>), dim3(tile_blocks), dim3(256), 0, s, a);
+            hipLaunchKernelGGL((mlp_split_joint_action_kernel<ACT>), dim3(static_cast<unsigned>((tiles + 7) / 8)), dim3(512), 0, s, a);
             return ILX_OK;
         }
         scene_inside = scene && scene->num_envs > 0 && three;
