@@ -790,8 +790,25 @@ int ilx_scene_update_prepare_raycaster(const ilx_scene* scene, const ilx_raycast
  * it grows with hipMalloc, this entry point uses a 3,162,144-byte buffer built into the library's code object (one per
  * GPU, held until the process ends) and calls no allocating routine.  Limit: 32,768 envs per call (at up to 1,024 rays
  * each); more is refused with ILX_ESHAPE before anything is queued.  All calls on one GPU share that buffer: calls that
- * overlap on one GPU (different streams or threads of the process) race -- keep them on one stream.  Nothing in the buffer has to be cleared between calls. */
+ * overlap on one GPU (different streams or threads of the process) race -- keep them on one stream.  Nothing in the buffer has to be cleared between calls.
+ * The limit applies where the refresh keeps something between its launches (a mesh with height-field patches, a
+ * vertical pattern of up to 1,024 rays, attach_yaw_only); other refreshes keep nothing and have no such limit.
+ * ILX_RAYS_PREPARED is refused with ILX_EINVAL (ilx_scene_update_prepare_raycaster prepares in the per-stream workspace,
+ * which this entry point never reads) and ILX_RAYS_PATTERN_STATIC has no effect (the buffer keeps nothing from call to
+ * call).  The buffer's device address is looked up when ilx_mesh_create runs on the device, not here, so the first call
+ * may already be under capture. */
 int ilx_raycaster_refresh_static(const ilx_raycaster* rc, void* stream);
+/* No counterpart in the reference (Warp allocates as it goes): sets aside, now, the per-stream workspaces that
+ * ilx_raycaster_refresh / ilx_scene_update_prepare_raycaster would otherwise allocate with hipMalloc on their first call
+ * on a stream -- `streams` buffers sized for num_envs x num_rays (buffers set aside earlier and still unused count).  A
+ * stream's first refresh of up to that size then takes one of them and allocates nothing; call it where allocation is
+ * allowed (sensor set-up), so that no step under graph capture allocates. */
+int ilx_raycaster_reserve(ilx_mesh_t mesh, int64_t num_envs, int32_t num_rays, int32_t streams);
+/* No counterpart in the reference: drops what ILX_RAYS_PATTERN_STATIC lets a stream's workspace keep (the packed scan
+ * pattern of the previous refresh), so the next refresh on every stream packs its pattern again.  For owners of pattern
+ * arrays: call it when a pattern array is created or released -- an allocator may hand a released array's address to the
+ * next pattern, which the promise behind ILX_RAYS_PATTERN_STATIC could not tell apart. */
+int ilx_mesh_forget_patterns(ilx_mesh_t mesh);
 
 /* RayCasterCamera._update_buffers_impl (sensors/ray_caster/ray_caster_camera.py:257-318) for the cameras flagged in
  * is_outdated (NULL = all), without temporaries:

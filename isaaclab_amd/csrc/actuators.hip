@@ -962,12 +962,9 @@ static int launch_mlp(const NetArgs& a, bool force_generic, bool exact_f32, hipS
             const int rc = ilx_scene_update(scene, s);
             if (rc != ILX_OK) return rc;
         }
-        if (scene_inside)
-        {
-            static const bool su_first = getenv("ILX_FUSED_SU_FIRST") && atoi(getenv("ILX_FUSED_SU_FIRST")) != 0;
-            hipLaunchKernelGGL((mlp_split_scene_kernel<ACT>), dim3(tile_blocks + su_blocks), dim3(256), 0, s, a, sa,
-                               su_first ? su_blocks : 0u, tile_blocks, su_first ? 0u : tile_blocks);
-        }
+        if (scene_inside)   // the network's workgroups first in the grid, the update's behind them
+            hipLaunchKernelGGL((mlp_split_scene_kernel<ACT>), dim3(tile_blocks + su_blocks), dim3(256), 0, s, a, sa, 0u, tile_blocks,
+                               tile_blocks);
         else if (nhid == 3 && small && split && pos_vel && a.hist_len == 3) {  // the ANYdrive network's shape: three samples
             // eight tiles per workgroup: half as many copies of the weight image into LDS (9.9 -> 9.6 us)
             hipLaunchKernelGGL((mlp_mfma_split8_kernel<ACT>), dim3(static_cast<unsigned>((tiles + 7) / 8)), dim3(512), 0, s, a);

@@ -1114,6 +1114,9 @@ struct MeshHost {
     };
     std::unordered_map<void*, Workspace> ws_by_stream;
     std::vector<void*> ws_retired;
+    // buffers set aside by ilx_raycaster_reserve: a stream that needs a (larger) workspace takes one of these before it
+    // turns to hipMalloc
+    std::vector<std::pair<void*, size_t>> ws_spare;
     int32_t* d_off_grid = nullptr;  // kFlagSlots flags, one raised by a column kernel for the tree kernel launched after it
     std::atomic<uint32_t> calls{0}; // hinted casts so far: call c uses slot c % kFlagSlots and the ticket c + 1
     int depth = 0;
@@ -1162,6 +1165,8 @@ using namespace ilx;
 struct ilx_mesh_s {
     MeshHost h;
 };
+
+static int static_scratch(void** out);   // the built-in buffer of ilx_raycaster_refresh_static on the current device
 
 extern "C" int ilx_mesh_create(const float* verts_host, int64_t num_verts, const int32_t* tris_host, int64_t num_tris,
                                ilx_mesh_t* out) {
@@ -1608,6 +1613,15 @@ extern "C" int ilx_mesh_create(const float* verts_host, int64_t num_verts, const
     h.lat_cells = lat.cells, h.lat_simple = lat.simple, h.lat_faces = lat.faces;
     h.grid = gstats;
     h.depth = bld.max_depth, h.num_verts = num_verts;
+    {   // The address of ilx_raycaster_refresh_static's built-in buffer on this device is looked up now: the runtime loads
+        // the code object and registers the symbol on that first request, which a stream under capture may not survive.
+        void* unused = nullptr;
+        const int status = static_scratch(&unused);
+        if (status != ILX_OK) {
+            ilx_mesh_destroy(obj);
+            return status;
+        }
+    }
     *out = obj;
     return ILX_OK;
 }
@@ -1630,6 +1644,7 @@ extern "C" void ilx_mesh_destroy(ilx_mesh_t mesh) {
     if (mesh->h.d_lat_served) (void)hipFree(mesh->h.d_lat_served);
     for (auto& kv : mesh->h.ws_by_stream) (void)hipFree(kv.second.first);
     for (void* p : mesh->h.ws_retired) (void)hipFree(p);
+    for (auto& sp : mesh->h.ws_spare) (void)hipFree(sp.first);
     delete mesh;
 }
 
@@ -1733,22 +1748,63 @@ static void launch_lattice(ilx_mesh_t mesh, ScanArgs a, int hints, void* ws, flo
 // The workspace of `stream` with room for `bytes`, and the four floats behind it that keep the scan pattern's bounding
 // box from one refresh to the next.  `reuse`: the workspace still holds the packed pattern and the box of exactly this
 // pattern (same arrays, same length) from the previous refresh on the stream.
-static int lattice_workspace(ilx_mesh_t mesh, void* stream, size_t bytes, const ScanArgs& a, void** out, float** box, bool* reuse) {
+static size_t workspace_capacity(size_t bytes) { return (std::max<size_t>(bytes + bytes / 4, size_t(1) << 16) + 31) & ~size_t(15); }
+
+// `packs`: the call's preparation launch (re)writes the packed pattern unless `reuse` comes back true; a call that
+// launches no preparation (ILX_RAYS_PREPARED) leaves the record of what the workspace holds as it is.
+static int lattice_workspace(ilx_mesh_t mesh, void* stream, size_t bytes, const ScanArgs& a, bool packs, void** out, float** box,
+                             bool* reuse) {
     MeshHost& h = mesh->h;
     std::lock_guard<std::mutex> guard(h.ws_lock);
     auto& slot = h.ws_by_stream[stream];
     if (slot.second < bytes + 16) {
         void* fresh = nullptr;
-        const size_t cap = (std::max<size_t>(bytes + bytes / 4, size_t(1) << 16) + 31) & ~size_t(15);
-        const int rc = check_hip(hipMalloc(&fresh, cap), "ilx_raycaster: hipMalloc(workspace)");
-        if (rc != ILX_OK) return rc;
+        size_t cap = 0;
+        for (size_t i = 0; i < h.ws_spare.size(); ++i)   // a buffer set aside by ilx_raycaster_reserve, if one is large enough
+            if (h.ws_spare[i].second >= bytes + 16) {
+                fresh = h.ws_spare[i].first, cap = h.ws_spare[i].second;
+                h.ws_spare.erase(h.ws_spare.begin() + static_cast<std::ptrdiff_t>(i));
+                break;
+            }
+        if (!fresh) {
+            cap = workspace_capacity(bytes);
+            const int rc = check_hip(hipMalloc(&fresh, cap), "ilx_raycaster: hipMalloc(workspace)");
+            if (rc != ILX_OK) return rc;
+        }
         if (slot.first) h.ws_retired.push_back(slot.first);
         slot = MeshHost::Workspace{fresh, cap, nullptr, nullptr, 0};
     }
     *out = slot.first;
     *box = reinterpret_cast<float*>(static_cast<char*>(slot.first) + slot.second - 16);
     *reuse = slot.starts == a.ray_starts && slot.dirs == a.ray_dirs && slot.rays == a.r;
-    slot.starts = a.ray_starts, slot.dirs = a.ray_dirs, slot.rays = a.r;
+    if (packs) slot.starts = a.ray_starts, slot.dirs = a.ray_dirs, slot.rays = a.r;
+    return ILX_OK;
+}
+
+extern "C" int ilx_raycaster_reserve(ilx_mesh_t mesh, int64_t num_envs, int32_t num_rays, int32_t streams) {
+    ILX_REQUIRE(mesh, ILX_EINVAL, "ilx_raycaster_reserve: mesh is NULL");
+    ILX_REQUIRE(num_envs >= 0 && num_rays > 0 && streams >= 0 && streams <= 64, ILX_EINVAL,
+                "ilx_raycaster_reserve: bad arguments (%lld envs, %d rays, %d streams)", (long long)num_envs, num_rays, streams);
+    if (num_envs == 0 || mesh->h.dev.num_patches == 0 || num_rays > kLatMaxRays) return ILX_OK;   // such refreshes keep nothing between launches
+    const size_t bytes = lattice_workspace_bytes(num_envs, num_rays);
+    MeshHost& h = mesh->h;
+    std::lock_guard<std::mutex> guard(h.ws_lock);
+    int have = 0;
+    for (auto& sp : h.ws_spare) have += sp.second >= bytes + 16;
+    for (; have < streams; ++have) {
+        void* fresh = nullptr;
+        const size_t cap = workspace_capacity(bytes);
+        const int rc = check_hip(hipMalloc(&fresh, cap), "ilx_raycaster_reserve: hipMalloc");
+        if (rc != ILX_OK) return rc;
+        h.ws_spare.emplace_back(fresh, cap);
+    }
+    return ILX_OK;
+}
+
+extern "C" int ilx_mesh_forget_patterns(ilx_mesh_t mesh) {
+    ILX_REQUIRE(mesh, ILX_EINVAL, "ilx_mesh_forget_patterns: mesh is NULL");
+    std::lock_guard<std::mutex> guard(mesh->h.ws_lock);
+    for (auto& kv : mesh->h.ws_by_stream) kv.second.starts = kv.second.dirs = nullptr, kv.second.rays = 0;
     return ILX_OK;
 }
 
@@ -1870,7 +1926,7 @@ extern "C" int ilx_scene_update_prepare_raycaster(const ilx_scene* scene, const 
         void* ws = nullptr;
         float* box = nullptr;
         bool same_pattern = false;
-        int status = lattice_workspace(d.mesh, stream, lattice_workspace_bytes(a.n, a.r), a, &ws, &box, &same_pattern);
+        int status = lattice_workspace(d.mesh, stream, lattice_workspace_bytes(a.n, a.r), a, true, &ws, &box, &same_pattern);
         if (status != ILX_OK) return status;
         LatEnvRec* recs = reinterpret_cast<LatEnvRec*>(static_cast<char*>(ws) + lattice_workspace_bytes(0, a.r));
         if (same_pattern && (d.hints & ILX_RAYS_PATTERN_STATIC)) {   // the packed pattern and its box are in the workspace: one launch
@@ -1903,7 +1959,7 @@ extern "C" int ilx_scene_update_prepare_raycaster(const ilx_scene* scene, const 
 static __device__ __align__(256) unsigned char scratch[kStaticScratchBytes];
 
 // The array's address on the current device (in host code `scratch` itself is only a handle for the runtime, not a
-// device address), looked up on the first call per device.
+// device address), looked up once per device: when the device's first mesh is created.
 static int static_scratch(void** out) {
     constexpr int kMaxDevices = 64;
     static std::mutex lock;
@@ -1935,6 +1991,11 @@ extern "C" int ilx_raycaster_refresh_static(const ilx_raycaster* rc, void* strea
                     d.ray_hits_w && d.timestamp && d.timestamp_last_update && d.is_outdated,
                 ILX_EINVAL, "ilx_raycaster_refresh_static: NULL operand");
     ILX_REQUIRE(d.pose_pos_stride >= 3 && d.pose_quat_stride >= 4, ILX_EINVAL, "ilx_raycaster_refresh_static: bad pose strides");
+    // ilx_scene_update_prepare_raycaster writes the mesh's per-stream workspace, never the built-in buffer: no
+    // preparation can have been issued for this entry point
+    ILX_REQUIRE(!(d.hints & ILX_RAYS_PREPARED), ILX_EINVAL,
+                "ilx_raycaster_refresh_static: ILX_RAYS_PREPARED names a preparation in the per-stream workspace; this entry "
+                "point prepares in the built-in buffer itself");
     void* ws = nullptr;
     int status = static_scratch(&ws);
     if (status != ILX_OK) return status;
@@ -1964,7 +2025,7 @@ static int launch_scan(ilx_mesh_t mesh, ScanArgs a, int hints, void* stream, voi
                         "buffer holds %zu (at most %d envs at %d rays); use ilx_raycaster_refresh",
                         (long long)a.n, a.r, lattice_workspace_bytes(a.n, a.r), fixed_bytes, kStaticEnvs, kLatMaxRays);
         } else {
-            const int rc = lattice_workspace(mesh, stream, lattice_workspace_bytes(a.n, a.r), a, &ws, &box, &same_pattern);
+            const int rc = lattice_workspace(mesh, stream, lattice_workspace_bytes(a.n, a.r), a, !(hints & ILX_RAYS_PREPARED), &ws, &box, &same_pattern);
             if (rc != ILX_OK) return rc;
         }
         take_ticket(mesh, a.ticket, a.off_grid);

@@ -98,6 +98,7 @@ class LocomotionVelocityStep:
         # the height_scan observation term's input, written by the scanner refresh with the term's offset
         self.height_scan = torch.zeros(n, self.scanner.num_rays, device=dev)
         self.height_scan_offset = next(float(t.aux) for t in self.mdp.observations if t.kind == "height_scan")
+        self.scanner.bind_height_scan(self.height_scan, self.height_scan_offset)   # whoever triggers the refresh
         self._bind()
         # see step(): worth it when the step is replayed from a HIP graph and the actuator chain is long (network
         # actuators); issued launch by launch, the fork and join cost the host more than the overlap returns
@@ -105,7 +106,7 @@ class LocomotionVelocityStep:
         # the managers add the done envs' statistics to mdp.log_sums; set, every step starts the vector at zero itself
         self.clear_log_sums = False
         self._advance_count_first = False   # see count_steps_on_device
-        self._side_stream = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
+        self._side_streams: dict[int, torch.cuda.Stream] = {}   # by priority, see _fork_stream
         # the last scene update of a step also issues the preparation of the scanner's refresh (see step_sensors)
         self.fuse_scanner_preparation = True
         # the step as one chain with scene.update(k) and the actuator model of substep k + 1 as one launch (see
@@ -167,7 +168,7 @@ class LocomotionVelocityStep:
         if self.paired_substeps and isinstance(self.actuator, (ActuatorNetMLP, DCMotor)) and not self.concurrent_chains:
             return self._step_paired(raw_action, noise_u, command_samples, reset_command_samples)
         main = torch.cuda.current_stream()
-        side = self._side_stream if self.concurrent_chains else main
+        side = self._fork_stream(main) if self.concurrent_chains else main
         if side is not main:
             side.wait_stream(main)
         with torch.cuda.stream(side):
@@ -181,6 +182,25 @@ class LocomotionVelocityStep:
         if side is not main:
             main.wait_stream(side)
         return self.step_managers(noise_u, command_samples, reset_command_samples)
+
+    @staticmethod
+    def check_fork_priorities(main_priority: int, side_priority: int) -> None:
+        """A fork / join between two streams of unequal priority, recorded into a HIP graph, stalled the graph's replay
+        on this stack (a high-priority capture stream forking onto a normal one never came back): the step refuses to
+        build that shape."""
+        if main_priority != side_priority:
+            raise _abi.IlxError(f"LocomotionVelocityStep: the step would fork from a stream of priority {main_priority} onto one of "
+                                f"priority {side_priority}; both chains of a step must run at one priority")
+
+    def _fork_stream(self, main):
+        """The stream chain (B) is issued on beside ``main``: one per priority of the streams the caller steps on, made
+        with that priority when first needed (outside any capture: creating a stream is not a stream operation)."""
+        prio = int(main.priority)
+        side = self._side_streams.get(prio)
+        if side is None:
+            side = self._side_streams[prio] = torch.cuda.Stream(device=self.device, priority=prio)
+        self.check_fork_priorities(prio, int(side.priority))
+        return side
 
     def _step_paired(self, raw_action, noise_u, command_samples, reset_command_samples):
         """The step as one chain in the reference's own order (manager_based_rl_env.py:172-195), with the launches that

@@ -32,32 +32,28 @@ class JointAction(ActionTerm):
         self._num_joints = len(self._joint_ids)
         if self._num_joints == self._asset.num_joints and not cfg.preserve_order:  # :71-73
             self._joint_ids = slice(None)
-        n, dev = self.num_envs, self.device
-        self._raw_actions = torch.zeros(n, self.action_dim, device=dev)
+        self._raw_actions = torch.zeros(self.num_envs, self.action_dim, device=self.device)
         self._processed_actions = torch.zeros_like(self._raw_actions)
-        if isinstance(cfg.scale, (float, int)):
-            self._scale = float(cfg.scale)
-        elif isinstance(cfg.scale, dict):
-            self._scale = torch.ones(n, self.action_dim, device=dev)
-            index_list, _, value_list = string_utils.resolve_matching_names_values(cfg.scale, self._joint_names)
-            self._scale[:, index_list] = torch.tensor(value_list, device=dev)
-        else:
-            raise ValueError(f"Unsupported scale type: {type(cfg.scale)}. Supported types are float and dict.")
-        if isinstance(cfg.offset, (float, int)):
-            self._offset = float(cfg.offset)
-        elif isinstance(cfg.offset, dict):
-            self._offset = torch.zeros_like(self._raw_actions)
-            index_list, _, value_list = string_utils.resolve_matching_names_values(cfg.offset, self._joint_names)
-            self._offset[:, index_list] = torch.tensor(value_list, device=dev)
-        else:
-            raise ValueError(f"Unsupported offset type: {type(cfg.offset)}. Supported types are float and dict.")
-        self._clip = None
-        if cfg.clip is not None:
-            if not isinstance(cfg.clip, dict):
-                raise ValueError(f"Unsupported clip type: {type(cfg.clip)}. Supported types are dict.")
-            self._clip = torch.tensor([[-float("inf"), float("inf")]], device=dev).repeat(n, self.action_dim, 1)
-            index_list, _, value_list = string_utils.resolve_matching_names_values(cfg.clip, self._joint_names)
-            self._clip[:, index_list] = torch.tensor(value_list, device=dev)
+        # scale and offset: one number for every joint stays a number (the kernel takes it as a scalar argument), a
+        # {joint-name regex: value} table becomes a per-joint row over `neutral`; clip: a table of (low, high) pairs only
+        self._scale = self._per_joint("scale", cfg.scale, 1.0, numbers=True)
+        self._offset = self._per_joint("offset", cfg.offset, 0.0, numbers=True)
+        self._clip = None if cfg.clip is None else self._per_joint("clip", cfg.clip, (-float("inf"), float("inf")), numbers=False)
+
+    def _per_joint(self, what: str, spec, neutral, numbers: bool):
+        """One parameter of the term's cfg as the kernel wants it (joint_actions.py:78-108: same types accepted, same
+        errors raised)."""
+        if numbers and isinstance(spec, (float, int)):
+            return float(spec)
+        if not isinstance(spec, dict):
+            accepted = "float and dict" if numbers else "dict"
+            raise ValueError(f"Unsupported {what} type: {type(spec)}. Supported types are {accepted}.")
+        shape = (self.num_envs, self.action_dim) if numbers else (self.num_envs, self.action_dim, len(neutral))
+        table = torch.empty(shape, dtype=torch.float32, device=self.device)
+        table[...] = torch.tensor(neutral, dtype=torch.float32, device=self.device)
+        columns, _, values = string_utils.resolve_matching_names_values(spec, self._joint_names)
+        table[:, columns] = torch.tensor(values, dtype=torch.float32, device=self.device)
+        return table
 
     @property
     def action_dim(self) -> int:

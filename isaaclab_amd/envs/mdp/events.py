@@ -193,7 +193,7 @@ def reset_scene_to_default(env, env_ids):
                                                      _abi.ptr(d.joint_vel), d.joint_pos.shape[1], _abi.stream()),
                    "ilx_event_reset_scene_to_default")
         _root_state_written(d)
-    if hasattr(asset, "write_root_pose_to_sim"):
+        if hasattr(asset, "write_root_pose_to_sim"):
             asset.write_root_pose_to_sim(d.root_state_w[ids, :7], env_ids=ids)
             asset.write_root_velocity_to_sim(d.root_state_w[ids, 7:], env_ids=ids)
             asset.write_joint_state_to_sim(d.joint_pos[ids], d.joint_vel[ids], env_ids=ids)

@@ -102,8 +102,8 @@ class InteractiveScene:
     def update(self, dt: float, prepare_scanner: bool = False) -> bool:
         """interactive_scene.py:496-513.  ``prepare_scanner`` (no counterpart in the reference): this is the last update
         before the height scanner is read, and the scanner's pose is final (``set_pose``): the launch also issues the
-        preparation of the scanner's refresh.  Returns whether it did -- then the refresh that follows on this stream is
-        ``scanner._update_outdated_buffers(..., prepared=True)``."""
+        preparation of the scanner's refresh.  Returns whether it did -- the sensor then knows (``RayCaster._prepared``) that
+        its next refresh on this stream, from the step or from a reader of ``scanner.data``, is the cast alone."""
         desc = self._describe(dt)
         if desc is None:
             for a in self.articulations.values():
@@ -117,6 +117,7 @@ class InteractiveScene:
             rc = rays[0]._descriptor()
             _abi.check(_abi.scene_update_prepare_raycaster(ctypes.byref(sc), ctypes.byref(rc), _abi.stream()),
                        "ilx_scene_update_prepare_raycaster")
+            rays[0]._prepared = True   # consumed by the sensor's next refresh, whoever issues it
             return True
         _abi.check(_abi.scene_update(ctypes.byref(sc), _abi.stream()), "ilx_scene_update")
         if eager_rays:

@@ -90,6 +90,18 @@ class RayCaster:
         # True: refresh through the entry point that allocates nothing (a buffer built into the library, shared by all
         # calls on the GPU, limited to 32,768 envs); for callers under graph capture or otherwise unable to allocate
         self.static_workspace = False
+        # The scene update that ran last also issued this sensor's refresh preparation (InteractiveScene.update(dt,
+        # prepare_scanner=True)): the clocks of the due envs are already advanced and their records wait in the
+        # stream's workspace, so the next refresh -- whoever asks for it -- must be the cast alone.
+        self._prepared = False
+        # where every refresh also writes the height scan of the `height_scan` observation term (bind_height_scan)
+        self._height_out, self._height_offset = None, 0.0
+        # a new pattern array may sit where a released one sat: the mesh's streams pack their pattern again; and the
+        # per-stream workspaces of this sensor's refreshes are set aside now, so that no refresh allocates (`streams`
+        # of them: the stream the owner steps on, one it may fork onto, and two capture streams)
+        if self._device.type == "cuda":
+            _abi.check(_abi.mesh_forget_patterns(mesh.handle), "ilx_mesh_forget_patterns")
+            _abi.check(_abi.raycaster_reserve(mesh.handle, n, self.num_rays, 4), "ilx_raycaster_reserve")
 
     @property
     def num_instances(self) -> int:
@@ -115,6 +127,11 @@ class RayCaster:
         """What ``ArticulationView.get_root_transforms`` returns: (N,7) with an xyzw quaternion (ray_caster.py:225-227)."""
         pos, quat = root_transforms_xyzw.split([3, 4], dim=-1)
         self.set_pose(pos.contiguous(), math_utils.convert_quat(quat, to="wxyz").contiguous())
+
+    def bind_height_scan(self, out: torch.Tensor | None, offset: float = 0.0):
+        """Every refresh from now on also writes ``pos_w.z - hit.z - offset`` per ray into ``out`` (N, R): the value of
+        the ``height_scan`` observation term (observations.py:165-173)."""
+        self._height_out, self._height_offset = out, float(offset)
 
     # -- operations
     def reset(self, env_ids: Sequence[int] | None = None):
@@ -154,7 +171,13 @@ class RayCaster:
         """sensor_base.py:284-293 + ray_caster.py:220-260: the flagged envs take the new pose (+ drift), cast their
         rays and record the refresh time -- two launches, the env subset is the ``_is_outdated`` mask on the device.
         ``prepared``: the scene update just before issued the refresh's preparation with its own launch
-        (``InteractiveScene.update(dt, prepare_scanner=True)``, same stream, same pose); only the cast follows."""
+        (``InteractiveScene.update(dt, prepare_scanner=True)``, same stream, same pose); only the cast follows.  The
+        scene records that on the sensor (``_prepared``), so the argument is only needed by callers that issue the
+        preparation themselves."""
+        if height_out is None:
+            height_out, height_offset = self._height_out, self._height_offset
+        # the preparation is consumed by the first refresh after it, whether the step asks for it or a reader of `data`
+        prepared, self._prepared = (prepared or self._prepared), False
         rc = self._descriptor(height_out, height_offset, _abi.RAYS_PREPARED if (prepared and not self.static_workspace) else 0)
         if self.static_workspace:
             _abi.check(_abi.raycaster_refresh_static(ctypes.byref(rc), _abi.stream()), "ilx_raycaster_refresh_static")
