@@ -236,8 +236,23 @@ typedef struct ilx_mdp {
 typedef struct ilx_mdp_plan_s* ilx_mdp_plan_t;
 int ilx_mdp_plan_create(const ilx_mdp* desc, ilx_mdp_plan_t* out);
 void ilx_mdp_plan_destroy(ilx_mdp_plan_t plan);
-/* Re-read the pointer / scalar fields of `desc` (term tables are fixed at creation) and launch `phases`. */
+/* Re-read the pointer / scalar fields of `desc` (term tables are fixed at creation) and launch `phases`.
+ *
+ * Two kinds of kernel stand behind this call.  The plan-interpreting kernel serves every term list.  For the term lists
+ * of the reference's own task configurations -- velocity_env_cfg.py:119-265 (ANYmal-C rough), config/h1/rough_env_cfg.py:19-115,
+ * classic/cartpole/cartpole_env_cfg.py:58-181, manipulation/reach/reach_env_cfg.py:65-208 -- the library also holds a
+ * kernel compiled for exactly that list (every term straight-line code, sizes known at compile time).  A plan whose
+ * term kinds, index-list lengths, zero weights and sizes equal one of those lists (parameters and weights are free) is
+ * served by that kernel whenever the call asks for all phases, every optional output is given and, for the height
+ * scan, `height_scan` is given; every other call goes to the plan-interpreting kernel.  Both kernels write the same
+ * bits into every output (log_sums: the same addends in another order). */
 int ilx_mdp_step(ilx_mdp_plan_t plan, const ilx_mdp* desc, void* stream);
+/* No counterpart in the reference: the name of the kernel that serves full steps of this plan -- "generic" or the
+ * compiled kernel's ("anymal_c_rough", "h1_rough", "cartpole", "reach_j9_a7", ...).  The string is static. */
+const char* ilx_mdp_plan_kernel(ilx_mdp_plan_t plan);
+/* No counterpart in the reference: compiled == 0 sends every step of the plan to the plan-interpreting kernel (for
+ * checking one kernel against the other); non-zero restores the default. */
+int ilx_mdp_plan_select_kernel(ilx_mdp_plan_t plan, int compiled);
 /* What a caller does between the launches of two env steps, as one small launch: clears `log_sums` (`count` floats, or
  * NULL: the reference's managers rebuild their `extras["log"]` entries at every reset, reward_manager.py:100-126) and
  * adds one to `step_index_device` (or NULL).  For steps recorded in a HIP graph, where each extra node costs. */

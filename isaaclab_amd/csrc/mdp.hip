@@ -14,12 +14,7 @@
 // The chain termination -> reward -> reset -> command -> observation never round-trips through memory.
 // Term tables are data (`kind` dispatch); term formulas cite the reference file:line; op order for decisions
 // follows math_dev.h.
-#include "common.h"
-#include "math_dev.h"
-#include "philox.h"
-#include "uniform_access.h"
-
-#include "../../include/isaaclab_amd_mdp.h"
+#include "mdp_shared.h"
 
 #include <cstring>
 #include <algorithm>
@@ -27,11 +22,10 @@
 
 namespace ilx {
 
-constexpr int kMaxTerms = 32;      // per manager
 constexpr int kE = 16;             // environments per block
 constexpr int kBlock = 256;        // threads per block (measured on the ANYmal-C plan, envs x threads -> us:
                                    // 8x256 66, 16x256 46, 32x256 56, 16x512 77, 32x512 45)
-constexpr int kWaves = kBlock / 64;
+static_assert(kWaves == kBlock / 64, "the reward terms are dealt to the block's wavefronts");
 constexpr int kMaxLdsBytes = 64 * 1024;
 constexpr int kMaxSegs = 160;      // STAGE copy instructions per block (a kernel-argument table of 16-byte records)
 
@@ -117,7 +111,7 @@ struct Hot {
     uint64_t reward_owner;  // two bits per reward term: the wavefront that evaluates it
 };
 
-// One environment as seen by its lane in the DECIDE stage.
+// One environment as seen by its lane in the DECIDE stage: the accessor type of mdp_shared.h over the block's LDS image.
 struct Env {
     const MdpDev& m;
     const Hot& h;
@@ -131,14 +125,42 @@ struct Env {
     float time_left;
     int64_t command_counter;
 
+    ILX_DEV const ilx_mdp& desc() const { return m.d; }
     ILX_DEV int id(const ilx_term& t, int k) const { return t.ids_cnt < 0 ? k : ids[t.ids_off + k]; }
     ILX_DEV int id2(const ilx_term& t, int k) const { return t.ids2_cnt < 0 ? k : ids[t.ids2_off + k]; }
     ILX_DEV int jcount(const ilx_term& t) const { return t.ids_cnt < 0 ? h.num_joints : t.ids_cnt; }
     ILX_DEV int bcount_sensor(const ilx_term& t) const { return t.ids_cnt < 0 ? h.num_sensor_bodies : t.ids_cnt; }
     ILX_DEV int bcount_asset(const ilx_term& t) const { return t.ids_cnt < 0 ? h.num_bodies : t.ids_cnt; }
-    ILX_DEV float joint(int off, int j) const { return S[off + e * h.num_joints + j]; }
-    ILX_DEV float sbody(int off, int b) const { return S[off + e * h.num_sensor_bodies + b]; }
-    ILX_DEV float abody(int off, int b) const { return S[off + e * h.num_bodies + b]; }
+    ILX_DEV int num_actions() const { return h.action_dim; }
+    ILX_DEV int num_rays() const { return h.num_rays; }
+    ILX_DEV int row(Fld f) const {  // the image row of a field (the field is a constant at every call site)
+        const Layout& L = h.L;
+        switch (f) {
+            case Fld::q: return L.q;
+            case Fld::qd: return L.qd;
+            case Fld::qdd: return L.qdd;
+            case Fld::tau_a: return L.tau_a;
+            case Fld::tau_c: return L.tau_c;
+            case Fld::q0: return L.q0;
+            case Fld::qd0: return L.qd0;
+            case Fld::vlim: return L.vlim;
+            case Fld::air: return L.air;
+            case Fld::last_air: return L.last_air;
+            case Fld::contact_t: return L.contact_t;
+            case Fld::bvx: return L.bvx;
+            case Fld::bvy: return L.bvy;
+            case Fld::bacc: return L.bacc;
+        }
+        return 0;
+    }
+    ILX_DEV float joint(Fld f, int j) const { return S[row(f) + e * h.num_joints + j]; }
+    ILX_DEV float limit(int j, int side) const { return S[h.L.lim + 2 * (e * h.num_joints + j) + side]; }
+    ILX_DEV float sbody(Fld f, int b) const { return S[row(f) + e * h.num_sensor_bodies + b]; }
+    ILX_DEV float abody(Fld f, int b) const { return S[row(f) + e * h.num_bodies + b]; }
+    ILX_DEV float action(int k) const { return S[h.L.act + e * h.action_dim + k]; }
+    ILX_DEV float prev_action(int k) const { return S[h.L.pact + e * h.action_dim + k]; }
+    ILX_DEV const float* body_row(int b) const { return m.d.body_state_w + 13 * (env * h.num_bodies + b); }
+    ILX_DEV float ray_hit_z(int k) const { return m.d.ray_hits_w[3 * (env * h.num_rays + k) + 2]; }
     // max over the history of |F| of one sensor body (rewards.py:266 / terminations.py:157), from the force history as
     // it lies in memory: the largest sum of squares, then one square root (the root is monotonic and correctly
     // rounded, so this is the largest norm, bit for bit)
@@ -150,237 +172,7 @@ struct Env {
         return mx < 0.0f ? -__builtin_inff() : sqrt_(mx);
     }
     ILX_DEV float cmd(int k) const { return S[h.L.cmd + e * h.command_dim + k]; }
-    template <typename F>
-    ILX_DEV float joint_sum(const ilx_term& t, F f) const {
-        const int n = jcount(t);
-        float acc = 0.0f;
-        // four elements' reads in flight together; the additions keep their order (the sum is compared bit for bit)
-        int k = 0;
-        for (; k + 4 <= n; k += 4) {
-            const float f0 = f(id(t, k)), f1 = f(id(t, k + 1)), f2 = f(id(t, k + 2)), f3 = f(id(t, k + 3));
-            acc += f0;
-            acc += f1;
-            acc += f2;
-            acc += f3;
-        }
-        for (; k < n; ++k) acc += f(id(t, k));
-        return acc;
-    }
-    template <typename F>
-    ILX_DEV bool joint_any(const ilx_term& t, F f) const {
-        const int n = jcount(t);
-        bool hit = false;
-        for (int k = 0; k < n; ++k) hit = hit | f(id(t, k));  // no short circuit: the reads do not wait for each other
-        return hit;
-    }
 };
-
-// --------------------------------------------------------------------------------------------------
-ILX_DEV bool eval_termination(const Env& e, const ilx_term& t, int64_t ep_len) {
-    const ilx_mdp& d = e.m.d;
-    const Layout& L = e.h.L;
-    switch (t.kind) {
-        case ILX_TERM_TIME_OUT:  // terminations.py:30-32
-            return ep_len >= d.max_episode_length;
-        case ILX_TERM_COMMAND_RESAMPLE:  // :35-42
-            return (e.time_left <= t.p[0]) && (e.command_counter == static_cast<int64_t>(t.p[1]));
-        case ILX_TERM_BAD_ORIENTATION:  // :50-59
-            return fabsf(acosf(-e.grav_b.z)) > t.p[0];
-        case ILX_TERM_ROOT_HEIGHT_BELOW_MINIMUM:  // :62-72
-            return e.pos.z < t.p[0];
-        case ILX_TERM_JOINT_POS_OUT_OF_MANUAL_LIMIT:  // :90-105
-            return e.joint_any(t, [&](int j) { const float q = e.joint(L.q, j); return (q > t.p[1]) || (q < t.p[0]); });
-        case ILX_TERM_JOINT_VEL_OUT_OF_LIMIT:  // :108-114
-            return e.joint_any(t, [&](int j) { return fabsf(e.joint(L.qd, j)) > e.joint(L.vlim, j); });
-        case ILX_TERM_JOINT_VEL_OUT_OF_MANUAL_LIMIT:  // :117-124
-            return e.joint_any(t, [&](int j) { return fabsf(e.joint(L.qd, j)) > t.p[0]; });
-        case ILX_TERM_JOINT_EFFORT_OUT_OF_LIMIT:  // :127-142, torch.isclose(rtol=1e-5, atol=1e-8)
-            return e.joint_any(t, [&](int j) {
-                const float a = e.joint(L.tau_c, j), b = e.joint(L.tau_a, j);
-                return (a == b) || (fabsf(a - b) <= (1.0e-8f + 1.0e-5f * fabsf(b)));
-            });
-        case ILX_TERM_ILLEGAL_CONTACT: {  // :150-158
-            const int n = e.bcount_sensor(t);
-            bool hit = false;
-            for (int k = 0; k < n; ++k) hit = hit | (e.force_peak(e.id(t, k)) > t.p[0]);
-            return hit;
-        }
-    }
-    return false;
-}
-
-ILX_DEV float eval_reward(const Env& e, const ilx_term& t, bool terminated, bool time_out, uint32_t term_bits) {
-    const ilx_mdp& d = e.m.d;
-    const Layout& L = e.h.L;
-    const int B = e.h.num_bodies, A = e.h.action_dim, R = e.h.num_rays;
-    switch (t.kind) {
-        case ILX_REW_IS_ALIVE: return terminated ? 0.0f : 1.0f;       // rewards.py:31-33
-        case ILX_REW_IS_TERMINATED: return terminated ? 1.0f : 0.0f;  // :36-38
-        case ILX_REW_IS_TERMINATED_TERM:                              // :41-68
-            return static_cast<float>(__popc(term_bits & static_cast<uint32_t>(t.flags))) * (time_out ? 0.0f : 1.0f);
-        case ILX_REW_LIN_VEL_Z_L2: return e.lin_b.z * e.lin_b.z;                              // :76-80
-        case ILX_REW_ANG_VEL_XY_L2: return e.ang_b.x * e.ang_b.x + e.ang_b.y * e.ang_b.y;    // :83-87
-        case ILX_REW_FLAT_ORIENTATION_L2: return e.grav_b.x * e.grav_b.x + e.grav_b.y * e.grav_b.y;  // :90-97
-        case ILX_REW_BASE_HEIGHT_L2: {  // :100-122
-            float target = t.p[0];
-            if (t.flags & 1) {
-                float acc = 0.0f;
-                for (int k = 0; k < R; ++k) acc += d.ray_hits_w[3 * (e.env * R + k) + 2];
-                target = t.p[0] + div_(acc, static_cast<float>(R));
-            }
-            const float dz = e.pos.z - target;
-            return dz * dz;
-        }
-        case ILX_REW_BODY_LIN_ACC_L2: {  // :125-128
-            const int n = e.bcount_asset(t);
-            float acc = 0.0f;
-            for (int k = 0; k < n; ++k) acc += e.abody(L.bacc, e.id(t, k));
-            return acc;
-        }
-        case ILX_REW_JOINT_TORQUES_L2:  // :136-143
-            return e.joint_sum(t, [&](int j) { const float v = e.joint(L.tau_a, j); return v * v; });
-        case ILX_REW_JOINT_VEL_L1:  // :146-150
-            return e.joint_sum(t, [&](int j) { return fabsf(e.joint(L.qd, j)); });
-        case ILX_REW_JOINT_VEL_L2:  // :153-160
-            return e.joint_sum(t, [&](int j) { const float v = e.joint(L.qd, j); return v * v; });
-        case ILX_REW_JOINT_ACC_L2:  // :163-170
-            return e.joint_sum(t, [&](int j) { const float v = e.joint(L.qdd, j); return v * v; });
-        case ILX_REW_JOINT_DEVIATION_L1:  // :173-179
-            return e.joint_sum(t, [&](int j) { return fabsf(e.joint(L.q, j) - e.joint(L.q0, j)); });
-        case ILX_REW_JOINT_POS_LIMITS:  // :182-196
-            return e.joint_sum(t, [&](int j) {
-                const float q = e.joint(L.q, j);
-                const float lo = e.S[L.lim + 2 * (e.e * e.h.num_joints + j)], hi = e.S[L.lim + 2 * (e.e * e.h.num_joints + j) + 1];
-                return -fminf(q - lo, 0.0f) + fmaxf(q - hi, 0.0f);
-            });
-        case ILX_REW_JOINT_VEL_LIMITS:  // :199-218
-            return e.joint_sum(t, [&](int j) {
-                return fminf(fmaxf(fabsf(e.joint(L.qd, j)) - e.joint(L.vlim, j) * t.p[0], 0.0f), 1.0f);
-            });
-        case ILX_REW_APPLIED_TORQUE_LIMITS:  // :226-242
-            return e.joint_sum(t, [&](int j) { return fabsf(e.joint(L.tau_a, j) - e.joint(L.tau_c, j)); });
-        case ILX_REW_ACTION_RATE_L2: {  // :245-247
-            float acc = 0.0f;
-            for (int k = 0; k < A; ++k) {
-                const float v = e.S[L.act + e.e * A + k] - e.S[L.pact + e.e * A + k];
-                acc += v * v;
-            }
-            return acc;
-        }
-        case ILX_REW_ACTION_L2: {  // :250-252
-            float acc = 0.0f;
-            for (int k = 0; k < A; ++k) {
-                const float v = e.S[L.act + e.e * A + k];
-                acc += v * v;
-            }
-            return acc;
-        }
-        case ILX_REW_UNDESIRED_CONTACTS: {  // :260-268 (count of bodies above the threshold)
-            const int n = e.bcount_sensor(t);
-            float acc = 0.0f;
-            for (int k = 0; k < n; ++k) acc += (e.force_peak(e.id(t, k)) > t.p[0]) ? 1.0f : 0.0f;
-            return acc;
-        }
-        case ILX_REW_CONTACT_FORCES: {  // :271-279
-            const int n = e.bcount_sensor(t);
-            float acc = 0.0f;
-            for (int k = 0; k < n; ++k) acc += fmaxf(e.force_peak(e.id(t, k)) - t.p[0], 0.0f);
-            return acc;
-        }
-        case ILX_REW_TRACK_LIN_VEL_XY_EXP: {  // :287-298
-            const float dx = e.cmd(0) - e.lin_b.x, dy = e.cmd(1) - e.lin_b.y;
-            return expf(div_(-(dx * dx + dy * dy), t.p[0]));
-        }
-        case ILX_REW_TRACK_ANG_VEL_Z_EXP: {  // :301-309
-            const float dz = e.cmd(2) - e.ang_b.z;
-            return expf(div_(-(dz * dz), t.p[0]));
-        }
-        case ILX_REW_FEET_AIR_TIME: {  // velocity/mdp/rewards.py:25-44
-            const int n = e.bcount_sensor(t);
-            float acc = 0.0f;
-            for (int k = 0; k < n; ++k) {
-                const int b = e.id(t, k);
-                const float cc = e.sbody(L.contact_t, b);
-                const bool first = (cc > 0.0f) && (cc < t.p[1]);  // contact_sensor.py:200-203
-                acc += (e.sbody(L.last_air, b) - t.p[0]) * (first ? 1.0f : 0.0f);
-            }
-            return acc * ((norm2(e.cmd(0), e.cmd(1)) > 0.1f) ? 1.0f : 0.0f);
-        }
-        case ILX_REW_FEET_AIR_TIME_POSITIVE_BIPED: {  // velocity/mdp/rewards.py:47-66
-            const int n = e.bcount_sensor(t);
-            float cnt = 0.0f;
-            for (int k = 0; k < n; ++k) cnt += (e.sbody(L.contact_t, e.id(t, k)) > 0.0f) ? 1.0f : 0.0f;
-            const bool single = cnt == 1.0f;
-            float mn = __builtin_inff();
-            for (int k = 0; k < n; ++k) {
-                const int b = e.id(t, k);
-                const float cc = e.sbody(L.contact_t, b);
-                const float mode = (cc > 0.0f) ? cc : e.sbody(L.air, b);
-                mn = fminf(mn, single ? mode : 0.0f);
-            }
-            return fminf(mn, t.p[0]) * ((norm2(e.cmd(0), e.cmd(1)) > 0.1f) ? 1.0f : 0.0f);
-        }
-        case ILX_REW_FEET_SLIDE: {  // velocity/mdp/rewards.py:69-83
-            const int n = e.bcount_sensor(t);
-            float acc = 0.0f;
-            for (int k = 0; k < n; ++k) {
-                const bool contact = e.force_peak(e.id(t, k)) > 1.0f;
-                const int ab = e.id2(t, k);
-                acc += norm2(e.abody(L.bvx, ab), e.abody(L.bvy, ab)) * (contact ? 1.0f : 0.0f);
-            }
-            return acc;
-        }
-        case ILX_REW_TRACK_LIN_VEL_XY_YAW_FRAME_EXP: {  // velocity/mdp/rewards.py:86-96
-            const f3 v = quat_rotate_inverse(yaw_quat(e.quat), e.lin_w);
-            const float dx = e.cmd(0) - v.x, dy = e.cmd(1) - v.y;
-            return expf(div_(-(dx * dx + dy * dy), t.p[0]));
-        }
-        case ILX_REW_TRACK_ANG_VEL_Z_WORLD_EXP: {  // velocity/mdp/rewards.py:99-106
-            const float dz = e.cmd(2) - e.ang_w.z;
-            return expf(div_(-(dz * dz), t.p[0]));
-        }
-        case ILX_REW_POSITION_COMMAND_ERROR:
-        case ILX_REW_POSITION_COMMAND_ERROR_TANH: {  // reach/mdp/rewards.py:19-52
-            const f3 rr = quat_apply(e.quat, f3{e.cmd(0), e.cmd(1), e.cmd(2)});
-            const f3 des = {e.pos.x + rr.x, e.pos.y + rr.y, e.pos.z + rr.z};
-            const float* b = d.body_state_w + 13 * (e.env * B + e.ids[t.ids_off]);
-            const float dist = norm3(b[0] - des.x, b[1] - des.y, b[2] - des.z);
-            return t.kind == ILX_REW_POSITION_COMMAND_ERROR ? dist : (1.0f - tanhf(div_(dist, t.p[0])));
-        }
-        case ILX_REW_ORIENTATION_COMMAND_ERROR: {  // reach/mdp/rewards.py:55-69
-            const f4 des = quat_mul(e.quat, f4{e.cmd(3), e.cmd(4), e.cmd(5), e.cmd(6)});
-            const float* b = d.body_state_w + 13 * (e.env * B + e.ids[t.ids_off]) + 3;
-            return quat_error_magnitude(f4{b[0], b[1], b[2], b[3]}, des);
-        }
-        case ILX_REW_JOINT_POS_TARGET_L2:  // cartpole/mdp/rewards.py:19-26
-            return e.joint_sum(t, [&](int j) { const float v = wrap_to_pi(e.joint(L.q, j)) - t.p[0]; return v * v; });
-    }
-    return 0.0f;
-}
-
-ILX_DEV int obs_dim_of(const ilx_mdp& d, const ilx_term& t) {
-    const int nj = t.ids_cnt < 0 ? d.num_joints : t.ids_cnt;
-    switch (t.kind) {
-        case ILX_OBS_BASE_POS_Z: return 1;
-        case ILX_OBS_BASE_LIN_VEL:
-        case ILX_OBS_BASE_ANG_VEL:
-        case ILX_OBS_PROJECTED_GRAVITY:
-        case ILX_OBS_ROOT_POS_W:
-        case ILX_OBS_ROOT_LIN_VEL_W:
-        case ILX_OBS_ROOT_ANG_VEL_W: return 3;
-        case ILX_OBS_ROOT_QUAT_W: return 4;
-        case ILX_OBS_JOINT_POS:
-        case ILX_OBS_JOINT_POS_REL:
-        case ILX_OBS_JOINT_POS_LIMIT_NORMALIZED:
-        case ILX_OBS_JOINT_VEL:
-        case ILX_OBS_JOINT_VEL_REL: return nj;
-        case ILX_OBS_HEIGHT_SCAN: return d.num_rays;
-        case ILX_OBS_LAST_ACTION: return d.action_dim;
-        case ILX_OBS_GENERATED_COMMANDS: return d.command_dim;
-        case ILX_OBS_EXTERNAL: return d.external_obs_dim[static_cast<int>(t.aux)];
-    }
-    return 0;
-}
 
 // Column k of an observation term for env slot e (EMIT stage; everything except the height scan comes from LDS).
 ILX_DEV float eval_obs(const MdpDev& m, const Hot& h, const float* S, const int32_t* ids, int e, int64_t env, const ilx_term& t, int k) {
@@ -430,14 +222,6 @@ ILX_DEV float eval_obs(const MdpDev& m, const Hot& h, const float* S, const int3
     return 0.0f;
 }
 
-// Command term state of one env (held by the env's lane).
-struct CmdState {
-    float time_left = 0.0f, metric0 = 0.0f, metric1 = 0.0f, heading_target = 0.0f;
-    int64_t counter = 0;
-    bool is_heading = false, is_standing = false;
-    float c[7] = {0, 0, 0, 0, 0, 0, 0};
-};
-
 // A term record as wave-uniform values, read from the plan's table in memory with scalar loads (three of them, through
 // the constant cache; no vector instruction).  A copy from the LDS image would land in vector registers and the
 // compiler would then treat `kind`, the id ranges and the parameters as per-lane data: the dispatch on `kind` becomes
@@ -450,47 +234,6 @@ ILX_DEV ilx_term uniform_term(const ilx_term* table, int index) {
 #pragma unroll
     for (int w = 0; w < static_cast<int>(sizeof(ilx_term) / 4); ++w) out[w] = in[w];
     return t;
-}
-
-// The seven samples a resampling env consumes: injected values, or two generator calls mapped to the term's ranges
-// (the two coin flips of the velocity term stay in [0, 1)).
-template <typename P>
-ILX_DEV void command_draws(const ilx_mdp& d, uint64_t seed, uint64_t step, P injected, int64_t env, uint32_t salt, float (&smp)[7]) {
-    if (injected) {
-#pragma unroll
-        for (int k = 0; k < 7; ++k) smp[k] = injected[env * 7 + k];
-        return;
-    }
-    const u4 a = philox4(seed, step, static_cast<uint64_t>(env), 0x40000000u + salt),
-             b = philox4(seed, step, static_cast<uint64_t>(env), 0x40000001u + salt);
-    const float u[7] = {u01(a.x), u01(a.y), u01(a.z), u01(a.w), u01(b.x), u01(b.y), u01(b.z)};
-#pragma unroll
-    for (int k = 0; k < 7; ++k) {
-        const bool coin = d.command_kind == ILX_CMD_VELOCITY && k >= 5;
-        smp[k] = coin ? u[k] : u[k] * (d.cmd_range[k][1] - d.cmd_range[k][0]) + d.cmd_range[k][0];
-    }
-}
-
-// CommandTerm._resample for one env: command_manager.py:172-187 + the term's _resample_command
-template <typename P>
-ILX_DEV void command_resample(const ilx_mdp& d, uint64_t seed, uint64_t step, int64_t env, P injected, uint32_t salt, CmdState& s) {
-    float v[7];
-    command_draws(d, seed, step, injected, env, salt, v);
-    s.time_left = v[0];
-    s.counter += 1;
-    if (d.command_kind == ILX_CMD_VELOCITY) {  // velocity_command.py:123-138
-        s.c[0] = v[1], s.c[1] = v[2], s.c[2] = v[3];
-        if (d.heading_command) {
-            s.heading_target = v[4];
-            s.is_heading = v[5] <= d.rel_heading_envs;
-        }
-        s.is_standing = v[6] <= d.rel_standing_envs;
-    } else if (d.command_kind == ILX_CMD_POSE) {  // pose_command.py:107-120
-        s.c[0] = v[1], s.c[1] = v[2], s.c[2] = v[3];
-        f4 q = quat_from_euler_xyz(v[4], v[5], v[6]);
-        if (d.make_quat_unique) q = quat_unique(q);
-        s.c[3] = q.w, s.c[4] = q.x, s.c[5] = q.y, s.c[6] = q.z;
-    }
 }
 
 // STAGE is a work list.  Every array a block stages is one contiguous chunk for its kE consecutive envs (or a table that
@@ -906,28 +649,8 @@ __global__ void __launch_bounds__(kBlock, 4) mdp_step_kernel(MdpDev args, const 
         if (o_len && (ph_term || (ph_reset && done))) st_at(o_len + env0, 8u * ue, ep_len);
         // ---- command term (command_manager.py:151-166)
         if (ph_cmd) {
-            if (velocity) {  // velocity_command.py:111-121
-                cs.metric0 = cs.metric0 + div_(norm2(cs.c[0] - en.lin_b.x, cs.c[1] - en.lin_b.y), max_command_step);
-                cs.metric1 = cs.metric1 + div_(fabsf(cs.c[2] - en.ang_b.z), max_command_step);
-            } else {  // pose_command.py:92-108 (metrics are overwritten each step)
-                f3 pw;
-                f4 qw;
-                combine_frame_transforms(en.pos, en.quat, f3{cs.c[0], cs.c[1], cs.c[2]}, f4{cs.c[3], cs.c[4], cs.c[5], cs.c[6]}, pw, qw);
-                const auto* b = p_body_state + 13 * (env * B + d.pose_body_index);
-                const f3 aa = axis_angle_from_quat(quat_error(qw, f4{b[3], b[4], b[5], b[6]}));
-                cs.metric0 = norm3(b[0] - pw.x, b[1] - pw.y, b[2] - pw.z);
-                cs.metric1 = norm3(aa);
-            }
-            cs.time_left = cs.time_left - dt;
-            if (cs.time_left <= 0.0f) command_resample(d, seed, gen_step, env, in_samples, 0u, cs);
-            if (velocity) {  // velocity_command.py:140-160
-                if (heading_command && cs.is_heading) {
-                    const f3 fwd = quat_apply(en.quat, f3{1.0f, 0.0f, 0.0f});  // articulation_data.py:416-425
-                    const float err = wrap_to_pi(cs.heading_target - atan2f(fwd.y, fwd.x));
-                    cs.c[2] = fminf(fmaxf(stiffness * err, yaw_lo), yaw_hi);
-                }
-                if (cs.is_standing) cs.c[0] = cs.c[1] = cs.c[2] = 0.0f;
-            }
+            command_compute(d, en, velocity, heading_command, dt, max_command_step, stiffness, yaw_lo, yaw_hi, seed, gen_step, env,
+                            in_samples, p_body_state + 13 * (env * B + d.pose_body_index), cs);
             cmd_dirty = true;
         }
         if (cmd_dirty) {
@@ -1090,24 +813,6 @@ __global__ void __launch_bounds__(kBlock, 4) mdp_step_kernel(MdpDev args, const 
 
 using namespace ilx;
 
-struct ilx_mdp_plan_s {
-    ilx_term* d_terms = nullptr;  // [terminations | rewards | observations]
-    int32_t* d_ids = nullptr;
-    uint32_t* d_cols = nullptr;  // one ColDesc per observation column
-    int dims[3] = {0, 0, 0};     // num_joints, action_dim, command_dim the column descriptors were made for
-    bool any_noise = false;
-    uint32_t noisy_terms = 0;
-    uint64_t reward_owner = 0;   // two bits per reward term: the wavefront that evaluates it
-    int nt = 0, nr = 0, no = 0, nids = 0;
-    int obs_dim = 0;
-    // data the term tables read, per phase group (checked against NULL at every step)
-    bool t_contact = false, t_joint = false, t_cmdstate = false;
-    bool r_contact = false, r_timers = false, r_body_state = false, r_body_vel = false, r_body_acc = false, r_joint = false,
-         r_action = false, r_rays = false, r_command = false;
-    bool o_joint = false, o_rays = false, o_action = false, o_command = false;
-    uint32_t o_external = 0;  // slots of the external observation buffers the plan reads
-};
-
 static int host_obs_dim(const ilx_mdp& d, const ilx_term& t) {
     const int nj = t.ids_cnt < 0 ? d.num_joints : t.ids_cnt;
     switch (t.kind) {
@@ -1218,34 +923,12 @@ extern "C" int ilx_mdp_plan_create(const ilx_mdp* desc, ilx_mdp_plan_t* out) {
         p->r_command |= (k >= ILX_REW_TRACK_LIN_VEL_XY_EXP && k <= ILX_REW_FEET_AIR_TIME_POSITIVE_BIPED) ||
                         (k >= ILX_REW_TRACK_LIN_VEL_XY_YAW_FRAME_EXP && k <= ILX_REW_ORIENTATION_COMMAND_ERROR);
     }
-    {   // The block's four wavefronts split the reward terms; the stage lasts as long as its most loaded wavefront, so the
-        // terms are dealt by a rough count of the LDS reads each makes, heaviest first, to the least loaded wavefront.
-        auto cost = [&](const ilx_term& t) {
-            if (t.weight == 0.0f) return 0;
-            const int k = t.kind;
-            const int nj = t.ids_cnt < 0 ? d.num_joints : t.ids_cnt, nb = t.ids_cnt < 0 ? d.num_sensor_bodies : t.ids_cnt;
-            if ((k >= ILX_REW_JOINT_TORQUES_L2 && k <= ILX_REW_APPLIED_TORQUE_LIMITS) || k == ILX_REW_JOINT_POS_TARGET_L2) return 10 + 3 * nj;
-            if (k == ILX_REW_ACTION_RATE_L2 || k == ILX_REW_ACTION_L2) return 10 + 3 * d.action_dim;
-            if (k == ILX_REW_UNDESIRED_CONTACTS || k == ILX_REW_CONTACT_FORCES || k == ILX_REW_FEET_SLIDE)
-                return 10 + (4 + 4 * d.history_len) * nb;
-            if (k == ILX_REW_FEET_AIR_TIME || k == ILX_REW_FEET_AIR_TIME_POSITIVE_BIPED) return 15 + 5 * nb;
-            if (k == ILX_REW_BODY_LIN_ACC_L2) return 10 + 2 * (t.ids_cnt < 0 ? d.num_bodies : t.ids_cnt);
-            if (k == ILX_REW_BASE_HEIGHT_L2 && (t.flags & 1)) return 10 + 4 * d.num_rays;
-            if (k >= ILX_REW_TRACK_LIN_VEL_XY_EXP && k <= ILX_REW_TRACK_ANG_VEL_Z_EXP) return 25;
-            if (k >= ILX_REW_TRACK_LIN_VEL_XY_YAW_FRAME_EXP) return 40;
-            return 8;
-        };
-        std::vector<int> order(static_cast<size_t>(d.num_rewards));
-        for (int i = 0; i < d.num_rewards; ++i) order[i] = i;
-        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cost(d.rewards[a]) > cost(d.rewards[b]); });
-        int load[kWaves] = {0, 0, 0, 0};
-        for (int i : order) {
-            int w = 0;
-            for (int k = 1; k < kWaves; ++k)
-                if (load[k] < load[w]) w = k;
-            load[w] += cost(d.rewards[i]) + 12;   // + the fixed part of a term: its record, the dispatch, the sums it updates
-            p->reward_owner |= static_cast<uint64_t>(w) << (2 * i);
-        }
+    {   // the reward terms dealt to the block's four wavefronts (mdp_shared.h)
+        TermSig sig[kMaxTerms];
+        for (int i = 0; i < d.num_rewards; ++i)
+            sig[i] = TermSig{d.rewards[i].kind, d.rewards[i].ids_cnt, d.rewards[i].ids2_cnt, d.rewards[i].flags, d.rewards[i].weight != 0.0f};
+        p->reward_owner = deal_rewards(sig, d.num_rewards, MdpDims{d.num_joints, d.num_bodies, d.num_sensor_bodies, d.history_len,
+                                                                     d.num_rays, d.action_dim, d.command_dim});
     }
     for (int i = 0; i < d.num_observations; ++i) {
         const int k = d.observations[i].kind;
@@ -1330,16 +1013,43 @@ extern "C" int ilx_mdp_plan_create(const ilx_mdp* desc, ilx_mdp_plan_t* out) {
             rc = check_hip(hipMemcpy(p->d_cols, cols.data(), cols.size() * sizeof(ColDesc), hipMemcpyHostToDevice),
                            "ilx_mdp_plan_create: hipMemcpy");
     }
+    // host copies of the tables, the neutral post-processing record of every observation column, and the kernel
+    // compiled for this term list, if there is one
+    for (size_t i = 0; i < all.size(); ++i) p->h_terms[i] = all[i];
+    for (int i = 0; i < d.num_ids && i < static_cast<int>(sizeof(p->h_ids) / sizeof(p->h_ids[0])); ++i) p->h_ids[i] = d.ids[i];
+    if (rc == ILX_OK && d.num_observations > 0) {
+        std::vector<ColParam> cp;
+        for (int i = 0; i < d.num_observations; ++i)
+            cp.insert(cp.end(), static_cast<size_t>(host_obs_dim(d, d.observations[i])), col_param_of(d.observations[i]));
+        cp.resize((cp.size() + 3) & ~size_t(3), ColParam{0.0f, 0.0f, -__builtin_inff(), __builtin_inff(), 1.0f, {0.0f, 0.0f, 0.0f}});
+        rc = check_hip(hipMalloc(&p->d_colparam, cp.size() * sizeof(ColParam)), "ilx_mdp_plan_create: hipMalloc");
+        if (rc == ILX_OK)
+            rc = check_hip(hipMemcpy(p->d_colparam, cp.data(), cp.size() * sizeof(ColParam), hipMemcpyHostToDevice),
+                           "ilx_mdp_plan_create: hipMemcpy");
+    }
     if (rc != ILX_OK) {
         ilx_mdp_plan_destroy(p);
         return rc;
     }
+    p->fast_kernel = mdp_fast_match(*p, d);
     *out = p;
+    return ILX_OK;
+}
+
+extern "C" const char* ilx_mdp_plan_kernel(ilx_mdp_plan_t plan) {
+    if (!plan) return "";
+    return (plan->fast_kernel >= 0 && plan->fast_enabled) ? mdp_fast_name(plan->fast_kernel) : "generic";
+}
+
+extern "C" int ilx_mdp_plan_select_kernel(ilx_mdp_plan_t plan, int compiled) {
+    ILX_REQUIRE(plan, ILX_EINVAL, "ilx_mdp_plan_select_kernel: plan is NULL");
+    plan->fast_enabled = compiled != 0;
     return ILX_OK;
 }
 
 extern "C" void ilx_mdp_plan_destroy(ilx_mdp_plan_t plan) {
     if (!plan) return;
+    if (plan->d_colparam) (void)hipFree(plan->d_colparam);
     if (plan->d_terms) (void)hipFree(plan->d_terms);
     if (plan->d_ids) (void)hipFree(plan->d_ids);
     if (plan->d_cols) (void)hipFree(plan->d_cols);
@@ -1428,6 +1138,10 @@ extern "C" int ilx_mdp_step(ilx_mdp_plan_t plan, const ilx_mdp* desc, void* stre
     if ((d.phases & ILX_PHASE_COMMAND) && d.command_kind == ILX_CMD_POSE)
         ILX_REQUIRE(d.body_state_w && d.pose_body_index >= 0 && d.pose_body_index < d.num_bodies, ILX_EINVAL,
                     "ilx_mdp_step: the pose command needs body_state_w and a valid body index");
+    if (plan->fast_kernel >= 0 && plan->fast_enabled) {   // the kernel compiled for this term list takes the whole step
+        const int status = mdp_fast_step(*plan, d, stream);
+        if (status <= 0) return status;
+    }
     const bool pt = d.phases & ILX_PHASE_TERMINATION, pr = d.phases & ILX_PHASE_REWARD, po = d.phases & ILX_PHASE_OBSERVATION;
     MdpDev m;
     m.d = d;

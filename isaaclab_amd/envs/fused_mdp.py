@@ -87,6 +87,10 @@ _abi.lib.ilx_mdp_step.argtypes = [c_void_p, POINTER(MdpDesc), c_void_p]
 _abi.lib.ilx_mdp_step.restype = ctypes.c_int
 _abi.lib.ilx_mdp_begin_step.argtypes = [c_void_p, ctypes.c_int32, c_void_p, c_void_p]
 _abi.lib.ilx_mdp_begin_step.restype = ctypes.c_int
+_abi.lib.ilx_mdp_plan_kernel.argtypes = [c_void_p]
+_abi.lib.ilx_mdp_plan_kernel.restype = ctypes.c_char_p
+_abi.lib.ilx_mdp_plan_select_kernel.argtypes = [c_void_p, ctypes.c_int]
+_abi.lib.ilx_mdp_plan_select_kernel.restype = ctypes.c_int
 
 
 class TermSpec:
@@ -231,6 +235,16 @@ class FusedMdp:
             self._own("command_metrics", torch.zeros(2, n, device=dev))
         self.plan = c_void_p()
         _abi.check(_abi.lib.ilx_mdp_plan_create(ctypes.byref(d), ctypes.byref(self.plan)), "ilx_mdp_plan_create")
+
+    @property
+    def kernel(self) -> str:
+        """The kernel that serves full steps of this plan: "generic" (the plan-interpreting kernel) or the name of the
+        kernel compiled for exactly this term list (``ilx_mdp_plan_kernel``)."""
+        return _abi.lib.ilx_mdp_plan_kernel(self.plan).decode()
+
+    def select_kernel(self, compiled: bool = True):
+        """``compiled=False``: every step goes to the plan-interpreting kernel (``ilx_mdp_plan_select_kernel``)."""
+        _abi.check(_abi.lib.ilx_mdp_plan_select_kernel(self.plan, int(compiled)), "ilx_mdp_plan_select_kernel")
 
     def _obs_dim(self, s: TermSpec) -> int:
         d = self.desc
