@@ -4,14 +4,15 @@
 // lists of the reference's own task configurations, with every size and every term kind a compile-time constant: the
 // term formulas of mdp_shared.h inline into straight-line code, no term records are fetched, no kind is dispatched on.
 // The work is cut differently, too:
-//   DECIDE blocks   256 threads own 64 consecutive envs.  Each of the four wavefronts has ONE LANE PER ENV (all 64 lanes
-//                   busy) and evaluates, for its env, the terminations plus its share of the reward terms -- the same
-//                   dealing of terms to wavefronts as the plan-interpreting kernel, so the per-wavefront partial sums and
-//                   with them every bit of the reward are the same.  A lane reads its env's rows straight from memory
-//                   (a wavefront's 64 rows are one contiguous range; the loads of one row are issued together).  Wavefront
-//                   0 also runs the reset bookkeeping and the command term.  The non-scan observation columns are put
-//                   into LDS by the lanes that hold their values, then all 256 threads add noise / clip / scale and
-//                   store them, one lane per group of four columns (one Philox4x32 call, keyed as in mdp.hip).
+//   DECIDE blocks   320 threads own 64 consecutive envs.  Each of the five wavefronts has ONE LANE PER ENV (all 64 lanes
+//                   busy).  Wavefronts 0..3 evaluate, for their env, the terminations plus their share of the reward
+//                   terms -- the same dealing of terms to wavefronts as the plan-interpreting kernel, so the
+//                   per-wavefront partial sums and with them every bit of the reward are the same.  The fifth wavefront
+//                   runs the reset bookkeeping and the command term (the longest dependent chain of the step).  A lane
+//                   reads its env's rows straight from memory (a wavefront's 64 rows are one contiguous range; the loads
+//                   of one row are issued together).  The non-scan observation columns are put into LDS by the lanes
+//                   that hold their values, then all 320 threads add noise / clip / scale and store them, one lane per
+//                   group of four columns (one Philox4x32 call, keyed as in mdp.hip, drawn while the loads are in flight).
 //   SCAN blocks     the height-scan columns depend on nothing the DECIDE blocks compute: separate blocks of the same
 //                   grid stream them from the ray caster's dense height scan to the observation rows (noise, clip),
 //                   one lane per (env, group of four columns), beside the DECIDE blocks.
@@ -26,12 +27,31 @@
 namespace ilx {
 
 constexpr int kFastEnvs = 64;    // envs per DECIDE block
-constexpr int kScanEnvs = 16;    // envs per SCAN block
+constexpr int kScanEnvs = 34;    // envs per SCAN block
+constexpr int kCmdWave = kWaves; // the DECIDE block's fifth wavefront: reset bookkeeping and the command term
+constexpr int kFastBlock = 64 * (kWaves + 1);
 constexpr int kFastMaxIds = 64;
 constexpr int kFastMaxTerms = 24;   // terminations + rewards of a compiled term list
 
 typedef const __attribute__((address_space(1))) char GBytes;
 typedef __attribute__((address_space(1))) char GBytesW;
+
+// A uniform address pinned to scalar registers (so that the lane's 32-bit offset stays a separate operand of the memory
+// instruction).  Not volatile: a volatile statement would fence the instruction scheduler, and a wavefront's loads are
+// meant to travel together.
+ILX_DEV GBytes* pinned(GBytes* p) {
+    uint64_t a = reinterpret_cast<uint64_t>(p);
+    asm("" : "+s"(a));
+    return (GBytes*)a;
+}
+template <typename Tp>
+ILX_DEV Tp ldg(const Tp* base, int64_t first_elem, uint32_t voff) {   // base[first_elem] + lane's byte offset
+    return *reinterpret_cast<const __attribute__((address_space(1))) Tp*>(pinned((GBytes*)base + static_cast<int64_t>(sizeof(Tp)) * first_elem) + voff);
+}
+template <typename Tp, typename V>
+ILX_DEV void stg(Tp* base, int64_t first_elem, uint32_t voff, V v) {
+    *reinterpret_cast<__attribute__((address_space(1))) Tp*>((GBytesW*)pinned((GBytes*)base + static_cast<int64_t>(sizeof(Tp)) * first_elem) + voff) = static_cast<Tp>(v);
+}
 
 struct FastArgs {
     ilx_mdp d;                          // by value; the host pointers inside are nulled
@@ -40,6 +60,26 @@ struct FastArgs {
     const ColParam* colparam;           // one per observation column
     uint32_t decide_blocks;
 };
+
+#ifdef ILX_FAST_STAMPS  // diagnostics build only: wall-clock stamps (10 ns ticks) of lane 0 of every wavefront of the first blocks
+__device__ unsigned long long g_fast_stamps[512 * 5 * 8];
+__device__ unsigned long long g_scan_stamps[2048 * 2];
+#define SCAN_STAMP(k)                                                                                                   \
+    do {                                                                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                                              \
+        if (threadIdx.x == 0 && block < 2048) g_scan_stamps[block * 2 + (k)] = wall_clock64();                         \
+        __builtin_amdgcn_sched_barrier(0);                                                                              \
+    } while (0)
+#define FAST_STAMP(k)                                                                                                   \
+    do {                                                                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                                              \
+        if ((threadIdx.x & 63) == 0 && blockIdx.x < 512) g_fast_stamps[(blockIdx.x * 5 + (threadIdx.x >> 6)) * 8 + (k)] = wall_clock64(); \
+        __builtin_amdgcn_sched_barrier(0);                                                                              \
+    } while (0)
+#else
+#define FAST_STAMP(k)
+#define SCAN_STAMP(k)
+#endif
 
 // ---- compile-time loops -----------------------------------------------------------------------------
 template <int... I, class F>
@@ -61,6 +101,7 @@ constexpr TermSig T(int kind, int ids_cnt = -1, int ids2_cnt = -1, int flags = 0
 // velocity_env_cfg.py:119-265 with config/anymal_c/rough_env_cfg.py (ANYmal-C, rough terrain)
 struct AnymalRough {
     static constexpr const char* name = "anymal_c_rough";
+    static constexpr int kWavesPerSimd = 5;
     static constexpr int J = 12, B = 17, CB = 17, H = 3, A = 12, CD = 3, R = 187, cmd_kind = ILX_CMD_VELOCITY;
     static constexpr int NT = 2, NR = 11, NO = 8;
     static constexpr TermSig term[NT] = {T(ILX_TERM_TIME_OUT, -1, -1, 1), T(ILX_TERM_ILLEGAL_CONTACT, 1)};
@@ -77,6 +118,7 @@ struct AnymalRough {
 // config/h1/rough_env_cfg.py:19-115 over velocity_env_cfg.py (Unitree H1, rough terrain)
 struct H1Rough {
     static constexpr const char* name = "h1_rough";
+    static constexpr int kWavesPerSimd = 3;
     static constexpr int J = 19, B = 20, CB = 20, H = 3, A = 19, CD = 3, R = 187, cmd_kind = ILX_CMD_VELOCITY;
     static constexpr int NT = 2, NR = 14, NO = 8;
     static constexpr TermSig term[NT] = {T(ILX_TERM_TIME_OUT, -1, -1, 1), T(ILX_TERM_ILLEGAL_CONTACT, 1)};
@@ -94,6 +136,7 @@ struct H1Rough {
 // classic/cartpole/cartpole_env_cfg.py:58-181
 struct Cartpole {
     static constexpr const char* name = "cartpole";
+    static constexpr int kWavesPerSimd = 4;
     static constexpr int J = 2, B = 3, CB = 0, H = 0, A = 1, CD = 0, R = 0, cmd_kind = ILX_CMD_NONE;
     static constexpr int NT = 2, NR = 5, NO = 2;
     static constexpr TermSig term[NT] = {T(ILX_TERM_TIME_OUT, -1, -1, 1), T(ILX_TERM_JOINT_POS_OUT_OF_MANUAL_LIMIT, 1)};
@@ -107,6 +150,7 @@ struct Cartpole {
 template <int J_, int B_, int A_>
 struct Reach {
     static constexpr const char* name = J_ == 9 ? (A_ == 7 ? "reach_j9_a7" : "reach_j9_a6") : (A_ == 7 ? "reach_j8_a7" : "reach_j8_a6");
+    static constexpr int kWavesPerSimd = 4;
     static constexpr int J = J_, B = B_, CB = 0, H = 0, A = A_, CD = 7, R = 0, cmd_kind = ILX_CMD_POSE;
     static constexpr int NT = 1, NR = 5, NO = 4;
     static constexpr TermSig term[NT] = {T(ILX_TERM_TIME_OUT, -1, -1, 1)};
@@ -167,7 +211,8 @@ struct Derived {
             case ILX_OBS_JOINT_POS: case ILX_OBS_JOINT_POS_REL: return 1;
             case ILX_OBS_JOINT_VEL: case ILX_OBS_JOINT_VEL_REL: return 2;
             case ILX_OBS_LAST_ACTION: case ILX_OBS_HEIGHT_SCAN: return 3;
-            default: return 0;   // root-frame quantities and the command, which wavefront 0 has just updated
+            case ILX_OBS_GENERATED_COMMANDS: return kCmdWave;   // the wavefront that has just updated the command
+            default: return 0;   // root-frame quantities
         }
     }
     static constexpr bool reads(int kind) {
@@ -202,7 +247,7 @@ struct FastEnv {
 
     template <typename Tp>
     static ILX_DEV GBytes* block_base(const Tp* p, int64_t first_elem) {
-        return scalar_base((GBytes*)p + static_cast<int64_t>(sizeof(Tp)) * first_elem);
+        return pinned((GBytes*)p + static_cast<int64_t>(sizeof(Tp)) * first_elem);
     }
     static ILX_DEV float ldf(GBytes* base, uint32_t voff) { return *reinterpret_cast<const __attribute__((address_space(1))) float*>(base + voff); }
 
@@ -312,32 +357,65 @@ struct FastShared {   // the LDS of a DECIDE block apart from the observation va
 
 // One wavefront of a DECIDE block: lane = env.  Everything up to the barrier only reads memory (and writes outputs that
 // nothing in this launch reads); the in-place updates follow it.
+// A thread's place in the block's last stage: one group of four observation columns, every kPerTrip-th env.
+template <class S>
+struct EmitLane {
+    static constexpr int GP = Derived<S>::p_groups, O = Derived<S>::O;
+    static constexpr int kPerTrip = kFastBlock / GP, kTrips = (kFastEnvs + kPerTrip - 1) / kPerTrip;
+    int esub, g;
+    bool active, noisy;
+    float u[kTrips][4];   // the group's noise draws per trip
+};
+
 template <class S, int W>
-ILX_DEV void decide(const FastArgs& a, int64_t env0, int ne, uint32_t lane, uint64_t seed, uint64_t gen_step, float* P, FastShared& sh) {
+ILX_DEV void decide(const FastArgs& a, int64_t env0, int ne, uint32_t lane, uint64_t seed, uint64_t gen_step, float* P, FastShared& sh,
+                    EmitLane<S>& em) {
     using D = Derived<S>;
     const ilx_mdp& d = a.d;
     const int64_t N = d.num_envs;
     const bool valid = static_cast<int>(lane) < ne;
     const uint32_t le = valid ? lane : static_cast<uint32_t>(ne - 1);   // lanes past the launch's end shadow its last env and store nothing
     FastEnv<S> en(a, env0, le);
+    // The noise of the thread's observation columns needs nothing but (seed, step, env, group): drawn here, while the
+    // wavefront's loads are in flight.  A trip past the block's last env shadows that env (and stores nothing later).
+    {
+        using E = EmitLane<S>;
+        GBytes* noise = FastEnv<S>::block_base(d.noise_u, env0 * E::O);
+#pragma unroll
+        for (int trip = 0; trip < E::kTrips; ++trip) {
+            const int raw = trip * E::kPerTrip + em.esub, ee = raw < ne ? raw : ne - 1;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) em.u[trip][c] = 0.0f;
+            if (em.noisy) {
+                if (d.noise_u) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        em.u[trip][c] = FastEnv<S>::ldf(noise, 4u * static_cast<uint32_t>(ee * E::O + (4 * em.g + c < E::O ? 4 * em.g + c : E::O - 1)));
+                } else {
+                    const u4 r = philox4(seed, gen_step, static_cast<uint64_t>(env0 + ee), static_cast<uint32_t>(em.g));
+                    em.u[trip][0] = u01(r.x), em.u[trip][1] = u01(r.y), em.u[trip][2] = u01(r.z), em.u[trip][3] = u01(r.w);
+                }
+            }
+        }
+    }
     const int64_t env = en.env;
     const float dt = d.step_dt;
-    int64_t ep_len = ld_at(as_global(d.episode_length_buf) + env0, 8u * le);
+    int64_t ep_len = ldg(d.episode_length_buf, env0, 8u * le);
     CmdState cs;
     constexpr bool has_cmd = S::cmd_kind != ILX_CMD_NONE;
     constexpr bool velocity = S::cmd_kind == ILX_CMD_VELOCITY;
-    if constexpr (has_cmd && (W == 0 || D::term_is(ILX_TERM_COMMAND_RESAMPLE))) {
-        cs.time_left = ld_at(as_global(d.time_left) + env0, 4u * le);
-        cs.counter = ld_at(as_global(d.command_counter) + env0, 8u * le);
+    if constexpr (has_cmd && (W == kCmdWave || D::term_is(ILX_TERM_COMMAND_RESAMPLE))) {
+        cs.time_left = ldg(d.time_left, env0, 4u * le);
+        cs.counter = ldg(d.command_counter, env0, 8u * le);
         en.time_left = cs.time_left, en.command_counter = cs.counter;
     }
-    if constexpr (has_cmd && W == 0) {
-        cs.metric0 = ld_at(as_global(d.command_metrics) + env0, 4u * le);
-        cs.metric1 = ld_at(as_global(d.command_metrics) + N + env0, 4u * le);
+    if constexpr (has_cmd && W == kCmdWave) {
+        cs.metric0 = ldg(d.command_metrics, env0, 4u * le);
+        cs.metric1 = ldg(d.command_metrics, N + env0, 4u * le);
         if constexpr (velocity) {
-            cs.heading_target = ld_at(as_global(d.heading_target) + env0, 4u * le);
-            cs.is_heading = ld_at(as_global(d.is_heading_env) + env0, le) != 0;
-            cs.is_standing = ld_at(as_global(d.is_standing_env) + env0, le) != 0;
+            cs.heading_target = ldg(d.heading_target, env0, 4u * le);
+            cs.is_heading = ldg(d.is_heading_env, env0, le) != 0;
+            cs.is_standing = ldg(d.is_standing_env, env0, le) != 0;
         }
 #pragma unroll
         for (int k = 0; k < S::CD; ++k) cs.c[k] = en.cmd(k);
@@ -355,20 +433,22 @@ ILX_DEV void decide(const FastArgs& a, int64_t env0, int ne, uint32_t lane, uint
     });
     const bool done = terminated || time_out;
     const bool done_v = done && valid;
+    if (done) { FAST_STAMP(1); } else { FAST_STAMP(1); }
     // ---- rewards (reward_manager.py:128-157): this wavefront's share of the terms, in table order
     float value[S::NR] = {};
     float sums[S::NR] = {};
     float partial = 0.0f;
     static_for<S::NR>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
-        if constexpr (D::sum_owner(i) == W) sums[i] = ld_at(as_global(d.episode_sums) + static_cast<int64_t>(i) * N + env0, 4u * le);
+        if constexpr (D::sum_owner(i) == W) sums[i] = ldg(d.episode_sums, static_cast<int64_t>(i) * N + env0, 4u * le);
         if constexpr (S::rew[i].active && D::reward_owner(i) == W) {
             const ilx_term t = reward_of<S, i>(a);
             value[i] = eval_reward(en, t, terminated, time_out, term_bits) * t.weight * dt;
             partial += value[i];
         }
     });
-    sh.ptotal[W][lane] = partial;
+    if constexpr (W < kWaves) sh.ptotal[W][lane] = partial;
+    FAST_STAMP(2);
     // ---- the observation values this wavefront's lanes hold (observation_manager.py:260-335, before noise / clip / scale)
     float* row = P + lane * D::p_stride;
     static_for<S::NO>([&](auto ic) {
@@ -410,9 +490,9 @@ ILX_DEV void decide(const FastArgs& a, int64_t env0, int ne, uint32_t lane, uint
         }
     });
     // ---- reset bookkeeping of the managers for done envs (manager_based_rl_env.py:364-391) and the command term
-    // (command_manager.py:151-166), in registers; wavefront 0
+    // (command_manager.py:151-166), in registers; the fifth wavefront
     int64_t ep_len_out = ep_len;
-    if constexpr (W == 0) {
+    if constexpr (W == kCmdWave) {
         if (done) {
             if constexpr (has_cmd) {  // command_manager.py:120-149
                 if (valid) {
@@ -439,6 +519,7 @@ ILX_DEV void decide(const FastArgs& a, int64_t env0, int ne, uint32_t lane, uint
         }
         sh.done[lane] = done_v ? 1u : 0u;
     }
+    FAST_STAMP(3);
     // ---- logging sums of the done envs (reward_manager.py:115-121, termination_manager.py:142-144)
     if (done_v) {
         static_for<S::NR>([&](auto ic) {
@@ -460,41 +541,43 @@ ILX_DEV void decide(const FastArgs& a, int64_t env0, int ne, uint32_t lane, uint
         if constexpr (D::sum_owner(i) == W) {
             // the sum is the lane's own word: read above, written here
             const float s = done ? 0.0f : sums[i] + value[i];
-            if (valid && (active || done)) st_at(as_global(d.episode_sums) + static_cast<int64_t>(i) * N + env0, 4u * le, s);
+            if (valid && (active || done)) stg(d.episode_sums, static_cast<int64_t>(i) * N + env0, 4u * le, s);
             if constexpr (active)
-                if (valid) st_at(as_global(d.step_reward) + env0 * S::NR + i, le * (4u * S::NR), div_(value[i], dt));
+                if (valid) stg(d.step_reward, env0 * S::NR + i, le * (4u * S::NR), div_(value[i], dt));
         }
     });
     if constexpr (W == 3) {
         static_for<S::NT>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
-            if (valid) st_at(as_global(d.term_dones) + static_cast<int64_t>(i) * N + env0, le, static_cast<uint8_t>((term_bits >> i) & 1u));
+            if (valid) stg(d.term_dones, static_cast<int64_t>(i) * N + env0, le, static_cast<uint8_t>((term_bits >> i) & 1u));
         });
     }
     if constexpr (W == 2) {
         if (valid) {
-            st_at(as_global(d.terminated) + env0, le, terminated);
-            st_at(as_global(d.time_outs) + env0, le, time_out);
-            if (d.reset_buf) st_at(as_global(d.reset_buf) + env0, le, done);
+            stg(d.terminated, env0, le, terminated);
+            stg(d.time_outs, env0, le, time_out);
+            if (d.reset_buf) stg(d.reset_buf, env0, le, done);
         }
     }
+    FAST_STAMP(4);
     __syncthreads();
+    FAST_STAMP(5);
     // ---- in-place updates of what other wavefronts of the block have read by now
-    if constexpr (W == 0) {
+    if constexpr (W == kCmdWave) {
         if (valid) {
-            st_at(as_global(d.episode_length_buf) + env0, 8u * le, ep_len_out);
+            stg(d.episode_length_buf, env0, 8u * le, ep_len_out);
             if constexpr (has_cmd) {
                 constexpr int width = velocity ? 3 : 7;
 #pragma unroll
-                for (int k = 0; k < width; ++k) st_at(as_global(d.command) + env0 * S::CD + k, le * (4u * S::CD), cs.c[k]);
-                st_at(as_global(d.time_left) + env0, 4u * le, cs.time_left);
-                st_at(as_global(d.command_counter) + env0, 8u * le, cs.counter);
-                st_at(as_global(d.command_metrics) + env0, 4u * le, cs.metric0);
-                st_at(as_global(d.command_metrics) + N + env0, 4u * le, cs.metric1);
+                for (int k = 0; k < width; ++k) stg(d.command, env0 * S::CD + k, le * (4u * S::CD), cs.c[k]);
+                stg(d.time_left, env0, 4u * le, cs.time_left);
+                stg(d.command_counter, env0, 8u * le, cs.counter);
+                stg(d.command_metrics, env0, 4u * le, cs.metric0);
+                stg(d.command_metrics, N + env0, 4u * le, cs.metric1);
                 if constexpr (velocity) {
-                    st_at(as_global(d.heading_target) + env0, 4u * le, cs.heading_target);
-                    st_at(as_global(d.is_heading_env) + env0, le, cs.is_heading);
-                    st_at(as_global(d.is_standing_env) + env0, le, cs.is_standing);
+                    stg(d.heading_target, env0, 4u * le, cs.heading_target);
+                    stg(d.is_heading_env, env0, le, cs.is_heading);
+                    stg(d.is_standing_env, env0, le, cs.is_standing);
                 }
             }
         }
@@ -503,7 +586,7 @@ ILX_DEV void decide(const FastArgs& a, int64_t env0, int ne, uint32_t lane, uint
         float total = sh.ptotal[0][lane];
 #pragma unroll
         for (int w = 1; w < kWaves; ++w) total += sh.ptotal[w][lane];
-        if (valid) st_at(as_global(d.reward_buf) + env0, 4u * le, total);
+        if (valid) stg(d.reward_buf, env0, 4u * le, total);
     }
 }
 
@@ -517,7 +600,7 @@ ILX_DEV void scan_emit(const FastArgs& a, uint32_t block, uint64_t seed, uint64_
         const int64_t left = d.num_envs - env0;
         const int ne = static_cast<int>(left < kScanEnvs ? left : kScanEnvs);
         constexpr int GS = D::scan_groups, G0 = D::p_groups, O = D::O, R = S::R;
-        constexpr int kTrips = (kScanEnvs * GS + 255) / 256;
+        constexpr int kTrips = (kScanEnvs * GS + kFastBlock - 1) / kFastBlock;
         // the term's post-processing: one record for all its columns, read as uniform values
         const auto* cp = reinterpret_cast<const __attribute__((address_space(4))) float*>(
             (const __attribute__((address_space(4))) char*)(a.colparam + 4 * G0));
@@ -528,9 +611,10 @@ ILX_DEV void scan_emit(const FastArgs& a, uint32_t block, uint64_t seed, uint64_
         GBytes* noise = FastEnv<S>::block_base(d.noise_u, env0 * O);
         const bool inject = d.noise_u != nullptr;
         const int items = ne * GS;
+        SCAN_STAMP(0);
 #pragma unroll
         for (int trip = 0; trip < kTrips; ++trip) {
-            const int raw = static_cast<int>(threadIdx.x) + 256 * trip;
+            const int raw = static_cast<int>(threadIdx.x) + kFastBlock * trip;
             const int idx = raw < items ? raw : items - 1;   // lanes past the end shadow the last item and store nothing
             const int el = idx / GS, gs = idx - el * GS, g = G0 + gs;
             const int k0 = 4 * g - D::scan_col;              // the group's first ray
@@ -556,11 +640,16 @@ ILX_DEV void scan_emit(const FastArgs& a, uint32_t block, uint64_t seed, uint64_
                     *reinterpret_cast<__attribute__((address_space(1))) float*>(rows + out_at + 4u * c) = v;
             }
         }
+        SCAN_STAMP(1);
     }
 }
 
+// S::kWavesPerSimd: the registers are held to what that many resident wavefronts per SIMD leave each of them.  The
+// headline list runs 16 384 envs per GPU as 256 DECIDE + 482 SCAN blocks: at five wavefronts per SIMD three blocks of five
+// wavefronts fit a CU however their wavefronts fall on its four SIMDs, so all of them are resident together; the lists
+// that run a few thousand envs per GPU fill a fraction of the GPU and take the registers instead.
 template <class S>
-__global__ void __launch_bounds__(256) mdp_fast_kernel(const FastArgs a) {
+__global__ void __launch_bounds__(kFastBlock) __attribute__((amdgpu_waves_per_eu(S::kWavesPerSimd))) mdp_fast_kernel(const FastArgs a) {
     using D = Derived<S>;
     const ilx_mdp& d = a.d;
     // The generator's step word: the argument plus the caller's device-side count when there is one (a scalar load; the
@@ -582,21 +671,43 @@ __global__ void __launch_bounds__(256) mdp_fast_kernel(const FastArgs a) {
     const int64_t left = d.num_envs - env0;
     const int ne = static_cast<int>(left < kFastEnvs ? left : kFastEnvs);
     if (tid < S::NR + S::NT + 3) sh.logp[tid] = 0.0f;
-    __syncthreads();
-    switch (wave) {
-        case 0: decide<S, 0>(a, env0, ne, lane, seed, gen_step, P, sh); break;
-        case 1: decide<S, 1>(a, env0, ne, lane, seed, gen_step, P, sh); break;
-        case 2: decide<S, 2>(a, env0, ne, lane, seed, gen_step, P, sh); break;
-        default: decide<S, 3>(a, env0, ne, lane, seed, gen_step, P, sh); break;
+    // The thread's place in the last stage (a group of four observation columns, a first env) and its columns'
+    // post-processing parameters: requested now, so that they are there when the block comes out of its barrier.
+    using E = EmitLane<S>;
+    constexpr int GP = E::GP, O = E::O, kPerTrip = E::kPerTrip, kTrips = E::kTrips;
+    E em;
+    em.esub = static_cast<int>(tid) / GP, em.g = static_cast<int>(tid) - em.esub * GP;
+    em.active = em.esub < kPerTrip;
+    em.noisy = false;
+    const int g = em.g, esub = em.esub;
+    float n_off[4], n_rng[4], c_lo[4], c_hi[4], scl[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {   // a column past the row's end is treated like the row's last one (not stored)
+        const int col = 4 * g + c < O ? 4 * g + c : O - 1;
+        const ColParam cp = a.colparam[em.active ? col : 0];
+        n_off[c] = cp.n_off, n_rng[c] = cp.n_rng, c_lo[c] = cp.c_lo, c_hi[c] = cp.c_hi, scl[c] = cp.scale;
+        em.noisy = em.noisy || cp.n_rng != 0.0f;
     }
-    // (each of the four paths above ends behind the block's barrier)
+    em.noisy = em.noisy && em.active;
+    FAST_STAMP(0);
+    __syncthreads();
+    static_assert(kWaves == 4, "one path per wavefront below");
+    switch (wave) {
+        case 0: decide<S, 0>(a, env0, ne, lane, seed, gen_step, P, sh, em); break;
+        case 1: decide<S, 1>(a, env0, ne, lane, seed, gen_step, P, sh, em); break;
+        case 2: decide<S, 2>(a, env0, ne, lane, seed, gen_step, P, sh, em); break;
+        case 3: decide<S, 3>(a, env0, ne, lane, seed, gen_step, P, sh, em); break;
+        default: decide<S, kCmdWave>(a, env0, ne, lane, seed, gen_step, P, sh, em); break;
+    }
+    // (each of the five paths above ends behind the block's barrier)
+    FAST_STAMP(6);
     // ---- a done env's action history restarts (action_manager.py:309-311)
     if constexpr (D::needs_action) {
-        for (int i = static_cast<int>(tid); i < ne * S::A; i += 256) {
+        for (int i = static_cast<int>(tid); i < ne * S::A; i += kFastBlock) {
             const int e = i / S::A;
             if (sh.done[e]) {
-                st_at(as_global(d.action) + env0 * S::A, 4u * i, 0.0f);
-                st_at(as_global(d.prev_action) + env0 * S::A, 4u * i, 0.0f);
+                stg(d.action, env0 * S::A, 4u * i, 0.0f);
+                stg(d.prev_action, env0 * S::A, 4u * i, 0.0f);
             }
         }
     }
@@ -605,54 +716,35 @@ __global__ void __launch_bounds__(256) mdp_fast_kernel(const FastArgs a) {
         const float v = sh.logp[tid];
         if (v != 0.0f) unsafeAtomicAdd(d.log_sums + tid, v);
     }
-    // ---- the observation columns that went through LDS: noise, clip, scale, store (observation_manager.py:313-318).  A
-    // lane owns one group of four columns (its noise is one Philox4x32 call) and walks down the block's envs with it.
-    {
-        constexpr int GP = D::p_groups, O = D::O;
-        constexpr int kPerTrip = 256 / GP, kTrips = (kFastEnvs + kPerTrip - 1) / kPerTrip;
-        const int esub = static_cast<int>(tid) / GP, g = static_cast<int>(tid) - esub * GP;
-        if (esub < kPerTrip) {
-            float n_off[4], n_rng[4], c_lo[4], c_hi[4], scl[4];
-            bool noisy = false;
+    // ---- the observation columns that went through LDS: noise (drawn above), clip, scale, store
+    // (observation_manager.py:313-318).  A lane owns one group of four columns and walks down the block's envs with it.
+    if (em.active) {
+        GBytesW* rows = (GBytesW*)FastEnv<S>::block_base(d.obs, env0 * O);
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {   // a column past the row's end is treated like the row's last one (not stored)
-                const int col = 4 * g + c < O ? 4 * g + c : O - 1;
-                const ColParam cp = a.colparam[col];
-                n_off[c] = cp.n_off, n_rng[c] = cp.n_rng, c_lo[c] = cp.c_lo, c_hi[c] = cp.c_hi, scl[c] = cp.scale;
-                noisy = noisy || cp.n_rng != 0.0f;
-            }
-            const bool inject = d.noise_u != nullptr;
-            GBytesW* rows = (GBytesW*)FastEnv<S>::block_base(d.obs, env0 * O);
-            GBytes* noise = FastEnv<S>::block_base(d.noise_u, env0 * O);
+        for (int trip = 0; trip < kTrips; ++trip) {
+            const int raw = trip * kPerTrip + esub, ee = raw < ne ? raw : ne - 1;
+            const uint32_t out_at = 4u * static_cast<uint32_t>(raw * O + 4 * g);
 #pragma unroll
-            for (int trip = 0; trip < kTrips; ++trip) {
-                const int ee = trip * kPerTrip + esub;
-                if (ee < ne) {
-                    const uint32_t out_at = 4u * static_cast<uint32_t>(ee * O + 4 * g);
-                    float u[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-                    if (noisy) {
-                        if (inject) {
-#pragma unroll
-                            for (int c = 0; c < 4; ++c)
-                                u[c] = FastEnv<S>::ldf(noise, 4 * g + c < O ? out_at + 4u * c : 4u * static_cast<uint32_t>(ee * O + O - 1));
-                        } else {
-                            const u4 r = philox4(seed, gen_step, static_cast<uint64_t>(env0 + ee), static_cast<uint32_t>(g));
-                            u[0] = u01(r.x), u[1] = u01(r.y), u[2] = u01(r.z), u[3] = u01(r.w);
-                        }
-                    }
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        float v = P[ee * D::p_stride + 4 * g + c];
-                        v = v + u[c] * n_rng[c] + n_off[c];                  // noise_model.py:63-64
-                        v = __builtin_amdgcn_fmed3f(v, c_lo[c], c_hi[c]);    // observation_manager.py:315-316
-                        v = v * scl[c];                                      // :317-318
-                        if (4 * g + c < O) *reinterpret_cast<__attribute__((address_space(1))) float*>(rows + out_at + 4u * c) = v;
-                    }
-                }
+            for (int c = 0; c < 4; ++c) {
+                float x = P[ee * D::p_stride + 4 * g + c];
+                x = x + em.u[trip][c] * n_rng[c] + n_off[c];         // noise_model.py:63-64
+                x = __builtin_amdgcn_fmed3f(x, c_lo[c], c_hi[c]);    // observation_manager.py:315-316
+                x = x * scl[c];                                      // :317-318
+                if (raw < ne && 4 * g + c < O) *reinterpret_cast<__attribute__((address_space(1))) float*>(rows + out_at + 4u * c) = x;
             }
         }
     }
+    FAST_STAMP(7);
 }
+
+#ifdef ILX_FAST_STAMPS
+extern "C" int ilx_debug_scan_stamps(unsigned long long* out, int count) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(ilx::g_scan_stamps), sizeof(unsigned long long) * count) == hipSuccess ? 0 : 1;
+}
+extern "C" int ilx_debug_fast_stamps(unsigned long long* out, int count) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(ilx::g_fast_stamps), sizeof(unsigned long long) * count) == hipSuccess ? 0 : 1;
+}
+#endif
 
 // ---- the table of compiled kernels ---------------------------------------------------------------------------
 template <class S>
@@ -665,7 +757,7 @@ template <class S>
 static bool matches(const ilx_mdp_plan_s& p, const ilx_mdp& d) {
     using D = Derived<S>;
     static_assert(S::NT + S::NR <= kFastMaxTerms && D::num_ids <= kFastMaxIds, "term list too long for the kernel arguments");
-    static_assert(S::NR + S::NT + 3 <= 2 * kMaxTerms + 3 && D::p_groups >= 1 && D::p_groups <= 256, "block geometry");
+    static_assert(S::NR + S::NT + 3 <= 2 * kMaxTerms + 3 && D::p_groups >= 1 && D::p_groups <= kFastBlock, "block geometry");
     if (p.nt != S::NT || p.nr != S::NR || p.no != S::NO || p.obs_dim != D::O || p.nids != D::num_ids) return false;
     if (d.num_joints != S::J || d.num_bodies != S::B || d.num_sensor_bodies != S::CB || d.history_len != S::H ||
         d.num_rays != S::R || d.action_dim != S::A || d.command_dim != S::CD || d.command_kind != S::cmd_kind)
@@ -712,7 +804,7 @@ static int launch(const ilx_mdp_plan_s& p, const ilx_mdp& d, void* stream) {
     a.colparam = p.d_colparam;
     a.decide_blocks = static_cast<uint32_t>((d.num_envs + kFastEnvs - 1) / kFastEnvs);
     const uint32_t scan_blocks = D::scan_groups > 0 ? static_cast<uint32_t>((d.num_envs + kScanEnvs - 1) / kScanEnvs) : 0u;
-    hipLaunchKernelGGL(mdp_fast_kernel<S>, dim3(a.decide_blocks + scan_blocks), dim3(256), 0, as_stream(stream), a);
+    hipLaunchKernelGGL(mdp_fast_kernel<S>, dim3(a.decide_blocks + scan_blocks), dim3(kFastBlock), 0, as_stream(stream), a);
     ILX_LAUNCH_CHECK("ilx_mdp_step");
     return ILX_OK;
 }
