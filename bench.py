@@ -28,8 +28,17 @@ NUM_ENVS = 16384
 TERM_EVALS_PER_ENV_STEP = 29  # 8 obs + 9 active rewards + 2 terminations + 1 command + 4 x (actuator + contact) + 1 ray cast
 HBM_PEAK_GBS = 8000.0         # MI355X HBM3E peak (spec); measured float4-copy ceiling is ~6300 GB/s
 MFMA_F32_PEAK_TFLOPS = 157.3  # dense fp32 MFMA peak (256 CUs x 256 FLOP/clk/CU x 2.4 GHz)
+MFMA_F16_PEAK_TFLOPS = 2500.0 # dense f16 MFMA peak
 # 6-32-32-32-1 MLP: multiply-adds per row x 2, rows = envs x 12 joints
 MLP_FLOP_PER_ENV = 12 * 2 * (6 * 32 + 32 * 32 + 32 * 32 + 32 * 1)
+# ... and as the default kernel executes it: the first layer on the f32 MFMA, the two hidden 32 x 32 layers on the f16 matrix
+# cores as three products each (head x head, head x remainder, remainder x head)
+MLP_F32_MFMA_FLOP_PER_ENV = 12 * 2 * (6 * 32)
+MLP_F16_MFMA_FLOP_PER_ENV = 12 * 3 * 2 * (32 * 32 + 32 * 32)
+# the byte table of the workload's measurement recipe for the headline configuration (4 substeps x 1 960 B + 3 645 B per
+# env step: without the second actuator history and the dense height scan that this build's launches also move)
+RECIPE_BYTES_PER_ENV_STEP = 4 * 1960 + 3645
+GRAPH_WARMUP_REPLAYS = 20      # per recorded graph, whatever --warmup says
 
 def build_env(device, num_envs, seed, actuator="mlp"):
     """The headline configuration's step object and its synthetic state (what the probe scripts under tools/ use)."""
@@ -39,7 +48,7 @@ def build_env(device, num_envs, seed, actuator="mlp"):
     return cfg.env, cfg.state, None
 
 
-def time_kernels(cfg, device, reps=20):
+def time_kernels(cfg, device, reps=20, only=None):
     """Average duration of each launch of the step, measured with events on the stream the kernels run on."""
     # The launches of one measurement are queued behind a long-running blocker, so that they run back to back on the
     # device: the host (Python + ctypes, ~10 us per call) would otherwise pace the short kernels and the events would
@@ -63,6 +72,8 @@ def time_kernels(cfg, device, reps=20):
 
     out = {}
     for name, (fn, _) in cfg.launches.items():
+        if only is not None and name not in only:
+            continue
         # (fn, setup): the launch needs a setup launch before each call, whose own span is taken off
         out[name] = span(fn[0]) - span(fn[1]) if isinstance(fn, tuple) else span(fn)
     return out
@@ -219,10 +230,12 @@ def main():
 
     restart_clocks = getattr(cfg, "restart_sensor_clocks", None)
 
-    def timed(one_step):
+    def timed(one_step, replayed=False):
         if restart_clocks is not None:   # the sensors' clocks start every timed region where an env reset leaves them
             restart_clocks()
-        for _ in range(args.warmup):
+        # a recorded graph settles over its first replays: each gets its share of warm-up whatever --warmup says
+        warm = max(args.warmup, GRAPH_WARMUP_REPLAYS * len(graphs)) if replayed else args.warmup
+        for _ in range(warm):
             one_step()
         if dist is not None:
             dist.barrier()
@@ -237,31 +250,32 @@ def main():
             dist.barrier()
         return time.perf_counter() - t0
 
-    # The step is eleven short launches (2-40 us each): issued one by one from the host they are launch-bound, so the
-    # measured mode records the step in a HIP graph and replays it.  The in-hand env (four launches, a collective between
-    # them on several GPUs) is measured eagerly (replayed from a graph it takes 30 us against 24; reported beside it on one GPU).  The other mode is timed as well and reported beside the headline.
+    # The step is eight to eleven short launches (2-40 us each): issued one by one from the host they are launch-bound, so
+    # the measured mode records the step in a HIP graph and replays it.  The in-hand env (four launches, a collective between
+    # them on several GPUs) is measured eagerly (replayed from a graph it takes 30 us against 24; reported beside it on one
+    # GPU).  The other mode is timed as well and reported beside the headline.
     use_graph = not args.eager and args.config != "shadow"   # four launches: a replay's fixed cost is above their host time
     other_s = None
+    # The headline is the step recorded as ONE chain in the reference's own order (manager_based_rl_env.py:172-195; scene
+    # update k and the actuator model of substep k + 1 paired in one launch): nothing runs ahead of a physics step it would
+    # depend on, so the number holds with a simulator between the substeps.  Beside it, for the network actuators: the
+    # recording with the sensor chain as a branch parallel to the actuator chain -- possible here only because all four
+    # substeps' physics results are already in memory.
+    two_branch_s = None
     if use_graph:
         other_s = timed(eager_step)
+        if getattr(cfg, "overlap_in_graph", False):
+            graphs = capture_step(cfg, reducer)
+            two_branch_s = timed(graph_step, replayed=True)
+            cfg.overlap_in_graph = False
         graphs = capture_step(cfg, reducer)
-        elapsed = timed(graph_step)
+        elapsed = timed(graph_step, replayed=True)
     else:
         elapsed = timed(eager_step)
         if world == 1:
+            cfg.overlap_in_graph = False
             graphs = capture_step(cfg, reducer)
-            other_s = timed(graph_step)
-    # The two-branch recording lets the sensor chain run ahead of actuator launches that, with a simulator between them,
-    # it would have to wait for.  Beside it: the step recorded as ONE chain in the reference's own order (scene update k
-    # and the actuator model of substep k + 1 paired in one launch), where nothing runs ahead of a physics step.
-    one_chain_s = None
-    if use_graph and getattr(cfg, "overlap_in_graph", False):
-        cfg.overlap_in_graph = False
-        branch_graphs = graphs
-        graphs = capture_step(cfg, reducer)
-        one_chain_s = timed(graph_step)
-        graphs = branch_graphs
-        cfg.overlap_in_graph = True
+            other_s = timed(graph_step, replayed=True)
     # The same run of steps once more, untimed, with a look at the sensor clocks after every step: on how many steps did
     # every env's contact sensor and height scanner refresh (a step on which the clocks skip the refresh does less work).
     refresh_check = None
@@ -297,38 +311,66 @@ def main():
         rank_ms = [float(t_min.item()) / args.steps * 1e3, elapsed / args.steps * 1e3]
 
     kern = time_kernels(cfg, device)
+    exact_us = None
+    if args.config == "anymal" and args.actuator == "mlp":   # the same network launch with every product in f32 (ILX_MLP_EXACT_F32)
+        from isaaclab_amd import _abi
+        cfg.env.actuator._flags |= _abi.MLP_EXACT_F32
+        exact_us = time_kernels(cfg, device, only=("actuator_net_mlp",))["actuator_net_mlp"]
+        cfg.env.actuator._flags &= ~_abi.MLP_EXACT_F32
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         value = args.envs * world * args.steps / elapsed
         launches = {k: n for k, (_, n) in cfg.launches.items()}
         nbytes = cfg.bytes_per_env
-        # (the network launch that also carries the joint action counts with the other network launches)
-        share = {k: kern[k] * launches[k] for k in kern}
-        if "actuator_net_mlp_joint_action" in share:
-            share["actuator_net_mlp"] += share.pop("actuator_net_mlp_joint_action")
-        dominant = max(share, key=share.get)
-        # HBM-side bytes per launch of that kernel from the committed counter passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
-        # of this same command, corrected as stated in the file); only meaningful for the config and env count it was taken at
-        traffic = None
-        try:
-            with open(os.path.join(ROOT, "profiles", "r2_hbm_traffic.json")) as f:
-                prof = json.load(f)
-            if prof.get("envs") == args.envs and prof.get("config", "anymal") == args.config:
-                traffic = prof["kernels"][dominant]["hbm_bytes_per_launch"]
-        except (OSError, KeyError, ValueError):
-            pass
+        # Per kernel: the fraction of the roof it is bound by.  Every launch of this path streams its inputs and outputs once,
+        # so the roof is HBM bandwidth (algorithmic bytes / duration / 8 TB/s); the actuator network also has matrix work,
+        # priced per data type as it executes (f32 MFMA flops / 157.3 TF + f16 MFMA flops / 2.5 PF = the time the matrix
+        # pipes need), and is bound by whichever of the two fractions is larger.  `roofline` is the kernel furthest below
+        # its roof among those that take at least 5 % of the step.
         mlp = "actuator_net_mlp"
-        mfma_frac = MLP_FLOP_PER_ENV * args.envs / (kern[mlp] * 1e-6) / 1e12 / MFMA_F32_PEAK_TFLOPS if mlp in kern else None
-        if dominant == mlp:  # the one kernel of the step that is matrix work
-            achieved = MLP_FLOP_PER_ENV * args.envs / (kern[dominant] * 1e-6) / 1e12
-            roofline = {"bound": "mfma", "kernel": dominant, "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": achieved / MFMA_F32_PEAK_TFLOPS, "traffic": traffic, "launch_us": kern[dominant],
-                        "algorithmic_flop_per_launch": MLP_FLOP_PER_ENV * args.envs}
+        profiles = {}
+        for key, fname in (("traffic", "r3_hbm_traffic.json"), ("sq", "r3_sq_counters.json")):
+            try:
+                with open(os.path.join(ROOT, "profiles", fname)) as f:
+                    prof = json.load(f)
+                if prof.get("envs") == args.envs and prof.get("config", "anymal") == args.config:
+                    profiles[key] = prof["kernels"]
+            except (OSError, KeyError, ValueError):
+                pass
+        step_us = ms * 1e3
+        per_kernel = {}
+        for k, us in kern.items():
+            entry = {"launch_us": round(us, 2), "algorithmic_bytes_per_launch": nbytes[k] * args.envs,
+                     "hbm_frac": nbytes[k] * args.envs / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, "bound": "hbm"}
+            entry["frac"] = entry["hbm_frac"]
+            if k.startswith(mlp) and args.actuator == "mlp":
+                f32, f16 = MLP_F32_MFMA_FLOP_PER_ENV * args.envs, MLP_F16_MFMA_FLOP_PER_ENV * args.envs
+                matrix_us = (f32 / (MFMA_F32_PEAK_TFLOPS * 1e12) + f16 / (MFMA_F16_PEAK_TFLOPS * 1e12)) * 1e6
+                entry.update(mfma_f32_flop_per_launch=f32, mfma_f16_flop_per_launch=f16, mfma_frac=matrix_us / us,
+                             f32_grade_tflops=MLP_FLOP_PER_ENV * args.envs / (us * 1e-6) / 1e12)
+                if entry["mfma_frac"] > entry["hbm_frac"]:
+                    entry["bound"], entry["frac"] = "mfma", entry["mfma_frac"]
+            per_kernel[k] = entry
+        share = {k: kern[k] * launches[k] / step_us for k in kern}
+        candidates = [k for k in kern if share[k] >= 0.05] or list(kern)
+        worst = min(candidates, key=lambda k: per_kernel[k]["frac"])
+        w = per_kernel[worst]
+        if w["bound"] == "mfma":
+            achieved = (w["mfma_f32_flop_per_launch"] + w["mfma_f16_flop_per_launch"]) / (kern[worst] * 1e-6) / 1e12
+            roofline = {"bound": "mfma", "kernel": worst, "achieved": achieved, "peak": achieved / w["frac"], "unit": "TFLOP/s",
+                        "frac": w["frac"]}
         else:
-            achieved = nbytes[dominant] * args.envs / (kern[dominant] * 1e-6) / 1e9
-            roofline = {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "launch_us": kern[dominant],
-                        "algorithmic_bytes_per_launch": nbytes[dominant] * args.envs}
+            roofline = {"bound": "hbm", "kernel": worst, "achieved": w["hbm_frac"] * HBM_PEAK_GBS, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": w["hbm_frac"]}
+        roofline.update(launch_us=kern[worst], launches_per_step=launches[worst], share_of_step=share[worst],
+                        algorithmic_bytes_per_launch=nbytes[worst] * args.envs, traffic=None)
+        if "traffic" in profiles and worst in profiles["traffic"]:   # HBM-side bytes per launch from the committed counter passes
+            roofline["traffic"] = profiles["traffic"][worst]["hbm_bytes_per_launch"]
+        if "mfma_frac" in w:
+            roofline.update(mfma_frac=w["mfma_frac"], hbm_frac=w["hbm_frac"])
+            if "sq" in profiles and worst in profiles["sq"] and "mfma_busy_frac" in profiles["sq"][worst]:
+                roofline["mfma_busy_frac_counters"] = profiles["sq"][worst]["mfma_busy_frac"]
+        mfma_frac = per_kernel[mlp]["mfma_frac"] if mlp in per_kernel and "mfma_frac" in per_kernel[mlp] else None
         per_step = cfg.bytes_per_env_step()
         line = {
             "metric": "env-steps/sec (non-physics step) ANYmal-C rough" if args.config == "anymal" else
@@ -341,6 +383,7 @@ def main():
             "algorithmic_bytes_per_env_step": per_step,
             "step_hbm_frac": per_step * args.envs / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "roofline": roofline,
+            "kernel_rooflines": {k: {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in v.items()} for k, v in per_kernel.items()},
             "kernels_us": {k: round(v, 2) for k, v in kern.items()},
             "launches_per_step": launches,
             "bytes_per_env_per_launch": nbytes,
@@ -354,17 +397,23 @@ def main():
             line["raycast_mrays_per_s"] = round(args.envs * cfg.info["rays"] / kern[cast], 1)
         if args.config == "anymal":
             line["env_term_steps_per_s"] = value * TERM_EVALS_PER_ENV_STEP
-        line["launch_mode"] = ("hip-graph replay: the step's launches recorded once per statistics vector, replayed per step"
-                               if use_graph else "eager: one host call per launch")
+            # the same step against the byte table of the measurement recipe (which leaves out what this build adds)
+            line["step_hbm_frac_recipe_bytes"] = RECIPE_BYTES_PER_ENV_STEP * args.envs / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+            if exact_us is not None:
+                line["mlp_exact_f32_us"] = round(exact_us, 2)
+        if use_graph:
+            line["graph_warmup_replays"] = max(args.warmup, GRAPH_WARMUP_REPLAYS * len(graphs)) // len(graphs)
+        line["launch_mode"] = ("hip-graph replay of the step recorded as one chain in the reference's order (no launch ahead of a physics "
+                               "step it would depend on), once per statistics vector" if use_graph else "eager: one host call per launch")
         if other_s is not None:
             line["eager" if use_graph else "hip_graph"] = {
                 "ms_per_step": other_s / args.steps * 1e3, "value": args.envs * world * args.steps / other_s,
                 "note": "the same step " + ("issued launch by launch from the host" if use_graph else "replayed from a captured graph")}
-        if one_chain_s is not None:
-            line["hip_graph_one_chain"] = {
-                "ms_per_step": one_chain_s / args.steps * 1e3, "value": args.envs * world * args.steps / one_chain_s,
-                "note": "the same step recorded as one chain in the reference's order (scene update k and the actuator model of "
-                        "substep k + 1 as one launch): no launch runs ahead of a physics step it would depend on"}
+        if two_branch_s is not None:
+            line["hip_graph_two_branches"] = {
+                "ms_per_step": two_branch_s / args.steps * 1e3, "value": args.envs * world * args.steps / two_branch_s,
+                "note": "the same step recorded with the sensor chain (scene updates, scanner refresh) as a branch beside the actuator "
+                        "chain: an overlap that needs all substeps' physics results in memory beforehand, so not the headline"}
         if not args.no_cpu_baseline and world == 1 and args.config == "anymal" and args.actuator == "mlp":
             line["cpu_baseline"] = cpu_baseline(3000, envs=args.envs, root_scatter=args.root_scatter)
         else:

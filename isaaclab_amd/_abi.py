@@ -111,6 +111,7 @@ mesh_grid_stats = _sig("ilx_mesh_grid_stats", P, P)
 mesh_lattice_stats = _sig("ilx_mesh_lattice_stats", P, P)
 mesh_lattice_counter = _sig("ilx_mesh_lattice_counter", P, c_int, P)
 mesh_lattice_probe = _sig("ilx_mesh_lattice_probe", P, c_int64, P, c_int64, P)
+MLP_FORCE_GENERIC, MLP_EXACT_F32 = 1, 2   # ilx_actuator_net_mlp flags (ILX_MLP_*)
 RAYS_Z_PARALLEL = 1
 RAYS_Z_PARALLEL_CHECKED = 2
 RAYS_PATTERN_STATIC = 4
