@@ -727,7 +727,16 @@ enum ilx_ray_hint {
      * this descriptor, on this stream, with nothing that touches the sensor in between; only the cast is launched.
      * Where a refresh has no preparation launch (no height-field patches, a pattern above 1 024 rays, no vertical-ray
      * hint) the hint changes nothing. */
-    ILX_RAYS_PREPARED = 8
+    ILX_RAYS_PREPARED = 8,
+    /* For ilx_raycaster_refresh with `height_scan` given: the caller reads only the height scan for now.  Where the
+     * refresh goes over the height-field patches under ILX_RAYS_Z_PARALLEL_CHECKED (its cast is then the last launch and
+     * nothing reads the hit records as a work list) the cast writes `height_scan` alone and leaves `ray_hits_w` as it
+     * is: a quarter of the bytes.  RayCasterData.pos_w / quat_w are written as always, so the hit records of the same
+     * refresh can be formed later by ilx_raycaster_update on those poses -- bit for bit what this refresh would have
+     * stored (ray_caster.py:220-260 evaluates eagerly; the sensor is lazy anyway, sensor_base.py:197-205).  Every other
+     * refresh ignores the hint and writes the hit records.  A ray that breaks the ILX_RAYS_Z_PARALLEL_CHECKED promise
+     * is then left with a NaN in `height_scan`. */
+    ILX_RAYS_HEIGHT_ONLY = 16
 };
 int ilx_raycast_mesh(ilx_mesh_t mesh, const float* ray_starts, const float* ray_directions, int64_t num_rays,
                      float max_dist, float* ray_hits, float* ray_distance, float* ray_normal, int32_t* ray_face_id,

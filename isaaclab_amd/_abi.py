@@ -116,6 +116,7 @@ RAYS_Z_PARALLEL = 1
 RAYS_Z_PARALLEL_CHECKED = 2
 RAYS_PATTERN_STATIC = 4
 RAYS_PREPARED = 8
+RAYS_HEIGHT_ONLY = 16
 raycast_mesh = _sig("ilx_raycast_mesh", P, P, P, c_int64, c_float, P, P, P, P, c_int, P)
 raycaster_update = _sig("ilx_raycaster_update", P, P, P, P, P, P, c_int, c_float, P, P, c_float, c_int64, c_int, c_int, P)
 joint_action_process = _sig("ilx_joint_action_process", P, P, P, P, c_float, P, c_float, P, P, c_int64, c_int, P)

@@ -353,7 +353,7 @@ ILX_DEV void write_hit(const Hit& h, f3 o, f3 d, float* hits, float* dist, float
     const bool ok = h.face >= 0;
     // kernels.py:69: start + t * dir (no fused multiply-add)
     const f3 p = ok ? f3{o.x + h.t * d.x, o.y + h.t * d.y, o.z + h.t * d.z} : f3{inf, inf, inf};
-    store3(hits + 3 * i, p);
+    if (hits) store3(hits + 3 * i, p);
     if (dist) dist[i] = ok ? h.t : inf;
     if (face) face[i] = ok ? h.face : -1;
     if (normal) store3(normal + 3 * i, ok ? normalize3(h.normal_raw) : f3{inf, inf, inf});
@@ -834,7 +834,7 @@ raycaster_update_lattice_kernel(ScanArgs a, const LatEnvRec* __restrict__ recs, 
 
     const f3 pos = {E.px, E.py, E.pz};
     const f4 rot = {E.rw, E.rx, E.ry, E.rz};
-    float* const hits_env = a.ray_hits_w + 3 * (env * a.r);
+    float* const hits_env = a.ray_hits_w ? a.ray_hits_w + 3 * (env * a.r) : nullptr;   // null: height scan only (ILX_RAYS_HEIGHT_ONLY)
     float* const height_env = a.height ? a.height + env * a.r : nullptr;
     // World start of a pattern entry: quat_apply(rot, l) + pos (ray_caster.py:245-246) for a yaw quaternion.  rot.x and
     // rot.y are exact zeros (yaw_quat builds (cos, 0, 0, sin) and divides by the norm), so the products with them in
@@ -888,11 +888,13 @@ raycaster_update_lattice_kernel(ScanArgs a, const LatEnvRec* __restrict__ recs, 
         // streaming stores for the hit records: nothing on the step reads them again (the managers read the height
         // scan, which is stored the usual way and waits for them in the caches), and written the usual way they would
         // push the height grid out of the L2 that the other envs' windows are read from
-        const f3 hit = ok ? f3{o.x, o.y, hz} : f3{inf, inf, inf};
-        float* const hp = hits_env + 3 * ray;
-        __builtin_nontemporal_store(hit.x, hp);
-        __builtin_nontemporal_store(hit.y, hp + 1);
-        __builtin_nontemporal_store(hit.z, hp + 2);
+        if (hits_env) {
+            const f3 hit = ok ? f3{o.x, o.y, hz} : f3{inf, inf, inf};
+            float* const hp = hits_env + 3 * ray;
+            __builtin_nontemporal_store(hit.x, hp);
+            __builtin_nontemporal_store(hit.y, hp + 1);
+            __builtin_nontemporal_store(hit.z, hp + 2);
+        }
         if (height_env) height_env[ray] = pos.z - (ok ? hz : inf) - a.height_offset;
         if (a.mesh.lat_served) atomicAdd(a.mesh.lat_served, 1ull);
         return true;
@@ -919,7 +921,8 @@ raycaster_update_lattice_kernel(ScanArgs a, const LatEnvRec* __restrict__ recs, 
         const int64_t i = env * a.r + ray;
         if (!z_parallel(d) || !a.mesh.cells) {  // left to the tree kernel that follows
             *a.off_grid = a.ticket;
-            a.ray_hits_w[3 * i] = __uint_as_float(kLeftOverBits);
+            if (a.ray_hits_w) a.ray_hits_w[3 * i] = __uint_as_float(kLeftOverBits);
+            else a.height[i] = __uint_as_float(kLeftOverBits);   // height scan only: no launch follows (the caller's promise was broken)
             continue;
         }
         const Hit h = trace_column<false>(a.mesh, o, d, a.max_dist);
@@ -1738,9 +1741,12 @@ static void launch_lattice(ilx_mesh_t mesh, ScanArgs a, int hints, void* ws, flo
     if (!(hints & ILX_RAYS_PREPARED))
         hipLaunchKernelGGL(raycaster_prepare_kernel, dim3(blocks_for(a.n)), dim3(256), 0, as_stream(stream), a, recs, pattern, box,
                            (box && reuse) ? 1 : 0);
+    const bool last_launch = (hints & ILX_RAYS_Z_PARALLEL_CHECKED) && mesh->h.d_cells;
+    ScanArgs cast = a;
+    if ((hints & ILX_RAYS_HEIGHT_ONLY) && last_launch && a.height) cast.ray_hits_w = nullptr;   // nothing reads the hit records as a work list
     hipLaunchKernelGGL(raycaster_update_lattice_kernel, dim3(static_cast<unsigned>((a.n + kLatWaves - 1) / kLatWaves)),
-                       dim3(64 * kLatWaves), 0, as_stream(stream), a, recs, pattern);
-    if ((hints & ILX_RAYS_Z_PARALLEL_CHECKED) && mesh->h.d_cells) return;
+                       dim3(64 * kLatWaves), 0, as_stream(stream), cast, recs, pattern);
+    if (last_launch) return;
     a.outdated = nullptr;
     hipLaunchKernelGGL(raycaster_update_kernel, dim3(std::min(ray_grid(a.n * a.r), 256u)), dim3(kRayBlock), 0, as_stream(stream), a);
 }

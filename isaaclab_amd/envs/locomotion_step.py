@@ -99,6 +99,9 @@ class LocomotionVelocityStep:
         self.height_scan = torch.zeros(n, self.scanner.num_rays, device=dev)
         self.height_scan_offset = next(float(t.aux) for t in self.mdp.observations if t.kind == "height_scan")
         self.scanner.bind_height_scan(self.height_scan, self.height_scan_offset)   # whoever triggers the refresh
+        # the managers of these tasks read the height scan, not the hit records: the refresh leaves those to whoever reads
+        # `scanner.data.ray_hits_w` (formed then, the same bits)
+        self.scanner.lean_hits = True
         self._bind()
         # see step(): worth it when the step is replayed from a HIP graph and the actuator chain is long (network
         # actuators); issued launch by launch, the fork and join cost the host more than the overlap returns
@@ -123,7 +126,7 @@ class LocomotionVelocityStep:
                       soft_joint_vel_limits=d.soft_joint_vel_limits, body_state_w=d.body_state_w,
                       net_forces_w_history=c.net_forces_w_history, current_air_time=c.current_air_time,
                       last_air_time=c.last_air_time, current_contact_time=c.current_contact_time,
-                      last_contact_time=c.last_contact_time, ray_hits_w=self.scanner._data.ray_hits_w,
+                      last_contact_time=c.last_contact_time, ray_hits_w=self.scanner._data.hits_storage,
                       sensor_pos_w=self.scanner._data.pos_w, action=self.action, prev_action=self.prev_action,
                       height_scan=self.height_scan)
 
@@ -310,6 +313,6 @@ class LocomotionVelocityStep:
         m = self.mdp
         m.bind(root_state_w=d.root_state_w, joint_pos=d.joint_pos, joint_vel=d.joint_vel, noise_u=noise_u,
                command_samples=command_samples, reset_command_samples=reset_command_samples,
-               sensor_pos_w=self.scanner._data.pos_w, ray_hits_w=self.scanner._data.ray_hits_w)
+               sensor_pos_w=self.scanner._data.pos_w, ray_hits_w=self.scanner._data.hits_storage)
         m.step(phases, hold_step_count=self._advance_count_first or not (phases & FM.PHASE_OBSERVATION))
         return m.obs, m.reward_buf, m.terminated, m.time_outs

@@ -43,13 +43,25 @@ class RayCasterCfg:
     drift_range: tuple[float, float] = (0.0, 0.0)
 
 
-@dataclass
 class RayCasterData:
-    """ray_caster_data.py:10-30."""
+    """ray_caster_data.py:10-30.  ``ray_hits_w`` is a property: a sensor that refreshes with ``lean_hits`` leaves the hit
+    records to the first reader (they are formed then, from ``pos_w`` / ``quat_w`` of the refresh, by the same device
+    code -- the same bits as an eager refresh stores)."""
 
-    pos_w: torch.Tensor = None
-    quat_w: torch.Tensor = None
-    ray_hits_w: torch.Tensor = None
+    def __init__(self, pos_w: torch.Tensor = None, quat_w: torch.Tensor = None, ray_hits_w: torch.Tensor = None):
+        self.pos_w, self.quat_w = pos_w, quat_w
+        self.hits_storage = ray_hits_w     # the (N, R, 3) buffer itself, whatever its state
+        self._bring_up_to_date = None      # set by the owning sensor
+
+    @property
+    def ray_hits_w(self) -> torch.Tensor:
+        if self._bring_up_to_date is not None:
+            self._bring_up_to_date()
+        return self.hits_storage
+
+    @ray_hits_w.setter
+    def ray_hits_w(self, value: torch.Tensor):
+        self.hits_storage = value
 
 
 class RayCaster:
@@ -96,6 +108,12 @@ class RayCaster:
         self._prepared = False
         # where every refresh also writes the height scan of the `height_scan` observation term (bind_height_scan)
         self._height_out, self._height_offset = None, 0.0
+        # True: a refresh that writes a bound height scan writes nothing else per ray (ILX_RAYS_HEIGHT_ONLY, a quarter of
+        # the bytes); the hit records follow when `data.ray_hits_w` is read.  For owners that read the scan every step and
+        # the hit records rarely (the fused env steps).
+        self.lean_hits = False
+        self._hits_behind = False          # a lean refresh has run since the hit records were last formed
+        self._data._bring_up_to_date = self._form_hits
         # a new pattern array may sit where a released one sat: the mesh's streams pack their pattern again; and the
         # per-stream workspaces of this sensor's refreshes are set aside now, so that no refresh allocates (`streams`
         # of them: the stream the owner steps on, one it may fork onto, and two capture streams)
@@ -163,7 +181,7 @@ class RayCaster:
             hints=self._hints | hints, max_distance=float(self.cfg.max_distance), pose_pos=pp, pose_quat=qp, pose_pos_stride=ps,
             pose_quat_stride=qs, drift=_abi.ptr(self.drift),
             ray_starts_local=_abi.ptr(self.ray_starts), ray_directions_local=_abi.ptr(self.ray_directions),
-            pos_w=_abi.ptr(d.pos_w), quat_w=_abi.ptr(d.quat_w), ray_hits_w=_abi.ptr(d.ray_hits_w),
+            pos_w=_abi.ptr(d.pos_w), quat_w=_abi.ptr(d.quat_w), ray_hits_w=_abi.ptr(d.hits_storage),
             height_scan=_abi.ptr(height_out), height_offset=float(height_offset), timestamp=_abi.ptr(self._timestamp),
             timestamp_last_update=_abi.ptr(self._timestamp_last_update), is_outdated=self._is_outdated.data_ptr())
 
@@ -178,8 +196,29 @@ class RayCaster:
             height_out, height_offset = self._height_out, self._height_offset
         # the preparation is consumed by the first refresh after it, whether the step asks for it or a reader of `data`
         prepared, self._prepared = (prepared or self._prepared), False
-        rc = self._descriptor(height_out, height_offset, _abi.RAYS_PREPARED if (prepared and not self.static_workspace) else 0)
+        hints = _abi.RAYS_PREPARED if (prepared and not self.static_workspace) else 0
+        if self.lean_hits and height_out is not None and (self._hints & _abi.RAYS_Z_PARALLEL_CHECKED):
+            # the library takes the hint only where its cast is the refresh's last launch; elsewhere it writes the records
+            # as always and forming them again later changes nothing
+            hints |= _abi.RAYS_HEIGHT_ONLY
+            self._hits_behind = True
+        rc = self._descriptor(height_out, height_offset, hints)
         if self.static_workspace:
             _abi.check(_abi.raycaster_refresh_static(ctypes.byref(rc), _abi.stream()), "ilx_raycaster_refresh_static")
         else:
             _abi.check(_abi.raycaster_refresh(ctypes.byref(rc), _abi.stream()), "ilx_raycaster_refresh")
+
+    def _form_hits(self):
+        """The hit records of every env's last refresh, from the pose that refresh recorded (``pos_w`` holds pose + drift,
+        ``quat_w`` the sensor orientation: ray_caster.py:233-260): the cast of ``ilx_raycaster_update`` on them is the cast
+        the refresh ran.  Every env has been refreshed by the time ``data`` hands the container out."""
+        if not self._hits_behind:
+            return
+        d = self._data
+        mesh = self.meshes[self.cfg.mesh_prim_paths[0]]
+        hints = self._hints & (_abi.RAYS_Z_PARALLEL | _abi.RAYS_Z_PARALLEL_CHECKED)
+        _abi.check(_abi.raycaster_update(mesh.handle, _abi.ptr(d.pos_w), _abi.ptr(d.quat_w), _abi.ptr(self.ray_starts),
+                                         _abi.ptr(self.ray_directions), None, int(self.cfg.attach_yaw_only), float(self.cfg.max_distance),
+                                         _abi.ptr(d.hits_storage), None, 0.0, self._num_envs, self.num_rays, hints, _abi.stream()),
+                   "ilx_raycaster_update")
+        self._hits_behind = False

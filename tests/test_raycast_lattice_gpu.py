@@ -252,3 +252,49 @@ def test_kept_pattern_is_reused_only_for_the_same_pattern(dev):
         assert torch.equal(refresh(a), first["a"]) and torch.equal(refresh(a), first["a"])   # second one reuses
         assert torch.equal(refresh(b), first["b"])                                           # other pattern: packed anew
     assert torch.equal(refresh(a), first["a"])
+
+
+def test_lean_refresh_leaves_the_hit_records_to_their_reader(dev):
+    """``lean_hits``: refreshes that write only the bound height scan (ILX_RAYS_HEIGHT_ONLY) and hit records formed when
+    ``data.ray_hits_w`` is read, against a sensor that stores the records eagerly -- bit for bit, over three refreshes with
+    moving poses, drift, envs that are not due, and a read in between."""
+    from isaaclab_amd.sensors.patterns import GridPatternCfg
+    from isaaclab_amd.sensors.ray_caster import OffsetCfg, RayCaster, RayCasterCfg
+    from isaaclab_amd.utils.mesh import convert_to_mesh
+
+    v, t, rows, cols = hf_case(rows=81, cols=97, seed=23, origin=(10.0, 20.0))
+    mesh = convert_to_mesh(v, t, str(dev))
+    gen = torch.Generator().manual_seed(9)
+    n = 200
+    cfg = RayCasterCfg(offset=OffsetCfg(pos=(0.0, 0.0, 20.0)), attach_yaw_only=True, pattern_cfg=GridPatternCfg(resolution=0.1, size=(1.6, 1.0)),
+                       update_period=0.02, drift_range=(-0.05, 0.05))
+    eager, lean = RayCaster(cfg, n, mesh, dev), RayCaster(cfg, n, mesh, dev)
+    lean.lean_hits = True
+    scans = [torch.zeros(n, eager.num_rays, device=dev) for _ in range(2)]
+    for rc, scan in zip((eager, lean), scans):
+        rc.bind_height_scan(scan, 0.5)
+        rc.reset()
+    lean.drift.copy_(eager.drift)
+    for step in range(3):
+        pos = torch.cat([torch.rand(n, 1, generator=gen) * 7.0 + 10.5, torch.rand(n, 1, generator=gen) * 8.6 + 20.5,
+                         torch.rand(n, 1, generator=gen) + 0.5], -1).to(dev)
+        pos[3, :2] = torch.tensor([40.0, 40.0])     # off the mesh: misses
+        yaw = torch.rand(n, generator=gen) * 6.28 - 3.14
+        quat = torch.stack([torch.cos(yaw / 2), torch.zeros(n), torch.zeros(n), torch.sin(yaw / 2)], -1).to(dev)
+        due = torch.rand(n, generator=gen) < (1.0 if step == 0 else 0.6)
+        for rc in (eager, lean):
+            rc.set_pose(pos, quat)
+            rc._timestamp += 0.02
+            rc._is_outdated.copy_(due)
+            rc._update_outdated_buffers()
+        assert lean._hits_behind and not eager._hits_behind
+        assert_exact(scans[1], scans[0].cpu(), f"height scan, refresh {step}")
+        if step == 1:
+            continue   # the records of two refreshes are formed at once by the read after the third
+        untouched = lean._data.hits_storage.clone()
+        got = lean.data.ray_hits_w
+        assert not lean._hits_behind and got.data_ptr() == lean._data.hits_storage.data_ptr()
+        assert_exact(got, eager.data.ray_hits_w.cpu(), f"hit records, refresh {step}")
+        assert step > 0 or not torch.equal(untouched, got)   # ... and they were not there before the read
+        assert_exact(lean._data.pos_w, eager._data.pos_w.cpu(), "pos_w")
+    assert torch.isinf(eager.data.ray_hits_w[3]).all()
