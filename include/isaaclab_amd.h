@@ -176,9 +176,11 @@ void ilx_mlp_destroy(ilx_mlp_t net);
 
 #define ILX_MLP_FORCE_GENERIC 1 /* flags: skip the MFMA path (testing) */
 #define ILX_MLP_EXACT_F32 2     /* flags: every product in f32 (an f32 fmaf chain per unit).  Without it the hidden layers of
-                                 * a 32-wide net run on the f16 matrix cores with both factors split into an f16 head and an
-                                 * f16 remainder: relative error of a product ~1e-6 instead of 6e-8, outputs within 1e-5 of
-                                 * the f32 evaluation */
+                                 * a 32-wide net with a bounded activation (softsign, tanh) and hidden weights below 6e4 run
+                                 * on the f16 matrix cores with both factors split into an f16 head and an f16 remainder:
+                                 * relative error of a product ~1e-6 instead of 6e-8, outputs within 1e-5 |y| + 2e-5 of the
+                                 * float64 evaluation.  Networks with ELU / ReLU / identity activations (unbounded hidden
+                                 * values) always take the f32 kernels. */
 
 /* ActuatorNetMLP.compute — actuator_net.py:147-188.  In one launch: roll pos_error_history / velocity_history
  * (n, history_length, j; slot 0 newest) and write q_des - q / qd into slot 0, gather input_idx, scale,

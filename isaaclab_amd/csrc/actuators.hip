@@ -840,8 +840,13 @@ extern "C" int ilx_mlp_create(int num_layers, const int32_t* dims, int activatio
         img16.insert(img16.end(), weights_host[nhid], weights_host[nhid] + 32);
         img16.push_back(biases_host[nhid][0]);
         while (img16.size() % 4) img16.push_back(0.0f);
-        // the split needs every hidden weight inside the f16 range; otherwise the f32 kernels serve the net
-        bool in_range = true;
+        // The split needs every factor inside the f16 range.  Hidden weights: checked here.  Hidden activations: only the
+        // bounded ones (softsign, tanh: |x| <= 1) are known to be; behind ELU / ReLU / identity a pre-activation beyond
+        // 65 504 would saturate the f16 head, so those networks are served by the f32 kernels.  Small factors are no
+        // hazard: below 2^-14 the f16 head and remainder lose relative precision, but each such factor is then off by at
+        // most half an f16 subnormal step (3e-8), which the product with a factor of at most one carries into the sum as
+        // an absolute error of that size.
+        bool in_range = activation == ILX_ACT_SOFTSIGN || activation == ILX_ACT_TANH;
         for (int l = 1; l < nhid; ++l)
             for (int i = 0; i < 32 * 32; ++i) in_range = in_range && std::fabs(weights_host[l][i]) < 6.0e4f;
         if (rc == ILX_OK && in_range) {

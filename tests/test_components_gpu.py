@@ -183,6 +183,94 @@ def test_actuator_net_mlp_split_and_f32_products(dev):
         assert not torch.equal(out[0], out[2]), "the default path is the split one"
 
 
+def _mlp_float64(act, ws, bs, activation):
+    """The network of an ActuatorNetMLP on the histories it holds (actuator_net.py:158-178), every operation in float64."""
+    fn = {"softsign": torch.nn.functional.softsign, "elu": torch.nn.functional.elu, "relu": torch.relu, "tanh": torch.tanh}[activation]
+    idx = list(act.cfg.input_idx)
+    pe = act._joint_pos_error_history.double().cpu()[:, idx, :]      # (n, K, j)
+    ve = act._joint_vel_history.double().cpu()[:, idx, :]
+    n, k, j = pe.shape
+    x = torch.cat([pe.permute(0, 2, 1).reshape(n * j, k) * act.cfg.pos_scale, ve.permute(0, 2, 1).reshape(n * j, k) * act.cfg.vel_scale], -1)
+    for i, (w, b) in enumerate(zip(ws, bs)):
+        x = x @ w.double().T + b.double()
+        if i + 1 < len(ws):
+            x = fn(x)
+    return (x.reshape(n, j) * act.cfg.torque_scale)
+
+
+def _run_mlp(dev, ws, bs, activation, flags, n=2048, j=12, steps=3, seed=3, amp=(1.0, 0.3, 3.0)):
+    from isaaclab_amd.actuators import ActuatorNetMLP, ActuatorNetMLPCfg
+    from isaaclab_amd.utils.types import ArticulationActions
+
+    cfg = ActuatorNetMLPCfg(network=dict(weights=ws, biases=bs, activation=activation), pos_scale=-1.0, vel_scale=1.0, torque_scale=1.0,
+                            input_order="pos_vel", input_idx=[0, 1, 2], effort_limit=1e30, velocity_limit=7.5, saturation_effort=1e30)
+    act = ActuatorNetMLP(cfg, joint_names=_names(j), joint_ids=slice(None), num_envs=n, device=dev)
+    act._flags = flags
+    g2 = torch.Generator().manual_seed(seed)
+    for _ in range(steps):
+        q_des = amp[0] * torch.randn(n, j, generator=g2)
+        act.compute(ArticulationActions(joint_positions=q_des.to(dev)), (q_des + amp[1] * torch.randn(n, j, generator=g2)).to(dev),
+                    (amp[2] * torch.randn(n, j, generator=g2)).to(dev))
+    return act
+
+
+def _random_net(gen, gain=1.0, hidden_gain=None, dims=(6, 32, 32, 32, 1)):
+    hidden_gain = gain if hidden_gain is None else hidden_gain
+    ws = [(hidden_gain if 0 < i < len(dims) - 2 else gain) * torch.randn(dims[i + 1], dims[i], generator=gen) / dims[i] ** 0.5
+          for i in range(len(dims) - 1)]
+    bs = [torch.randn(dims[i + 1], generator=gen) * 0.1 for i in range(len(dims) - 1)]
+    return ws, bs
+
+
+def test_actuator_net_mlp_element_wise_against_float64(dev):
+    """Every output of the default evaluation (split-f16 hidden layers) and of ILX_MLP_EXACT_F32 against the float64
+    evaluation of the same network on the same histories: |err| <= 1e-5 |ref| + 2e-5, element by element, for the headline
+    net's shape at two gains (gain 6: saturated softsign, products of tens) and for a tanh net."""
+    gen = torch.Generator().manual_seed(29)
+    for activation, gain in (("softsign", 1.0), ("softsign", 6.0), ("tanh", 1.5)):
+        ws, bs = _random_net(gen, gain)
+        for flags in (0, 2):
+            act = _run_mlp(dev, ws, bs, activation, flags)
+            ref = _mlp_float64(act, ws, bs, activation)
+            err = (act.computed_effort.double().cpu() - ref).abs()
+            bad = err > 1e-5 * ref.abs() + 2e-5
+            assert not bool(bad.any()), (f"{activation} gain {gain} flags {flags}: {int(bad.sum())} outputs beyond 1e-5 |ref| + 2e-5; "
+                                         f"largest error {float(err.max()):.3g} at |ref| {float(ref.abs().flatten()[err.argmax()]):.3g}")
+
+
+def test_actuator_net_mlp_unbounded_activations_stay_in_f32(dev):
+    """ELU / ReLU networks whose hidden pre-activations reach 1e5 (beyond the f16 range of 65 504): never the split-f16
+    kernel -- the default evaluation is the f32 one bit for bit, and matches float64 element-wise to float32's own accuracy."""
+    gen = torch.Generator().manual_seed(31)
+    for activation in ("elu", "relu"):
+        ws, bs = _random_net(gen, gain=40.0)     # first-layer outputs of hundreds, hidden pre-activations of 1e4 .. 1e6
+        out = {}
+        for flags in (0, 2):
+            act = _run_mlp(dev, ws, bs, activation, flags, amp=(2.0, 1.0, 10.0))
+            out[flags] = act.computed_effort.clone()
+        ref = _mlp_float64(act, ws, bs, activation)
+        assert float(ref.abs().max()) > 1e5, "the case is meant to leave the f16 range"
+        assert torch.equal(out[0], out[2]), f"{activation}: the default path must be the f32 one"
+        # sums of terms of 1e6 .. 1e7 in float32: the absolute part of the bound scales with them (cancellation)
+        err = (out[0].double().cpu() - ref).abs()
+        scale = float(ref.abs().max())
+        assert bool((err <= 1e-5 * ref.abs() + 1e-6 * scale).all()), f"{activation}: largest error {float(err.max()):.3g} (outputs up to {scale:.3g})"
+
+
+def test_actuator_net_mlp_small_factors(dev):
+    """Hidden weights of magnitude 1e-4 .. 1e-3 and with them hidden activations of that size (f16 heads near and below
+    the f16 normal range, remainders subnormal): the split evaluation stays within 1e-5 |ref| + 2e-5 of float64, and in fact
+    within 1e-6 absolute."""
+    gen = torch.Generator().manual_seed(37)
+    ws, bs = _random_net(gen, gain=1.0, hidden_gain=3e-3)    # hidden weights ~ N(0, 5e-4)
+    bs = [b * (1e-3 if 0 < i < 3 else 1.0) for i, b in enumerate(bs)]
+    assert 1e-4 < float(ws[1].abs().median()) < 1e-3
+    act = _run_mlp(dev, ws, bs, "softsign", 0)
+    ref = _mlp_float64(act, ws, bs, "softsign")
+    err = (act.computed_effort.double().cpu() - ref).abs()
+    assert bool((err <= 1e-5 * ref.abs() + 2e-5).all()) and float(err.max()) < 1e-6, f"largest error {float(err.max()):.3g}"
+
+
 def _lstm_net(g, tag, act):
     hidden, layers, nhead = (int(v) for v in g[f"{tag}_shape"])
     lstm = {f"{nm}_l{l}": g[f"{tag}_{nm}_l{l}"] for l in range(layers) for nm in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")}
