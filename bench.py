@@ -179,6 +179,8 @@ def main():
     ap.add_argument("--actuator", choices=("mlp", "lstm"), default="mlp",
                     help="anymal only -- actuator network: the headline 6-32-32-32-1 MLP, or the ANYdrive-shaped LSTM(2, 8, 2) + "
                          "head (no CPU baseline, reported as a side measurement)")
+    ap.add_argument("--robot", choices=("franka", "xarm6"), default="franka",
+                    help="reach only -- the arm: Franka Panda (9 joints), or the fork's UFactory xArm6 with gripper (8 joints)")
     ap.add_argument("--root-scatter", choices=("origins", "uniform"), default="origins",
                     help="anymal / h1 -- where the robots stand: within 0.5 m of the env origins that the reference's terrain "
                          "importer deals (default), or uniformly over the whole terrain (no two envs near each other)")
@@ -202,7 +204,7 @@ def main():
 
     cfg_id = list(BC.ENVS).index(args.config) + 1
     cfg = BC.build(args.config, device, args.envs, seed=cfg_id * 1000 + rank, actuator=args.actuator,
-                   root_scatter=args.root_scatter)
+                   root_scatter=args.root_scatter, robot=args.robot)
 
     # episode statistics of the done envs: the only cross-rank exchange of the path, one all-reduce per step, started
     # after the step and completed beside the next two (nothing in the step consumes it).  The in-hand env reduces its two
@@ -378,7 +380,9 @@ def main():
             "value": value, "unit": "env-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": dict({"workload": BC.WORKLOAD[args.config], "envs_per_gpu": args.envs}, **cfg.info,
+            "config": dict({"workload": BC.WORKLOAD[args.config] + (", the task on the fork's UFactory xArm6 with gripper"
+                                                                   if args.config == "reach" and args.robot == "xarm6" else ""),
+                            "envs_per_gpu": args.envs}, **cfg.info,
                            parallelism=f"env-shard x{world}"),
             "algorithmic_bytes_per_env_step": per_step,
             "step_hbm_frac": per_step * args.envs / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,

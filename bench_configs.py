@@ -232,18 +232,28 @@ def build_cartpole(device, envs, seed):
     return cfg
 
 
-def build_reach(device, envs, seed):
+def build_reach(device, envs, seed, robot="franka"):
+    from isaaclab_amd import synth
     from isaaclab_amd.envs import fused_mdp as FM
     from isaaclab_amd.envs.manager_based_step import ReachStep
     from isaaclab_amd.tasks import reach as RE
+    from isaaclab_amd.utils.string import resolve_matching_names_values
 
     g = torch.Generator().manual_seed(seed)
     n = envs
-    env = ReachStep(n, device, arm_action="joint_pos", seed=seed)
-    default = torch.tensor([0.0, -0.569, 0.0, -2.81, 0.0, 3.037, 0.741, 0.04, 0.04]).repeat(n, 1)   # franka.py:38-48
+    env = ReachStep(n, device, arm_action="joint_pos", seed=seed, robot=robot)
+    spec = RE.ROBOTS[robot]
+    nj, nb_bodies, arm = len(spec["joints"]), len(spec["bodies"]), env.arm_dof
+    if robot == "franka":
+        default = torch.tensor([0.0, -0.569, 0.0, -2.81, 0.0, 3.037, 0.741, 0.04, 0.04]).repeat(n, 1)   # franka.py:38-48
+    else:
+        idx, _, vals = resolve_matching_names_values(RE.XARM6_DEFAULT_JOINT_POS, spec["joints"])
+        default = torch.zeros(nj)
+        default[idx] = torch.tensor(vals)
+        default = default.repeat(n, 1)
     env.set_default_joint_pos(default)
-    q = default + 0.3 * torch.randn(n, 9, generator=g)
-    env.data.joint_pos, env.data.joint_vel = q.to(device), torch.zeros(n, 9, device=device)
+    q = default + 0.3 * torch.randn(n, nj, generator=g)
+    env.data.joint_pos, env.data.joint_vel = q.to(device), torch.zeros(n, nj, device=device)
     env.mdp.episode_length_buf.copy_(torch.randint(0, RE.MAX_EPISODE_LENGTH, (n,), generator=g))
     quat = torch.randn(n, 4, generator=g)
     env.mdp.command.copy_(torch.cat([torch.rand(n, 3, generator=g) * 0.5, quat / quat.norm(dim=-1, keepdim=True)], -1))
@@ -252,29 +262,32 @@ def build_reach(device, envs, seed):
     root[:, :3] = torch.randn(n, 3, generator=g)
     yaw = torch.rand(n, generator=g) * 6.28 - 3.14
     root[:, 3], root[:, 6] = torch.cos(yaw / 2), torch.sin(yaw / 2)
-    nb_bodies = len(RE.FRANKA_BODIES)
     body = torch.zeros(n, nb_bodies, 13)
     body[..., :3] = root[:, None, :3] + 0.4 * torch.randn(n, nb_bodies, 3, generator=g)
     bq = torch.randn(n, nb_bodies, 4, generator=g)
     body[..., 3:7] = bq / bq.norm(dim=-1, keepdim=True)
-    env.load_physics(dict(joint_pos=torch.stack([default + 0.2 * torch.randn(n, 9, generator=g) for _ in range(RE.DECIMATION)]),
-                          joint_vel=torch.stack([0.5 * torch.randn(n, 9, generator=g) for _ in range(RE.DECIMATION)]),
+    q_steps = torch.stack([default + 0.2 * torch.randn(n, nj, generator=g) for _ in range(RE.DECIMATION)])
+    if robot == "xarm6":   # the end effector where the arm's own forward kinematics puts it (urdf:79-225)
+        ee_pos, ee_quat, _ = synth.serial_arm_kinematics(q_steps[-1][:, :arm].numpy(), root[:, :3].numpy(), root[:, 3:7].numpy())
+        body[:, env.ee_body, :3], body[:, env.ee_body, 3:7] = torch.from_numpy(ee_pos), torch.from_numpy(ee_quat)
+    env.load_physics(dict(joint_pos=q_steps, joint_vel=torch.stack([0.5 * torch.randn(n, nj, generator=g) for _ in range(RE.DECIMATION)]),
                           root_state_w=root, body_state_w=body))
-    raw = (torch.rand(n, 7, generator=g) * 2 - 1).to(device)
+    raw = (torch.rand(n, arm, generator=g) * 2 - 1).to(device)
     launches = {"joint_action_process": (lambda: env.process_action(raw), 1), "actuator_pd": (lambda: env.apply_action(first=False), RE.DECIMATION),
                 "scene_update": (lambda: env.scene.update(RE.PHYSICS_DT), RE.DECIMATION),
                 "mdp_step": (lambda: env.mdp.step(FM.PHASE_ALL, hold_step_count=True), 1)}
+    f, fa = 4 * nj, 4 * arm
     nb = {
-        "joint_action_process": 5 * 28,             # read raw, default; write action, previous action, arm target (7 joints)
-        # arm target into the 9-joint target 28 + read q_des, qd_des, tau_ff, q, qd (5 x 36); write computed, applied (2 x 36)
-        "actuator_pd": 28 + 7 * 36,
-        "scene_update": 36 + 72 + 36,               # joint_acc: read vel, read+write previous vel, write acc
-        # read root 52, end-effector pose 28, joint pos / vel 72, actions 56; command r+w 56, time_left r+w 8, counter r+w
-        # 16, ep_len r+w 16; write obs 4 x 32, reward 4, step_reward 20, episode sums r+w 40, flags 3
-        "mdp_step": 52 + 28 + 72 + 56 + 56 + 8 + 16 + 16 + 4 * int(env.mdp.obs_dim) + 4 + 20 + 40 + 3,
+        "joint_action_process": 5 * fa,             # read raw, default; write action, previous action, arm target (arm joints)
+        # arm target into the joint target + read q_des, qd_des, tau_ff, q, qd (5 x J); write computed, applied (2 x J)
+        "actuator_pd": fa + 7 * f,
+        "scene_update": f + 2 * f + f,              # joint_acc: read vel, read+write previous vel, write acc
+        # read root 52, end-effector pose 28, joint pos / vel 2J, actions 2A; command r+w 56, time_left r+w 8, counter r+w
+        # 16, ep_len r+w 16; write obs, reward 4, step_reward 20, episode sums r+w 40, flags 3
+        "mdp_step": 52 + 28 + 2 * f + 2 * fa + 56 + 8 + 16 + 16 + 4 * int(env.mdp.obs_dim) + 4 + 20 + 40 + 3,
     }
-    info = {"decimation": RE.DECIMATION, "joints": 9, "bodies": nb_bodies, "obs_dim": int(env.mdp.obs_dim),
-            "actuator": "ImplicitActuator (PD estimate)", "arm_action": "JointPositionAction scale 0.5"}
+    info = {"robot": robot, "decimation": RE.DECIMATION, "joints": nj, "bodies": nb_bodies, "obs_dim": int(env.mdp.obs_dim),
+            "actuator": "ImplicitActuator (PD estimate)", "arm_action": "JointPositionAction scale 0.5", "mdp_kernel": env.mdp.kernel}
     cfg = Config("reach", n, lambda: env.step(raw), launches, nb, info, env.mdp.log_sums, lambda buf: env.mdp.bind(log_sums=buf))
     cfg.env = env
     return cfg
@@ -319,7 +332,7 @@ def build_shadow(device, envs, seed):
     return cfg
 
 
-def build(name, device, envs=None, seed=0, actuator="mlp", static_scan=False, root_scatter="origins"):
+def build(name, device, envs=None, seed=0, actuator="mlp", static_scan=False, root_scatter="origins", robot="franka"):
     envs = envs or ENVS[name]
     if name == "anymal":
         return build_locomotion(device, envs, seed, "anymal_c", actuator, static_scan, root_scatter)
@@ -328,7 +341,7 @@ def build(name, device, envs=None, seed=0, actuator="mlp", static_scan=False, ro
     if name == "cartpole":
         return build_cartpole(device, envs, seed)
     if name == "reach":
-        return build_reach(device, envs, seed)
+        return build_reach(device, envs, seed, robot)
     if name == "shadow":
         return build_shadow(device, envs, seed)
     raise ValueError(f"unknown config '{name}'")

@@ -194,37 +194,41 @@ class ReachStep(ManagerBasedStep):
     """Isaac-Reach-Franka-v0 and its IK variants (reach_env_cfg.py + config/franka/*): arm action = JointPositionAction
     (scale 0.5, default offset) or the DifferentialIK action term (relative / absolute pose, DLS), implicit actuators
     (isaaclab_assets/robots/franka.py:50-72), UniformPoseCommand, five rewards, time-out, 32-wide observation
-    (9 + 9 + 7 + arm action width)."""
+    (9 + 9 + 7 + arm action width).  ``robot="xarm6"``: the same task on the fork's UFactory xArm6 with gripper (8 joints,
+    10 bodies, implicit actuators 2000 / 100; 29-wide observation with the 6-wide joint-position or relative-pose action)."""
 
-    def __init__(self, num_envs: int, device, arm_action: str = "joint_pos", seed: int = 0):
+    def __init__(self, num_envs: int, device, arm_action: str = "joint_pos", seed: int = 0, robot: str = "franka"):
         if arm_action not in ("joint_pos", "ik_rel", "ik_abs"):
             raise ValueError(f"unknown arm action '{arm_action}'")
-        self.arm_action = arm_action
-        adim = {"joint_pos": 7, "ik_rel": 6, "ik_abs": 7}[arm_action]
-        cmd = dict(RE.POSE_COMMAND, body_index=RE.FRANKA_BODIES.index(RE.EE_BODY))
-        super().__init__(num_envs, device, RE.FRANKA_JOINTS, RE.FRANKA_BODIES, RE.reach_terms(), action_dim=adim, step_dt=RE.STEP_DT,
+        if robot not in RE.ROBOTS:
+            raise ValueError(f"unknown robot '{robot}' (known: {sorted(RE.ROBOTS)})")
+        self.arm_action, self.robot = arm_action, robot
+        spec = RE.ROBOTS[robot]
+        joints, bodies = spec["joints"], spec["bodies"]
+        arm = resolve_matching_names(spec["arm_joints"], joints)[0]
+        self._arm, self.arm_dof = arm, len(arm)
+        adim = {"joint_pos": self.arm_dof, "ik_rel": 6, "ik_abs": 7}[arm_action]
+        self.ee_body = bodies.index(spec["ee_body"])
+        cmd = dict(RE.POSE_COMMAND, body_index=self.ee_body)
+        super().__init__(num_envs, device, joints, bodies, RE.reach_terms(bodies, spec["ee_body"]), action_dim=adim, step_dt=RE.STEP_DT,
                          physics_dt=RE.PHYSICS_DT, decimation=RE.DECIMATION, max_episode_length=RE.MAX_EPISODE_LENGTH,
                          command=cmd, command_dim=7, seed=seed)
         n, dev = num_envs, self.device
-        arm = resolve_matching_names(["panda_joint.*"], RE.FRANKA_JOINTS)[0]
-        self._arm = arm
         # the same joints as an index that costs no host-to-device copy per use: a slice when they are consecutive
         self._arm_index = (slice(arm[0], arm[-1] + 1) if arm == list(range(arm[0], arm[-1] + 1)) else
                            torch.tensor(arm, dtype=torch.long, device=dev))
-        cfg = ImplicitActuatorCfg(effort_limit={"panda_joint[1-4]": 87.0, "panda_joint[5-7]": 12.0, "panda_finger_joint.*": 200.0},
-                                  velocity_limit={"panda_joint[1-4]": 2.175, "panda_joint[5-7]": 2.61, "panda_finger_joint.*": 0.2},
-                                  stiffness={"panda_joint.*": 80.0, "panda_finger_joint.*": 2e3},
-                                  damping={"panda_joint.*": 4.0, "panda_finger_joint.*": 1e2})
-        self.actuator = ImplicitActuator(cfg, joint_names=RE.FRANKA_JOINTS, joint_ids=slice(None), num_envs=n, device=dev)
+        cfg = ImplicitActuatorCfg(**spec["actuators"])
+        self.actuator = ImplicitActuator(cfg, joint_names=joints, joint_ids=slice(None), num_envs=n, device=dev)
         self.actuator.computed_effort, self.actuator.applied_effort = self.data.computed_torque, self.data.applied_torque
-        self._arm_target = torch.zeros(n, 7, device=dev)
-        self._arm_default = torch.zeros(n, 7, device=dev)
+        self._arm_target = torch.zeros(n, self.arm_dof, device=dev)
+        self._arm_default = torch.zeros(n, self.arm_dof, device=dev)
         self.ik = None
         self.opens_with_joint_action = arm_action == "joint_pos"
         if arm_action != "joint_pos":
             env = types.SimpleNamespace(num_envs=n, device=dev, scene={"robot": self.asset})
+            offset = None if spec["ik_body_offset"] is None else OffsetCfg(*spec["ik_body_offset"])
             ik_cfg = DifferentialInverseKinematicsActionCfg(
-                joint_names=["panda_joint.*"], body_name=RE.EE_BODY, body_offset=OffsetCfg(*RE.IK_BODY_OFFSET),
+                joint_names=spec["arm_joints"], body_name=spec["ee_body"], body_offset=offset,
                 scale=0.5 if arm_action == "ik_rel" else 1.0,   # ik_rel_env_cfg.py:29-36 / ik_abs_env_cfg.py:29-34
                 controller=DifferentialIKControllerCfg("pose", arm_action == "ik_rel", "dls"))
             self.ik = DifferentialInverseKinematicsAction(ik_cfg, env)
@@ -243,7 +247,7 @@ class ReachStep(ManagerBasedStep):
     def process_action(self, raw):
         raw = _abi.f32c(raw)
         if self.ik is None:  # JointPositionAction: processed = raw * 0.5 + default (joint_actions.py:145-160)
-            self._joint_action(raw, RE.ARM_ACTION_SCALE, self._arm_default, self._arm_target, 7)
+            self._joint_action(raw, RE.ARM_ACTION_SCALE, self._arm_default, self._arm_target, self.arm_dof)
         else:  # ActionManager bookkeeping (action_manager.py:331-332), then the term
             self.prev_action.copy_(self.action)
             self.action.copy_(raw)
