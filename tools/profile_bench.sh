@@ -6,7 +6,7 @@
 # launch (--eager): the counters are collected per dispatch.
 # tools/reduce_profiles.py <tag> then turns them into the committed summaries under profiles/.
 set -e
-tag=${1:-r2}
+tag=${1:-r3}
 out=gpurun_out/$tag
 mkdir -p $out
 export TMPDIR=/tmp
