@@ -406,6 +406,34 @@ ILX_DEV f32x16 activate16(f32x16 v) {
     return v;
 }
 
+// Softsign of sixteen values with one reciprocal per four.  v_rcp_f32 issues at a quarter of the rate of a multiply, and
+// the split kernel is bound by vector issue, so the four denominators d = 1 + |x| of a group share one:
+//   r = 1 / (da dc db dd),  1 / (da dc) = r (db dd),  1 / da = dc / (da dc), ...
+// in packed multiplies (two values per instruction): 16 issue slots per four values instead of 24.  Every d is >= 1, so
+// the product cannot underflow; it must stay finite, which |x| <= 2^24 guarantees (2^100 at most).  CLAMP: the inputs
+// are held to that range first -- beyond it softsign is +-1 to within 6e-8 either way; without it the caller knows the
+// bound.  Each result carries the reciprocal's 1 ulp and four roundings (<= 3e-7 relative).
+using f2 = __attribute__((ext_vector_type(2))) float;
+template <bool CLAMP>
+ILX_DEV f32x16 softsign16_shared_rcp(f32x16 v) {
+    constexpr float kBound = 16777216.0f;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        f2 ab = {v[4 * g], v[4 * g + 1]}, cd = {v[4 * g + 2], v[4 * g + 3]};
+        if (CLAMP) {
+            ab = {__builtin_amdgcn_fmed3f(ab.x, -kBound, kBound), __builtin_amdgcn_fmed3f(ab.y, -kBound, kBound)};
+            cd = {__builtin_amdgcn_fmed3f(cd.x, -kBound, kBound), __builtin_amdgcn_fmed3f(cd.y, -kBound, kBound)};
+        }
+        const f2 dab = {1.0f + fabsf(ab.x), 1.0f + fabsf(ab.y)}, dcd = {1.0f + fabsf(cd.x), 1.0f + fabsf(cd.y)};
+        const f2 p = dab * dcd;                                    // (da dc, db dd)
+        const float r = __builtin_amdgcn_rcpf(p.x * p.y);
+        const f2 q = f2{p.y, p.x} * r;                             // (1 / (da dc), 1 / (db dd))
+        const f2 ya = ab * (q * dcd), yc = cd * (q * dab);         // x / d
+        v[4 * g] = ya.x, v[4 * g + 1] = ya.y, v[4 * g + 2] = yc.x, v[4 * g + 3] = yc.y;
+    }
+    return v;
+}
+
 template <int ACT>
 __global__ void __launch_bounds__(256) mlp_mfma_kernel(NetArgs a) {
     const int lane = threadIdx.x & 63;
@@ -665,7 +693,10 @@ ILX_DEV void mlp_split_block(const NetArgs& a, unsigned block) {
         }
     }
     ILX_MLP_STAMP(3)
-    acc = activate16<ACT>(acc);
+    // the first layer's inputs are physical quantities of any size; the hidden layers' pre-activations are bounded by
+    // the weights (ilx_mlp_create: the split image exists only when 32 |w| + |b| stays far below 2^24)
+    if constexpr (ACT == ILX_ACT_SOFTSIGN) acc = softsign16_shared_rcp<true>(acc);
+    else acc = activate16<ACT>(acc);
     ILX_MLP_STAMP(4)
 #pragma unroll
     for (int l = 1; l < NHID; ++l) {
@@ -682,7 +713,8 @@ ILX_DEV void mlp_split_block(const NetArgs& a, unsigned block) {
         for (int s = 0; s < 2; ++s) y = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[s * 64], xl[s], y, 0, 0, 0);
 #pragma unroll
         for (int s = 0; s < 2; ++s) y = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[s * 64], xh[s], y, 0, 0, 0);
-        acc = activate16<ACT>(y);
+        if constexpr (ACT == ILX_ACT_SOFTSIGN) acc = softsign16_shared_rcp<false>(y);
+        else acc = activate16<ACT>(y);
     }
     ILX_MLP_STAMP(5)
     float part = 0.0f;
@@ -702,31 +734,212 @@ __global__ void __launch_bounds__(256, 8) mlp_mfma_split_kernel(NetArgs a) {
     mlp_split_block<ACT, NHID, POS_VEL>(a, blockIdx.x);
 }
 
-// Eight tiles per workgroup: half as many copies of the weight image.
+// The ANYdrive shape (three hidden layers, three samples in the usual feature order) with wavefronts that stay: the grid
+// is a few workgroups of four wavefronts per CU however many tiles there are, wavefront w of all `nblocks * 4` takes tiles
+// w, w + nblocks * 4, ... and has the next tile's rows in flight while it computes the current one.  With a wavefront
+// per tile (mlp_split_block) all six tiles of a SIMD run their address preamble at once, sharing its issue slots, so the
+// first row load leaves after a microsecond, and every workgroup waits for its own copy of the weight image; here a
+// SIMD's two wavefronts pay both once and the other four tiles' loads travel under compute.  The free wavefront slots
+// are what mlp_split_scene_kernel's scene-update workgroups run in.
+struct TileAt {
+    RowAt<uint32_t> at;
+    bool valid;
+};
+ILX_DEV TileAt split_tile_at(const NetArgs& a, uint32_t tile, int lane) {
+    const uint32_t j = static_cast<uint32_t>(a.j);
+    const uint32_t row0 = tile * 32u;
+    const uint32_t env0 = row0 / j, joint0 = row0 - env0 * j;   // wave-uniform: scalar
+    const uint32_t x = joint0 + (lane & 31);  // < j + 32
+    uint32_t q = static_cast<uint32_t>(static_cast<float>(x) * a.inv_j);  // exact up to +-1 for x < 2^22
+    q = (q * j > x) ? q - 1 : q;
+    q = ((q + 1) * j <= x) ? q + 1 : q;
+    const uint32_t env = env0 + q, joint = x - q * j, row = row0 + (lane & 31);
+    const bool valid = row < static_cast<uint32_t>(a.rows);
+    return {{valid ? row : 0u, valid ? env * static_cast<uint32_t>(a.hist_len) * j + joint : 0u, valid ? (a.per_env ? row : joint) : 0u},
+            valid};
+}
+struct JointActionRaw {
+    float raw, old, offset;
+};
+template <bool JA>
+ILX_DEV void split_tile_issue(const NetArgs& a, const TileAt& t, RowRawT<kResidentHist>& raw, JointActionRaw& ja) {
+    issue_row(a, t.at, t.valid, raw, false);
+    ja = {0.0f, 0.0f, 0.0f};
+    if constexpr (JA) {
+        if (t.valid) ja = {rd(a.ja_raw, t.at.row), rd(a.ja_action, t.at.row), rd(a.ja_offset, t.at.row)};
+    }
+}
+
+template <int ACT, bool JA>
+ILX_DEV void mlp_split_persistent(const NetArgs& a, unsigned block, unsigned nblocks) {
+    constexpr int NHID = 3, K = 3, W = 4;
+    constexpr int kHiddenWords = (NHID - 1) * 1024;
+    __shared__ __attribute__((aligned(16))) float img[kResidentHist * 64 + kHiddenWords + NHID * 32 + 32 + 4];
+    const int lane = threadIdx.x & 63;
+    const int half = lane >> 5;
+    const uint32_t tiles = static_cast<uint32_t>((a.rows + 31) / 32);
+    const uint32_t stride = nblocks * W;
+    uint32_t tile = block * W + static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(threadIdx.x >> 6));
+
+    ILX_MLP_STAMP(0)
+    TileAt cur{};
+    RowRawT<kResidentHist> raw;
+    JointActionRaw ja{};
+    const bool any = tile < tiles;  // wave-uniform
+    if (any) {
+        cur = split_tile_at(a, tile, lane);
+        split_tile_issue<JA>(a, cur, raw, ja);
+    }
+    ILX_MLP_STAMP(1)
+    if constexpr (JA) {
+        if (block == 0) {
+            for (int k = threadIdx.x; k < a.begin_count; k += 64 * W) a.begin_log[k] = 0.0f;
+            if (a.begin_counter && threadIdx.x == 0) *a.begin_counter += 1;
+        }
+    }
+    {   // the image is padded to whole 16-byte words
+        const float4* src = reinterpret_cast<const float4*>(a.net.image16);
+        float4* dst = reinterpret_cast<float4*>(img);
+        for (int i = threadIdx.x; i < a.net.image16_floats / 4; i += 64 * W) dst[i] = src[i];
+    }
+    __syncthreads();
+    ILX_MLP_STAMP(2)
+    if (!any) return;
+
+    const int ks0 = a.net.ks0;
+    const float* w0 = img + lane;
+    const h8* wh = reinterpret_cast<const h8*>(img + ks0 * 64) + lane;   // fragment f of layer l: wh[(4 (l - 1) + f) * 64]
+    const float* bias = img + ks0 * 64 + kHiddenWords + 4 * half;
+    const float* wo = bias + NHID * 32;
+    const float bo = img[ks0 * 64 + kHiddenWords + NHID * 32 + 32];
+
+    // one tile, up to its stores: joint action (JA), features, the four layers
+    struct TileOut {
+        RowInT<kResidentHist> in;
+        float out, q_des;
+    };
+    auto compute = [&](RowRawT<kResidentHist>& raw, const JointActionRaw& ja) {
+        TileOut r;
+        if constexpr (JA) raw.q_des = ja.raw * a.ja_scale + ja.offset;   // joint_actions.py:133: raw * scale + offset
+        r.q_des = raw.q_des;
+        finish_row_pos_vel<kResidentHist, K>(a, raw, r.in);
+
+        f32x16 acc;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc[k] = bias[acc_unit(k, 0)];
+#pragma unroll
+        for (int s = 0; s < K; ++s) {
+            const float bop = half ? r.in.feat[2 * s + 1] : r.in.feat[2 * s];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w0[s * 64], bop, acc, 0, 0, 0);
+        }
+        if constexpr (ACT == ILX_ACT_SOFTSIGN) acc = softsign16_shared_rcp<true>(acc);
+        else acc = activate16<ACT>(acc);
+#pragma unroll
+        for (int l = 1; l < NHID; ++l) {
+            h8 xh[2], xl[2];
+            split_f16(acc, xh, xl);
+            f32x16 y;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) y[k] = bias[l * 32 + acc_unit(k, 0)];
+            const h8* w = wh + (l - 1) * 256;
+            // small terms first
+#pragma unroll
+            for (int s = 0; s < 2; ++s) y = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[(2 + s) * 64], xh[s], y, 0, 0, 0);
+#pragma unroll
+            for (int s = 0; s < 2; ++s) y = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[s * 64], xl[s], y, 0, 0, 0);
+#pragma unroll
+            for (int s = 0; s < 2; ++s) y = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[s * 64], xh[s], y, 0, 0, 0);
+            if constexpr (ACT == ILX_ACT_SOFTSIGN) acc = softsign16_shared_rcp<false>(y);
+            else acc = activate16<ACT>(y);
+        }
+        float part = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) part = fmaf_(wo[acc_unit(k, 0)], acc[k], part);
+        const float other = __shfl_xor(part, 32, 64);
+        r.out = (half ? other + part : part + other) + bo;
+        return r;
+    };
+    auto store = [&](const TileAt& t, const TileOut& r, const JointActionRaw& ja) {
+        if (!t.valid) return;
+        if constexpr (JA) {
+            if (half == 0) {                               // each row is held by a lane of either half: one of them writes
+                wr(a.ja_prev_action, t.at.row, ja.old);    // action_manager.py:331-332
+                wr(a.ja_action, t.at.row, ja.raw);
+                wr(a.ja_target, t.at.row, r.q_des);
+            }
+        }
+        if (half == 0) store_torque(a, t.at, r.out, r.in);
+        store_history(a, t.at, r.in, half == 0, half == 1);
+    };
+    // The registers a load fills are named here: the wavefront waits for them at this point and nowhere earlier.
+    auto landed = [](const RowRawT<kResidentHist>& w, const JointActionRaw& ja) {
+        asm volatile("" ::"v"(w.q_des), "v"(w.q), "v"(w.qd), "v"(w.vel_limit), "v"(w.effort_limit), "v"(w.pe_old[0]), "v"(w.pe_old[1]),
+                     "v"(w.v_old[0]), "v"(w.v_old[1]));
+        if constexpr (JA) asm volatile("" ::"v"(ja.raw), "v"(ja.old), "v"(ja.offset));
+    };
+    // Two sets of row registers, used in turn.  Loads and stores share one in-order counter that the compiler can only
+    // wait on as a whole once both kinds are pending, so the order within a tile is: next tile's loads out, arithmetic,
+    // wait (for those loads and the previous tile's stores, which have had the arithmetic to finish), stores.
+    TileAt other{};
+    RowRawT<kResidentHist> raw_o;
+    JointActionRaw ja_o{};
+    landed(raw, ja);
+    for (;;) {
+        bool more = tile + stride < tiles;  // wave-uniform
+        if (more) {
+            other = split_tile_at(a, tile + stride, lane);
+            split_tile_issue<JA>(a, other, raw_o, ja_o);
+        }
+        {
+            const TileOut r = compute(raw, ja);
+            landed(raw_o, ja_o);   // (unconditional: the compiler places the wait by paths, not by conditions)
+            store(cur, r, ja);
+        }
+        ILX_MLP_STAMP(4)
+        if (!more) break;
+        tile += stride;
+        more = tile + stride < tiles;
+        if (more) {
+            cur = split_tile_at(a, tile + stride, lane);
+            split_tile_issue<JA>(a, cur, raw, ja);
+        }
+        {
+            const TileOut r = compute(raw_o, ja_o);
+            landed(raw, ja);
+            store(other, r, ja_o);
+        }
+        ILX_MLP_STAMP(5)
+        if (!more) break;
+        tile += stride;
+    }
+    ILX_MLP_STAMP(6)
+}
+
 template <int ACT>
-__global__ void __launch_bounds__(512, 8) mlp_mfma_split8_kernel(NetArgs a) {
-    mlp_split_block<ACT, 3, 3, false, 8>(a, blockIdx.x);
+__global__ void __launch_bounds__(256, 4) mlp_split_persistent_kernel(NetArgs a) {
+    mlp_split_persistent<ACT, false>(a, blockIdx.x, gridDim.x);
 }
 
 // The three-sample launch that also processes the joint action and opens the step (NetArgs::ja_raw).
 template <int ACT>
-__global__ void __launch_bounds__(512, 8) mlp_split_joint_action_kernel(NetArgs a) {
-    mlp_split_block<ACT, 3, 3, true, 8>(a, blockIdx.x);
+__global__ void __launch_bounds__(256, 4) mlp_split_joint_action_kernel(NetArgs a) {
+    mlp_split_persistent<ACT, true>(a, blockIdx.x, gridDim.x);
 }
 
 // The actuator network of one physics substep and the scene update of the substep before it, which have no physics step
 // between them and share no buffer (articulation.py:1399-1436 writes torques and the network's histories;
 // interactive_scene.py:496-513 reads joint velocities and contact forces and writes joint_acc, the contact buffers and
-// the sensor clocks), as workgroups of one grid: the network's first -- it is the longer of the two and bound by the
-// vector and matrix pipes --, the update's, bound by memory, fill in beside them.  One launch and its fixed cost fewer
-// per substep, and the overlap of the two does not depend on how two queues happen to run.
-// Registers: seven wavefronts per SIMD (72 vector registers) -- held to eight (64) the two bodies in one function spill.
+// the sensor clocks), as workgroups of one grid: the network's first -- two per CU, which stay for the whole launch and
+// are bound by the vector and matrix pipes --, the update's, bound by memory, run in the wavefront slots beside them.  One
+// launch and its fixed cost fewer per substep, and the overlap of the two does not depend on how two queues happen to run.
+// Registers: six wavefronts per SIMD (80 vector registers, what the network's body needs): two of the network, four of
+// the update.
 // `mlp_first`, `su_first`: where each kind's workgroups start in the grid.
 template <int ACT>
-__global__ void __launch_bounds__(256, 7) mlp_split_scene_kernel(NetArgs a, SceneArgs s, unsigned mlp_first, unsigned mlp_blocks,
+__global__ void __launch_bounds__(256, 6) mlp_split_scene_kernel(NetArgs a, SceneArgs s, unsigned mlp_first, unsigned mlp_blocks,
                                                                  unsigned su_first) {
     const unsigned b = blockIdx.x;
-    if (b >= mlp_first && b - mlp_first < mlp_blocks) mlp_split_block<ACT, 3, 3>(a, b - mlp_first);
+    if (b >= mlp_first && b - mlp_first < mlp_blocks) mlp_split_persistent<ACT, false>(a, b - mlp_first, mlp_blocks);
     else scene_update_thread(s, b - su_first);
 }
 
@@ -846,9 +1059,13 @@ extern "C" int ilx_mlp_create(int num_layers, const int32_t* dims, int activatio
         // hazard: below 2^-14 the f16 head and remainder lose relative precision, but each such factor is then off by at
         // most half an f16 subnormal step (3e-8), which the product with a factor of at most one carries into the sum as
         // an absolute error of that size.
+        // The same bound on weights and biases keeps a hidden pre-activation (32 products with factors of at most one,
+        // and the bias) below 2^22, which the shared reciprocal of the softsign needs (softsign16_shared_rcp).
         bool in_range = activation == ILX_ACT_SOFTSIGN || activation == ILX_ACT_TANH;
-        for (int l = 1; l < nhid; ++l)
+        for (int l = 1; l < nhid; ++l) {
             for (int i = 0; i < 32 * 32; ++i) in_range = in_range && std::fabs(weights_host[l][i]) < 6.0e4f;
+            for (int i = 0; i < 32; ++i) in_range = in_range && std::fabs(biases_host[l][i]) < 6.0e4f;
+        }
         if (rc == ILX_OK && in_range) {
             rc = check_hip(hipMalloc(&h.d_image16, img16.size() * sizeof(float)), "ilx_mlp_create: hipMalloc");
             if (rc == ILX_OK)
@@ -934,6 +1151,28 @@ extern "C" int ilx_actuator_pd_scene_update(int model, const float* q_des, const
                        saturation_effort, computed, applied, n, j, scene, stream);
 }
 
+// Workgroups per CU of the network kernels whose wavefronts stay (mlp_split_persistent).  Three wavefronts per SIMD: the
+// vector pipe takes an instruction every other cycle and a wavefront alone offers one every four, while the matrix
+// products and LDS reads of one wavefront want the arithmetic of another to hide behind; more than three only delays the
+// first row loads (every wavefront runs its address preamble first) and, in the launch shared with the scene update,
+// takes the wavefront slots the update's workgroups run in.  Measured at 196 608 rows: 2 / 3 / 4 / 6 per CU = 9.5 / 9.2 /
+// 9.1 / 9.0 us alone, 12.0 / 11.9 / 12.6 / 12.9 us with the scene update in the grid.
+constexpr unsigned kStayPerCu = 3;
+
+// Compute units of the current device (asked once per device).
+static int device_cu_count() {
+    static int cached[64] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64) dev = 0;
+    if (cached[dev] == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cached[dev] = n;
+    }
+    return cached[dev];
+}
+
 // `scene` (or null): the scene update that goes with this launch -- as workgroups of the same grid where the launch is
 // the three-sample split kernel's, else as a launch of its own ahead of it.
 template <int ACT>
@@ -952,6 +1191,8 @@ static int launch_mlp(const NetArgs& a, bool force_generic, bool exact_f32, hipS
         const bool small = a.hist_len <= kResidentHist && a.n_feat <= 2 * kResidentHist && a.j < (1 << 20) &&
                            a.rows * a.hist_len < (int64_t(1) << 30);  // byte offsets of the history below 2^32
         const unsigned tile_blocks = static_cast<unsigned>((tiles + 3) / 4);
+        // the kernels whose wavefronts stay: kStayPerCu workgroups of four wavefronts per CU, or fewer when the tiles run out
+        const unsigned stay_blocks = std::min(tile_blocks, kStayPerCu * static_cast<unsigned>(device_cu_count()));
         const bool split = a.net.image16 && !exact_f32;
         // the usual feature list: position errors of samples 0 .. K-1, then the velocities of the same samples
         bool pos_vel = a.n_feat == 2 * a.hist_len;
@@ -959,7 +1200,7 @@ static int launch_mlp(const NetArgs& a, bool force_generic, bool exact_f32, hipS
             pos_vel = a.feat_slot[f] == f % a.hist_len && (((a.feat_is_pos >> f) & 1u) != 0) == (f < a.hist_len);
         const bool three = nhid == 3 && small && split && pos_vel && a.hist_len == 3;
         if (a.ja_raw && three) {   // the step's first actuator launch: the joint action's processing rides on it
-            hipLaunchKernelGGL((mlp_split_joint_action_kernel<ACT>), dim3(static_cast<unsigned>((tiles + 7) / 8)), dim3(512), 0, s, a);
+            hipLaunchKernelGGL((mlp_split_joint_action_kernel<ACT>), dim3(stay_blocks), dim3(256), 0, s, a);
             return ILX_OK;
         }
         scene_inside = scene && scene->num_envs > 0 && three;
@@ -968,11 +1209,10 @@ static int launch_mlp(const NetArgs& a, bool force_generic, bool exact_f32, hipS
             if (rc != ILX_OK) return rc;
         }
         if (scene_inside)   // the network's workgroups first in the grid, the update's behind them
-            hipLaunchKernelGGL((mlp_split_scene_kernel<ACT>), dim3(tile_blocks + su_blocks), dim3(256), 0, s, a, sa, 0u, tile_blocks,
-                               tile_blocks);
+            hipLaunchKernelGGL((mlp_split_scene_kernel<ACT>), dim3(stay_blocks + su_blocks), dim3(256), 0, s, a, sa, 0u, stay_blocks,
+                               stay_blocks);
         else if (nhid == 3 && small && split && pos_vel && a.hist_len == 3) {  // the ANYdrive network's shape: three samples
-            // eight tiles per workgroup: half as many copies of the weight image into LDS (9.9 -> 9.6 us)
-            hipLaunchKernelGGL((mlp_mfma_split8_kernel<ACT>), dim3(static_cast<unsigned>((tiles + 7) / 8)), dim3(512), 0, s, a);
+            hipLaunchKernelGGL((mlp_split_persistent_kernel<ACT>), dim3(stay_blocks), dim3(256), 0, s, a);
         }
         else if (nhid == 3 && small && split)
             hipLaunchKernelGGL((mlp_mfma_split_kernel<ACT, 3, 0>), dim3(tile_blocks), dim3(256), 0, s, a);

@@ -17,12 +17,12 @@ fn = fn[0] if isinstance(fn, tuple) else fn
 for _ in range(5):
     fn()
 torch.cuda.synchronize()
-blocks = min(2048, (envs * 12 + 127) // 128)
+blocks = min(2048, (envs * 12 + 127) // 128, 2 * 256 * int(os.environ.get("ILX_STAY", 2)) // 2)
 buf = (ctypes.c_ulonglong * (8 * 2048))()
 assert _abi.lib.ilx_debug_mlp_stamps(buf, 8 * 2048) == 0
 t = np.frombuffer(buf, dtype=np.uint64).reshape(2048, 8)[:blocks].astype(np.int64)
 t0 = t[:, 0].min()
-labels = ["entry", "row loads issued", "image in LDS", "layer 0 done", "activation 0", "hidden layers done", "stored"]
+labels = ["entry", "row loads issued", "image in LDS", "tile 0: activation 0 done", "tile 0 stored", "tile 1 stored", "last tile stored"]
 prev = t[:, 0]
 for k, lab in enumerate(labels):
     print(f"{k} {lab:20s} {(t[:, k] - t0).mean() / 100:8.2f} us   +{(t[:, k] - prev).mean() / 100:6.2f}   (max +{(t[:, k] - prev).max() / 100:6.2f})")

@@ -19,12 +19,12 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 KERNELS = {  # substring of the kernel symbol -> bench kernel name (launches of one bench kernel are summed per call)
     "mlp_split_joint_action": "actuator_net_mlp_joint_action", "mlp_split_scene": "actuator_net_mlp+scene_update",
-    "joint_action_kernel": "joint_action_process", "mlp_mfma": "actuator_net_mlp", "actuator_lstm_kernel": "actuator_net_lstm", "scene_update_kernel": "scene_update",
+    "joint_action_kernel": "joint_action_process", "mlp_split_persistent": "actuator_net_mlp", "mlp_mfma": "actuator_net_mlp", "actuator_lstm_kernel": "actuator_net_lstm", "scene_update_kernel": "scene_update",
     "raycaster_update": "raycaster_cast", "raycaster_prepare_kernel": "raycaster_prepare", "sensor_refreshed_kernel": "raycaster_cast",
     "scene_update_prepare_kernel": "scene_update_prepare",
     "mdp_step_kernel": "mdp_step", "mdp_fast_kernel": "mdp_step",
 }
-PRIMARY = {"actuator_net_mlp_joint_action": "mlp_split_joint_action", "actuator_net_mlp+scene_update": "mlp_split_scene", "actuator_net_lstm": "actuator_lstm_kernel", "joint_action_process": "joint_action_kernel", "actuator_net_mlp": "mlp_mfma", "scene_update": "scene_update_kernel",
+PRIMARY = {"actuator_net_mlp_joint_action": "mlp_split_joint_action", "actuator_net_mlp+scene_update": "mlp_split_scene", "actuator_net_lstm": "actuator_lstm_kernel", "joint_action_process": "joint_action_kernel", "actuator_net_mlp": "mlp_", "scene_update": "scene_update_kernel",
            "raycaster_cast": "raycaster_update_lattice_kernel", "raycaster_prepare": "raycaster_prepare_kernel",
            "scene_update_prepare": "scene_update_prepare_kernel", "mdp_step": "mdp_"}
 
