@@ -164,6 +164,14 @@ struct Env {
     // max over the history of |F| of one sensor body (rewards.py:266 / terminations.py:157), from the force history as
     // it lies in memory: the largest sum of squares, then one square root (the root is monotonic and correctly
     // rounded, so this is the largest norm, bit for bit)
+    // (the staged rows are in LDS: a body's peak is formed where it is asked for)
+    static constexpr bool kReadsMemory = false;
+    static constexpr int kBatch = 4;
+    struct ForceRaw {
+        float peak;
+    };
+    ILX_DEV ForceRaw force_raw(int b) const { return {force_peak(b)}; }
+    ILX_DEV float force_peak_of(const ForceRaw& r) const { return r.peak; }
     ILX_DEV float force_peak(int b) const {
         const int H = h.history_len, CB = h.num_sensor_bodies;
         const float* f = S + h.L.fraw + 3 * (e * H * CB + b);

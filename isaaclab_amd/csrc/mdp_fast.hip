@@ -63,11 +63,11 @@ struct FastArgs {
 
 #ifdef ILX_FAST_STAMPS  // diagnostics build only: wall-clock stamps (10 ns ticks) of lane 0 of every wavefront of the first blocks
 __device__ unsigned long long g_fast_stamps[512 * 5 * 8];
-__device__ unsigned long long g_scan_stamps[2048 * 2];
+__device__ unsigned long long g_scan_stamps[2048 * 8];
 #define SCAN_STAMP(k)                                                                                                   \
     do {                                                                                                                \
         __builtin_amdgcn_sched_barrier(0);                                                                              \
-        if (threadIdx.x == 0 && block < 2048) g_scan_stamps[block * 2 + (k)] = wall_clock64();                         \
+        if (threadIdx.x == 0 && block < 2048) g_scan_stamps[block * 8 + (k)] = wall_clock64();                         \
         __builtin_amdgcn_sched_barrier(0);                                                                              \
     } while (0)
 #define FAST_STAMP(k)                                                                                                   \
@@ -102,6 +102,7 @@ constexpr TermSig T(int kind, int ids_cnt = -1, int ids2_cnt = -1, int flags = 0
 struct AnymalRough {
     static constexpr const char* name = "anymal_c_rough";
     static constexpr int kWavesPerSimd = 5;
+    static constexpr int kBatch = 2;
     static constexpr int J = 12, B = 17, CB = 17, H = 3, A = 12, CD = 3, R = 187, cmd_kind = ILX_CMD_VELOCITY;
     static constexpr int NT = 2, NR = 11, NO = 8;
     static constexpr TermSig term[NT] = {T(ILX_TERM_TIME_OUT, -1, -1, 1), T(ILX_TERM_ILLEGAL_CONTACT, 1)};
@@ -119,6 +120,7 @@ struct AnymalRough {
 struct H1Rough {
     static constexpr const char* name = "h1_rough";
     static constexpr int kWavesPerSimd = 3;
+    static constexpr int kBatch = 4;
     static constexpr int J = 19, B = 20, CB = 20, H = 3, A = 19, CD = 3, R = 187, cmd_kind = ILX_CMD_VELOCITY;
     static constexpr int NT = 2, NR = 14, NO = 8;
     static constexpr TermSig term[NT] = {T(ILX_TERM_TIME_OUT, -1, -1, 1), T(ILX_TERM_ILLEGAL_CONTACT, 1)};
@@ -137,6 +139,7 @@ struct H1Rough {
 struct Cartpole {
     static constexpr const char* name = "cartpole";
     static constexpr int kWavesPerSimd = 4;
+    static constexpr int kBatch = 4;
     static constexpr int J = 2, B = 3, CB = 0, H = 0, A = 1, CD = 0, R = 0, cmd_kind = ILX_CMD_NONE;
     static constexpr int NT = 2, NR = 5, NO = 2;
     static constexpr TermSig term[NT] = {T(ILX_TERM_TIME_OUT, -1, -1, 1), T(ILX_TERM_JOINT_POS_OUT_OF_MANUAL_LIMIT, 1)};
@@ -151,6 +154,7 @@ template <int J_, int B_, int A_>
 struct Reach {
     static constexpr const char* name = J_ == 9 ? (A_ == 7 ? "reach_j9_a7" : "reach_j9_a6") : (A_ == 7 ? "reach_j8_a7" : "reach_j8_a6");
     static constexpr int kWavesPerSimd = 4;
+    static constexpr int kBatch = 4;
     static constexpr int J = J_, B = B_, CB = 0, H = 0, A = A_, CD = 7, R = 0, cmd_kind = ILX_CMD_POSE;
     static constexpr int NT = 1, NR = 5, NO = 4;
     static constexpr TermSig term[NT] = {T(ILX_TERM_TIME_OUT, -1, -1, 1)};
@@ -317,16 +321,27 @@ struct FastEnv {
         return reinterpret_cast<const __attribute__((address_space(1))) float*>(b_body + 52 * b + le * (52u * S::B));
     }
     ILX_DEV float ray_hit_z(int k) const { return ldf(b_hits + 12 * k + 8, le * (12u * S::R)); }
-    // max over the history of |F| of one sensor body: as Env::force_peak of mdp.hip, the same operations on the same values
-    ILX_DEV float force_peak(int b) const {
+    // max over the history of |F| of one sensor body: as Env::force_peak of mdp.hip, the same operations on the same
+    // values; the history's entries are requested (force_raw) apart from their use (force_peak_of)
+    static constexpr bool kReadsMemory = true;
+    static constexpr int kBatch = S::kBatch;   // bodies whose values are in flight together (registers: 3 H + 2 floats each)
+    struct ForceRaw {
+        float f[S::H > 0 ? S::H : 1][3];
+    };
+    ILX_DEV ForceRaw force_raw(int b) const {
         const uint32_t v = le * (12u * S::H * S::CB);
-        float mx = -1.0f;
+        ForceRaw r;
 #pragma unroll
         for (int k = 0; k < S::H; ++k) {
             GBytes* f = b_force + 12 * (k * S::CB + b);
-            const float f0 = ldf(f, v), f1 = ldf(f + 4, v), f2 = ldf(f + 8, v);
-            mx = fmaxf(mx, fmaf_(f2, f2, fmaf_(f1, f1, f0 * f0)));
+            r.f[k][0] = ldf(f, v), r.f[k][1] = ldf(f + 4, v), r.f[k][2] = ldf(f + 8, v);
         }
+        return r;
+    }
+    ILX_DEV float force_peak_of(const ForceRaw& r) const {
+        float mx = -1.0f;
+#pragma unroll
+        for (int k = 0; k < S::H; ++k) mx = fmaxf(mx, fmaf_(r.f[k][2], r.f[k][2], fmaf_(r.f[k][1], r.f[k][1], r.f[k][0] * r.f[k][0])));
         return mx < 0.0f ? -__builtin_inff() : sqrt_(mx);
     }
 };
@@ -364,6 +379,7 @@ struct EmitLane {
     static constexpr int kPerTrip = kFastBlock / GP, kTrips = (kFastEnvs + kPerTrip - 1) / kPerTrip;
     int esub, g;
     bool active, noisy;
+    float n_rng[4];       // the noise ranges of the group's columns (0: none)
     float u[kTrips][4];   // the group's noise draws per trip
 };
 
@@ -381,6 +397,8 @@ ILX_DEV void decide(const FastArgs& a, int64_t env0, int ne, uint32_t lane, uint
     {
         using E = EmitLane<S>;
         GBytes* noise = FastEnv<S>::block_base(d.noise_u, env0 * E::O);
+        // (the columns' parameters were requested at the kernel's entry; this is their first use, behind the env's loads)
+        em.noisy = em.active && (em.n_rng[0] != 0.0f || em.n_rng[1] != 0.0f || em.n_rng[2] != 0.0f || em.n_rng[3] != 0.0f);
 #pragma unroll
         for (int trip = 0; trip < E::kTrips; ++trip) {
             const int raw = trip * E::kPerTrip + em.esub, ee = raw < ne ? raw : ne - 1;
@@ -612,6 +630,9 @@ ILX_DEV void scan_emit(const FastArgs& a, uint32_t block, uint64_t seed, uint64_
         const bool inject = d.noise_u != nullptr;
         const int items = ne * GS;
         SCAN_STAMP(0);
+        // Every trip's loads leave before the first trip's stores: loads and stores share one in-order counter, and a wait
+        // for a load behind a store waits for the store to reach memory too (a trip to memory and back per trip).
+        float z[kTrips][4], u[kTrips][4];
 #pragma unroll
         for (int trip = 0; trip < kTrips; ++trip) {
             const int raw = static_cast<int>(threadIdx.x) + kFastBlock * trip;
@@ -619,26 +640,35 @@ ILX_DEV void scan_emit(const FastArgs& a, uint32_t block, uint64_t seed, uint64_
             const int el = idx / GS, gs = idx - el * GS, g = G0 + gs;
             const int k0 = 4 * g - D::scan_col;              // the group's first ray
             const uint32_t in_at = 4u * static_cast<uint32_t>(el * R + k0), out_at = 4u * static_cast<uint32_t>(el * O + 4 * g);
-            float z[4], u[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
             for (int c = 0; c < 4; ++c) {   // a column past the row's end repeats the row's last one (not stored)
                 const uint32_t cc = (O % 4 == 0 || 4 * g + c < O) ? static_cast<uint32_t>(c) : static_cast<uint32_t>(O - 1 - 4 * g);
-                z[c] = FastEnv<S>::ldf(scan, in_at + 4u * cc);
-                if (inject && noisy) u[c] = FastEnv<S>::ldf(noise, out_at + 4u * cc);
+                z[trip][c] = FastEnv<S>::ldf(scan, in_at + 4u * cc);
+                u[trip][c] = 0.0f;
+                if (inject && noisy) u[trip][c] = FastEnv<S>::ldf(noise, out_at + 4u * cc);
             }
+        }
+        __builtin_amdgcn_sched_barrier(0x3cf);   // the loads stay above
+#pragma unroll
+        for (int trip = 0; trip < kTrips; ++trip) {
+            const int raw = static_cast<int>(threadIdx.x) + kFastBlock * trip;
+            const int idx = raw < items ? raw : items - 1;
+            const int el = idx / GS, gs = idx - el * GS, g = G0 + gs;
+            const uint32_t out_at = 4u * static_cast<uint32_t>(el * O + 4 * g);
             if (!inject && noisy) {
                 const u4 r = philox4(seed, gen_step, static_cast<uint64_t>(env0 + el), static_cast<uint32_t>(g));
-                u[0] = u01(r.x), u[1] = u01(r.y), u[2] = u01(r.z), u[3] = u01(r.w);
+                u[trip][0] = u01(r.x), u[trip][1] = u01(r.y), u[trip][2] = u01(r.z), u[trip][3] = u01(r.w);
             }
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                float v = z[c];
-                v = v + u[c] * n_rng + n_off;                    // noise_model.py:63-64
+                float v = z[trip][c];
+                v = v + u[trip][c] * n_rng + n_off;              // noise_model.py:63-64
                 v = __builtin_amdgcn_fmed3f(v, c_lo, c_hi);      // observation_manager.py:315-316
                 v = v * scale;                                   // :317-318
                 if (raw < items && (O % 4 == 0 || 4 * g + c < O))
                     *reinterpret_cast<__attribute__((address_space(1))) float*>(rows + out_at + 4u * c) = v;
             }
+            if (trip < 6) SCAN_STAMP(2 + trip);
         }
         SCAN_STAMP(1);
     }
@@ -686,11 +716,14 @@ __global__ void __launch_bounds__(kFastBlock) __attribute__((amdgpu_waves_per_eu
         const int col = 4 * g + c < O ? 4 * g + c : O - 1;
         const ColParam cp = a.colparam[em.active ? col : 0];
         n_off[c] = cp.n_off, n_rng[c] = cp.n_rng, c_lo[c] = cp.c_lo, c_hi[c] = cp.c_hi, scl[c] = cp.scale;
-        em.noisy = em.noisy || cp.n_rng != 0.0f;
+        em.n_rng[c] = cp.n_rng;
     }
-    em.noisy = em.noisy && em.active;
     FAST_STAMP(0);
-    __syncthreads();
+    // The block's first barrier orders the zeroed logging sums (LDS) ahead of the wavefronts' additions and nothing else:
+    // a wait for the LDS writes and the barrier instruction, without the fence of __syncthreads(), which would also wait
+    // for the column parameters' loads above -- a trip to memory before the env's loads could leave.
+    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0)
+    __builtin_amdgcn_s_barrier();
     static_assert(kWaves == 4, "one path per wavefront below");
     switch (wave) {
         case 0: decide<S, 0>(a, env0, ne, lane, seed, gen_step, P, sh, em); break;

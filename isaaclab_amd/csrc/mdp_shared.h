@@ -6,7 +6,7 @@
 //   e.desc()                       the ilx_mdp descriptor (uniform scalars, pointers for the rare direct reads)
 //   e.pos, quat, lin_w, ang_w, lin_b, ang_b, grav_b, time_left, command_counter     per-env values in registers
 //   e.joint(Fld, j), e.limit(j, side), e.sbody(Fld, b), e.abody(Fld, b), e.action(k), e.prev_action(k), e.cmd(k)
-//   e.force_peak(b), e.body_row(b), e.ray_hit_z(k)
+//   e.force_raw(b) -> E::ForceRaw, e.force_peak_of(raw), e.body_row(b), e.ray_hit_z(k), E::kReadsMemory, E::kBatch
 //   e.id(t, k), e.id2(t, k), e.jcount(t), e.bcount_sensor(t), e.bcount_asset(t), e.num_actions(), e.num_rays()
 // The plan-interpreting kernel reads them from its LDS image (mdp.hip), the compiled kernels from memory with
 // compile-time shapes (mdp_fast.hip).
@@ -52,6 +52,25 @@ ILX_DEV bool joint_any(const E& e, const ilx_term& t, F f) {
     return hit;
 }
 
+// Per-body values of a term, requested E::kBatch bodies at a time and folded in order.  An accessor that reads memory
+// (E::kReadsMemory) gets all of a batch's loads out before the first value is used: left alone, the compiler reuses one
+// set of registers and waits for every load before it issues the next -- a trip to memory per value.
+template <class E, class G, class F>
+ILX_DEV void gather_fold(const E&, int n, G get, F fold) {
+    using V = decltype(get(0));
+    constexpr int B = E::kBatch;
+    for (int k0 = 0; k0 < n; k0 += B) {
+        V v[B];
+#pragma unroll
+        for (int i = 0; i < B; ++i)
+            if (k0 + i < n) v[i] = get(k0 + i);
+        if constexpr (E::kReadsMemory) __builtin_amdgcn_sched_barrier(0x3cf);   // only the loads are held in place
+#pragma unroll
+        for (int i = 0; i < B; ++i)
+            if (k0 + i < n) fold(k0 + i, v[i]);
+    }
+}
+
 // --------------------------------------------------------------------------------------------------
 template <class E>
 ILX_DEV bool eval_termination(const E& e, const ilx_term& t, int64_t ep_len) {
@@ -77,9 +96,9 @@ ILX_DEV bool eval_termination(const E& e, const ilx_term& t, int64_t ep_len) {
                 return (a == b) || (fabsf(a - b) <= (1.0e-8f + 1.0e-5f * fabsf(b)));
             });
         case ILX_TERM_ILLEGAL_CONTACT: {  // :150-158
-            const int n = e.bcount_sensor(t);
             bool hit = false;
-            for (int k = 0; k < n; ++k) hit = hit | (e.force_peak(e.id(t, k)) > t.p[0]);
+            gather_fold(e, e.bcount_sensor(t), [&](int k) { return e.force_raw(e.id(t, k)); },
+                        [&](int, const typename E::ForceRaw& r) { hit = hit | (e.force_peak_of(r) > t.p[0]); });
             return hit;
         }
     }
@@ -152,15 +171,15 @@ ILX_DEV float eval_reward(const E& e, const ilx_term& t, bool terminated, bool t
             return acc;
         }
         case ILX_REW_UNDESIRED_CONTACTS: {  // :260-268 (count of bodies above the threshold)
-            const int n = e.bcount_sensor(t);
             float acc = 0.0f;
-            for (int k = 0; k < n; ++k) acc += (e.force_peak(e.id(t, k)) > t.p[0]) ? 1.0f : 0.0f;
+            gather_fold(e, e.bcount_sensor(t), [&](int k) { return e.force_raw(e.id(t, k)); },
+                        [&](int, const typename E::ForceRaw& r) { acc += (e.force_peak_of(r) > t.p[0]) ? 1.0f : 0.0f; });
             return acc;
         }
         case ILX_REW_CONTACT_FORCES: {  // :271-279
-            const int n = e.bcount_sensor(t);
             float acc = 0.0f;
-            for (int k = 0; k < n; ++k) acc += fmaxf(e.force_peak(e.id(t, k)) - t.p[0], 0.0f);
+            gather_fold(e, e.bcount_sensor(t), [&](int k) { return e.force_raw(e.id(t, k)); },
+                        [&](int, const typename E::ForceRaw& r) { acc += fmaxf(e.force_peak_of(r) - t.p[0], 0.0f); });
             return acc;
         }
         case ILX_REW_TRACK_LIN_VEL_XY_EXP: {  // :287-298
@@ -172,38 +191,52 @@ ILX_DEV float eval_reward(const E& e, const ilx_term& t, bool terminated, bool t
             return expf(div_(-(dz * dz), t.p[0]));
         }
         case ILX_REW_FEET_AIR_TIME: {  // velocity/mdp/rewards.py:25-44
-            const int n = e.bcount_sensor(t);
+            struct Foot {
+                float contact_t, last_air;
+            };
             float acc = 0.0f;
-            for (int k = 0; k < n; ++k) {
-                const int b = e.id(t, k);
-                const float cc = e.sbody(Fld::contact_t, b);
-                const bool first = (cc > 0.0f) && (cc < t.p[1]);  // contact_sensor.py:200-203
-                acc += (e.sbody(Fld::last_air, b) - t.p[0]) * (first ? 1.0f : 0.0f);
-            }
+            gather_fold(e, e.bcount_sensor(t),
+                        [&](int k) {
+                            const int b = e.id(t, k);
+                            return Foot{e.sbody(Fld::contact_t, b), e.sbody(Fld::last_air, b)};
+                        },
+                        [&](int, const Foot& f) {
+                            const bool first = (f.contact_t > 0.0f) && (f.contact_t < t.p[1]);  // contact_sensor.py:200-203
+                            acc += (f.last_air - t.p[0]) * (first ? 1.0f : 0.0f);
+                        });
             return acc * ((norm2(e.cmd(0), e.cmd(1)) > 0.1f) ? 1.0f : 0.0f);
         }
         case ILX_REW_FEET_AIR_TIME_POSITIVE_BIPED: {  // velocity/mdp/rewards.py:47-66
+            struct Foot {
+                float contact_t, air;
+            };
             const int n = e.bcount_sensor(t);
+            const auto foot = [&](int k) {
+                const int b = e.id(t, k);
+                return Foot{e.sbody(Fld::contact_t, b), e.sbody(Fld::air, b)};
+            };
             float cnt = 0.0f;
-            for (int k = 0; k < n; ++k) cnt += (e.sbody(Fld::contact_t, e.id(t, k)) > 0.0f) ? 1.0f : 0.0f;
+            gather_fold(e, n, foot, [&](int, const Foot& f) { cnt += (f.contact_t > 0.0f) ? 1.0f : 0.0f; });
             const bool single = cnt == 1.0f;
             float mn = __builtin_inff();
-            for (int k = 0; k < n; ++k) {
-                const int b = e.id(t, k);
-                const float cc = e.sbody(Fld::contact_t, b);
-                const float mode = (cc > 0.0f) ? cc : e.sbody(Fld::air, b);
+            gather_fold(e, n, foot, [&](int, const Foot& f) {
+                const float mode = (f.contact_t > 0.0f) ? f.contact_t : f.air;
                 mn = fminf(mn, single ? mode : 0.0f);
-            }
+            });
             return fminf(mn, t.p[0]) * ((norm2(e.cmd(0), e.cmd(1)) > 0.1f) ? 1.0f : 0.0f);
         }
         case ILX_REW_FEET_SLIDE: {  // velocity/mdp/rewards.py:69-83
-            const int n = e.bcount_sensor(t);
+            struct Foot {
+                typename E::ForceRaw force;
+                float vx, vy;
+            };
             float acc = 0.0f;
-            for (int k = 0; k < n; ++k) {
-                const bool contact = e.force_peak(e.id(t, k)) > 1.0f;
-                const int ab = e.id2(t, k);
-                acc += norm2(e.abody(Fld::bvx, ab), e.abody(Fld::bvy, ab)) * (contact ? 1.0f : 0.0f);
-            }
+            gather_fold(e, e.bcount_sensor(t),
+                        [&](int k) {
+                            const int ab = e.id2(t, k);
+                            return Foot{e.force_raw(e.id(t, k)), e.abody(Fld::bvx, ab), e.abody(Fld::bvy, ab)};
+                        },
+                        [&](int, const Foot& f) { acc += norm2(f.vx, f.vy) * ((e.force_peak_of(f.force) > 1.0f) ? 1.0f : 0.0f); });
             return acc;
         }
         case ILX_REW_TRACK_LIN_VEL_XY_YAW_FRAME_EXP: {  // velocity/mdp/rewards.py:86-96

@@ -537,7 +537,10 @@ __global__ void __launch_bounds__(kRayBlock) raycaster_update_column_kernel(Scan
 // ------------------------------------------------------------------------------------------------
 constexpr int kLatWin = 32;         // lattice lines per axis that an env's staged window can hold
 constexpr int kLatMaskWords = 2;    // 31 cells starting anywhere inside a 32-bit word touch at most two words
-constexpr int kLatWaves = 4;        // wavefronts (= envs) per workgroup of the cast
+// Wavefronts (= envs) per workgroup of the cast.  One: the wavefronts' lives differ (3.9 to 11 us at 16 384 envs: where the
+// window's lines come from, how many wavefronts share the SIMD), and a slot that waits for the slowest of a workgroup's
+// wavefronts is a slot the second round cannot start in (4 per workgroup: 18.5 us per launch, 1: 18.0).
+constexpr int kLatWaves = 1;
 constexpr int kLatKeep = 3;         // rays per lane whose pattern entry stays in registers (patterns up to 192 rays)
 constexpr int kLatMaxRays = 1024;   // longest scan pattern served per env; longer ones use the per-ray kernels
 constexpr float kLatMargin = 1.0f / 32768.0f;   // of the cell width; the barycentric slack is 1e-6 of a face
@@ -772,10 +775,10 @@ ILX_DEV bool lattice_cell(const float* l, int n, float x, float x0, float inv, i
 // (uniform: scalar registers), copies the window of the height grid into LDS and intersects its rays there; a
 // wavefront's own LDS traffic is ordered.  Rays that are not strictly inside a simple cell use the column grid (or
 // are left to the tree launch that follows).
-// Registers: a CU admits floor(800 / (scalar registers rounded up to 16, + 16)) workgroups of 256 threads, eight at most.
-// Left alone the compiler takes 98 scalar and 70 vector registers: six workgroups per CU, 2.7 rounds of wavefronts for
-// 16 384 envs.  Held to 80 scalar registers (the surplus lives in lanes of a vector register) and eight wavefronts per
-// SIMD (64 vector registers), eight workgroups fit -- and their LDS, 8 x 18 KB: two rounds.
+// Registers: a SIMD admits floor(800 / (scalar registers rounded up to 16, + 16)) wavefronts, eight at most.  Left alone
+// the compiler takes 98 scalar and 70 vector registers: six wavefronts per SIMD, 2.7 rounds of wavefronts for 16 384
+// envs.  Held to 80 scalar registers (the surplus lives in lanes of a vector register) and eight wavefronts per SIMD
+// (64 vector registers), eight fit -- and their LDS, 32 x 4.6 KB per CU: two rounds.
 __global__ void __launch_bounds__(64 * kLatWaves) ILX_CAST_ATTR
 raycaster_update_lattice_kernel(ScanArgs a, const LatEnvRec* __restrict__ recs, const float4* __restrict__ pattern) {
     __shared__ LatStage stage_s[kLatWaves];
@@ -799,33 +802,34 @@ raycaster_update_lattice_kernel(ScanArgs a, const LatEnvRec* __restrict__ recs, 
     const int w0 = j_lo >> 5;
     ILX_RAY_STAMP(1)
     if (sel >= 0) {
-        // a wavefront load takes two window rows (lanes 0-31 and 32-63): row-contiguous runs of the height grid, no
-        // index arithmetic, and the LDS address of load k is 64 k + lane
+        // Every load of the window leaves at once -- one trip to memory -- and without a branch: a 16-byte load per lane
+        // takes eight window rows (lane = row * 8 + quad of columns), four of them the whole 32 x 32 window.  A row past the
+        // window's last repeats that one; the words of a quad past the window's last column belong to the same patch or to
+        // the padding behind the last one (ilx_mesh_create); neither is ever read back.
         const int half = lane >> 5, col = lane & 31;
+        const int qrow = lane >> 3, qcol = (lane & 7) * 4;
         const uint32_t ny = static_cast<uint32_t>(E.ny);
-        const float* zg = a.mesh.lat_z + E.z_off + (static_cast<uint32_t>(i_lo) + half) * ny + j_lo + col;
+        struct __attribute__((packed, aligned(4))) Quad {
+            float v[4];
+        };
+        const float* zg = a.mesh.lat_z + E.z_off + static_cast<uint32_t>(i_lo) * ny + j_lo + qcol;
+        Quad v[kLatWin / 8];
 #pragma unroll
-        for (int k0 = 0; k0 < kLatWin / 2; k0 += 8) {
-            if (2 * k0 >= wi) break;
-            float v[8];
+        for (int k = 0; k < kLatWin / 8; ++k)
+            v[k] = *reinterpret_cast<const Quad*>(zg + static_cast<uint32_t>(min(8 * k + qrow, wi - 1)) * ny);
+        // lattice lines: x lines by lanes 0-31, y lines by lanes 32-63 (past the window: its last line again)
+        const uint32_t line_at = E.line_off + (half ? static_cast<uint32_t>(E.nx + j_lo) : static_cast<uint32_t>(i_lo)) +
+                                 static_cast<uint32_t>(min(col, (half ? wj : wi) - 1));
+        const float line = a.mesh.lat_lines[line_at];
+        // the cells' bits: kLatMaskWords words per window row (past the patch's words: the last one again, bits of cells
+        // the window does not hold)
+        const int mrow = min(lane / kLatMaskWords, max(wi - 2, 0)), mw = min(w0 + (lane & (kLatMaskWords - 1)), E.mask_stride - 1);
+        const uint32_t bits = a.mesh.lat_mask[E.mask_off + static_cast<uint32_t>(i_lo + mrow) * E.mask_stride + mw];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int row = 2 * (k0 + k) + half;
-                v[k] = (row < wi && col < wj) ? zg[static_cast<uint32_t>(2 * (k0 + k)) * ny] : 0.0f;
-            }
-#pragma unroll
-            for (int k = 0; k < 8; ++k) st.z[64 * (k0 + k) + lane] = v[k];
-        }
-        {   // lattice lines: x lines by lanes 0-31, y lines by lanes 32-63
-            const uint32_t at = E.line_off + (half ? static_cast<uint32_t>(E.nx + j_lo) : static_cast<uint32_t>(i_lo)) + col;
-            st.lines[lane] = col < (half ? wj : wi) ? a.mesh.lat_lines[at] : 0.0f;
-        }
-        if (lane < (wi - 1) * kLatMaskWords) {
-            const int row = lane / kLatMaskWords, w = lane - row * kLatMaskWords;
-            st.mask[lane] = (w0 + w < E.mask_stride)
-                                ? a.mesh.lat_mask[E.mask_off + static_cast<uint32_t>(i_lo + row) * E.mask_stride + w0 + w]
-                                : 0u;
-        }
+        for (int k = 0; k < kLatWin / 8; ++k)
+            *reinterpret_cast<float4*>(&st.z[(8 * k + qrow) * kLatWin + qcol]) = make_float4(v[k].v[0], v[k].v[1], v[k].v[2], v[k].v[3]);
+        st.lines[lane] = line;
+        st.mask[lane] = bits;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -1577,6 +1581,7 @@ extern "C" int ilx_mesh_create(const float* verts_host, int64_t num_verts, const
     if (rc == ILX_OK && !lat.patches.empty()) {
         rc = upload(&h.d_patches, lat.patches, "lattice patches");
         if (rc == ILX_OK) rc = upload(&h.d_patch_bins, patch_bins, "lattice patch finder");
+        lat.z.resize(lat.z.size() + kLatWin + 4, 0.0f);   // the cast reads whole quads of a 32-wide window wherever it starts
         if (rc == ILX_OK) rc = upload(&h.d_lat_z, lat.z, "lattice heights");
         if (rc == ILX_OK) rc = upload(&h.d_lat_lines, lat.lines, "lattice lines");
         if (rc == ILX_OK) rc = upload(&h.d_lat_mask, lat.mask, "lattice cell bits");

@@ -28,11 +28,13 @@ for k, lab in enumerate(labels):
           f"    max {(t[:, :, k] - t0).max() / 100:6.2f}")
 print(f"entry spread over blocks: {(t[:, 0, 0].max() - t0) / 100:.2f} us; last exit {(t[:, :, 7].max() - t0) / 100:.2f} us")
 
-sb = (ctypes.c_ulonglong * (2048 * 2))()
-if hasattr(_abi.lib, "ilx_debug_scan_stamps") and _abi.lib.ilx_debug_scan_stamps(sb, 2048 * 2) == 0:
-    st = np.frombuffer(sb, dtype=np.uint64).reshape(2048, 2).astype(np.int64)
+sb = (ctypes.c_ulonglong * (2048 * 8))()
+if hasattr(_abi.lib, "ilx_debug_scan_stamps") and _abi.lib.ilx_debug_scan_stamps(sb, 2048 * 8) == 0:
+    st = np.frombuffer(sb, dtype=np.uint64).reshape(2048, 8).astype(np.int64)
     st = st[st[:, 0] > 0]
     if len(st):
         ent, ext = (st[:, 0] - t0) / 100.0, (st[:, 1] - t0) / 100.0
         print(f"{len(st)} SCAN blocks: entry " + "  ".join(f"p{q}={np.percentile(ent, q):.2f}" for q in (0, 10, 50, 90, 100)) +
               "; exit " + "  ".join(f"p{q}={np.percentile(ext, q):.2f}" for q in (0, 10, 50, 90, 100)) + f"; mean life {(ext - ent).mean():.2f} us")
+        trips = [(st[:, 2 + k] - st[:, 0]).mean() / 100.0 for k in range(6) if (st[:, 2 + k] > 0).all()]
+        print("stores of trip k issued, us after the block's entry (first wavefront): " + "  ".join(f"{x:.2f}" for x in trips))

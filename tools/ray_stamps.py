@@ -23,7 +23,7 @@ def fn():   # the whole refresh (preparation + cast) with every env due
 for _ in range(5):
     fn()
 torch.cuda.synchronize()
-blocks = min(4096, (envs + 3) // 4)
+blocks = min(4096, envs)   # one wavefront (env) per workgroup; the first 4096 are stamped
 buf = (ctypes.c_ulonglong * (8 * 4096))()
 assert _abi.lib.ilx_debug_ray_stamps(buf, 8 * 4096) == 0
 t = np.frombuffer(buf, dtype=np.uint64).reshape(4096, 8)[:blocks].astype(np.int64)
