@@ -438,6 +438,13 @@ ILX_DEV void decide(const FastArgs& a, int64_t env0, int ne, uint32_t lane, uint
 #pragma unroll
         for (int k = 0; k < S::CD; ++k) cs.c[k] = en.cmd(k);
     }
+    // the pose command's tracked body (pose_command.py:92-108): requested with the wavefront's other loads
+    float tracked[7] = {};
+    if constexpr (has_cmd && !velocity && W == kCmdWave) {
+        const auto body = en.body_row(d.pose_body_index);
+#pragma unroll
+        for (int k = 0; k < 7; ++k) tracked[k] = body[k];
+    }
     // ---- terminations (manager_based_rl_env.py:199-202, termination_manager.py:151-174): every wavefront needs the result
     ep_len += 1;
     bool terminated = false, time_out = false;
@@ -511,22 +518,45 @@ ILX_DEV void decide(const FastArgs& a, int64_t env0, int ne, uint32_t lane, uint
     // (command_manager.py:151-166), in registers; the fifth wavefront
     int64_t ep_len_out = ep_len;
     if constexpr (W == kCmdWave) {
-        if (done) {
-            if constexpr (has_cmd) {  // command_manager.py:120-149
+        if (done) ep_len_out = 0;  // manager_based_rl_env.py:391
+        if constexpr (has_cmd) {
+            // The reference resamples a done env's command in the reset (command_manager.py:120-149) and any env's whose
+            // interval runs out in compute (:151-166); each is two generator calls and, for a pose, three sine / cosine
+            // pairs, and a wavefront with lanes of both kinds would run the two one after the other.  Which lanes draw is
+            // known here -- a done lane with the reset's stream, the others by their clocks -- so the wavefront draws once,
+            // every lane with its own stream, and the values are put in place where the reference has them.  (A done lane
+            // whose new interval is over within this very step draws again, as in the reference: the second call below.)
+            const auto reset_samples = as_global(d.reset_command_samples);
+            const auto step_samples = as_global(d.command_samples);
+            if (done) {
                 if (valid) {
                     atomicAdd(&sh.logp[S::NR + S::NT], cs.metric0);
                     atomicAdd(&sh.logp[S::NR + S::NT + 1], cs.metric1);
                 }
                 cs.metric0 = cs.metric1 = 0.0f;
                 cs.counter = 0;
-                command_resample(d, seed, gen_step, env, as_global(d.reset_command_samples), 16u, cs);
             }
-            ep_len_out = 0;  // manager_based_rl_env.py:391
-        }
-        if constexpr (has_cmd) {
-            command_compute(d, en, velocity, d.heading_command != 0, dt, d.max_command_step, d.heading_control_stiffness,
-                            d.cmd_range[3][0], d.cmd_range[3][1], seed, gen_step, env, as_global(d.command_samples),
-                            en.body_row(d.pose_body_index), cs);
+            if constexpr (velocity) {   // a draw of the velocity term is a handful of instructions: the reference's order as it is
+                if (done) command_resample(d, seed, gen_step, env, reset_samples, 16u, cs);
+                command_compute(d, en, true, d.heading_command != 0, dt, d.max_command_step, d.heading_control_stiffness,
+                                d.cmd_range[3][0], d.cmd_range[3][1], seed, gen_step, env, step_samples, en.body_row(d.pose_body_index), cs);
+            } else {
+                const bool runs_out = (cs.time_left - dt) <= 0.0f;
+                CmdState drawn = cs;
+                if (done || runs_out) command_resample(d, seed, gen_step, env, done ? reset_samples : step_samples, done ? 16u : 0u, drawn);
+                if (done) cs = drawn;
+                command_metrics(en, false, d.max_command_step, tracked, cs);
+                cs.time_left = cs.time_left - dt;
+                if (cs.time_left <= 0.0f) {
+                    if (!done) {
+                        const float m0 = cs.metric0, m1 = cs.metric1;
+                        cs = drawn;
+                        cs.metric0 = m0, cs.metric1 = m1;
+                    } else {
+                        command_resample(d, seed, gen_step, env, step_samples, 0u, cs);
+                    }
+                }
+            }
             static_for<S::NO>([&](auto ic) {   // generated_commands (observations.py:529-531) sees the updated command
                 constexpr int i = decltype(ic)::value;
                 if constexpr (S::obs[i].kind == ILX_OBS_GENERATED_COMMANDS) {

@@ -316,13 +316,11 @@ ILX_DEV void command_resample(const ilx_mdp& d, uint64_t seed, uint64_t step, in
     }
 }
 
-// CommandTerm.compute for one env (command_manager.py:151-166): metrics, time left, resampling, the term's
-// _update_command.  `velocity` / `heading_command` and the scalars are the descriptor's, handed in as uniform values;
-// `body` is the tracked body's 13-wide state row (pose command only).
-template <class E, typename P, typename BP>
-ILX_DEV void command_compute(const ilx_mdp& d, const E& en, bool velocity, bool heading_command, float dt, float max_command_step,
-                             float stiffness, float yaw_lo, float yaw_hi, uint64_t seed, uint64_t step, int64_t env, P in_samples,
-                             BP body, CmdState& cs) {
+// CommandTerm.compute for one env (command_manager.py:151-166) in its three parts: metrics, time left + resampling, the
+// term's _update_command.  `velocity` / `heading_command` and the scalars are the descriptor's, handed in as uniform
+// values; `body` is the tracked body's 13-wide state row (pose command only).
+template <class E, typename BP>
+ILX_DEV void command_metrics(const E& en, bool velocity, float max_command_step, BP body, CmdState& cs) {
     if (velocity) {  // velocity_command.py:111-121
         cs.metric0 = cs.metric0 + div_(norm2(cs.c[0] - en.lin_b.x, cs.c[1] - en.lin_b.y), max_command_step);
         cs.metric1 = cs.metric1 + div_(fabsf(cs.c[2] - en.ang_b.z), max_command_step);
@@ -334,8 +332,9 @@ ILX_DEV void command_compute(const ilx_mdp& d, const E& en, bool velocity, bool 
         cs.metric0 = norm3(body[0] - pw.x, body[1] - pw.y, body[2] - pw.z);
         cs.metric1 = norm3(aa);
     }
-    cs.time_left = cs.time_left - dt;
-    if (cs.time_left <= 0.0f) command_resample(d, seed, step, env, in_samples, 0u, cs);
+}
+template <class E>
+ILX_DEV void command_update(const E& en, bool velocity, bool heading_command, float stiffness, float yaw_lo, float yaw_hi, CmdState& cs) {
     if (velocity) {  // velocity_command.py:140-160
         if (heading_command && cs.is_heading) {
             const f3 fwd = quat_apply(en.quat, f3{1.0f, 0.0f, 0.0f});  // articulation_data.py:416-425
@@ -344,6 +343,15 @@ ILX_DEV void command_compute(const ilx_mdp& d, const E& en, bool velocity, bool 
         }
         if (cs.is_standing) cs.c[0] = cs.c[1] = cs.c[2] = 0.0f;
     }
+}
+template <class E, typename P, typename BP>
+ILX_DEV void command_compute(const ilx_mdp& d, const E& en, bool velocity, bool heading_command, float dt, float max_command_step,
+                             float stiffness, float yaw_lo, float yaw_hi, uint64_t seed, uint64_t step, int64_t env, P in_samples,
+                             BP body, CmdState& cs) {
+    command_metrics(en, velocity, max_command_step, body, cs);
+    cs.time_left = cs.time_left - dt;
+    if (cs.time_left <= 0.0f) command_resample(d, seed, step, env, in_samples, 0u, cs);
+    command_update(en, velocity, heading_command, stiffness, yaw_lo, yaw_hi, cs);
 }
 
 // What a term list looks like to the code that is compiled for it: everything about a term except its parameters.
