@@ -1,6 +1,6 @@
 """GPU: the sensor refresh that allocates nothing (ilx_raycaster_refresh_static, a buffer built into the library in
 place of the workspace ilx_raycaster_refresh grows with hipMalloc) against ilx_raycaster_refresh, bit for bit: two
-calls in a row, the second with fewer envs, then the size limit."""
+calls in a row, the second with fewer envs, then the size limit and the hint it refuses."""
 
 import ctypes
 
@@ -68,4 +68,8 @@ def test_static_refresh_matches_refresh(dev):
         is_outdated=rc._is_outdated.data_ptr())
     status = _abi.raycaster_refresh_static(ctypes.byref(big), _abi.stream())
     assert status == -2 and b"32768 envs" in _abi.lib.ilx_last_error()   # ILX_ESHAPE
+    # a preparation kept in the per-stream workspace is not what this entry point reads: refused, nothing launched
+    big.num_envs, big.hints = 8, rc._hints | _abi.RAYS_PREPARED
+    status = _abi.raycaster_refresh_static(ctypes.byref(big), _abi.stream())
+    assert status == -1 and b"ILX_RAYS_PREPARED" in _abi.lib.ilx_last_error()   # ILX_EINVAL
     torch.cuda.synchronize()
