@@ -1159,20 +1159,6 @@ extern "C" int ilx_actuator_pd_scene_update(int model, const float* q_des, const
 // 9.1 / 9.0 us alone, 12.0 / 11.9 / 12.6 / 12.9 us with the scene update in the grid.
 constexpr unsigned kStayPerCu = 3;
 
-// Compute units of the current device (asked once per device).
-static int device_cu_count() {
-    static int cached[64] = {};
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (dev < 0 || dev >= 64) dev = 0;
-    if (cached[dev] == 0) {
-        int n = 0;
-        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-        cached[dev] = n;
-    }
-    return cached[dev];
-}
-
 // `scene` (or null): the scene update that goes with this launch -- as workgroups of the same grid where the launch is
 // the three-sample split kernel's, else as a launch of its own ahead of it.
 template <int ACT>

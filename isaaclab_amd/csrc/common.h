@@ -27,6 +27,20 @@ inline unsigned blocks_for(int64_t items, int threads = 256) {
 
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
+// Compute units of the current device (asked once per device).
+inline int device_cu_count() {
+    static int cached[64] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64) dev = 0;
+    if (cached[dev] == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cached[dev] = n;
+    }
+    return cached[dev];
+}
+
 }  // namespace ilx
 
 #define ILX_REQUIRE(cond, code, ...)                 \

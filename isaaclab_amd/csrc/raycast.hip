@@ -860,10 +860,12 @@ raycaster_update_lattice_kernel(ScanArgs a, const LatEnvRec* __restrict__ recs, 
         const bool in_x = lattice_cell(st.lines, wi, o.x, E.x0, E.inv_dx, i_lo, ci, xlo, xhi);
         const bool in_y = lattice_cell(st.lines + kLatWin, wj, o.y, E.y0, E.inv_dy, j_lo, cj, ylo, yhi);
         const int jabs = j_lo + cj;
+        // the cell's bit and its four heights are asked for with the lines (their addresses need the cell's indices, not
+        // the lines' values): one LDS latency for the ray instead of three
         const uint32_t word = st.mask[ci * kLatMaskWords + ((jabs >> 5) - w0)];
-        if (!(in_x && in_y && ((word >> (jabs & 31)) & 1u) && dz != 0.0f)) return false;
         const float* zc = st.z + ci * kLatWin + cj;
         const float z00 = zc[0], z01 = zc[1], z10 = zc[kLatWin], z11 = zc[kLatWin + 1];
+        if (!(in_x && in_y && ((word >> (jabs & 31)) & 1u) && dz != 0.0f)) return false;
         const float wx = xhi - xlo, wy = yhi - ylo;
         const float sx = o.x - xlo, sy = o.y - ylo, sz = o.z - z00;  // ray start relative to v0 = v00
         const float side = sy * wx - sx * wy;  // > 0: the half that holds v01, face (ind0, ind3, ind1); else (ind0, ind2, ind3)
