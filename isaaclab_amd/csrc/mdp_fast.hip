@@ -438,12 +438,17 @@ ILX_DEV void decide(const FastArgs& a, int64_t env0, int ne, uint32_t lane, uint
 #pragma unroll
         for (int k = 0; k < S::CD; ++k) cs.c[k] = en.cmd(k);
     }
-    // the pose command's tracked body (pose_command.py:92-108): requested with the wavefront's other loads
+    // the pose command's tracked body (pose_command.py:92-108): requested with the wavefront's other loads; and the
+    // generator's output for both of the step's resampling streams, made while those loads travel (which lanes will use
+    // which stream is known only behind the terminations)
     float tracked[7] = {};
+    CommandBits bits_reset{}, bits_step{};
     if constexpr (has_cmd && !velocity && W == kCmdWave) {
         const auto body = en.body_row(d.pose_body_index);
 #pragma unroll
         for (int k = 0; k < 7; ++k) tracked[k] = body[k];
+        bits_reset = command_bits(seed, gen_step, env, 16u);
+        bits_step = command_bits(seed, gen_step, env, 0u);
     }
     // ---- terminations (manager_based_rl_env.py:199-202, termination_manager.py:151-174): every wavefront needs the result
     ep_len += 1;
@@ -543,7 +548,8 @@ ILX_DEV void decide(const FastArgs& a, int64_t env0, int ne, uint32_t lane, uint
             } else {
                 const bool runs_out = (cs.time_left - dt) <= 0.0f;
                 CmdState drawn = cs;
-                if (done || runs_out) command_resample(d, seed, gen_step, env, done ? reset_samples : step_samples, done ? 16u : 0u, drawn);
+                const CommandBits bits = done ? bits_reset : bits_step;
+                if (done || runs_out) command_resample(d, seed, gen_step, env, done ? reset_samples : step_samples, done ? 16u : 0u, drawn, &bits);
                 if (done) cs = drawn;
                 command_metrics(en, false, d.max_command_step, tracked, cs);
                 cs.time_left = cs.time_left - dt;

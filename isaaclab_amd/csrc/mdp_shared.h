@@ -277,15 +277,24 @@ struct CmdState {
 
 // The seven samples a resampling env consumes: injected values, or two generator calls mapped to the term's ranges
 // (the two coin flips of the velocity term stay in [0, 1)).
+// The two generator calls behind a resampling env's seven samples (stream `salt`: 0 in compute, 16 in the reset).
+struct CommandBits {
+    u4 a, b;
+};
+ILX_DEV CommandBits command_bits(uint64_t seed, uint64_t step, int64_t env, uint32_t salt) {
+    return {philox4(seed, step, static_cast<uint64_t>(env), 0x40000000u + salt), philox4(seed, step, static_cast<uint64_t>(env), 0x40000001u + salt)};
+}
+// `drawn` (or null): the generator's output for this env and stream, made ahead of time.
 template <typename P>
-ILX_DEV void command_draws(const ilx_mdp& d, uint64_t seed, uint64_t step, P injected, int64_t env, uint32_t salt, float (&smp)[7]) {
+ILX_DEV void command_draws(const ilx_mdp& d, uint64_t seed, uint64_t step, P injected, int64_t env, uint32_t salt, float (&smp)[7],
+                           const CommandBits* drawn = nullptr) {
     if (injected) {
 #pragma unroll
         for (int k = 0; k < 7; ++k) smp[k] = injected[env * 7 + k];
         return;
     }
-    const u4 a = philox4(seed, step, static_cast<uint64_t>(env), 0x40000000u + salt),
-             b = philox4(seed, step, static_cast<uint64_t>(env), 0x40000001u + salt);
+    const CommandBits bits = drawn ? *drawn : command_bits(seed, step, env, salt);
+    const u4 a = bits.a, b = bits.b;
     const float u[7] = {u01(a.x), u01(a.y), u01(a.z), u01(a.w), u01(b.x), u01(b.y), u01(b.z)};
 #pragma unroll
     for (int k = 0; k < 7; ++k) {
@@ -296,9 +305,10 @@ ILX_DEV void command_draws(const ilx_mdp& d, uint64_t seed, uint64_t step, P inj
 
 // CommandTerm._resample for one env: command_manager.py:172-187 + the term's _resample_command
 template <typename P>
-ILX_DEV void command_resample(const ilx_mdp& d, uint64_t seed, uint64_t step, int64_t env, P injected, uint32_t salt, CmdState& s) {
+ILX_DEV void command_resample(const ilx_mdp& d, uint64_t seed, uint64_t step, int64_t env, P injected, uint32_t salt, CmdState& s,
+                              const CommandBits* drawn = nullptr) {
     float v[7];
-    command_draws(d, seed, step, injected, env, salt, v);
+    command_draws(d, seed, step, injected, env, salt, v, drawn);
     s.time_left = v[0];
     s.counter += 1;
     if (d.command_kind == ILX_CMD_VELOCITY) {  // velocity_command.py:123-138
