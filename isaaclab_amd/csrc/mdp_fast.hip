@@ -29,6 +29,7 @@ namespace ilx {
 constexpr int kFastEnvs = 64;    // envs per DECIDE block
 constexpr int kScanEnvs = 34;    // envs per SCAN block
 constexpr int kCmdWave = kWaves; // the DECIDE block's fifth wavefront: reset bookkeeping and the command term
+constexpr int kDrawWave = 3;     // the reward wavefront that draws the new pose commands beside it
 constexpr int kFastBlock = 64 * (kWaves + 1);
 constexpr int kFastMaxIds = 64;
 constexpr int kFastMaxTerms = 24;   // terminations + rewards of a compiled term list
@@ -368,6 +369,7 @@ struct FastShared {   // the LDS of a DECIDE block apart from the observation va
     float ptotal[kWaves][kFastEnvs];
     float logp[2 * kMaxTerms + 3];
     uint32_t done[kFastEnvs];
+    float drawn[2][8][kFastEnvs];   // pose command: a lane's new command (time left, then the pose), first and second draw
 };
 
 // One wavefront of a DECIDE block: lane = env.  Everything up to the barrier only reads memory (and writes outputs that
@@ -441,12 +443,20 @@ ILX_DEV void decide(const FastArgs& a, int64_t env0, int ne, uint32_t lane, uint
     // the pose command's tracked body (pose_command.py:92-108): requested with the wavefront's other loads; and the
     // generator's output for both of the step's resampling streams, made while those loads travel (which lanes will use
     // which stream is known only behind the terminations)
+    // The pose command is dealt to two wavefronts: the command wavefront keeps the bookkeeping and the metrics, one of
+    // the reward wavefronts draws the new commands of the lanes that resample (two generator calls, three sine / cosine
+    // pairs) and hands them over through LDS at the block's barrier.
+    constexpr bool pose = has_cmd && !velocity;
     float tracked[7] = {};
     CommandBits bits_reset{}, bits_step{};
-    if constexpr (has_cmd && !velocity && W == kCmdWave) {
+    float draw_time_left = 0.0f;
+    if constexpr (pose && W == kCmdWave) {
         const auto body = en.body_row(d.pose_body_index);
 #pragma unroll
         for (int k = 0; k < 7; ++k) tracked[k] = body[k];
+    }
+    if constexpr (pose && W == kDrawWave) {
+        draw_time_left = ldg(d.time_left, env0, 4u * le);
         bits_reset = command_bits(seed, gen_step, env, 16u);
         bits_step = command_bits(seed, gen_step, env, 0u);
     }
@@ -525,12 +535,6 @@ ILX_DEV void decide(const FastArgs& a, int64_t env0, int ne, uint32_t lane, uint
     if constexpr (W == kCmdWave) {
         if (done) ep_len_out = 0;  // manager_based_rl_env.py:391
         if constexpr (has_cmd) {
-            // The reference resamples a done env's command in the reset (command_manager.py:120-149) and any env's whose
-            // interval runs out in compute (:151-166); each is two generator calls and, for a pose, three sine / cosine
-            // pairs, and a wavefront with lanes of both kinds would run the two one after the other.  Which lanes draw is
-            // known here -- a done lane with the reset's stream, the others by their clocks -- so the wavefront draws once,
-            // every lane with its own stream, and the values are put in place where the reference has them.  (A done lane
-            // whose new interval is over within this very step draws again, as in the reference: the second call below.)
             const auto reset_samples = as_global(d.reset_command_samples);
             const auto step_samples = as_global(d.command_samples);
             if (done) {
@@ -546,32 +550,54 @@ ILX_DEV void decide(const FastArgs& a, int64_t env0, int ne, uint32_t lane, uint
                 command_compute(d, en, true, d.heading_command != 0, dt, d.max_command_step, d.heading_control_stiffness,
                                 d.cmd_range[3][0], d.cmd_range[3][1], seed, gen_step, env, step_samples, en.body_row(d.pose_body_index), cs);
             } else {
-                const bool runs_out = (cs.time_left - dt) <= 0.0f;
-                CmdState drawn = cs;
-                const CommandBits bits = done ? bits_reset : bits_step;
-                if (done || runs_out) command_resample(d, seed, gen_step, env, done ? reset_samples : step_samples, done ? 16u : 0u, drawn, &bits);
-                if (done) cs = drawn;
-                command_metrics(en, false, d.max_command_step, tracked, cs);
-                cs.time_left = cs.time_left - dt;
-                if (cs.time_left <= 0.0f) {
-                    if (!done) {
-                        const float m0 = cs.metric0, m1 = cs.metric1;
-                        cs = drawn;
-                        cs.metric0 = m0, cs.metric1 = m1;
-                    } else {
-                        command_resample(d, seed, gen_step, env, step_samples, 0u, cs);
-                    }
-                }
+                // metrics on the command as it stands, for the lanes that are not reset (a reset lane's are formed behind the
+                // barrier, on its new command)
+                CmdState standing = cs;
+                command_metrics(en, false, d.max_command_step, tracked, standing);
+                if (!done) cs.metric0 = standing.metric0, cs.metric1 = standing.metric1;
             }
+            const bool drawn_elsewhere = pose && (done || (cs.time_left - dt) <= 0.0f);   // kDrawWave writes these lanes' columns
             static_for<S::NO>([&](auto ic) {   // generated_commands (observations.py:529-531) sees the updated command
                 constexpr int i = decltype(ic)::value;
                 if constexpr (S::obs[i].kind == ILX_OBS_GENERATED_COMMANDS) {
+                    if (!drawn_elsewhere) {
 #pragma unroll
-                    for (int k = 0; k < S::CD; ++k) row[D::obs_col(i) + k] = cs.c[k];
+                        for (int k = 0; k < S::CD; ++k) row[D::obs_col(i) + k] = cs.c[k];
+                    }
                 }
             });
         }
         sh.done[lane] = done_v ? 1u : 0u;
+    }
+    if constexpr (pose && W == kDrawWave) {
+        // Which lanes draw is known here: a done lane with the reset's stream (command_manager.py:120-149), the others by
+        // their clocks with compute's (:151-166); the wavefront draws once, every lane with its own stream.  A done lane
+        // whose new interval is over within this very step draws again, as in the reference.
+        const auto reset_samples = as_global(d.reset_command_samples);
+        const auto step_samples = as_global(d.command_samples);
+        if (done || (draw_time_left - dt) <= 0.0f) {
+            CmdState fresh;
+            const CommandBits bits = done ? bits_reset : bits_step;
+            command_resample(d, seed, gen_step, env, done ? reset_samples : step_samples, done ? 16u : 0u, fresh, &bits);
+            sh.drawn[0][0][lane] = fresh.time_left;
+#pragma unroll
+            for (int k = 0; k < 7; ++k) sh.drawn[0][1 + k][lane] = fresh.c[k];
+            float second = __builtin_nanf("");
+            if (done && (fresh.time_left - dt) <= 0.0f) {
+                command_resample(d, seed, gen_step, env, step_samples, 0u, fresh);
+                second = fresh.time_left;
+#pragma unroll
+                for (int k = 0; k < 7; ++k) sh.drawn[1][1 + k][lane] = fresh.c[k];
+            }
+            sh.drawn[1][0][lane] = second;
+            static_for<S::NO>([&](auto ic) {   // generated_commands (observations.py:529-531) of these lanes
+                constexpr int i = decltype(ic)::value;
+                if constexpr (S::obs[i].kind == ILX_OBS_GENERATED_COMMANDS) {
+#pragma unroll
+                    for (int k = 0; k < S::CD; ++k) row[D::obs_col(i) + k] = fresh.c[k];
+                }
+            });
+        }
     }
     FAST_STAMP(3);
     // ---- logging sums of the done envs (reward_manager.py:115-121, termination_manager.py:142-144)
@@ -617,6 +643,26 @@ ILX_DEV void decide(const FastArgs& a, int64_t env0, int ne, uint32_t lane, uint
     __syncthreads();
     FAST_STAMP(5);
     // ---- in-place updates of what other wavefronts of the block have read by now
+    if constexpr (pose && W == kCmdWave) {   // the drawn commands take their places (pose_command.py:92-120)
+        if (done || (cs.time_left - dt) <= 0.0f) {
+            cs.time_left = sh.drawn[0][0][lane];
+#pragma unroll
+            for (int k = 0; k < 7; ++k) cs.c[k] = sh.drawn[0][1 + k][lane];
+            cs.counter += 1;
+            if (done) {
+                command_metrics(en, false, d.max_command_step, tracked, cs);
+                cs.time_left = cs.time_left - dt;
+                if (cs.time_left <= 0.0f) {
+                    cs.time_left = sh.drawn[1][0][lane];
+#pragma unroll
+                    for (int k = 0; k < 7; ++k) cs.c[k] = sh.drawn[1][1 + k][lane];
+                    cs.counter += 1;
+                }
+            }
+        } else {
+            cs.time_left = cs.time_left - dt;
+        }
+    }
     if constexpr (W == kCmdWave) {
         if (valid) {
             stg(d.episode_length_buf, env0, 8u * le, ep_len_out);
