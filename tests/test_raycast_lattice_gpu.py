@@ -298,3 +298,41 @@ def test_lean_refresh_leaves_the_hit_records_to_their_reader(dev):
         assert step > 0 or not torch.equal(untouched, got)   # ... and they were not there before the read
         assert_exact(lean._data.pos_w, eager._data.pos_w.cpu(), "pos_w")
     assert torch.isinf(eager.data.ray_hits_w[3]).all()
+
+
+def test_first_refresh_of_a_stream_can_be_recorded(dev):
+    """``RayCaster`` sizes the refresh's per-stream workspaces when it is set up (ilx_raycaster_reserve), so the very first
+    refresh on a stream needs no allocation: it is recorded into a graph on a stream the sensor has never run on -- an
+    allocation inside a capture would fail it -- and the replay equals a sensor refreshed launch by launch."""
+    from isaaclab_amd.sensors.patterns import GridPatternCfg
+    from isaaclab_amd.sensors.ray_caster import OffsetCfg, RayCaster, RayCasterCfg
+    from isaaclab_amd.utils.mesh import convert_to_mesh
+
+    v, t, rows, cols = hf_case(rows=81, cols=97, seed=41, origin=(10.0, 20.0))
+    mesh = convert_to_mesh(v, t, str(dev))
+    gen = torch.Generator().manual_seed(3)
+    n = 300
+    cfg = RayCasterCfg(offset=OffsetCfg(pos=(0.0, 0.0, 20.0)), attach_yaw_only=True, pattern_cfg=GridPatternCfg(resolution=0.1, size=(1.6, 1.0)),
+                       update_period=0.02)
+    recorded, eager = RayCaster(cfg, n, mesh, dev), RayCaster(cfg, n, mesh, dev)
+    pos = torch.cat([torch.rand(n, 1, generator=gen) * 7.0 + 10.5, torch.rand(n, 1, generator=gen) * 8.6 + 20.5,
+                     torch.rand(n, 1, generator=gen) + 0.5], -1).to(dev)
+    yaw = torch.rand(n, generator=gen) * 6.28 - 3.14
+    quat = torch.stack([torch.cos(yaw / 2), torch.zeros(n), torch.zeros(n), torch.sin(yaw / 2)], -1).to(dev)
+    for rc in (recorded, eager):
+        rc.reset()
+        rc.set_pose(pos, quat)
+        rc._timestamp += 0.02
+        rc._is_outdated.fill_(True)
+    eager._update_outdated_buffers()
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        recorded._update_outdated_buffers()
+    assert bool(recorded._is_outdated.all()), "recording must not run the refresh"
+    graph.replay()
+    torch.cuda.synchronize()
+    assert_exact(recorded._data.hits_storage, eager._data.hits_storage.cpu(), "hit records of the replayed first refresh")
+    assert_exact(recorded._data.pos_w, eager._data.pos_w.cpu(), "pos_w")
+    assert not bool(recorded._is_outdated.any())
