@@ -690,6 +690,10 @@ ILX_DEV void decide(const FastArgs& a, int64_t env0, int ne, uint32_t lane, uint
     }
 }
 
+// Four consecutive floats at any 4-byte boundary, moved by one 16-byte instruction (observation rows and scan rows are
+// 4 O and 4 R bytes long: a group of four columns starts at a multiple of four bytes, not of sixteen).
+typedef float Group4 __attribute__((ext_vector_type(4), aligned(4)));
+
 // The height-scan columns that fill whole groups of four: dense scan -> noise -> clip -> scale -> observation row.
 template <class S>
 ILX_DEV void scan_emit(const FastArgs& a, uint32_t block, uint64_t seed, uint64_t gen_step) {
@@ -722,10 +726,20 @@ ILX_DEV void scan_emit(const FastArgs& a, uint32_t block, uint64_t seed, uint64_
             const int el = idx / GS, gs = idx - el * GS, g = G0 + gs;
             const int k0 = 4 * g - D::scan_col;              // the group's first ray
             const uint32_t in_at = 4u * static_cast<uint32_t>(el * R + k0), out_at = 4u * static_cast<uint32_t>(el * O + 4 * g);
+            if (O % 4 == 0 || 4 * g + 3 < O) {   // a whole group: one 16-byte load
+                const Group4 q = *reinterpret_cast<const __attribute__((address_space(1))) Group4*>(scan + in_at);
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {   // a column past the row's end repeats the row's last one (not stored)
+                for (int c = 0; c < 4; ++c) z[trip][c] = q[c];
+            } else {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {   // the row's last group: a column past its end repeats the last one (not stored)
+                    const uint32_t cc = 4 * g + c < O ? static_cast<uint32_t>(c) : static_cast<uint32_t>(O - 1 - 4 * g);
+                    z[trip][c] = FastEnv<S>::ldf(scan, in_at + 4u * cc);
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
                 const uint32_t cc = (O % 4 == 0 || 4 * g + c < O) ? static_cast<uint32_t>(c) : static_cast<uint32_t>(O - 1 - 4 * g);
-                z[trip][c] = FastEnv<S>::ldf(scan, in_at + 4u * cc);
                 u[trip][c] = 0.0f;
                 if (inject && noisy) u[trip][c] = FastEnv<S>::ldf(noise, out_at + 4u * cc);
             }
@@ -741,14 +755,22 @@ ILX_DEV void scan_emit(const FastArgs& a, uint32_t block, uint64_t seed, uint64_
                 const u4 r = philox4(seed, gen_step, static_cast<uint64_t>(env0 + el), static_cast<uint32_t>(g));
                 u[trip][0] = u01(r.x), u[trip][1] = u01(r.y), u[trip][2] = u01(r.z), u[trip][3] = u01(r.w);
             }
+            Group4 out;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 float v = z[trip][c];
                 v = v + u[trip][c] * n_rng + n_off;              // noise_model.py:63-64
                 v = __builtin_amdgcn_fmed3f(v, c_lo, c_hi);      // observation_manager.py:315-316
-                v = v * scale;                                   // :317-318
-                if (raw < items && (O % 4 == 0 || 4 * g + c < O))
-                    *reinterpret_cast<__attribute__((address_space(1))) float*>(rows + out_at + 4u * c) = v;
+                out[c] = v * scale;                            // :317-318
+            }
+            if (raw < items) {
+                if (O % 4 == 0 || 4 * g + 3 < O) {
+                    *reinterpret_cast<__attribute__((address_space(1))) Group4*>(rows + out_at) = out;
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        if (4 * g + c < O) *reinterpret_cast<__attribute__((address_space(1))) float*>(rows + out_at + 4u * c) = out[c];
+                }
             }
             if (trip < 6) SCAN_STAMP(2 + trip);
         }
@@ -839,13 +861,22 @@ __global__ void __launch_bounds__(kFastBlock) __attribute__((amdgpu_waves_per_eu
         for (int trip = 0; trip < kTrips; ++trip) {
             const int raw = trip * kPerTrip + esub, ee = raw < ne ? raw : ne - 1;
             const uint32_t out_at = 4u * static_cast<uint32_t>(raw * O + 4 * g);
+            Group4 out;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 float x = P[ee * D::p_stride + 4 * g + c];
                 x = x + em.u[trip][c] * n_rng[c] + n_off[c];         // noise_model.py:63-64
                 x = __builtin_amdgcn_fmed3f(x, c_lo[c], c_hi[c]);    // observation_manager.py:315-316
-                x = x * scl[c];                                      // :317-318
-                if (raw < ne && 4 * g + c < O) *reinterpret_cast<__attribute__((address_space(1))) float*>(rows + out_at + 4u * c) = x;
+                out[c] = x * scl[c];                               // :317-318
+            }
+            if (raw < ne) {
+                if (4 * g + 3 < O) {   // a whole group: one 16-byte store
+                    *reinterpret_cast<__attribute__((address_space(1))) Group4*>(rows + out_at) = out;
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        if (4 * g + c < O) *reinterpret_cast<__attribute__((address_space(1))) float*>(rows + out_at + 4u * c) = out[c];
+                }
             }
         }
     }
