@@ -276,7 +276,11 @@ struct FastEnv {
         quat = {ldf(root + 12, v), ldf(root + 16, v), ldf(root + 20, v), ldf(root + 24, v)};
         lin_w = {ldf(root + 28, v), ldf(root + 32, v), ldf(root + 36, v)};
         ang_w = {ldf(root + 40, v), ldf(root + 44, v), ldf(root + 48, v)};
-        // articulation_data.py:411-425, 502-518
+    }
+    // The root-frame quantities (articulation_data.py:411-425, 502-518): the first use of what the constructor asked for,
+    // so whatever else the wavefront can ask for without them is asked for between the two.
+    ILX_DEV void derive() {
+        const ilx_mdp& d = a.d;
         lin_b = quat_rotate_inverse(quat, lin_w);
         ang_b = quat_rotate_inverse(quat, ang_w);
         grav_b = quat_rotate_inverse(quat, f3{d.gravity_dir[0], d.gravity_dir[1], d.gravity_dir[2]});
@@ -394,30 +398,8 @@ ILX_DEV void decide(const FastArgs& a, int64_t env0, int ne, uint32_t lane, uint
     const bool valid = static_cast<int>(lane) < ne;
     const uint32_t le = valid ? lane : static_cast<uint32_t>(ne - 1);   // lanes past the launch's end shadow its last env and store nothing
     FastEnv<S> en(a, env0, le);
-    // The noise of the thread's observation columns needs nothing but (seed, step, env, group): drawn here, while the
-    // wavefront's loads are in flight.  A trip past the block's last env shadows that env (and stores nothing later).
-    {
-        using E = EmitLane<S>;
-        GBytes* noise = FastEnv<S>::block_base(d.noise_u, env0 * E::O);
-        // (the columns' parameters were requested at the kernel's entry; this is their first use, behind the env's loads)
-        em.noisy = em.active && (em.n_rng[0] != 0.0f || em.n_rng[1] != 0.0f || em.n_rng[2] != 0.0f || em.n_rng[3] != 0.0f);
-#pragma unroll
-        for (int trip = 0; trip < E::kTrips; ++trip) {
-            const int raw = trip * E::kPerTrip + em.esub, ee = raw < ne ? raw : ne - 1;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) em.u[trip][c] = 0.0f;
-            if (em.noisy) {
-                if (d.noise_u) {
-#pragma unroll
-                    for (int c = 0; c < 4; ++c)
-                        em.u[trip][c] = FastEnv<S>::ldf(noise, 4u * static_cast<uint32_t>(ee * E::O + (4 * em.g + c < E::O ? 4 * em.g + c : E::O - 1)));
-                } else {
-                    const u4 r = philox4(seed, gen_step, static_cast<uint64_t>(env0 + ee), static_cast<uint32_t>(em.g));
-                    em.u[trip][0] = u01(r.x), em.u[trip][1] = u01(r.y), em.u[trip][2] = u01(r.z), em.u[trip][3] = u01(r.w);
-                }
-            }
-        }
-    }
+    // Everything the wavefront can ask for before it knows anything: requested here, in one trip to memory with the root
+    // state (the code below is many basic blocks, and a load is not moved from one to another).
     const int64_t env = en.env;
     const float dt = d.step_dt;
     int64_t ep_len = ldg(d.episode_length_buf, env0, 8u * le);
@@ -460,6 +442,36 @@ ILX_DEV void decide(const FastArgs& a, int64_t env0, int ne, uint32_t lane, uint
         bits_reset = command_bits(seed, gen_step, env, 16u);
         bits_step = command_bits(seed, gen_step, env, 0u);
     }
+    float sums[S::NR] = {};
+    static_for<S::NR>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        if constexpr (D::sum_owner(i) == W) sums[i] = ldg(d.episode_sums, static_cast<int64_t>(i) * N + env0, 4u * le);
+    });
+    en.derive();
+    // The noise of the thread's observation columns needs nothing but (seed, step, env, group): drawn here, while the
+    // wavefront's loads are in flight.  A trip past the block's last env shadows that env (and stores nothing later).
+    {
+        using E = EmitLane<S>;
+        GBytes* noise = FastEnv<S>::block_base(d.noise_u, env0 * E::O);
+        // (the columns' parameters were requested at the kernel's entry; this is their first use, behind the env's loads)
+        em.noisy = em.active && (em.n_rng[0] != 0.0f || em.n_rng[1] != 0.0f || em.n_rng[2] != 0.0f || em.n_rng[3] != 0.0f);
+#pragma unroll
+        for (int trip = 0; trip < E::kTrips; ++trip) {
+            const int raw = trip * E::kPerTrip + em.esub, ee = raw < ne ? raw : ne - 1;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) em.u[trip][c] = 0.0f;
+            if (em.noisy) {
+                if (d.noise_u) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        em.u[trip][c] = FastEnv<S>::ldf(noise, 4u * static_cast<uint32_t>(ee * E::O + (4 * em.g + c < E::O ? 4 * em.g + c : E::O - 1)));
+                } else {
+                    const u4 r = philox4(seed, gen_step, static_cast<uint64_t>(env0 + ee), static_cast<uint32_t>(em.g));
+                    em.u[trip][0] = u01(r.x), em.u[trip][1] = u01(r.y), em.u[trip][2] = u01(r.z), em.u[trip][3] = u01(r.w);
+                }
+            }
+        }
+    }
     // ---- terminations (manager_based_rl_env.py:199-202, termination_manager.py:151-174): every wavefront needs the result
     ep_len += 1;
     bool terminated = false, time_out = false;
@@ -476,11 +488,9 @@ ILX_DEV void decide(const FastArgs& a, int64_t env0, int ne, uint32_t lane, uint
     if (done) { FAST_STAMP(1); } else { FAST_STAMP(1); }
     // ---- rewards (reward_manager.py:128-157): this wavefront's share of the terms, in table order
     float value[S::NR] = {};
-    float sums[S::NR] = {};
     float partial = 0.0f;
     static_for<S::NR>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
-        if constexpr (D::sum_owner(i) == W) sums[i] = ldg(d.episode_sums, static_cast<int64_t>(i) * N + env0, 4u * le);
         if constexpr (S::rew[i].active && D::reward_owner(i) == W) {
             const ilx_term t = reward_of<S, i>(a);
             value[i] = eval_reward(en, t, terminated, time_out, term_bits) * t.weight * dt;
