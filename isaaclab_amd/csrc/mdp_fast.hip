@@ -104,6 +104,7 @@ struct AnymalRough {
     static constexpr const char* name = "anymal_c_rough";
     static constexpr int kWavesPerSimd = 5;
     static constexpr int kBatch = 2;
+    static constexpr bool kContactsAhead = false;
     static constexpr int J = 12, B = 17, CB = 17, H = 3, A = 12, CD = 3, R = 187, cmd_kind = ILX_CMD_VELOCITY;
     static constexpr int NT = 2, NR = 11, NO = 8;
     static constexpr TermSig term[NT] = {T(ILX_TERM_TIME_OUT, -1, -1, 1), T(ILX_TERM_ILLEGAL_CONTACT, 1)};
@@ -122,6 +123,7 @@ struct H1Rough {
     static constexpr const char* name = "h1_rough";
     static constexpr int kWavesPerSimd = 3;
     static constexpr int kBatch = 4;
+    static constexpr bool kContactsAhead = true;
     static constexpr int J = 19, B = 20, CB = 20, H = 3, A = 19, CD = 3, R = 187, cmd_kind = ILX_CMD_VELOCITY;
     static constexpr int NT = 2, NR = 14, NO = 8;
     static constexpr TermSig term[NT] = {T(ILX_TERM_TIME_OUT, -1, -1, 1), T(ILX_TERM_ILLEGAL_CONTACT, 1)};
@@ -141,6 +143,7 @@ struct Cartpole {
     static constexpr const char* name = "cartpole";
     static constexpr int kWavesPerSimd = 4;
     static constexpr int kBatch = 4;
+    static constexpr bool kContactsAhead = true;
     static constexpr int J = 2, B = 3, CB = 0, H = 0, A = 1, CD = 0, R = 0, cmd_kind = ILX_CMD_NONE;
     static constexpr int NT = 2, NR = 5, NO = 2;
     static constexpr TermSig term[NT] = {T(ILX_TERM_TIME_OUT, -1, -1, 1), T(ILX_TERM_JOINT_POS_OUT_OF_MANUAL_LIMIT, 1)};
@@ -156,6 +159,7 @@ struct Reach {
     static constexpr const char* name = J_ == 9 ? (A_ == 7 ? "reach_j9_a7" : "reach_j9_a6") : (A_ == 7 ? "reach_j8_a7" : "reach_j8_a6");
     static constexpr int kWavesPerSimd = 4;
     static constexpr int kBatch = 4;
+    static constexpr bool kContactsAhead = true;
     static constexpr int J = J_, B = B_, CB = 0, H = 0, A = A_, CD = 7, R = 0, cmd_kind = ILX_CMD_POSE;
     static constexpr int NT = 1, NR = 5, NO = 4;
     static constexpr TermSig term[NT] = {T(ILX_TERM_TIME_OUT, -1, -1, 1)};
@@ -447,6 +451,28 @@ ILX_DEV void decide(const FastArgs& a, int64_t env0, int ne, uint32_t lane, uint
         constexpr int i = decltype(ic)::value;
         if constexpr (D::sum_owner(i) == W) sums[i] = ldg(d.episode_sums, static_cast<int64_t>(i) * N + env0, 4u * le);
     });
+    // ... and the contact histories the terminations look at (terminations.py:150-158): a few bodies, read by every wavefront
+    constexpr int kContactBodies = [] {
+        int n = 0;
+        for (int i = 0; i < S::NT; ++i)
+            if (S::term[i].kind == ILX_TERM_ILLEGAL_CONTACT) n += S::term[i].ids_cnt < 0 ? S::CB : S::term[i].ids_cnt;
+        return n;
+    }();
+    constexpr bool kContactsAhead = S::kContactsAhead && kContactBodies > 0 && kContactBodies <= 2;   // (where the registers are there)
+    typename FastEnv<S>::ForceRaw contact_raw[kContactsAhead ? kContactBodies : 1];
+    if constexpr (kContactsAhead) {
+        int at = 0;
+        static_for<S::NT>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            if constexpr (S::term[i].kind == ILX_TERM_ILLEGAL_CONTACT) {
+                const ilx_term t = termination_of<S, i>(a);
+                constexpr int n = S::term[i].ids_cnt < 0 ? S::CB : S::term[i].ids_cnt;
+#pragma unroll
+                for (int k = 0; k < n; ++k) contact_raw[at + k] = en.force_raw(en.id(t, k));
+                at += n;
+            }
+        });
+    }
     en.derive();
     // The noise of the thread's observation columns needs nothing but (seed, step, env, group): drawn here, while the
     // wavefront's loads are in flight.  A trip past the block's last env shadows that env (and stores nothing later).
@@ -476,10 +502,20 @@ ILX_DEV void decide(const FastArgs& a, int64_t env0, int ne, uint32_t lane, uint
     ep_len += 1;
     bool terminated = false, time_out = false;
     uint32_t term_bits = 0;
+    int contact_at = 0;
     static_for<S::NT>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
         const ilx_term t = termination_of<S, i>(a);
-        const bool v = eval_termination(en, t, ep_len);
+        bool v;
+        if constexpr (kContactsAhead && S::term[i].kind == ILX_TERM_ILLEGAL_CONTACT) {   // as eval_termination, on the values asked for above
+            constexpr int n = S::term[i].ids_cnt < 0 ? S::CB : S::term[i].ids_cnt;
+            v = false;
+#pragma unroll
+            for (int k = 0; k < n; ++k) v = v | (en.force_peak_of(contact_raw[contact_at + k]) > t.p[0]);
+            contact_at += n;
+        } else {
+            v = eval_termination(en, t, ep_len);
+        }
         term_bits |= v ? (1u << i) : 0u;
         if constexpr ((S::term[i].flags & 1) != 0) time_out = time_out || v; else terminated = terminated || v;
     });
