@@ -373,7 +373,9 @@ ILX_DEV ilx_term reward_of(const FastArgs& a) {
     return t;
 }
 
+constexpr int kFastMaxGroups = 32;   // groups of four observation columns that a DECIDE block passes through LDS, at most
 struct FastShared {   // the LDS of a DECIDE block apart from the observation values
+    alignas(16) float colp[5][4 * kFastMaxGroups];   // those columns' post-processing parameters: n_off, n_rng, c_lo, c_hi, scale
     float ptotal[kWaves][kFastEnvs];
     float logp[2 * kMaxTerms + 3];
     uint32_t done[kFastEnvs];
@@ -393,14 +395,26 @@ struct EmitLane {
     float u[kTrips][4];   // the group's noise draws per trip
 };
 
-template <class S, int W>
-ILX_DEV void decide(const FastArgs& a, int64_t env0, int ne, uint32_t lane, uint64_t seed, uint64_t gen_step, float* P, FastShared& sh,
-                    EmitLane<S>& em) {
+template <class S, int W, class Emit>
+ILX_DEV void decide(const FastArgs& a, int64_t env0, int ne, uint32_t lane, uint64_t seed, uint64_t steps_dev, float* P, FastShared& sh,
+                    EmitLane<S>& em, Emit&& emit) {
     using D = Derived<S>;
     const ilx_mdp& d = a.d;
     const int64_t N = d.num_envs;
     const bool valid = static_cast<int>(lane) < ne;
     const uint32_t le = valid ? lane : static_cast<uint32_t>(ne - 1);   // lanes past the launch's end shadow its last env and store nothing
+    // the command wavefront (the one with time to spare) fills the block's table of column parameters in LDS: a lane asks
+    // for the whole records of columns lane, lane + 64, ...
+    constexpr bool kFillsTable = W == kCmdWave;
+    constexpr int kTableTrips = (4 * EmitLane<S>::GP + 63) / 64;
+    ColParam column[kTableTrips];
+    if constexpr (kFillsTable) {
+#pragma unroll
+        for (int k = 0; k < kTableTrips; ++k) {
+            const int col = 64 * k + static_cast<int>(lane);
+            column[k] = a.colparam[col < EmitLane<S>::O ? col : EmitLane<S>::O - 1];
+        }
+    }
     FastEnv<S> en(a, env0, le);
     // Everything the wavefront can ask for before it knows anything: requested here, in one trip to memory with the root
     // state (the code below is many basic blocks, and a load is not moved from one to another).
@@ -441,11 +455,7 @@ ILX_DEV void decide(const FastArgs& a, int64_t env0, int ne, uint32_t lane, uint
 #pragma unroll
         for (int k = 0; k < 7; ++k) tracked[k] = body[k];
     }
-    if constexpr (pose && W == kDrawWave) {
-        draw_time_left = ldg(d.time_left, env0, 4u * le);
-        bits_reset = command_bits(seed, gen_step, env, 16u);
-        bits_step = command_bits(seed, gen_step, env, 0u);
-    }
+    if constexpr (pose && W == kDrawWave) draw_time_left = ldg(d.time_left, env0, 4u * le);
     float sums[S::NR] = {};
     static_for<S::NR>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
@@ -473,7 +483,29 @@ ILX_DEV void decide(const FastArgs& a, int64_t env0, int ne, uint32_t lane, uint
             }
         });
     }
+    // The generator's step word: the argument plus the caller's device-side count, which the kernel asked for before any
+    // other load (so it is here before them).
+    const uint64_t gen_step = d.step_index + uni(steps_dev);
+    if constexpr (pose && W == kDrawWave) {
+        bits_reset = command_bits(seed, gen_step, env, 16u);
+        bits_step = command_bits(seed, gen_step, env, 0u);
+    }
     en.derive();
+    // The columns' records go to the block's table (they were asked for before the env's state, so they are here): the
+    // block's last stage reads them from LDS.  Kept in registers from the kernel's entry to that stage they would cost
+    // twenty registers, and the wait for them there -- the compiler cannot see that they arrived long before -- would stand
+    // behind the stores issued in between (loads and stores share one in-order counter): a wait for those stores' trip to
+    // memory, once per pass over the block's envs.
+    if constexpr (kFillsTable) {
+#pragma unroll
+        for (int k = 0; k < kTableTrips; ++k) {
+            const uint32_t col = 64u * k + lane;
+            if (col < 4u * EmitLane<S>::GP) {
+                sh.colp[0][col] = column[k].n_off, sh.colp[1][col] = column[k].n_rng, sh.colp[2][col] = column[k].c_lo;
+                sh.colp[3][col] = column[k].c_hi, sh.colp[4][col] = column[k].scale;
+            }
+        }
+    }
     // The noise of the thread's observation columns needs nothing but (seed, step, env, group): drawn here, while the
     // wavefront's loads are in flight.  A trip past the block's last env shadows that env (and stores nothing later).
     {
@@ -491,6 +523,7 @@ ILX_DEV void decide(const FastArgs& a, int64_t env0, int ne, uint32_t lane, uint
 #pragma unroll
                     for (int c = 0; c < 4; ++c)
                         em.u[trip][c] = FastEnv<S>::ldf(noise, 4u * static_cast<uint32_t>(ee * E::O + (4 * em.g + c < E::O ? 4 * em.g + c : E::O - 1)));
+                    __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0): handed-in draws (tests) are waited for here, not behind the block's stores
                 } else {
                     const u4 r = philox4(seed, gen_step, static_cast<uint64_t>(env0 + ee), static_cast<uint32_t>(em.g));
                     em.u[trip][0] = u01(r.x), em.u[trip][1] = u01(r.y), em.u[trip][2] = u01(r.z), em.u[trip][3] = u01(r.w);
@@ -688,6 +721,10 @@ ILX_DEV void decide(const FastArgs& a, int64_t env0, int ne, uint32_t lane, uint
     FAST_STAMP(4);
     __syncthreads();
     FAST_STAMP(5);
+    // ---- the block's observation rows first: their stores then leave ahead of, not behind, the in-place stores below.  (The
+    // compiler guards registers it believes to be still awaited with waits on the counter that loads and stores share, in
+    // order; behind a batch of stores such a wait is a wait for the stores' trip to memory.)
+    emit();
     // ---- in-place updates of what other wavefronts of the block have read by now
     if constexpr (pose && W == kCmdWave) {   // the drawn commands take their places (pose_command.py:92-120)
         if (done || (cs.time_left - dt) <= 0.0f) {
@@ -831,17 +868,29 @@ ILX_DEV void scan_emit(const FastArgs& a, uint32_t block, uint64_t seed, uint64_
 template <class S>
 __global__ void __launch_bounds__(kFastBlock) __attribute__((amdgpu_waves_per_eu(S::kWavesPerSimd))) mdp_fast_kernel(const FastArgs a) {
     using D = Derived<S>;
+    request_kernel_arguments<sizeof(FastArgs)>();
     const ilx_mdp& d = a.d;
-    // The generator's step word: the argument plus the caller's device-side count when there is one (a scalar load; the
-    // caller advances the word between launches, so it is constant over this one).
+    // The generator's step word is the argument plus the caller's device-side count when there is one (the caller
+    // advances the count between launches, so it is constant over this one).
     const uint64_t seed = d.seed;
-    uint64_t gen_step = d.step_index;
-    if (d.step_index_device)
-        gen_step += *reinterpret_cast<const __attribute__((address_space(4))) uint64_t*>(
-            (const __attribute__((address_space(4))) char*)d.step_index_device);
     if (blockIdx.x >= a.decide_blocks) {
+        uint64_t gen_step = d.step_index;   // (a scalar load: these workgroups wait for their columns' parameters, scalar loads too, anyway)
+        if (d.step_index_device)
+            gen_step += *reinterpret_cast<const __attribute__((address_space(4))) uint64_t*>(
+                (const __attribute__((address_space(4))) char*)d.step_index_device);
         scan_emit<S>(a, blockIdx.x - a.decide_blocks, seed, gen_step);
         return;
+    }
+    // Here the count is asked for first of all and through the vector memory path, and turned into a uniform value where
+    // the step word is first needed: its trip to memory runs beside the wavefront's other loads.  (As a scalar load it
+    // would be waited for by the next wait for any scalar load -- the scalar counter has no order -- that is, before the
+    // first vector load could leave.)
+    uint64_t steps_dev = 0;
+    if (d.step_index_device) {
+        uint32_t lane_zero = 0;
+        asm volatile("" : "+v"(lane_zero));   // no instruction: the address is no longer known to be uniform
+        steps_dev = *reinterpret_cast<const __attribute__((address_space(1))) uint64_t*>(
+            (const __attribute__((address_space(1))) char*)d.step_index_device + lane_zero);
     }
     __shared__ float P[kFastEnvs * D::p_stride];
     __shared__ FastShared sh;
@@ -860,27 +909,59 @@ __global__ void __launch_bounds__(kFastBlock) __attribute__((amdgpu_waves_per_eu
     em.active = em.esub < kPerTrip;
     em.noisy = false;
     const int g = em.g, esub = em.esub;
-    float n_off[4], n_rng[4], c_lo[4], c_hi[4], scl[4];
+    static_assert(GP <= kFastMaxGroups, "the block's table of column parameters");
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {   // a column past the row's end is treated like the row's last one (not stored)
-        const int col = 4 * g + c < O ? 4 * g + c : O - 1;
-        const ColParam cp = a.colparam[em.active ? col : 0];
-        n_off[c] = cp.n_off, n_rng[c] = cp.n_rng, c_lo[c] = cp.c_lo, c_hi[c] = cp.c_hi, scl[c] = cp.scale;
-        em.n_rng[c] = cp.n_rng;
-    }
+    for (int c = 0; c < 4; ++c)   // a column past the row's end is treated like the row's last one (not stored)
+        em.n_rng[c] = a.colparam[em.active ? (4 * g + c < O ? 4 * g + c : O - 1) : 0].n_rng;
+
     FAST_STAMP(0);
     // The block's first barrier orders the zeroed logging sums (LDS) ahead of the wavefronts' additions and nothing else:
     // a wait for the LDS writes and the barrier instruction, without the fence of __syncthreads(), which would also wait
     // for the column parameters' loads above -- a trip to memory before the env's loads could leave.
     __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0)
     __builtin_amdgcn_s_barrier();
+    auto emit = [&]() {
+        // ---- the observation columns that went through LDS: noise (drawn above), clip, scale, store
+        // (observation_manager.py:313-318).  A lane owns one group of four columns and walks down the block's envs with it.
+        if (em.active) {
+            GBytesW* rows = (GBytesW*)FastEnv<S>::block_base(d.obs, env0 * O);
+            float n_off[4], n_rng[4], c_lo[4], c_hi[4], scl[4];
+    #pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                n_off[c] = sh.colp[0][4 * g + c], n_rng[c] = sh.colp[1][4 * g + c], c_lo[c] = sh.colp[2][4 * g + c];
+                c_hi[c] = sh.colp[3][4 * g + c], scl[c] = sh.colp[4][4 * g + c];
+            }
+    #pragma unroll
+            for (int trip = 0; trip < kTrips; ++trip) {
+                const int raw = trip * kPerTrip + esub, ee = raw < ne ? raw : ne - 1;
+                const uint32_t out_at = 4u * static_cast<uint32_t>(raw * O + 4 * g);
+                Group4 out;
+    #pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    float x = P[ee * D::p_stride + 4 * g + c];
+                    x = x + em.u[trip][c] * n_rng[c] + n_off[c];         // noise_model.py:63-64
+                    x = __builtin_amdgcn_fmed3f(x, c_lo[c], c_hi[c]);    // observation_manager.py:315-316
+                    out[c] = x * scl[c];                               // :317-318
+                }
+                if (raw < ne) {
+                    if (4 * g + 3 < O) {   // a whole group: one 16-byte store
+                        *reinterpret_cast<__attribute__((address_space(1))) Group4*>(rows + out_at) = out;
+                    } else {
+    #pragma unroll
+                        for (int c = 0; c < 4; ++c)
+                            if (4 * g + c < O) *reinterpret_cast<__attribute__((address_space(1))) float*>(rows + out_at + 4u * c) = out[c];
+                    }
+                }
+            }
+        }
+    };
     static_assert(kWaves == 4, "one path per wavefront below");
     switch (wave) {
-        case 0: decide<S, 0>(a, env0, ne, lane, seed, gen_step, P, sh, em); break;
-        case 1: decide<S, 1>(a, env0, ne, lane, seed, gen_step, P, sh, em); break;
-        case 2: decide<S, 2>(a, env0, ne, lane, seed, gen_step, P, sh, em); break;
-        case 3: decide<S, 3>(a, env0, ne, lane, seed, gen_step, P, sh, em); break;
-        default: decide<S, kCmdWave>(a, env0, ne, lane, seed, gen_step, P, sh, em); break;
+        case 0: decide<S, 0>(a, env0, ne, lane, seed, steps_dev, P, sh, em, emit); break;
+        case 1: decide<S, 1>(a, env0, ne, lane, seed, steps_dev, P, sh, em, emit); break;
+        case 2: decide<S, 2>(a, env0, ne, lane, seed, steps_dev, P, sh, em, emit); break;
+        case 3: decide<S, 3>(a, env0, ne, lane, seed, steps_dev, P, sh, em, emit); break;
+        default: decide<S, kCmdWave>(a, env0, ne, lane, seed, steps_dev, P, sh, em, emit); break;
     }
     // (each of the five paths above ends behind the block's barrier)
     FAST_STAMP(6);
@@ -898,33 +979,6 @@ __global__ void __launch_bounds__(kFastBlock) __attribute__((amdgpu_waves_per_eu
     if (d.log_sums && tid < S::NR + S::NT + 3) {
         const float v = sh.logp[tid];
         if (v != 0.0f) unsafeAtomicAdd(d.log_sums + tid, v);
-    }
-    // ---- the observation columns that went through LDS: noise (drawn above), clip, scale, store
-    // (observation_manager.py:313-318).  A lane owns one group of four columns and walks down the block's envs with it.
-    if (em.active) {
-        GBytesW* rows = (GBytesW*)FastEnv<S>::block_base(d.obs, env0 * O);
-#pragma unroll
-        for (int trip = 0; trip < kTrips; ++trip) {
-            const int raw = trip * kPerTrip + esub, ee = raw < ne ? raw : ne - 1;
-            const uint32_t out_at = 4u * static_cast<uint32_t>(raw * O + 4 * g);
-            Group4 out;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                float x = P[ee * D::p_stride + 4 * g + c];
-                x = x + em.u[trip][c] * n_rng[c] + n_off[c];         // noise_model.py:63-64
-                x = __builtin_amdgcn_fmed3f(x, c_lo[c], c_hi[c]);    // observation_manager.py:315-316
-                out[c] = x * scl[c];                               // :317-318
-            }
-            if (raw < ne) {
-                if (4 * g + 3 < O) {   // a whole group: one 16-byte store
-                    *reinterpret_cast<__attribute__((address_space(1))) Group4*>(rows + out_at) = out;
-                } else {
-#pragma unroll
-                    for (int c = 0; c < 4; ++c)
-                        if (4 * g + c < O) *reinterpret_cast<__attribute__((address_space(1))) float*>(rows + out_at + 4u * c) = out[c];
-                }
-            }
-        }
     }
     FAST_STAMP(7);
 }

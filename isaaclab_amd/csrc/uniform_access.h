@@ -41,4 +41,28 @@ ILX_DEV void st_at(__attribute__((address_space(1))) T* base, uint32_t byte_off,
     *reinterpret_cast<__attribute__((address_space(1))) T*>(scalar_base(base) + byte_off) = static_cast<T>(v);
 }
 
+// A kernel whose arguments fill many cache lines reads them with scalar loads as its code gets to them; where the scalar
+// registers do not hold all of them at once the compiler loads a few, waits, parks them in lanes of a vector register
+// and loads the next few -- a chain of trips to memory, one behind the other, before the kernel's first vector load
+// leaves.  Called first thing in a kernel, this asks for one word of every 64-byte line of the arguments (kBytes: their
+// total size, the kernel's kernarg segment) at once and waits for them: one trip, after which the loads that follow are
+// served by the scalar cache.  The words go to one register that nothing reads; the wait inside the block is what makes
+// that register safe to hand back to the compiler.
+template <int kBytes>
+ILX_DEV void request_kernel_arguments() {
+    static_assert(kBytes >= 4 && kBytes % 4 == 0, "the arguments' size in bytes");
+    uint32_t sink;
+    asm volatile(
+        ".set ilx_ka_off, 0\n"
+        ".rept %2\n"
+        "s_load_dword %0, %1, ilx_ka_off\n"
+        ".set ilx_ka_off, ilx_ka_off + 64\n"
+        ".endr\n"
+        "s_load_dword %0, %1, %3\n"   // (the arguments need not start on a line's boundary)
+        "s_waitcnt lgkmcnt(0)"
+        : "=&s"(sink)
+        : "s"(__builtin_amdgcn_kernarg_segment_ptr()), "n"((kBytes + 63) / 64), "n"(kBytes - 4)
+        : "memory");
+}
+
 }  // namespace ilx
