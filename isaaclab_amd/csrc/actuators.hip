@@ -917,12 +917,14 @@ ILX_DEV void mlp_split_persistent(const NetArgs& a, unsigned block, unsigned nbl
 
 template <int ACT>
 __global__ void __launch_bounds__(256, 4) mlp_split_persistent_kernel(NetArgs a) {
+    request_kernel_arguments<kernel_argument_bytes<NetArgs>()>();
     mlp_split_persistent<ACT, false>(a, blockIdx.x, gridDim.x);
 }
 
 // The three-sample launch that also processes the joint action and opens the step (NetArgs::ja_raw).
 template <int ACT>
 __global__ void __launch_bounds__(256, 4) mlp_split_joint_action_kernel(NetArgs a) {
+    request_kernel_arguments<kernel_argument_bytes<NetArgs>()>();
     mlp_split_persistent<ACT, true>(a, blockIdx.x, gridDim.x);
 }
 
@@ -938,6 +940,7 @@ __global__ void __launch_bounds__(256, 4) mlp_split_joint_action_kernel(NetArgs 
 template <int ACT>
 __global__ void __launch_bounds__(256, 6) mlp_split_scene_kernel(NetArgs a, SceneArgs s, unsigned mlp_first, unsigned mlp_blocks,
                                                                  unsigned su_first) {
+    request_kernel_arguments<kernel_argument_bytes<NetArgs, SceneArgs, unsigned, unsigned, unsigned>()>();
     const unsigned b = blockIdx.x;
     if (b >= mlp_first && b - mlp_first < mlp_blocks) mlp_split_persistent<ACT, false>(a, b - mlp_first, mlp_blocks);
     else scene_update_thread(s, b - su_first);

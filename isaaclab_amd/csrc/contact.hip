@@ -32,7 +32,10 @@ __global__ void __launch_bounds__(256) contact_update_kernel(ContactArgs a) {
     }
 }
 
-__global__ void __launch_bounds__(256) scene_update_kernel(SceneArgs s) { scene_update_thread(s, blockIdx.x); }
+__global__ void __launch_bounds__(256) scene_update_kernel(SceneArgs s) {
+    request_kernel_arguments<kernel_argument_bytes<SceneArgs>()>();
+    scene_update_thread(s, blockIdx.x);
+}
 
 }  // namespace ilx
 

@@ -6,6 +6,7 @@
 // The two global sums of compute_rewards are reduced per block in LDS and leave as one hardware float add each.
 #include "common.h"
 #include "math_dev.h"
+#include "uniform_access.h"
 
 #include "../../include/isaaclab_amd_inhand.h"
 
@@ -60,6 +61,7 @@ struct EnvShared {
 };
 
 __global__ void __launch_bounds__(256) inhand_step_kernel(ilx_inhand d) {
+    request_kernel_arguments<kernel_argument_bytes<ilx_inhand>()>();
     __shared__ EnvShared sh[kEnvsPerBlock];
     __shared__ float block_stats[2];
     const int tid = threadIdx.x;

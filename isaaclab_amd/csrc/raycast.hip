@@ -745,6 +745,7 @@ __global__ void __launch_bounds__(256) raycaster_prepare_kernel(ScanArgs a, LatE
 // wavefront of the update then runs the preparation's instruction stream.)  The pattern's box is the cached one.
 __global__ void __launch_bounds__(256) scene_update_prepare_kernel(SceneArgs s, ScanArgs a, LatEnvRec* __restrict__ recs,
                                                                    const float* __restrict__ box_cache, unsigned prep_blocks) {
+    request_kernel_arguments<kernel_argument_bytes<SceneArgs, ScanArgs, LatEnvRec*, const float*, unsigned>()>();
     if (blockIdx.x >= prep_blocks) {
         scene_update_thread(s, blockIdx.x - prep_blocks, false);
         return;
@@ -782,6 +783,7 @@ ILX_DEV bool lattice_cell(const float* l, int n, float x, float x0, float inv, i
 __global__ void __launch_bounds__(64 * kLatWaves) ILX_CAST_ATTR
 raycaster_update_lattice_kernel(ScanArgs a, const LatEnvRec* __restrict__ recs, const float4* __restrict__ pattern) {
     __shared__ LatStage stage_s[kLatWaves];
+    request_kernel_arguments<kernel_argument_bytes<ScanArgs, const LatEnvRec*, const float4*>()>();
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const float inf = __builtin_inff();
     const int64_t env = static_cast<int64_t>(xcd_block(blockIdx.x, gridDim.x)) * kLatWaves + wave;

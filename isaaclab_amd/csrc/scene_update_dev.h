@@ -5,6 +5,7 @@
 #pragma once
 #include "common.h"
 #include "math_dev.h"
+#include "uniform_access.h"
 
 namespace ilx {
 

@@ -48,6 +48,13 @@ ILX_DEV void st_at(__attribute__((address_space(1))) T* base, uint32_t byte_off,
 // total size, the kernel's kernarg segment) at once and waits for them: one trip, after which the loads that follow are
 // served by the scalar cache.  The words go to one register that nothing reads; the wait inside the block is what makes
 // that register safe to hand back to the compiler.
+// The size of a kernel's explicit arguments: each at the next multiple of its alignment.
+template <class... Args>
+constexpr int kernel_argument_bytes() {
+    int at = 0;
+    ((at = (at + static_cast<int>(alignof(Args)) - 1) / static_cast<int>(alignof(Args)) * static_cast<int>(alignof(Args)) + static_cast<int>(sizeof(Args))), ...);
+    return (at + 3) / 4 * 4;
+}
 template <int kBytes>
 ILX_DEV void request_kernel_arguments() {
     static_assert(kBytes >= 4 && kBytes % 4 == 0, "the arguments' size in bytes");
