@@ -135,52 +135,124 @@ struct SceneThread {
 // The whole update for the calling thread; contains one __syncthreads(): every thread of the block calls it.
 // `block`: the block's index among the update's blocks; `ray_clock_too` = false leaves the ray caster's clock to
 // somebody else (the launch that also prepares the scanner's refresh gives it to the workgroups that do that).
+// Addresses: a block owns a run of envs, so every array is reached as the run's first element (a scalar base, formed once
+// with scalar arithmetic) plus a 32-bit offset per thread; formed per access as 64-bit element indices the addresses were
+// two thirds of the kernel's vector instructions, a good part of them quarter-rate integer multiplies.
 ILX_DEV SceneThread scene_update_thread(const SceneArgs& s, unsigned block, bool ray_clock_too = true) {
+    typedef __attribute__((address_space(1))) char* Base;
     const ContactArgs& a = s.c;
-    const int t = threadIdx.x;
-    const int le = s.width > 1 ? static_cast<int>(__umulhi(static_cast<uint32_t>(t), s.inv_width)) : t;  // t / width
-    const int k0 = t - le * s.width;
-    const int64_t env = static_cast<int64_t>(block) * a.envs_per_block + le;
-    const bool active = le < a.envs_per_block && env < a.n;
+    const uint32_t t = threadIdx.x;
+    const uint32_t le = s.width > 1 ? __umulhi(t, s.inv_width) : t;  // t / width
+    const uint32_t k0 = t - __umul24(le, static_cast<uint32_t>(s.width));
+    const int64_t env0 = static_cast<int64_t>(block) * a.envs_per_block;
+    const int64_t env = env0 + le;
+    const bool active = le < static_cast<uint32_t>(a.envs_per_block) && env < a.n;
     const bool has_contact = a.in != nullptr;
+    const uint32_t nb = static_cast<uint32_t>(a.b), nj = static_cast<uint32_t>(s.j), nh = static_cast<uint32_t>(a.h);
+    const Base b_ts = block_base(a.ts, env0), b_ts_last = block_base(a.ts_last, env0), b_outdated = block_base(a.outdated, env0);
+    const Base b_head = block_base(a.head, env0);
+    const Base b_in = block_base(a.in, env0 * a.b * 3), b_net = block_base(a.net, env0 * a.b * 3);
+    const Base b_hist = block_base(a.hist, env0 * a.h * a.b * 3);
+    const Base b_cur_air = block_base(a.cur_air, env0 * a.b), b_last_air = block_base(a.last_air, env0 * a.b);
+    const Base b_cur_contact = block_base(a.cur_contact, env0 * a.b), b_last_contact = block_base(a.last_contact, env0 * a.b);
+    const Base b_vel = block_base(s.joint_vel, env0 * s.j), b_prev = block_base(s.prev_joint_vel, env0 * s.j);
+    const Base b_acc = block_base(s.joint_acc, env0 * s.j);
+    const Base b_ray_ts = block_base(s.ray_ts, env0), b_ray_last = block_base(s.ray_ts_last, env0);
+    const Base b_ray_outdated = block_base(s.ray_outdated, env0);
+    auto clock_at = [&](Base ts, Base ts_last, Base outdated, float period) {   // read_clock with tick = 1
+        Clock c{ld_b<float>(ts, 4u * le), ld_b<float>(ts_last, 4u * le), ld_b<uint8_t>(outdated, le) != 0};
+        c.ts_new = c.ts_new + a.dt;                                            // sensor_base.py:199
+        c.refresh = c.refresh || ((c.ts_new - c.last + 1e-6f) >= period);      // sensor_base.py:200
+        return c;
+    };
+    auto clock_to = [&](Base ts, Base ts_last, Base outdated, const Clock& c, bool lazy) {   // write_clock
+        st_b<float>(ts, 4u * le, c.ts_new);
+        if (lazy) {
+            st_b<uint8_t>(outdated, le, c.refresh);
+        } else {
+            if (c.refresh) st_b<float>(ts_last, 4u * le, c.ts_new);  // sensor_base.py:291
+            st_b<uint8_t>(outdated, le, 0);                          // refreshed now, or it was not outdated to begin with
+        }
+    };
+    auto body_at = [&](uint32_t body) {   // load_body
+        const uint32_t eb = __umul24(le, nb) + body, eb12 = __umul24(eb, 12u);
+        BodyIn in{f3{ld_b<float>(b_in, eb12), ld_b<float>(b_in, eb12 + 4u), ld_b<float>(b_in, eb12 + 8u)}, 0.0f, 0.0f};
+        if (a.cur_air) in.cur_air = ld_b<float>(b_cur_air, 4u * eb), in.cur_contact = ld_b<float>(b_cur_contact, 4u * eb);
+        return in;
+    };
 
     // Everything the thread may read goes out before the barrier, in one trip to memory: the clock, and the inputs of
     // the first body / joint the thread owns (read whether or not the env turns out to refresh).
     Clock c{0.0f, 0.0f, false};
     int slot = 0;
-    const bool body_ahead = active && has_contact && !s.contact_lazy && k0 < a.b;
-    const bool joint_ahead = active && s.joint_vel && k0 < s.j;
+    const bool body_ahead = active && has_contact && !s.contact_lazy && k0 < nb;
+    const bool joint_ahead = active && s.joint_vel && k0 < nj;
     BodyIn first_body{};
     float first_v = 0.0f, first_prev = 0.0f;
-    if (active && has_contact) c = read_clock(a.ts, a.ts_last, a.outdated, env, 1, a.dt, a.period);
-    if (active && has_contact && a.head) slot = next_slot(a.head[env], a.h);
-    if (body_ahead) first_body = load_body(a, env, k0);
-    if (joint_ahead) first_v = s.joint_vel[env * s.j + k0], first_prev = s.prev_joint_vel[env * s.j + k0];
+    if (active && has_contact) c = clock_at(b_ts, b_ts_last, b_outdated, a.period);
+    if (active && has_contact && a.head) slot = next_slot(ld_b<int32_t>(b_head, 4u * le), a.h);
+    if (body_ahead) first_body = body_at(k0);
+    if (joint_ahead) {
+        const uint32_t at = 4u * (__umul24(le, nj) + k0);
+        first_v = ld_b<float>(b_vel, at), first_prev = ld_b<float>(b_prev, at);
+    }
     // the ray caster's clock belongs to the env's first thread alone: read in the same trip
     const bool ray_clock = active && k0 == 0 && s.ray_ts && ray_clock_too;
     Clock r{0.0f, 0.0f, false};
-    if (ray_clock) r = read_clock(s.ray_ts, s.ray_ts_last, s.ray_outdated, env, 1, a.dt, s.ray_period);
+    if (ray_clock) r = clock_at(b_ray_ts, b_ray_last, b_ray_outdated, s.ray_period);
     __syncthreads();
     SceneThread out{env, active && k0 == 0, r};
     if (!active) return out;
     if (k0 == 0) {
-        if (has_contact) write_clock(a.ts, a.ts_last, a.outdated, env, c, s.contact_lazy != 0);
-        if (has_contact && a.head && c.refresh && !s.contact_lazy) a.head[env] = slot;
-        if (ray_clock) write_clock(s.ray_ts, s.ray_ts_last, s.ray_outdated, env, r, true);
+        if (has_contact) clock_to(b_ts, b_ts_last, b_outdated, c, s.contact_lazy != 0);
+        if (has_contact && a.head && c.refresh && !s.contact_lazy) st_b<int32_t>(b_head, 4u * le, slot);
+        if (ray_clock) clock_to(b_ray_ts, b_ray_last, b_ray_outdated, r, true);
     }
     if (s.joint_vel) {
-        for (int j = k0; j < s.j; j += s.width) {
-            const int64_t i = env * s.j + j;
-            const float v = j == k0 ? first_v : s.joint_vel[i];
-            const float prev = j == k0 ? first_prev : s.prev_joint_vel[i];
-            s.joint_acc[i] = div_(v - prev, s.joint_elapsed);
-            s.prev_joint_vel[i] = v;
+        for (uint32_t j = k0; j < nj; j += static_cast<uint32_t>(s.width)) {
+            const uint32_t at = 4u * (__umul24(le, nj) + j);
+            const float v = j == k0 ? first_v : ld_b<float>(b_vel, at);
+            const float prev = j == k0 ? first_prev : ld_b<float>(b_prev, at);
+            st_b<float>(b_acc, at, div_(v - prev, s.joint_elapsed));
+            st_b<float>(b_prev, at, v);
         }
     }
     if (has_contact && c.refresh && !s.contact_lazy) {
         const float elapsed = c.ts_new - c.last;
-        for (int body = k0; body < a.b; body += s.width)
-            contact_body(a, env, body, elapsed, slot, body == k0 ? first_body : load_body(a, env, body));
+        for (uint32_t body = k0; body < nb; body += static_cast<uint32_t>(s.width)) {
+            const BodyIn in = body == k0 ? first_body : body_at(body);
+            // contact_body with the block's addressing
+            const uint32_t eb = __umul24(le, nb) + body, eb12 = __umul24(eb, 12u);
+            const f3 f = in.f;
+            if (a.net) st_b<float>(b_net, eb12, f.x), st_b<float>(b_net, eb12 + 4u, f.y), st_b<float>(b_net, eb12 + 8u, f.z);
+            if (a.hist && a.head) {   // the ring: one row written
+                const uint32_t at = __umul24(__umul24(__umul24(le, nh) + static_cast<uint32_t>(slot), nb) + body, 12u);
+                st_b<float>(b_hist, at, f.x), st_b<float>(b_hist, at + 4u, f.y), st_b<float>(b_hist, at + 8u, f.z);
+            } else if (a.hist) {      // contact_sensor.py:326-328: every row moves one slot up
+                const uint32_t hb = __umul24(__umul24(__umul24(le, nh), nb) + body, 12u), row = __umul24(nb, 12u);
+                f3 old[kMaxContactHistory - 1];
+#pragma unroll
+                for (uint32_t k = 0; k < kMaxContactHistory - 1; ++k)
+                    if (k + 1 < nh) old[k] = f3{ld_b<float>(b_hist, hb + __umul24(k, row)), ld_b<float>(b_hist, hb + __umul24(k, row) + 4u), ld_b<float>(b_hist, hb + __umul24(k, row) + 8u)};
+                st_b<float>(b_hist, hb, f.x), st_b<float>(b_hist, hb + 4u, f.y), st_b<float>(b_hist, hb + 8u, f.z);
+#pragma unroll
+                for (uint32_t k = 0; k < kMaxContactHistory - 1; ++k)
+                    if (k + 1 < nh) {
+                        const uint32_t at = hb + __umul24(k + 1, row);
+                        st_b<float>(b_hist, at, old[k].x), st_b<float>(b_hist, at + 4u, old[k].y), st_b<float>(b_hist, at + 8u, old[k].z);
+                    }
+            }
+            if (a.cur_air) {  // contact_sensor.py:346-373
+                const bool contact = norm3(f) > a.thr;
+                const float ca = in.cur_air, cc = in.cur_contact;
+                const bool first_contact = (ca > 0.0f) && contact;
+                const bool first_detached = (cc > 0.0f) && !contact;
+                if (first_contact) st_b<float>(b_last_air, 4u * eb, ca + elapsed);
+                st_b<float>(b_cur_air, 4u * eb, contact ? 0.0f : ca + elapsed);
+                if (first_detached) st_b<float>(b_last_contact, 4u * eb, cc + elapsed);
+                st_b<float>(b_cur_contact, 4u * eb, contact ? cc + elapsed : 0.0f);
+            }
+        }
     }
     return out;
 }

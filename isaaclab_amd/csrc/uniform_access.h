@@ -41,6 +41,23 @@ ILX_DEV void st_at(__attribute__((address_space(1))) T* base, uint32_t byte_off,
     *reinterpret_cast<__attribute__((address_space(1))) T*>(scalar_base(base) + byte_off) = static_cast<T>(v);
 }
 
+// The same for a workgroup that owns a contiguous run of rows: the run's first element as a scalar base (computed once, with
+// scalar arithmetic), and 32-bit byte offsets from it per access.
+template <typename T>
+ILX_DEV __attribute__((address_space(1))) char* block_base(T* p, int64_t first_elem) {
+    uint64_t a = reinterpret_cast<uint64_t>(p) + static_cast<uint64_t>(sizeof(T)) * static_cast<uint64_t>(first_elem);
+    asm volatile("" : "+s"(a));   // no instruction: pins the base to scalar registers
+    return (__attribute__((address_space(1))) char*)a;
+}
+template <typename T>
+ILX_DEV T ld_b(const __attribute__((address_space(1))) char* base, uint32_t byte_off) {
+    return *reinterpret_cast<const __attribute__((address_space(1))) T*>(base + byte_off);
+}
+template <typename T, typename V>
+ILX_DEV void st_b(__attribute__((address_space(1))) char* base, uint32_t byte_off, V v) {
+    *reinterpret_cast<__attribute__((address_space(1))) T*>(base + byte_off) = static_cast<T>(v);
+}
+
 // A kernel whose arguments fill many cache lines reads them with scalar loads as its code gets to them; where the scalar
 // registers do not hold all of them at once the compiler loads a few, waits, parks them in lanes of a vector register
 // and loads the next few -- a chain of trips to memory, one behind the other, before the kernel's first vector load

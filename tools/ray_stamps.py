@@ -39,6 +39,11 @@ print("entry: " + "  ".join(f"p{q}={np.percentile((t[:, 0] - t0) / 100.0, q):.2f
 print("exit:  " + "  ".join(f"p{q}={np.percentile((t[:, 5] - t0) / 100.0, q):.2f}" for q in qs))
 resident = [(int(((t[:, 0] - t0) <= 100 * us).sum()) - int(((t[:, 5] - t0) <= 100 * us).sum())) for us in range(0, 28, 2)]
 print("workgroups resident at 0, 2, 4 ... us: " + " ".join(str(r) for r in resident))
+ 
+tail = (t[:, 5] - t[:, 4]) / 100.0   # the rays left to the column grid
+print("rays left over (all rays served -> exit): " + "  ".join(f"p{q}={np.percentile(tail, q):.2f}" for q in (50, 90, 95, 98, 99, 99.5, 100)) +
+      f";  wavefronts with more than 1 us of it: {(tail > 1.0).sum()} of {len(tail)}, their lives: " +
+      "  ".join(f"p{q}={np.percentile(life[tail > 1.0], q):.2f}" for q in (0, 50, 100)) if (tail > 1.0).any() else "")
 print("life of a wavefront: " + "  ".join(f"p{q}={np.percentile(life, q):.2f}" for q in (0, 10, 50, 90, 100)))
 
 pbuf = (ctypes.c_ulonglong * (8 * 256))()
