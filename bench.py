@@ -263,15 +263,23 @@ def main():
     # depend on, so the number holds with a simulator between the substeps.  Beside it, for the network actuators: the
     # recording with the sensor chain as a branch parallel to the actuator chain -- possible here only because all four
     # substeps' physics results are already in memory.
+    # The headline is measured before the two-branch recording has ever run: once a process has replayed a graph with
+    # parallel branches (more hardware queues in use), every later replay of the one-chain graph takes 3-4 us longer --
+    # a state that a deployment stepping in the reference's order never enters.
     two_branch_s = None
     if use_graph:
         other_s = timed(eager_step)
-        if getattr(cfg, "overlap_in_graph", False):
+        two_branches = getattr(cfg, "overlap_in_graph", False)
+        cfg.overlap_in_graph = False
+        graphs = capture_step(cfg, reducer)
+        elapsed = timed(graph_step, replayed=True)
+        if two_branches:
+            one_chain = graphs
+            cfg.overlap_in_graph = True
             graphs = capture_step(cfg, reducer)
             two_branch_s = timed(graph_step, replayed=True)
             cfg.overlap_in_graph = False
-        graphs = capture_step(cfg, reducer)
-        elapsed = timed(graph_step, replayed=True)
+            graphs = one_chain
     else:
         elapsed = timed(eager_step)
         if world == 1:

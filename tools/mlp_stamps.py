@@ -1,5 +1,5 @@
 """GPU probe (diagnostics build: CXXFLAGS+=-DILX_MLP_STAMPS): where a block of the actuator-network kernel spends its time.
-    python tools/mlp_stamps.py [envs]"""
+    python tools/mlp_stamps.py [envs] [launch name, e.g. actuator_net_mlp+scene_update]"""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -12,12 +12,12 @@ cfg = BC.build("anymal", torch.device("cuda:0"), envs, 3000)
 for _ in range(3):
     cfg.step()
 torch.cuda.synchronize()
-fn = cfg.launches["actuator_net_mlp"]
+fn = cfg.launches[sys.argv[2] if len(sys.argv) > 2 else "actuator_net_mlp"]
 fn = fn[0] if isinstance(fn, tuple) else fn
 for _ in range(5):
     fn()
 torch.cuda.synchronize()
-blocks = min(2048, (envs * 12 + 127) // 128, 2 * 256 * int(os.environ.get("ILX_STAY", 2)) // 2)
+blocks = min(2048, (envs * 12 + 127) // 128, 256 * int(os.environ.get("ILX_STAY", 3)))
 buf = (ctypes.c_ulonglong * (8 * 2048))()
 assert _abi.lib.ilx_debug_mlp_stamps(buf, 8 * 2048) == 0
 t = np.frombuffer(buf, dtype=np.uint64).reshape(2048, 8)[:blocks].astype(np.int64)

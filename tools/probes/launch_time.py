@@ -1,7 +1,9 @@
 """Diagnostic: duration of named launches of one configuration (events on the launch stream, back to back behind a
 blocker), and optionally of the whole step replayed from a graph:
-    python tools/probes/launch_time.py anymal "actuator_net_mlp+scene_update,raycaster_cast" [--step]"""
+    python tools/probes/launch_time.py anymal "actuator_net_mlp+scene_update,raycaster_cast" [--step [--stats]]
+(--stats: with the episode statistics, two graphs in turn, as bench.py replays the step)"""
 import sys
+import time
 
 import torch
 
@@ -16,20 +18,39 @@ cfg = BC.build(config, dev, BC.ENVS[config], seed=3000)
 for _ in range(3):
     cfg.step()
 torch.cuda.synchronize()
-for rep in range(3):
+for rep in range(0 if "--no-kernels" in sys.argv else 3):
     k = bench.time_kernels(cfg, dev, only=names)
     print(config, {n: round(v, 2) for n, v in k.items()})
 if "--step" in sys.argv:
-    graphs = bench.capture_step(cfg, None)
+    from isaaclab_amd.distributed import OverlappedLogReducer
+    reducer = OverlappedLogReducer(cfg.log_sums.numel(), dev) if "--stats" in sys.argv and cfg.log_sums is not None else None
+    if "--like-bench" in sys.argv:   # what bench.py does ahead of the headline's recording: eager steps, the two-branch recording
+        if "--no-eager" not in sys.argv:
+            for _ in range(210):
+                cfg.step()
+        if "--no-two" not in sys.argv:
+            cfg.overlap_in_graph = True
+            g2 = bench.capture_step(cfg, reducer)
+            for k in range(240):
+                g2[k % len(g2)].replay()
+            torch.cuda.synchronize()
+            cfg.overlap_in_graph = False
+    graphs = bench.capture_step(cfg, reducer)
+    run_on = torch.cuda.Stream() if "--own-stream" in sys.argv else torch.cuda.current_stream()
+    torch.cuda.set_stream(run_on)
     for rep in range(3):
         cfg.restart_sensor_clocks()
-        for _ in range(20):
-            graphs[0].replay()
+        for k in range(40):
+            graphs[k % len(graphs)].replay()
         torch.cuda.synchronize()
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
-        for _ in range(200):
-            graphs[0].replay()
+        h0 = time.perf_counter()
+        for k in range(200):
+            graphs[k % len(graphs)].replay()
+        h1 = time.perf_counter()
         b.record()
         torch.cuda.synchronize()
-        print("step replayed:", round(a.elapsed_time(b) * 1e3 / 200, 2), "us")
+        h2 = time.perf_counter()
+        print(f"step replayed ({len(graphs)} graph(s) in turn):", round(a.elapsed_time(b) * 1e3 / 200, 2), "us;  the host's share of a replay:",
+              round((h1 - h0) * 1e6 / 200, 2), "us;  by the host's clock, with the wait for the last one:", round((h2 - h0) * 1e6 / 200, 2), "us")
