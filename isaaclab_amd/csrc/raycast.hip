@@ -572,10 +572,12 @@ constexpr size_t kStaticScratchBytes =
     static_cast<size_t>(kStaticEnvs) * sizeof(LatEnvRec);
 
 // What one wavefront keeps in LDS for its env.
+// (Lines first: a ray's two line pairs and its cell's four heights are then all within reach of the 8-bit dword offsets of a
+// two-word LDS read from the index alone.)
 struct LatStage {
-    float z[kLatWin * kLatWin];
     float lines[2 * kLatWin];  // x lines, then y lines
-    uint32_t mask[kLatWin * kLatMaskWords];
+    float z[kLatWin * kLatWin];
+    uint32_t mask[kLatWin];    // per window row: bit cj = the simple-cell bit of the row's cell cj (a window row has at most 31)
 };
 
 ILX_DEV float wave_min(float v) {
@@ -765,8 +767,12 @@ __global__ void __launch_bounds__(256) scene_update_prepare_kernel(SceneArgs s, 
 // The staged lattice cell that the index estimate names for coordinate x (line l[k] is line lo_abs + k of the patch):
 // true when x lies strictly inside that cell c = [lo, hi] by the margin.  On an evenly spaced lattice the estimate
 // is the cell for every such x; where it is not (uneven lines, the window's edge, NaN) the ray is not served here.
+// (The estimate only picks the cell that the test below then accepts or refuses: floor and conversion as one instruction,
+// saturating like the conversion it replaces; the clamp to [0, n - 2], n >= 2, as a median.)
 ILX_DEV bool lattice_cell(const float* l, int n, float x, float x0, float inv, int lo_abs, int& c, float& lo, float& hi) {
-    c = max(0, min(lattice_guess(x, x0, inv) - lo_abs, n - 2));
+    int guess;
+    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(guess) : "v"((x - x0) * inv));
+    asm("v_med3_i32 %0, %1, 0, %2" : "=v"(c) : "v"(guess - lo_abs), "s"(n - 2));
     lo = l[c], hi = l[c + 1];
     const float m = (hi - lo) * kLatMargin;
     return (x - lo) > m && (hi - x) > m;
@@ -831,7 +837,10 @@ raycaster_update_lattice_kernel(ScanArgs a, const LatEnvRec* __restrict__ recs, 
         for (int k = 0; k < kLatWin / 8; ++k)
             *reinterpret_cast<float4*>(&st.z[(8 * k + qrow) * kLatWin + qcol]) = make_float4(v[k].v[0], v[k].v[1], v[k].v[2], v[k].v[3]);
         st.lines[lane] = line;
-        st.mask[lane] = bits;
+        // the row's two words, funnel-shifted so that the window's first cell is bit 0: the even lane of each pair has the low
+        // word, its neighbour the high one (a quad permute: lanes 0 and 2 of a quad read lanes 1 and 3)
+        const uint32_t high = static_cast<uint32_t>(__builtin_amdgcn_mov_dpp(static_cast<int>(bits), 0xF5, 0xF, 0xF, true));
+        if ((lane & 1) == 0) st.mask[lane >> 1] = __builtin_amdgcn_alignbit(high, bits, static_cast<uint32_t>(j_lo & 31));
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -864,10 +873,12 @@ raycaster_update_lattice_kernel(ScanArgs a, const LatEnvRec* __restrict__ recs, 
         const int jabs = j_lo + cj;
         // the cell's bit and its four heights are asked for with the lines (their addresses need the cell's indices, not
         // the lines' values): one LDS latency for the ray instead of three
-        const uint32_t word = st.mask[ci * kLatMaskWords + ((jabs >> 5) - w0)];
+        int mask_row = ci;
+        asm("" : "+v"(mask_row));   // no instruction: keeps the word's address a shift and an add of its own (derived from the heights' address it was a 64-bit multiply-add)
+        const uint32_t word = st.mask[mask_row];
         const float* zc = st.z + ci * kLatWin + cj;
         const float z00 = zc[0], z01 = zc[1], z10 = zc[kLatWin], z11 = zc[kLatWin + 1];
-        if (!(in_x && in_y && ((word >> (jabs & 31)) & 1u) && dz != 0.0f)) return false;
+        if (!(in_x && in_y && ((word >> cj) & 1u) && dz != 0.0f)) return false;
         const float wx = xhi - xlo, wy = yhi - ylo;
         const float sx = o.x - xlo, sy = o.y - ylo, sz = o.z - z00;  // ray start relative to v0 = v00
         const float side = sy * wx - sx * wy;  // > 0: the half that holds v01, face (ind0, ind3, ind1); else (ind0, ind2, ind3)
