@@ -39,6 +39,9 @@ MLP_F16_MFMA_FLOP_PER_ENV = 12 * 3 * 2 * (32 * 32 + 32 * 32)
 # env step: without the second actuator history and the dense height scan that this build's launches also move)
 RECIPE_BYTES_PER_ENV_STEP = 4 * 1960 + 3645
 GRAPH_WARMUP_REPLAYS = 20      # per recorded graph, whatever --warmup says
+# ... and the untimed steps go on until this much time has passed under load: the GPU reaches its sustained clocks only
+# after some tens of milliseconds of work (the same 200 steps take 88 us each behind 40 warm-up steps, 83 us behind 1000)
+WARMUP_SECONDS = 0.15
 
 def build_env(device, num_envs, seed, actuator="mlp"):
     """The headline configuration's step object and its synthetic state (what the probe scripts under tools/ use)."""
@@ -231,14 +234,28 @@ def main():
             reducer.end_step()
 
     restart_clocks = getattr(cfg, "restart_sensor_clocks", None)
+    warm_steps = {}   # untimed steps actually run ahead of each timed region
 
     def timed(one_step, replayed=False):
         if restart_clocks is not None:   # the sensors' clocks start every timed region where an env reset leaves them
             restart_clocks()
         # a recorded graph settles over its first replays: each gets its share of warm-up whatever --warmup says
         warm = max(args.warmup, GRAPH_WARMUP_REPLAYS * len(graphs)) if replayed else args.warmup
+        w0 = time.perf_counter()
         for _ in range(warm):
             one_step()
+        torch.cuda.synchronize()
+        extra = 0
+        while time.perf_counter() - w0 < WARMUP_SECONDS:
+            for _ in range(100):
+                one_step()
+            torch.cuda.synchronize()
+            extra += 100
+        warm_steps[one_step.__name__] = warm + extra
+        if extra and restart_clocks is not None:   # the timed steps start from the same clocks as they would behind `warm` steps alone
+            restart_clocks()
+            for _ in range(warm):
+                one_step()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
@@ -263,23 +280,15 @@ def main():
     # depend on, so the number holds with a simulator between the substeps.  Beside it, for the network actuators: the
     # recording with the sensor chain as a branch parallel to the actuator chain -- possible here only because all four
     # substeps' physics results are already in memory.
-    # The headline is measured before the two-branch recording has ever run: once a process has replayed a graph with
-    # parallel branches (more hardware queues in use), every later replay of the one-chain graph takes 3-4 us longer --
-    # a state that a deployment stepping in the reference's order never enters.
     two_branch_s = None
     if use_graph:
         other_s = timed(eager_step)
-        two_branches = getattr(cfg, "overlap_in_graph", False)
-        cfg.overlap_in_graph = False
-        graphs = capture_step(cfg, reducer)
-        elapsed = timed(graph_step, replayed=True)
-        if two_branches:
-            one_chain = graphs
-            cfg.overlap_in_graph = True
+        if getattr(cfg, "overlap_in_graph", False):
             graphs = capture_step(cfg, reducer)
             two_branch_s = timed(graph_step, replayed=True)
             cfg.overlap_in_graph = False
-            graphs = one_chain
+        graphs = capture_step(cfg, reducer)
+        elapsed = timed(graph_step, replayed=True)
     else:
         elapsed = timed(eager_step)
         if world == 1:
@@ -414,7 +423,8 @@ def main():
             if exact_us is not None:
                 line["mlp_exact_f32_us"] = round(exact_us, 2)
         if use_graph:
-            line["graph_warmup_replays"] = max(args.warmup, GRAPH_WARMUP_REPLAYS * len(graphs)) // len(graphs)
+            line["graph_warmup_replays"] = warm_steps.get("graph_step", 0) // len(graphs)
+            line["warmup_seconds"] = WARMUP_SECONDS
         line["launch_mode"] = ("hip-graph replay of the step recorded as one chain in the reference's order (no launch ahead of a physics "
                                "step it would depend on), once per statistics vector" if use_graph else "eager: one host call per launch")
         if other_s is not None:

@@ -1,7 +1,8 @@
 """Diagnostic: duration of named launches of one configuration (events on the launch stream, back to back behind a
 blocker), and optionally of the whole step replayed from a graph:
     python tools/probes/launch_time.py anymal "actuator_net_mlp+scene_update,raycaster_cast" [--step [--stats]]
-(--stats: with the episode statistics, two graphs in turn, as bench.py replays the step)"""
+(--stats: with the episode statistics, two graphs in turn, as bench.py replays the step; --two-branches: the recording
+with the sensor chain as a parallel branch instead of the one-chain headline; --blocks: per-100-step times of 3000 steps)"""
 import sys
 import time
 
@@ -24,17 +25,7 @@ for rep in range(0 if "--no-kernels" in sys.argv else 3):
 if "--step" in sys.argv:
     from isaaclab_amd.distributed import OverlappedLogReducer
     reducer = OverlappedLogReducer(cfg.log_sums.numel(), dev) if "--stats" in sys.argv and cfg.log_sums is not None else None
-    if "--like-bench" in sys.argv:   # what bench.py does ahead of the headline's recording: eager steps, the two-branch recording
-        if "--no-eager" not in sys.argv:
-            for _ in range(210):
-                cfg.step()
-        if "--no-two" not in sys.argv:
-            cfg.overlap_in_graph = True
-            g2 = bench.capture_step(cfg, reducer)
-            for k in range(240):
-                g2[k % len(g2)].replay()
-            torch.cuda.synchronize()
-            cfg.overlap_in_graph = False
+    cfg.overlap_in_graph = "--two-branches" in sys.argv   # (the sensor chain as a branch beside the actuator chain)
     graphs = bench.capture_step(cfg, reducer)
     run_on = torch.cuda.Stream() if "--own-stream" in sys.argv else torch.cuda.current_stream()
     torch.cuda.set_stream(run_on)
@@ -54,3 +45,14 @@ if "--step" in sys.argv:
         h2 = time.perf_counter()
         print(f"step replayed ({len(graphs)} graph(s) in turn):", round(a.elapsed_time(b) * 1e3 / 200, 2), "us;  the host's share of a replay:",
               round((h1 - h0) * 1e6 / 200, 2), "us;  by the host's clock, with the wait for the last one:", round((h2 - h0) * 1e6 / 200, 2), "us")
+    if "--blocks" in sys.argv:
+        cfg.restart_sensor_clocks()
+        torch.cuda.synchronize()
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(31)]
+        ev[0].record()
+        for blk in range(30):
+            for k in range(100):
+                graphs[k % len(graphs)].replay()
+            ev[blk + 1].record()
+        torch.cuda.synchronize()
+        print("per step, blocks of 100 steps:", " ".join(f"{ev[b].elapsed_time(ev[b + 1]) * 10:.1f}" for b in range(30)))
