@@ -39,9 +39,7 @@ MLP_F16_MFMA_FLOP_PER_ENV = 12 * 3 * 2 * (32 * 32 + 32 * 32)
 # env step: without the second actuator history and the dense height scan that this build's launches also move)
 RECIPE_BYTES_PER_ENV_STEP = 4 * 1960 + 3645
 GRAPH_WARMUP_REPLAYS = 20      # per recorded graph, whatever --warmup says
-# ... and the untimed steps go on until this much time has passed under load: the GPU reaches its sustained clocks only
-# after some tens of milliseconds of work (the same 200 steps take 88 us each behind 40 warm-up steps, 83 us behind 1000)
-WARMUP_SECONDS = 0.15
+CUS = 256                      # compute units of an MI355X (4 SIMDs each)
 
 def build_env(device, num_envs, seed, actuator="mlp"):
     """The headline configuration's step object and its synthetic state (what the probe scripts under tools/ use)."""
@@ -241,21 +239,9 @@ def main():
             restart_clocks()
         # a recorded graph settles over its first replays: each gets its share of warm-up whatever --warmup says
         warm = max(args.warmup, GRAPH_WARMUP_REPLAYS * len(graphs)) if replayed else args.warmup
-        w0 = time.perf_counter()
         for _ in range(warm):
             one_step()
-        torch.cuda.synchronize()
-        extra = 0
-        while time.perf_counter() - w0 < WARMUP_SECONDS:
-            for _ in range(100):
-                one_step()
-            torch.cuda.synchronize()
-            extra += 100
-        warm_steps[one_step.__name__] = warm + extra
-        if extra and restart_clocks is not None:   # the timed steps start from the same clocks as they would behind `warm` steps alone
-            restart_clocks()
-            for _ in range(warm):
-                one_step()
+        warm_steps[one_step.__name__] = warm
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
@@ -385,6 +371,9 @@ def main():
                         algorithmic_bytes_per_launch=nbytes[worst] * args.envs, traffic=None)
         if "traffic" in profiles and worst in profiles["traffic"]:   # HBM-side bytes per launch from the committed counter passes
             roofline["traffic"] = profiles["traffic"][worst]["hbm_bytes_per_launch"]
+        if "sq" in profiles and worst in profiles["sq"] and "SQ_INSTS_VALU" in profiles["sq"][worst]:
+            # what a kernel far below both roofs is busy with: vector instructions issued per SIMD and launch (committed counter pass)
+            roofline["valu_insts_per_simd"] = round(profiles["sq"][worst]["SQ_INSTS_VALU"] / (4 * CUS))
         if "mfma_frac" in w:
             roofline.update(mfma_frac=w["mfma_frac"], hbm_frac=w["hbm_frac"])
             if "sq" in profiles and worst in profiles["sq"] and "mfma_busy_frac" in profiles["sq"][worst]:
@@ -424,7 +413,6 @@ def main():
                 line["mlp_exact_f32_us"] = round(exact_us, 2)
         if use_graph:
             line["graph_warmup_replays"] = warm_steps.get("graph_step", 0) // len(graphs)
-            line["warmup_seconds"] = WARMUP_SECONDS
         line["launch_mode"] = ("hip-graph replay of the step recorded as one chain in the reference's order (no launch ahead of a physics "
                                "step it would depend on), once per statistics vector" if use_graph else "eager: one host call per launch")
         if other_s is not None:

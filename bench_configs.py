@@ -38,15 +38,16 @@ class Config:
         return sum(self.bytes_per_env[k] * n for k, (_, n) in self.launches.items())
 
 
-def _locomotion_bytes(j, b, r, obs_dim, n_rewards, actuator):
+def _locomotion_bytes(j, b, r, obs_dim, n_rewards, actuator, hit_records=True):
     f = 4 * j           # one fp32 per joint
     out = {
         # InteractiveScene.update in one launch -- contact: read net forces, write one history row (ring; net_forces_w
         # is its newest entry and not written apart) + head 8, read+write 4 timers, clock 18; joint_acc: read vel,
         # read+write previous vel, write acc; scanner clock 18
         "scene_update": 2 * 12 * b + 8 + 8 * 4 * b + 18 + 4 * f + 18,
-        # read pose 28 + clock 9, write pose 28, ray hits R*12, height scan R*4, clock 5
-        "raycaster_refresh": 28 + 9 + 28 + r * 12 + r * 4 + 5,
+        # read pose 28 + clock 9, write pose 28, ray hits R*12 (not in a refresh that leaves them to their first reader:
+        # RayCaster.lean_hits, what the fused steps run), height scan R*4, clock 5
+        "raycaster_refresh": 28 + 9 + 28 + (r * 12 if hit_records else 0) + r * 4 + 5,
         # read root 52, joints (pos, vel, acc, torque, default) 5f, actions 2f, contact history 3*B*12, timers 2*4B,
         # height scan 4R, sensor pos 12, command state r+w ~82, ep_len r+w 16 (noise: parity mode only, not counted);
         # write obs, reward 4, step_reward, episode sums r+w, flags 5
@@ -153,7 +154,7 @@ def build_locomotion(device, envs, seed, robot="anymal_c", actuator="mlp", stati
                             "ActuatorNetLSTM LSTM(2, 8, 2 layers) + 8-32-1 softsign head")
     else:
         info["actuator"] = "DCMotor (PD + torque-speed envelope)"
-    nbytes = _locomotion_bytes(j, b, r, int(env.mdp.obs_dim), n_rewards, act_kernel)
+    nbytes = _locomotion_bytes(j, b, r, int(env.mdp.obs_dim), n_rewards, act_kernel, hit_records=not env.scanner.lean_hits)
     if act_kernel == "actuator_net_mlp" and env.joint_action_rides:
         # process_action is done by the step's first network launch: three plain network launches and one that carries it
         def actuate_first():
