@@ -662,6 +662,18 @@ int ilx_actuator_net_mlp_joint_action(ilx_mlp_t net, const float* raw_action, fl
                                       float saturation_effort, float* computed, float* applied, int64_t n, int j,
                                       int flags, float* log_sums, int32_t log_count, uint64_t* step_index_device,
                                       void* stream);
+/* ... and for the PD models (ilx_actuator_pd, declared above), with a joint action term whose joints are consecutive
+ * (JointPositionAction / JointEffortAction, joint_actions.py:130-160, 214-225; action_manager.py:331-332): prev_action <-
+ * action <- raw_action (n, width); the target of joints first_joint .. first_joint + width - 1 <- raw_action *
+ * action_scale + action_offset ((n, width) or NULL: zeros) -- `target` 0: their position target in q_des, 1: their effort
+ * target in tau_ff, both OUTPUTS for those joints (the later substeps read them) --; the statistics vector cleared and the
+ * step count advanced as by ilx_joint_action_process_begin; then the model on all j joints.  One launch.  n > 0. */
+int ilx_actuator_pd_joint_action(int model, const float* raw_action, float* action, float* prev_action, float action_scale,
+                                 const float* action_offset, int32_t target, int32_t first_joint, int32_t width, float* q_des,
+                                 const float* qd_des, float* tau_ff, const float* q, const float* qd, const float* stiffness,
+                                 const float* damping, const float* effort_limit, const float* velocity_limit,
+                                 int params_per_env, float saturation_effort, float* computed, float* applied, int64_t n, int j,
+                                 float* log_sums, int32_t log_count, uint64_t* step_index_device, void* stream);
 /* The same pairing for the PD models (ilx_actuator_pd, declared above): always one launch. */
 int ilx_actuator_pd_scene_update(int model, const float* q_des, const float* qd_des, const float* tau_ff, const float* q,
                                  const float* qd, const float* stiffness, const float* damping, const float* effort_limit,

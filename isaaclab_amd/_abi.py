@@ -196,6 +196,8 @@ raycaster_reserve = _sig("ilx_raycaster_reserve", P, c_int64, ctypes.c_int32, ct
 mesh_forget_patterns = _sig("ilx_mesh_forget_patterns", P)
 actuator_net_mlp_joint_action = _sig("ilx_actuator_net_mlp_joint_action", P, P, P, P, c_float, P, P, P, P, P, P, c_int, P, c_int, c_int,
                                      c_float, c_float, c_float, P, P, c_int, c_float, P, P, c_int64, c_int, c_int, P, ctypes.c_int32, P, P)
+actuator_pd_joint_action = _sig("ilx_actuator_pd_joint_action", c_int, P, P, P, c_float, P, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+                                P, P, P, P, P, P, P, P, P, c_int, c_float, P, P, c_int64, c_int, P, ctypes.c_int32, P, P)
 actuator_pd_scene_update = _sig("ilx_actuator_pd_scene_update", c_int, P, P, P, P, P, P, P, P, P, c_int, c_float, P, P, c_int64, c_int,
                                 ctypes.POINTER(Scene), P)
 actuator_net_mlp_scene_update = _sig("ilx_actuator_net_mlp_scene_update", P, P, P, P, P, P, c_int, P, c_int, c_int, c_float, c_float, c_float,

@@ -18,7 +18,9 @@ from .actuator_base import ActuatorBase
 _IDEAL, _DC = 0, 1
 
 
-def _launch_pd(model, act, control_action, joint_pos, joint_vel, vel_limit, sat, scene_update=None):
+def _launch_pd(model, act, control_action, joint_pos, joint_vel, vel_limit, sat, scene_update=None, joint_action=None):
+    if joint_action is not None:
+        return _launch_pd_joint_action(model, act, control_action, joint_pos, joint_vel, vel_limit, sat, joint_action)
     q_des = _abi.f32c(control_action.joint_positions)
     qd_des = None if control_action.joint_velocities is None else _abi.f32c(control_action.joint_velocities)
     tau_ff = None if control_action.joint_efforts is None else _abi.f32c(control_action.joint_efforts)
@@ -34,14 +36,36 @@ def _launch_pd(model, act, control_action, joint_pos, joint_vel, vel_limit, sat,
         _abi.check(_abi.actuator_pd(*args, _abi.stream()), "ilx_actuator_pd")
 
 
+def _launch_pd_joint_action(model, act, control_action, joint_pos, joint_vel, vel_limit, sat, ja):
+    """The first substep's launch with the joint action term on it (``ilx_actuator_pd_joint_action``).  ``ja``: ``raw``,
+    ``action``, ``prev_action`` (n, width), ``scale``, ``offset`` ((n, width) or None), ``target`` ("position" / "effort"),
+    ``first_joint``, ``width`` and ``begin`` (``FusedMdp.begin_step_args`` or None).  The targets are written in place:
+    they must be the articulation's own (n, j) buffers."""
+    q_des, tau_ff = control_action.joint_positions, control_action.joint_efforts
+    for t in (q_des, tau_ff):
+        if t is not None and not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+            raise _abi.IlxError("a joint action that rides on the actuator launch needs contiguous float32 GPU target buffers")
+    qd_des = None if control_action.joint_velocities is None else _abi.f32c(control_action.joint_velocities)
+    q, qd = _abi.f32c(joint_pos), _abi.f32c(joint_vel)
+    n, j = q.shape
+    begin = ja.get("begin") or (None, 0, None)
+    _abi.check(_abi.actuator_pd_joint_action(
+        model, _abi.ptr(_abi.f32c(ja["raw"])), _abi.ptr(ja["action"]), _abi.ptr(ja["prev_action"]), float(ja["scale"]),
+        None if ja.get("offset") is None else _abi.ptr(ja["offset"]), {"position": 0, "effort": 1}[ja["target"]],
+        int(ja["first_joint"]), int(ja["width"]), _abi.ptr(q_des), _abi.ptr(qd_des), _abi.ptr(tau_ff), _abi.ptr(q), _abi.ptr(qd),
+        _abi.ptr(act.stiffness), _abi.ptr(act.damping), _abi.ptr(act.effort_limit),
+        None if vel_limit is None else _abi.ptr(vel_limit), 1, float(sat), _abi.ptr(act.computed_effort),
+        _abi.ptr(act.applied_effort), n, j, *begin, _abi.stream()), "ilx_actuator_pd_joint_action")
+
+
 class ImplicitActuator(ActuatorBase):
     """actuator_pd.py:32-87: targets pass through; the PD torque is only estimated (for reward terms)."""
 
     def reset(self, *args, **kwargs):
         pass
 
-    def compute(self, control_action, joint_pos, joint_vel, scene_update=None):
-        _launch_pd(_IDEAL, self, control_action, joint_pos, joint_vel, None, 0.0, scene_update)
+    def compute(self, control_action, joint_pos, joint_vel, scene_update=None, joint_action=None):
+        _launch_pd(_IDEAL, self, control_action, joint_pos, joint_vel, None, 0.0, scene_update, joint_action)
         return control_action
 
 
@@ -51,10 +75,11 @@ class IdealPDActuator(ActuatorBase):
     def reset(self, env_ids: Sequence[int]):
         pass
 
-    def compute(self, control_action, joint_pos, joint_vel, scene_update=None):
+    def compute(self, control_action, joint_pos, joint_vel, scene_update=None, joint_action=None):
         """``scene_update`` (no counterpart in the reference): the descriptor of the scene update of the substep before
-        (``InteractiveScene.describe_update``), which then travels with this launch."""
-        _launch_pd(_IDEAL, self, control_action, joint_pos, joint_vel, None, 0.0, scene_update)
+        (``InteractiveScene.describe_update``), which then travels with this launch.  ``joint_action`` (likewise): the
+        joint action term whose processing rides on the step's first launch (``_launch_pd_joint_action``)."""
+        _launch_pd(_IDEAL, self, control_action, joint_pos, joint_vel, None, 0.0, scene_update, joint_action)
         control_action.joint_efforts = self.applied_effort
         control_action.joint_positions = None
         control_action.joint_velocities = None
@@ -71,9 +96,10 @@ class DCMotor(IdealPDActuator):
         if self.cfg.velocity_limit is None:
             raise ValueError("The velocity limit must be provided for the DC motor actuator model.")
 
-    def compute(self, control_action, joint_pos, joint_vel, scene_update=None):
+    def compute(self, control_action, joint_pos, joint_vel, scene_update=None, joint_action=None):
         self._joint_vel = joint_vel  # kept for API compatibility; the kernel reads joint_vel directly
-        _launch_pd(_DC, self, control_action, joint_pos, joint_vel, self.velocity_limit, self._saturation_effort, scene_update)
+        _launch_pd(_DC, self, control_action, joint_pos, joint_vel, self.velocity_limit, self._saturation_effort, scene_update,
+                   joint_action)
         control_action.joint_efforts = self.applied_effort
         control_action.joint_positions = None
         control_action.joint_velocities = None

@@ -74,6 +74,65 @@ pd_scene_kernel(const float* __restrict__ q_des, const float* __restrict__ qd_de
                                   j, blockIdx.x - su_blocks);
 }
 
+// The PD actuator model of an env step's FIRST physics substep together with what precedes it in the step: the action
+// manager's bookkeeping and a joint action term with consecutive joints (action_manager.py:331-332, joint_actions.py:130-160,
+// 214-225), whose processed action becomes the position or effort target of joints first .. first + width - 1 before
+// the model reads it; the first workgroup also opens the step for the fused managers (as joint_action_kernel does).
+// A thread owns one (env, joint) and, where the joint is the action term's, the action element that goes with it.
+struct PdJointAction {
+    const float* raw;      // (n, width)
+    float* action;         // (n, width) or null
+    float* prev_action;    // (n, width) or null
+    const float* offset;   // (n, width) or null
+    float scale;
+    int target;            // 0: q_des, 1: tau_ff
+    int first, width;
+    float* log_sums;       // the step's opening (or null / 0 / null)
+    int log_count;
+    uint64_t* step_index_device;
+};
+template <int MODEL>
+__global__ void __launch_bounds__(256)
+pd_joint_action_kernel(PdJointAction ja, float* __restrict__ q_des, const float* __restrict__ qd_des, float* __restrict__ tau_ff,
+                       const float* __restrict__ q, const float* __restrict__ qd, const float* __restrict__ kp,
+                       const float* __restrict__ kd, const float* __restrict__ effort_limit, const float* __restrict__ vel_limit,
+                       int per_env, float sat, float* __restrict__ computed, float* __restrict__ applied, int64_t total, int j) {
+    if (blockIdx.x == 0) {
+        for (int k = threadIdx.x; k < ja.log_count; k += blockDim.x) ja.log_sums[k] = 0.0f;
+        if (ja.step_index_device && threadIdx.x == 0) *ja.step_index_device += 1;
+    }
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int64_t env = i / j;
+    const int joint = static_cast<int>(i - env * j);
+    const int64_t pi = per_env ? i : joint;
+    float target_q = q_des[i], target_tau = tau_ff ? tau_ff[i] : 0.0f;
+    const int a = joint - ja.first;
+    if (a >= 0 && a < ja.width) {
+        const int64_t ai = env * ja.width + a;
+        const float r = ja.raw[ai];
+        if (ja.prev_action) ja.prev_action[ai] = ja.action[ai];
+        if (ja.action) ja.action[ai] = r;
+        const float v = r * ja.scale + (ja.offset ? ja.offset[ai] : 0.0f);   // joint_actions.py:134-135
+        if (ja.target == 0) q_des[i] = v, target_q = v;
+        else tau_ff[i] = v, target_tau = v;
+    }
+    const float vel = qd[i];
+    // actuator_pd.py:135-138, evaluated left to right
+    const float e_pos = target_q - q[i];
+    const float e_vel = (qd_des ? qd_des[i] : 0.0f) - vel;
+    const float tau = kp[pi] * e_pos + kd[pi] * e_vel + target_tau;
+    const float lim = effort_limit[pi];
+    float out;
+    if (MODEL == 1) {
+        out = dc_motor_clip(tau, vel, sat, vel_limit[pi], lim);
+    } else {
+        out = fminf(fmaxf(tau, -lim), lim);  // actuator_base.py:252-261
+    }
+    computed[i] = tau;
+    applied[i] = out;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Delayed / remotized PD (actuator_pd.py:236-363)
 // ------------------------------------------------------------------------------------------------
@@ -1152,6 +1211,41 @@ extern "C" int ilx_actuator_pd_scene_update(int model, const float* q_des, const
     ILX_REQUIRE(scene, ILX_EINVAL, "ilx_actuator_pd_scene_update: scene is NULL");
     return actuator_pd(model, q_des, qd_des, tau_ff, q, qd, stiffness, damping, effort_limit, velocity_limit, params_per_env,
                        saturation_effort, computed, applied, n, j, scene, stream);
+}
+
+extern "C" int ilx_actuator_pd_joint_action(int model, const float* raw_action, float* action, float* prev_action,
+                                            float action_scale, const float* action_offset, int32_t target, int32_t first_joint,
+                                            int32_t width, float* q_des, const float* qd_des, float* tau_ff, const float* q,
+                                            const float* qd, const float* stiffness, const float* damping,
+                                            const float* effort_limit, const float* velocity_limit, int params_per_env,
+                                            float saturation_effort, float* computed, float* applied, int64_t n, int j,
+                                            float* log_sums, int32_t log_count, uint64_t* step_index_device, void* stream) {
+    ILX_REQUIRE(model == ILX_ACTUATOR_IDEAL_PD || model == ILX_ACTUATOR_DC_MOTOR, ILX_EINVAL,
+                "ilx_actuator_pd_joint_action: unknown model %d", model);
+    ILX_REQUIRE(n > 0 && j > 0, ILX_EINVAL, "ilx_actuator_pd_joint_action: bad shape (%lld, %d)", (long long)n, j);
+    ILX_REQUIRE(raw_action && q_des && q && qd && stiffness && damping && effort_limit && computed && applied, ILX_EINVAL,
+                "ilx_actuator_pd_joint_action: NULL operand");
+    ILX_REQUIRE(!prev_action || action, ILX_EINVAL, "ilx_actuator_pd_joint_action: prev_action needs action");
+    ILX_REQUIRE(target == 0 || (target == 1 && tau_ff), ILX_EINVAL,
+                "ilx_actuator_pd_joint_action: target %d (0: q_des, 1: tau_ff, which must then be given)", target);
+    ILX_REQUIRE(width > 0 && first_joint >= 0 && first_joint + width <= j, ILX_ESHAPE,
+                "ilx_actuator_pd_joint_action: joints %d .. %d of %d", first_joint, first_joint + width - 1, j);
+    ILX_REQUIRE(model != ILX_ACTUATOR_DC_MOTOR || velocity_limit, ILX_EINVAL,
+                "ilx_actuator_pd_joint_action: the DC motor model needs velocity_limit");
+    ILX_REQUIRE(log_count >= 0 && (log_count == 0 || log_sums), ILX_EINVAL,
+                "ilx_actuator_pd_joint_action: %d floats at a NULL pointer", log_count);
+    const PdJointAction ja{raw_action, action, prev_action, action_offset, action_scale, target, first_joint, width,
+                             log_sums, log_sums ? log_count : 0, step_index_device};
+    const int64_t total = n * j;
+    dim3 g(blocks_for(total)), b(256);
+    if (model == ILX_ACTUATOR_DC_MOTOR)
+        hipLaunchKernelGGL(pd_joint_action_kernel<1>, g, b, 0, as_stream(stream), ja, q_des, qd_des, tau_ff, q, qd, stiffness, damping,
+                           effort_limit, velocity_limit, params_per_env, saturation_effort, computed, applied, total, j);
+    else
+        hipLaunchKernelGGL(pd_joint_action_kernel<0>, g, b, 0, as_stream(stream), ja, q_des, qd_des, tau_ff, q, qd, stiffness, damping,
+                           effort_limit, velocity_limit, params_per_env, saturation_effort, computed, applied, total, j);
+    ILX_LAUNCH_CHECK("ilx_actuator_pd_joint_action");
+    return ILX_OK;
 }
 
 // Workgroups per CU of the network kernels whose wavefronts stay (mlp_split_persistent).  Three wavefronts per SIMD: the

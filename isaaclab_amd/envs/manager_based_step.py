@@ -98,6 +98,15 @@ class ManagerBasedStep:
 
     opens_with_joint_action = False   # process_action is one ilx_joint_action_process launch (see _joint_action)
     _begin = None
+    # True: inside step() the action term's processing and the manager's bookkeeping are part of the first substep's
+    # actuator launch (ilx_actuator_pd_joint_action) instead of a launch of their own plus a copy into the target buffer
+    joint_action_rides = True
+    _ride = None
+
+    def joint_action_ride(self, raw):
+        """The description of the action term for ``actuator.compute(..., joint_action=)``, or None when the term cannot
+        ride (then process_action / apply_action run as launches of their own)."""
+        return None
 
     def process_action(self, raw):
         raise NotImplementedError
@@ -130,7 +139,12 @@ class ManagerBasedStep:
                 self._begin = self.mdp.begin_step_args(self.clear_log_sums, self._advance_count_first)
             else:
                 self.mdp.begin_step(clear_log_sums=self.clear_log_sums, advance_step_count=self._advance_count_first)
-        self.process_action(raw_action)
+        # a joint action term with consecutive joints rides on the first substep's actuator launch (joint_action_ride)
+        self._ride = self.joint_action_ride(_abi.f32c(raw_action)) if self.joint_action_rides else None
+        if self._ride is None:
+            self.process_action(raw_action)
+        elif self._begin is None and (self.clear_log_sums or self._advance_count_first):
+            raise RuntimeError("a step whose joint action rides on the actuator launch opens with it")
         self._begin = None
         update = None
         for k in range(self.decimation):
@@ -181,13 +195,19 @@ class CartpoleStep(ManagerBasedStep):
     def process_action(self, raw):  # joint_actions.py:130-139, 214-225 (JointEffortAction, no offset)
         self._joint_action(_abi.f32c(raw), CP.ACTION_SCALE, None, self._effort, 1)
 
+    def joint_action_ride(self, raw):   # the cart's effort target = raw * 100 (joint_actions.py:214-225)
+        return dict(raw=raw, action=self.action, prev_action=self.prev_action, scale=CP.ACTION_SCALE, offset=None,
+                    target="effort", first_joint=0, width=1, begin=self._begin)
+
     def apply_action(self, scene_update=None, first=True):
         d = self.data
-        if first:
+        ride = self._ride if first else None
+        if first and ride is None:
             d.joint_effort_target[:, 0:1] = self._effort      # set_joint_effort_target(processed, joint_ids=[cart])
         ca = ArticulationActions(joint_positions=d.joint_pos_target, joint_velocities=d.joint_vel_target,
                                  joint_efforts=d.joint_effort_target, joint_indices=slice(None))
-        self.actuator.compute(ca, d.joint_pos, d.joint_vel, scene_update=scene_update)
+        self.actuator.compute(ca, d.joint_pos, d.joint_vel, scene_update=scene_update, joint_action=ride)
+        self._ride = None
 
 
 class ReachStep(ManagerBasedStep):
@@ -253,10 +273,18 @@ class ReachStep(ManagerBasedStep):
             self.action.copy_(raw)
             self.ik.process_actions(raw)
 
+    def joint_action_ride(self, raw):   # JointPositionAction on consecutive arm joints: target = raw * 0.5 + default
+        if self.ik is not None or not isinstance(self._arm_index, slice):
+            return None
+        return dict(raw=raw, action=self.action, prev_action=self.prev_action, scale=RE.ARM_ACTION_SCALE, offset=self._arm_default,
+                    target="position", first_joint=self._arm[0], width=self.arm_dof, begin=self._begin)
+
     def apply_action(self, scene_update=None, first=True):
         d = self.data
+        ride = self._ride if first else None
+        self._ride = None
         if self.ik is None:
-            if first:
+            if first and ride is None:
                 d.joint_pos_target[:, self._arm_index] = self._arm_target
         else:
             if scene_update is not None:   # the IK term reads what the update writes (joint state of the new substep): in order
@@ -265,4 +293,4 @@ class ReachStep(ManagerBasedStep):
             self.ik.apply_actions()
         ca = ArticulationActions(joint_positions=d.joint_pos_target, joint_velocities=d.joint_vel_target,
                                  joint_efforts=d.joint_effort_target, joint_indices=slice(None))
-        self.actuator.compute(ca, d.joint_pos, d.joint_vel, scene_update=scene_update)
+        self.actuator.compute(ca, d.joint_pos, d.joint_vel, scene_update=scene_update, joint_action=ride)

@@ -38,6 +38,13 @@ def test_math_and_articulation_arguments():
           "NULL pointer")
     fails(_abi.joint_action_process_begin(FAKE, FAKE, FAKE, NULL, 1.0, NULL, 0.0, NULL, FAKE, 0, 2, NULL, 0, NULL, NULL), EINVAL,
           "bad shape")
+    # the PD model with the joint action on its launch: an effort target without tau_ff; joints 2..3 of 3; no envs
+    pdja = lambda target, first, width, tau, n: _abi.actuator_pd_joint_action(
+        0, FAKE, FAKE, FAKE, 1.0, NULL, target, first, width, FAKE, NULL, tau, FAKE, FAKE, FAKE, FAKE, FAKE, NULL, 1, 0.0, FAKE, FAKE,
+        n, 3, NULL, 0, NULL, NULL)
+    fails(pdja(1, 0, 2, NULL, 4), EINVAL, "ilx_actuator_pd_joint_action")
+    fails(pdja(0, 2, 2, NULL, 4), ESHAPE, "joints 2 .. 3 of 3")
+    fails(pdja(0, 0, 2, NULL, 0), EINVAL, "bad shape")
 
 
 def test_actuator_arguments():

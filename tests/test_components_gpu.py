@@ -41,6 +41,46 @@ def test_pd_actuators(dev):
                 assert out.joint_positions is None and out.joint_efforts is act.applied_effort
 
 
+def test_pd_with_the_joint_action_on_its_launch_equals_the_separate_launches(dev):
+    """ilx_actuator_pd_joint_action (the step's first actuator launch with the action term on it) against
+    ilx_joint_action_process + the copy into the target buffer + ilx_actuator_pd: every output bit for bit, for a position
+    and an effort target, both models, an action term on a run of joints inside the articulation."""
+    from isaaclab_amd import _abi
+    from isaaclab_amd.actuators import DCMotor, DCMotorCfg, IdealPDActuator, IdealPDActuatorCfg
+    from isaaclab_amd.utils.types import ArticulationActions
+
+    n, j, first, width = 777, 9, 2, 5
+    gen = torch.Generator().manual_seed(5)
+    rnd = lambda *shape: torch.randn(*shape, generator=gen).to(dev)
+    cfgs = ((IdealPDActuator, IdealPDActuatorCfg(stiffness=25.0, damping=0.5, effort_limit=23.5, velocity_limit=30.0)),
+            (DCMotor, DCMotorCfg(stiffness=40.0, damping=5.0, effort_limit=80.0, velocity_limit=7.5, saturation_effort=120.0)))
+    for cls, cfg in cfgs:
+        for target in ("position", "effort"):
+            raw, offset = rnd(n, width), (rnd(n, width) if target == "position" else None)
+            q, qd, qd_des = rnd(n, j), rnd(n, j), rnd(n, j)
+            q_des0, tau0, action0 = rnd(n, j), rnd(n, j), rnd(n, width)
+            outs = []
+            for fused in (False, True):
+                act = cls(cfg, joint_names=_names(j), joint_ids=slice(None), num_envs=n, device=dev)
+                q_des, tau_ff = q_des0.clone(), tau0.clone()
+                action, prev = action0.clone(), torch.zeros(n, width, device=dev)
+                log, count = torch.ones(5, device=dev), torch.zeros(1, dtype=torch.int64, device=dev)
+                ca = ArticulationActions(joint_positions=q_des, joint_velocities=qd_des, joint_efforts=tau_ff, joint_indices=slice(None))
+                if fused:
+                    act.compute(ca, q, qd, joint_action=dict(raw=raw, action=action, prev_action=prev, scale=0.5, offset=offset, target=target,
+                                                             first_joint=first, width=width, begin=(_abi.ptr(log), 5, count.data_ptr())))
+                else:
+                    processed = torch.empty(n, width, device=dev)
+                    _abi.check(_abi.joint_action_process_begin(_abi.ptr(raw), _abi.ptr(action), _abi.ptr(prev), None, 0.5,
+                                                               None if offset is None else _abi.ptr(offset), 0.0, None, _abi.ptr(processed),
+                                                               n, width, _abi.ptr(log), 5, count.data_ptr(), _abi.stream()), "begin")
+                    (q_des if target == "position" else tau_ff)[:, first:first + width] = processed
+                    act.compute(ca, q, qd)
+                outs.append((q_des, tau_ff, action, prev, log, count.float(), act.computed_effort.clone(), act.applied_effort.clone()))
+            for a, b, name in zip(outs[0], outs[1], ("q_des", "tau_ff", "action", "prev_action", "log_sums", "step count", "computed", "applied")):
+                assert_exact(b, a.cpu(), f"{cls.__name__} {target}: {name}")
+
+
 def test_pd_regex_parameters(dev):
     from isaaclab_amd.actuators import DCMotor, DCMotorCfg
 

@@ -117,6 +117,27 @@ int main() {
             hipGraphExecDestroy(ge), hipGraphDestroy(g);
         }
     }
+    // what a replay costs beyond its kernels: graphs of k empty kernels, 200 replays back to back
+    for (int k : {1, 2, 4, 7, 14}) {
+        hipGraph_t g;
+        hipGraphExec_t ge;
+        hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
+        for (int i = 0; i < k; ++i) hipLaunchKernelGGL(nothing, dim3(256), dim3(256), 0, s, i);
+        hipStreamEndCapture(s, &g);
+        hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+        float best = 1e9f;
+        for (int rep = 0; rep < 5; ++rep) {
+            hipEventRecord(e0, s);
+            for (int r = 0; r < 200; ++r) hipGraphLaunch(ge, s);
+            hipEventRecord(e1, s);
+            hipStreamSynchronize(s);
+            float ms;
+            hipEventElapsedTime(&ms, e0, e1);
+            best = std::min(best, ms);
+        }
+        printf("graph of %2d empty kernels: %.2f us per replay (200 replays back to back)\n", k, best * 1e3 / 200);
+        hipGraphExecDestroy(ge), hipGraphDestroy(g);
+    }
     big.in = a, big.out = b, big.n = 256 * 256;
     for (int rep = 0; rep < 3; ++rep) {
         hipLaunchKernelGGL(stamped, dim3(256), dim3(256), 0, s, big);
