@@ -67,6 +67,27 @@ def _locomotion_bytes(j, b, r, obs_dim, n_rewards, actuator, hit_records=True):
     return out
 
 
+def _ride_on_first_actuator_launch(env, raw, launches, nb, decimation):
+    """The step classes whose joint action term rides on the first substep's actuator launch (ManagerBasedStep.
+    joint_action_ride): that launch as a kernel of its own in the tables; process_action and the plain first actuator
+    launch are still timed, at 0 launches per step."""
+    if not env.joint_action_rides or env.joint_action_ride(raw) is None:
+        return
+    from isaaclab_amd.utils.types import ArticulationActions
+
+    d = env.data
+
+    def first_substep():
+        ca = ArticulationActions(joint_positions=d.joint_pos_target, joint_velocities=d.joint_vel_target,
+                                 joint_efforts=d.joint_effort_target, joint_indices=slice(None))
+        env.actuator.compute(ca, d.joint_pos, d.joint_vel, joint_action=env.joint_action_ride(raw))
+
+    launches["actuator_pd_joint_action"] = (first_substep, 1)
+    launches["joint_action_process"] = (launches["joint_action_process"][0], 0)
+    launches["actuator_pd"] = (launches["actuator_pd"][0], decimation - 1)
+    nb["actuator_pd_joint_action"] = nb["actuator_pd"] + nb["joint_action_process"]
+
+
 def build_locomotion(device, envs, seed, robot="anymal_c", actuator="mlp", static_scan=False, root_scatter="origins"):
     from isaaclab_amd import synth
     from isaaclab_amd.envs import fused_mdp as FM
@@ -179,6 +200,17 @@ def build_locomotion(device, envs, seed, robot="anymal_c", actuator="mlp", stati
             launches["actuator_net_mlp+scene_update"] = (update_and_actuate, LV.DECIMATION - 1)
             nbytes["actuator_net_mlp+scene_update"] = nbytes[act_kernel] + nbytes["scene_update"]
             launches[act_kernel], launches["scene_update"] = (actuate, 0), (launches["scene_update"][0], 0)
+    if act_kernel == "actuator_dc_motor" and env.joint_action_rides:
+        # process_action is done by the step's first actuator launch (ilx_actuator_pd_joint_action)
+        def actuate_first_dc():
+            ca = ArticulationActions(joint_positions=d.joint_pos_target, joint_velocities=d.joint_vel_target,
+                                     joint_efforts=d.joint_effort_target)
+            env.actuator.compute(ca, d.joint_pos, d.joint_vel, joint_action=env._process_action(raw, None))
+
+        launches[act_kernel] = (actuate, LV.DECIMATION - 1)
+        launches["actuator_dc_motor_joint_action"] = (actuate_first_dc, 1)
+        del launches["joint_action_process"]
+        nbytes["actuator_dc_motor_joint_action"] = nbytes[act_kernel] + nbytes.pop("joint_action_process")
     if fused:   # the refresh's bytes dealt to the two launches: pose in / out and clocks with the update, the results with the cast
         nbytes["scene_update_prepare"] = nbytes["scene_update"] + 28 + 28 + 5
         nbytes["raycaster_cast"] = nbytes.pop("raycaster_refresh") - (28 + 28 + 5)
@@ -238,6 +270,7 @@ def build_cartpole(device, envs, seed):
         # step_reward 20, episode sums r+w 40, flags 5
         "mdp_step": 16 + 16 + 8 + 16 + 4 + 20 + 40 + 5,
     }
+    _ride_on_first_actuator_launch(env, raw, launches, nb, CP.DECIMATION)
     info = {"decimation": CP.DECIMATION, "joints": 2, "bodies": len(CP.BODIES), "obs_dim": int(env.mdp.obs_dim),
             "actuator": "ImplicitActuator (PD estimate)"}
     cfg = Config("cartpole", n, lambda: env.step(raw), launches, nb, info, env.mdp.log_sums, lambda buf: env.mdp.bind(log_sums=buf))
@@ -299,6 +332,7 @@ def build_reach(device, envs, seed, robot="franka"):
         # 16, ep_len r+w 16; write obs, reward 4, step_reward 20, episode sums r+w 40, flags 3
         "mdp_step": 52 + 28 + 2 * f + 2 * fa + 56 + 8 + 16 + 16 + 4 * int(env.mdp.obs_dim) + 4 + 20 + 40 + 3,
     }
+    _ride_on_first_actuator_launch(env, raw, launches, nb, RE.DECIMATION)
     info = {"robot": robot, "decimation": RE.DECIMATION, "joints": nj, "bodies": nb_bodies, "obs_dim": int(env.mdp.obs_dim),
             "actuator": "ImplicitActuator (PD estimate)", "arm_action": "JointPositionAction scale 0.5", "mdp_kernel": env.mdp.kernel}
     cfg = Config("reach", n, lambda: env.step(raw), launches, nb, info, env.mdp.log_sums, lambda buf: env.mdp.bind(log_sums=buf))

@@ -294,6 +294,9 @@ class LocomotionVelocityStep:
         d = self.data
         if self.joint_action_rides and isinstance(self.actuator, ActuatorNetMLP):
             return (raw_action, self.action, self.prev_action, self.action_scale, d.default_joint_pos, begin)
+        if self.joint_action_rides and isinstance(self.actuator, DCMotor):   # ilx_actuator_pd_joint_action
+            return dict(raw=raw_action, action=self.action, prev_action=self.prev_action, scale=self.action_scale,
+                        offset=d.default_joint_pos, target="position", first_joint=0, width=d._j, begin=begin)
         args = (_abi.ptr(raw_action), _abi.ptr(self.action), _abi.ptr(self.prev_action), None, self.action_scale,
                 _abi.ptr(d.default_joint_pos), 0.0, None, _abi.ptr(d.joint_pos_target), self.n, d._j)
         if begin is not None:
