@@ -247,6 +247,14 @@ void ilx_mdp_plan_destroy(ilx_mdp_plan_t plan);
  * scan, `height_scan` is given; every other call goes to the plan-interpreting kernel.  Both kernels write the same
  * bits into every output (log_sums: the same addends in another order). */
 int ilx_mdp_step(ilx_mdp_plan_t plan, const ilx_mdp* desc, void* stream);
+/* ilx_scene_update(scene) (isaaclab_amd.h: InteractiveScene.update of the last physics substep, scene/interactive_scene.py:
+ * 496-513) followed by ilx_mdp_step, as ManagerBasedRLEnv.step issues them (manager_based_rl_env.py:190-199): the results
+ * are those of the two calls.  Where a compiled kernel serves the plan, the scene holds an articulation only (no contact
+ * sensor, no ray caster clock) and no term of the list reads what the update writes (joint_acc), the update's workgroups
+ * are part of the managers' grid -- one launch instead of two (the Cartpole and Reach lists); every other case is the two
+ * launches. */
+struct ilx_scene;
+int ilx_mdp_step_scene_update(ilx_mdp_plan_t plan, const ilx_mdp* desc, const struct ilx_scene* scene, void* stream);
 /* No counterpart in the reference: the name of the kernel that serves full steps of this plan -- "generic" or the
  * compiled kernel's ("anymal_c_rough", "h1_rough", "cartpole", "reach_j9_a7", ...).  The string is static. */
 const char* ilx_mdp_plan_kernel(ilx_mdp_plan_t plan);

@@ -1086,7 +1086,17 @@ extern "C" int ilx_mdp_begin_step(float* log_sums, int32_t count, uint64_t* step
     return ILX_OK;
 }
 
-extern "C" int ilx_mdp_step(ilx_mdp_plan_t plan, const ilx_mdp* desc, void* stream) {
+// `scene` (or null): the scene update that precedes the step (ilx_mdp_step_scene_update).
+static int mdp_step(ilx_mdp_plan_t plan, const ilx_mdp* desc, void* stream, const ilx_scene* scene);
+
+extern "C" int ilx_mdp_step(ilx_mdp_plan_t plan, const ilx_mdp* desc, void* stream) { return mdp_step(plan, desc, stream, nullptr); }
+
+extern "C" int ilx_mdp_step_scene_update(ilx_mdp_plan_t plan, const ilx_mdp* desc, const ilx_scene* scene, void* stream) {
+    ILX_REQUIRE(scene, ILX_EINVAL, "ilx_mdp_step_scene_update: scene is NULL");
+    return mdp_step(plan, desc, stream, scene);
+}
+
+static int mdp_step(ilx_mdp_plan_t plan, const ilx_mdp* desc, void* stream, const ilx_scene* scene) {
     ILX_REQUIRE(plan && desc, ILX_EINVAL, "ilx_mdp_step: NULL argument");
     const ilx_mdp& d = *desc;
     ILX_REQUIRE(d.num_envs >= 0, ILX_EINVAL, "ilx_mdp_step: negative env count");
@@ -1096,7 +1106,7 @@ extern "C" int ilx_mdp_step(ilx_mdp_plan_t plan, const ilx_mdp* desc, void* stre
                 ILX_EINVAL, "ilx_mdp_step: term counts differ from the plan");
     ILX_REQUIRE(plan->no == 0 || (d.num_joints == plan->dims[0] && d.action_dim == plan->dims[1] && d.command_dim == plan->dims[2]),
                 ILX_EINVAL, "ilx_mdp_step: joint / action / command widths differ from the plan");
-    if (d.num_envs == 0 || (d.phases & ILX_PHASE_ALL) == 0) return ILX_OK;
+    if (d.num_envs == 0 || (d.phases & ILX_PHASE_ALL) == 0) return scene ? ilx_scene_update(scene, stream) : ILX_OK;
     ILX_REQUIRE(d.root_state_w, ILX_EINVAL, "ilx_mdp_step: root_state_w is NULL");
     ILX_REQUIRE(d.num_joints >= 0 && d.num_bodies >= 0 && d.num_sensor_bodies >= 0 && d.action_dim >= 0 &&
                     d.command_dim >= 0 && d.history_len >= 0 && d.num_rays >= 0,
@@ -1147,8 +1157,12 @@ extern "C" int ilx_mdp_step(ilx_mdp_plan_t plan, const ilx_mdp* desc, void* stre
         ILX_REQUIRE(d.body_state_w && d.pose_body_index >= 0 && d.pose_body_index < d.num_bodies, ILX_EINVAL,
                     "ilx_mdp_step: the pose command needs body_state_w and a valid body index");
     if (plan->fast_kernel >= 0 && plan->fast_enabled) {   // the kernel compiled for this term list takes the whole step
-        const int status = mdp_fast_step(*plan, d, stream);
+        const int status = mdp_fast_step(*plan, d, stream, scene);
         if (status <= 0) return status;
+    }
+    if (scene) {   // the plan-interpreting kernel: the update as a launch of its own ahead of it
+        const int status = ilx_scene_update(scene, stream);
+        if (status != ILX_OK) return status;
     }
     const bool pt = d.phases & ILX_PHASE_TERMINATION, pr = d.phases & ILX_PHASE_REWARD, po = d.phases & ILX_PHASE_OBSERVATION;
     MdpDev m;

@@ -59,7 +59,9 @@ struct FastArgs {
     ilx_term terms[kFastMaxTerms];      // [terminations | rewards]: weights and parameters
     int32_t ids[kFastMaxIds];
     const ColParam* colparam;           // one per observation column
-    uint32_t decide_blocks;
+    uint32_t decide_blocks, scan_blocks;
+    SceneArgs scene;                    // the scene update whose workgroups follow the step's in the grid (scene_blocks of them)
+    uint32_t scene_blocks;
 };
 
 #ifdef ILX_FAST_STAMPS  // diagnostics build only: wall-clock stamps (10 ns ticks) of lane 0 of every wavefront of the first blocks
@@ -105,6 +107,7 @@ struct AnymalRough {
     static constexpr int kWavesPerSimd = 5;
     static constexpr int kBatch = 2;
     static constexpr bool kContactsAhead = false;
+    static constexpr bool kSceneBeside = false;   // (the scene update beside the managers: lists without sensors that do not read joint_acc)
     static constexpr int J = 12, B = 17, CB = 17, H = 3, A = 12, CD = 3, R = 187, cmd_kind = ILX_CMD_VELOCITY;
     static constexpr int NT = 2, NR = 11, NO = 8;
     static constexpr TermSig term[NT] = {T(ILX_TERM_TIME_OUT, -1, -1, 1), T(ILX_TERM_ILLEGAL_CONTACT, 1)};
@@ -124,6 +127,7 @@ struct H1Rough {
     static constexpr int kWavesPerSimd = 3;
     static constexpr int kBatch = 4;
     static constexpr bool kContactsAhead = true;
+    static constexpr bool kSceneBeside = false;
     static constexpr int J = 19, B = 20, CB = 20, H = 3, A = 19, CD = 3, R = 187, cmd_kind = ILX_CMD_VELOCITY;
     static constexpr int NT = 2, NR = 14, NO = 8;
     static constexpr TermSig term[NT] = {T(ILX_TERM_TIME_OUT, -1, -1, 1), T(ILX_TERM_ILLEGAL_CONTACT, 1)};
@@ -144,6 +148,7 @@ struct Cartpole {
     static constexpr int kWavesPerSimd = 4;
     static constexpr int kBatch = 4;
     static constexpr bool kContactsAhead = true;
+    static constexpr bool kSceneBeside = true;
     static constexpr int J = 2, B = 3, CB = 0, H = 0, A = 1, CD = 0, R = 0, cmd_kind = ILX_CMD_NONE;
     static constexpr int NT = 2, NR = 5, NO = 2;
     static constexpr TermSig term[NT] = {T(ILX_TERM_TIME_OUT, -1, -1, 1), T(ILX_TERM_JOINT_POS_OUT_OF_MANUAL_LIMIT, 1)};
@@ -160,6 +165,7 @@ struct Reach {
     static constexpr int kWavesPerSimd = 4;
     static constexpr int kBatch = 4;
     static constexpr bool kContactsAhead = true;
+    static constexpr bool kSceneBeside = true;
     static constexpr int J = J_, B = B_, CB = 0, H = 0, A = A_, CD = 7, R = 0, cmd_kind = ILX_CMD_POSE;
     static constexpr int NT = 1, NR = 5, NO = 4;
     static constexpr TermSig term[NT] = {T(ILX_TERM_TIME_OUT, -1, -1, 1)};
@@ -873,6 +879,15 @@ __global__ void __launch_bounds__(kFastBlock) __attribute__((amdgpu_waves_per_eu
     // The generator's step word is the argument plus the caller's device-side count when there is one (the caller
     // advances the count between launches, so it is constant over this one).
     const uint64_t seed = d.seed;
+    // The scene update of the last physics substep beside the managers (lists without sensors, none of whose terms reads
+    // what the update writes -- joint_acc and the previous joint velocities): its workgroups are the grid's last.
+    if constexpr (S::kSceneBeside) {
+        static_assert(!D::reads(ILX_REW_JOINT_ACC_L2) && S::CB == 0 && S::R == 0, "the update writes what this list reads");
+        if (blockIdx.x >= a.decide_blocks + a.scan_blocks) {
+            scene_update_thread(a.scene, blockIdx.x - a.decide_blocks - a.scan_blocks);
+            return;
+        }
+    }
     if (blockIdx.x >= a.decide_blocks) {
         uint64_t gen_step = d.step_index;   // (a scalar load: these workgroups wait for their columns' parameters, scalar loads too, anyway)
         if (d.step_index_device)
@@ -1024,7 +1039,7 @@ static bool matches(const ilx_mdp_plan_s& p, const ilx_mdp& d) {
 }
 
 template <class S>
-static int launch(const ilx_mdp_plan_s& p, const ilx_mdp& d, void* stream) {
+static int launch(const ilx_mdp_plan_s& p, const ilx_mdp& d, void* stream, const ilx_scene* scene) {
     using D = Derived<S>;
     // every buffer the compiled list touches must be there; anything else is the plan-interpreting kernel's business
     const bool joints = d.joint_pos && d.joint_vel && d.joint_acc && d.applied_torque && d.computed_torque && d.default_joint_pos &&
@@ -1049,8 +1064,23 @@ static int launch(const ilx_mdp_plan_s& p, const ilx_mdp& d, void* stream) {
     std::memcpy(a.ids, p.h_ids, sizeof(int32_t) * D::num_ids);
     a.colparam = p.d_colparam;
     a.decide_blocks = static_cast<uint32_t>((d.num_envs + kFastEnvs - 1) / kFastEnvs);
-    const uint32_t scan_blocks = D::scan_groups > 0 ? static_cast<uint32_t>((d.num_envs + kScanEnvs - 1) / kScanEnvs) : 0u;
-    hipLaunchKernelGGL(mdp_fast_kernel<S>, dim3(a.decide_blocks + scan_blocks), dim3(kFastBlock), 0, as_stream(stream), a);
+    a.scan_blocks = D::scan_groups > 0 ? static_cast<uint32_t>((d.num_envs + kScanEnvs - 1) / kScanEnvs) : 0u;
+    a.scene = SceneArgs{};
+    a.scene_blocks = 0;
+    if (scene && scene->num_envs > 0) {
+        // beside the managers: an articulation-only update (joint_acc), which writes nothing that this list reads
+        const bool beside = S::kSceneBeside && !scene->net_forces_in && !scene->ray_timestamp;
+        if (beside) {
+            unsigned blocks = 0;
+            const int rc = scene_args_from(*scene, a.scene, blocks);
+            if (rc != ILX_OK) return rc;
+            a.scene_blocks = blocks;
+        } else {
+            const int rc = ilx_scene_update(scene, stream);
+            if (rc != ILX_OK) return rc;
+        }
+    }
+    hipLaunchKernelGGL(mdp_fast_kernel<S>, dim3(a.decide_blocks + a.scan_blocks + a.scene_blocks), dim3(kFastBlock), 0, as_stream(stream), a);
     ILX_LAUNCH_CHECK("ilx_mdp_step");
     return ILX_OK;
 }
@@ -1058,7 +1088,7 @@ static int launch(const ilx_mdp_plan_s& p, const ilx_mdp& d, void* stream) {
 struct FastKernel {
     const char* name;
     bool (*matches)(const ilx_mdp_plan_s&, const ilx_mdp&);
-    int (*launch)(const ilx_mdp_plan_s&, const ilx_mdp&, void*);
+    int (*launch)(const ilx_mdp_plan_s&, const ilx_mdp&, void*, const ilx_scene*);
 };
 template <class S>
 static constexpr FastKernel entry() {
@@ -1076,12 +1106,12 @@ int mdp_fast_match(const ilx_mdp_plan_s& plan, const ilx_mdp& d) {
 
 const char* mdp_fast_name(int index) { return (index >= 0 && index < kNumKernels) ? kKernels[index].name : "generic"; }
 
-int mdp_fast_step(const ilx_mdp_plan_s& plan, const ilx_mdp& d, void* stream) {
+int mdp_fast_step(const ilx_mdp_plan_s& plan, const ilx_mdp& d, void* stream, const ilx_scene* scene) {
     if (plan.fast_kernel < 0 || plan.fast_kernel >= kNumKernels) return 1;
     if ((d.phases & ILX_PHASE_ALL) != ILX_PHASE_ALL) return 1;
     // the sizes are part of the match; a descriptor that changed them since the plan was made goes the general way
     if (!kKernels[plan.fast_kernel].matches(plan, d)) return 1;
-    return kKernels[plan.fast_kernel].launch(plan, d, stream);
+    return kKernels[plan.fast_kernel].launch(plan, d, stream, scene);
 }
 
 }  // namespace ilx

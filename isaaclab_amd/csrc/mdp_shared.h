@@ -16,6 +16,7 @@
 #include "math_dev.h"
 #include "philox.h"
 #include "uniform_access.h"
+#include "scene_update_dev.h"
 
 #include "../../include/isaaclab_amd_mdp.h"
 
@@ -464,5 +465,8 @@ namespace ilx {
 // and its launch -- ILX_OK when launched, 1 when this step is not for it (other phases, missing optional buffers), <0 on error.
 int mdp_fast_match(const ilx_mdp_plan_s& plan, const ilx_mdp& d);
 const char* mdp_fast_name(int index);
-int mdp_fast_step(const ilx_mdp_plan_s& plan, const ilx_mdp& d, void* stream);
+// `scene` (or null): a scene update that is to precede the step (ilx_mdp_step_scene_update).  A kernel that launches takes
+// care of it -- as workgroups of its own grid where the term list and the scene allow, else as a launch ahead of its own --;
+// a kernel that declines (1) has launched nothing.
+int mdp_fast_step(const ilx_mdp_plan_s& plan, const ilx_mdp& d, void* stream, const ilx_scene* scene = nullptr);
 }  // namespace ilx

@@ -85,6 +85,8 @@ _abi.lib.ilx_mdp_plan_destroy.argtypes = [c_void_p]
 _abi.lib.ilx_mdp_plan_destroy.restype = None
 _abi.lib.ilx_mdp_step.argtypes = [c_void_p, POINTER(MdpDesc), c_void_p]
 _abi.lib.ilx_mdp_step.restype = ctypes.c_int
+_abi.lib.ilx_mdp_step_scene_update.argtypes = [c_void_p, POINTER(MdpDesc), POINTER(_abi.Scene), c_void_p]
+_abi.lib.ilx_mdp_step_scene_update.restype = ctypes.c_int
 _abi.lib.ilx_mdp_begin_step.argtypes = [c_void_p, ctypes.c_int32, c_void_p, c_void_p]
 _abi.lib.ilx_mdp_begin_step.restype = ctypes.c_int
 _abi.lib.ilx_mdp_plan_kernel.argtypes = [c_void_p]
@@ -277,8 +279,10 @@ class FusedMdp:
         self._external[slot] = t
         self.desc.external_obs[slot] = t.data_ptr()
 
-    def step(self, phases: int = PHASE_ALL, step_index: int | None = None, hold_step_count: bool = False):
-        """One launch of the given phases; afterwards the generator's step count advances by one (on the host, or -- see
+    def step(self, phases: int = PHASE_ALL, step_index: int | None = None, hold_step_count: bool = False, scene_update=None):
+        """``scene_update`` (``InteractiveScene.describe_update``): the scene update of the last physics substep, which then
+        precedes the managers -- inside their launch where the term list allows (``ilx_mdp_step_scene_update``).
+        One launch of the given phases; afterwards the generator's step count advances by one (on the host, or -- see
         :meth:`count_steps_on_device` -- by a one-word add on the stream).  An env step issued as several launches
         passes ``hold_step_count=True`` on all but the last, so that every launch of the step draws with the same
         step word; a caller that advances the device-side count itself (:meth:`advance_step_count`) passes it always."""
@@ -287,7 +291,11 @@ class FusedMdp:
             self.desc.step_index = step_index
         elif not self._own_generator and not self._holding:
             self.desc.seed, self.desc.step_index = _rng.seed(), _rng.next_draw("fused_mdp")
-        _abi.check(_abi.lib.ilx_mdp_step(self.plan, ctypes.byref(self.desc), _abi.stream()), "ilx_mdp_step")
+        if scene_update is not None:
+            _abi.check(_abi.lib.ilx_mdp_step_scene_update(self.plan, ctypes.byref(self.desc), ctypes.byref(scene_update), _abi.stream()),
+                       "ilx_mdp_step_scene_update")
+        else:
+            _abi.check(_abi.lib.ilx_mdp_step(self.plan, ctypes.byref(self.desc), _abi.stream()), "ilx_mdp_step")
         self._holding = hold_step_count
         if not hold_step_count:
             self.advance_step_count()

@@ -152,7 +152,8 @@ class ManagerBasedStep:
             # actuator model also carries the scene update of the substep before (no physics step lies between them)
             self.apply_action(update, first=k == 0)
             d.joint_pos, d.joint_vel = ph["joint_pos"][k], ph["joint_vel"][k]   # <sim.step>
-            update = self.scene.describe_update(self.physics_dt) if (self.paired_substeps and k + 1 < self.decimation) else None
+            # (the last substep's update travels with the managers' launch)
+            update = self.scene.describe_update(self.physics_dt) if self.paired_substeps else None
             if update is None:
                 self.scene.update(self.physics_dt)
         d.set_sim_state(root_state_w=ph["root_state_w"], body_state_w=ph.get("body_state_w"))
@@ -163,7 +164,7 @@ class ManagerBasedStep:
                soft_joint_vel_limits=d.soft_joint_vel_limits, body_state_w=d.body_state_w, action=self.action,
                prev_action=self.prev_action, noise_u=noise_u, command_samples=command_samples,
                reset_command_samples=reset_command_samples)
-        m.step(FM.PHASE_ALL, hold_step_count=self._advance_count_first)
+        m.step(FM.PHASE_ALL, hold_step_count=self._advance_count_first, scene_update=update)
         return m.obs, m.reward_buf, m.terminated, m.time_outs
 
     def _actuate(self, actuators):

@@ -253,3 +253,32 @@ def run_reach(dev, arm_action, n, spec=FRANKA):
         assert_close(env.mdp.episode_sums, sums, atol=2e-6, what=f"episode sums step {step}")
         assert trunc.any()
         phys = dict(new_phys)
+
+
+@pytest.mark.parametrize("config, robot", [("cartpole", None), ("reach", "franka"), ("reach", "xarm6")])
+def test_fused_first_and_last_launches_equal_the_separate_ones(dev, config, robot):
+    """The step with its joint action on the first actuator launch (ilx_actuator_pd_joint_action), the scene updates paired
+    with the next substep's actuator launch and the last one inside the managers' launch (ilx_mdp_step_scene_update) against
+    the same step issued as separate launches, and against the fused calls served by the plan-interpreting kernel (where
+    the last update is a launch of its own again): every buffer of the step bit for bit over three steps."""
+    import bench_configs as BC
+
+    def run(paired, rides, compiled):
+        cfg = BC.build(config, dev, 1000, seed=77, **({"robot": robot} if robot else {}))
+        env = cfg.env
+        env.paired_substeps, env.joint_action_rides = paired, rides
+        env.mdp.select_kernel(compiled)
+        for _ in range(3):
+            cfg.step()
+        torch.cuda.synchronize()
+        d, m = env.data, env.mdp
+        return dict(obs=m.obs, reward=m.reward_buf, terminated=m.terminated, time_outs=m.time_outs, episode_sums=m.episode_sums,
+                    episode_length=m.episode_length_buf, action=env.action, prev_action=env.prev_action, joint_acc=d._joint_acc,
+                    previous_joint_vel=d._previous_joint_vel, computed=d.computed_torque, applied=d.applied_torque,
+                    joint_pos_target=d.joint_pos_target, joint_effort_target=d.joint_effort_target)
+
+    fused = run(True, True, True)
+    assert fused["obs"].abs().sum() > 0
+    for name, other in (("separate launches", run(False, False, True)), ("plan-interpreting kernel", run(True, True, False))):
+        for key, value in fused.items():
+            assert_exact(value, other[key].cpu(), f"{config} {robot or ''}: {key} against the {name}")
