@@ -1,9 +1,12 @@
 // In-hand manipulation direct env (reference: isaaclab_tasks/direct/inhand_manipulation/inhand_manipulation_env.py).
 //
-// ilx_inhand_step: a 256-thread block owns 16 environments, 16 threads each.  The first thread of an env takes the
-// decisions (fall / time-out, reward, goal reached, new goal orientation) and leaves what the observation needs in
-// LDS; then the 16 threads write the env's observation row (157 columns for the Shadow hand) with coalesced stores.
-// The two global sums of compute_rewards are reduced per block in LDS and leave as one hardware float add each.
+// ilx_inhand_step: a 256-thread block owns 16 environments, 16 threads each.  For the shapes of the reference's hands
+// (inhand_step_kernel) every thread issues all of its loads -- the decisions' inputs, its columns of the observation
+// row -- before anything else; the env's 16 threads then each take the env's decisions (fall / time-out, reward, goal
+// reached, new goal orientation: the same values in all of them, so nothing is handed over through LDS), the first one
+// stores them, and the 16 write the observation row (157 columns for the Shadow hand) with coalesced stores.  Other
+// shapes take inhand_step_general_kernel: the first thread of an env decides and leaves what the row needs in LDS.
+// The two global sums of compute_rewards are reduced per wavefront / block and leave as one hardware float add each.
 #include "common.h"
 #include "math_dev.h"
 #include "uniform_access.h"
@@ -60,7 +63,7 @@ struct EnvShared {
     float obj_pos[3];
 };
 
-__global__ void __launch_bounds__(256) inhand_step_kernel(ilx_inhand d) {
+__global__ void __launch_bounds__(256) inhand_step_general_kernel(ilx_inhand d) {
     request_kernel_arguments<kernel_argument_bytes<ilx_inhand>()>();
     __shared__ EnvShared sh[kEnvsPerBlock];
     __shared__ float block_stats[2];
@@ -183,6 +186,229 @@ __global__ void __launch_bounds__(256) inhand_step_kernel(ilx_inhand d) {
     }
 }
 
+#ifdef ILX_INHAND_STAMPS
+__device__ unsigned long long g_inhand_stamps[8 * 1024];
+#define IH_STAMP(k) do { __builtin_amdgcn_sched_barrier(0); if (threadIdx.x == 0 && blockIdx.x < 1024) g_inhand_stamps[blockIdx.x * 8 + (k)] = wall_clock64(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define IH_STAMP(k)
+#endif
+
+// Shapes of the unrolled kernel: 2 J <= 64, 13 F <= 80, A <= 32 (Shadow hand: J = 24, F = 5, A = 20; Allegro: 16, 4, 16)
+constexpr int kJointRounds = 4, kTipRounds = 5, kActionRounds = 2;
+static bool inhand_unrolled_shape(int J, int F, int A) { return 2 * J <= 16 * kJointRounds && 13 * F <= 16 * kTipRounds && A <= 16 * kActionRounds; }
+
+// The launch is a chain of trips to memory, not a stream of bytes (one block per CU at 4096 envs), so the kernel is laid
+// out around the trips: one for every input (addresses clamped instead of branched around, since a load inside a branch
+// is waited for where the branch ends), a second one only for the fingertips' body states behind their body indices,
+// and no load after the first store (loads and stores share one in-order counter).
+__global__ void __launch_bounds__(256) inhand_step_kernel(ilx_inhand d) {
+    request_kernel_arguments<kernel_argument_bytes<ilx_inhand>()>();
+    IH_STAMP(0);
+    __shared__ float act_s[kEnvsPerBlock][16 * kActionRounds];
+    __shared__ float block_stats[2];
+    __shared__ uint32_t waves_done;
+    typedef __attribute__((address_space(1))) char* Base;
+    const uint32_t tid = threadIdx.x, e = tid >> 4, g = tid & 15;
+    const int64_t env0 = static_cast<int64_t>(blockIdx.x) * kEnvsPerBlock;
+    const int64_t env = env0 + e;
+    const bool live = env < d.num_envs;
+    const uint32_t ec = live ? e : static_cast<uint32_t>(d.num_envs - 1 - env0);   // the env whose values a thread past the end reads
+    const uint32_t J = d.num_joints, A = d.num_actuated, F = d.num_fingertips, B = d.num_bodies, O = 2 * J + 24 + 13 * F + A;
+    const Base b_act = block_base(d.actions, env0 * A), b_fid = block_base(d.fingertip_ids, 0);
+    const Base b_os = block_base(d.object_state_w, env0 * 13), b_origin = block_base(d.env_origins, env0 * 3);
+    const Base b_hand = block_base(d.in_hand_pos, env0 * 3), b_goal = block_base(d.goal_rot, env0 * 4);
+    const Base b_succ = block_base(d.successes, env0), b_ep = block_base(d.episode_length_buf, env0);
+    const Base b_rgb = block_base(d.reset_goal_buf, env0);
+    const Base b_q = block_base(d.joint_pos, env0 * J), b_qd = block_base(d.joint_vel, env0 * J);
+    const Base b_lo = block_base(d.lower_limits, env0 * J), b_hi = block_base(d.upper_limits, env0 * J);
+    const Base b_body = block_base(d.body_state_w, env0 * B * 13), b_row = block_base(d.obs, env0 * O);
+
+    // ---- first trip: the actions, the fingertips' body indices (both have something waiting for them), then the rest
+    float act[kActionRounds];
+#pragma unroll
+    for (int t = 0; t < kActionRounds; ++t)
+        act[t] = ld_b<float>(b_act, 4u * (__umul24(ec, A) + min(g + 16u * t, A - 1)));
+    uint32_t tip_a[kTipRounds];
+    int32_t tip_body[kTipRounds];
+#pragma unroll
+    for (int t = 0; t < kTipRounds; ++t) {   // fingertip positions (relative to the env origin, :267-270), then rotations, then velocities
+        const uint32_t k = min(g + 16u * t, 13 * F - 1), k1 = k - 3 * F, k2 = k - 7 * F;
+        const bool pos = k < 3 * F, rot = k < 7 * F;
+        // the three readings of k are all computed and one is selected: left to the compiler they become branches, and a
+        // 64-bit multiply-add in one of them takes a register with a load in flight as its unused upper half and waits for it
+        uint32_t f_pos = k / 3, f_vel = k2 / 6;
+        asm volatile("" : "+v"(f_pos), "+v"(f_vel));
+        uint32_t a_pos = k - __umul24(f_pos, 3u), a_vel = 7 + k2 - __umul24(f_vel, 6u);
+        asm volatile("" : "+v"(a_pos), "+v"(a_vel));
+        const uint32_t f = pos ? f_pos : rot ? k1 >> 2 : f_vel;
+        tip_a[t] = pos ? a_pos : rot ? 3 + (k1 & 3) : a_vel;
+        tip_body[t] = ld_b<int32_t>(b_fid, 4u * f);
+    }
+    float os[13];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) os[k] = ld_b<float>(b_os, 4u * (13u * ec + k));
+    float origin[3], hand[3], goal_in[4];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) origin[k] = ld_b<float>(b_origin, 4u * (3u * ec + k)), hand[k] = ld_b<float>(b_hand, 4u * (3u * ec + k));
+#pragma unroll
+    for (int k = 0; k < 4; ++k) goal_in[k] = ld_b<float>(b_goal, 4u * (4u * ec + k));
+    float successes = ld_b<float>(b_succ, 4u * ec);
+    int64_t ep = ld_b<int64_t>(b_ep, 8u * ec) + 1;   // direct_rl_env.py:352
+    const bool goal_flag = ld_b<uint8_t>(b_rgb, ec) != 0;
+    // optional inputs: read through a pointer that is valid either way (a value loaded inside a branch is waited for where
+    // the branch ends, and with it every load before it); what was read in place of an absent one is not used
+    const float* gs = d.goal_samples ? d.goal_samples + 2 * (env0 + ec) : d.goal_rot + 4 * (env0 + ec);
+    const float* rs = d.reset_goal_samples ? d.reset_goal_samples + 2 * (env0 + ec) : d.goal_rot + 4 * (env0 + ec);
+    const float sample[4] = {gs[0], gs[1], rs[0], rs[1]};
+    const uint64_t steps_before = *(d.step_index_device ? d.step_index_device : reinterpret_cast<const uint64_t*>(d.episode_length_buf));
+    float joint[kJointRounds], lo[kJointRounds], hi[kJointRounds];
+#pragma unroll
+    for (int t = 0; t < kJointRounds; ++t) {
+        const uint32_t c = g + 16u * t;
+        const uint32_t at = 4u * (__umul24(ec, J) + min(c < J ? c : c - J, J - 1));
+        joint[t] = ld_b<float>(c < J ? b_q : b_qd, at);
+        lo[t] = ld_b<float>(b_lo, at), hi[t] = ld_b<float>(b_hi, at);
+    }
+    // columns 3-12 of the 24 between the joints and the fingertips are the object's rotation and velocities, 13-15 the hand's position
+    const float misc_os = ld_b<float>(b_os, 4u * (13u * ec + min(max(g, 3u), 12u)));
+    const float misc_hand = ld_b<float>(b_hand, 4u * (3u * ec + min(max(g, 13u), 15u) - 13u));
+    // ---- second trip: the fingertips' states
+    float tip[kTipRounds];
+#pragma unroll
+    for (int t = 0; t < kTipRounds; ++t)
+        tip[t] = ld_b<float>(b_body, 4u * (__umul24(__umul24(ec, B) + static_cast<uint32_t>(tip_body[t]), 13u) + tip_a[t]));
+#pragma unroll
+    for (int t = 0; t < kActionRounds; ++t)
+        if (g + 16u * t < A) act_s[e][g + 16 * t] = act[t];
+    if (tid < 2) block_stats[tid] = 0.0f;
+    if (tid == 2) waves_done = 0;
+    __syncthreads();
+    IH_STAMP(1);
+
+    // ---- _get_dones :179-199, in every thread of the env
+    const f3 obj = {os[0] - origin[0], os[1] - origin[1], os[2] - origin[2]};   // :276
+    const f4 obj_rot = {os[3], os[4], os[5], os[6]};
+    f4 goal = {goal_in[0], goal_in[1], goal_in[2], goal_in[3]};
+    const float goal_dist = norm3(obj.x - hand[0], obj.y - hand[1], obj.z - hand[2]);
+    const bool out_of_reach = goal_dist >= d.fall_dist;
+    const float rot_dist = rotation_distance(obj_rot, goal);
+    const bool at_goal = fabsf(rot_dist) <= d.success_tolerance;
+    bool time_out;
+    if (d.max_consecutive_success > 0) {
+        if (at_goal) ep = 0;
+        time_out = (ep >= d.max_episode_length - 1) || (successes >= static_cast<float>(d.max_consecutive_success));
+    } else {
+        time_out = ep >= d.max_episode_length - 1;
+    }
+    const bool reset = out_of_reach || time_out;
+    IH_STAMP(2);
+    // ---- compute_rewards :349-420
+    float act2 = 0.0f;
+    {
+        uint32_t k = 0;
+        for (; k + 4 <= A; k += 4) {   // four reads in flight, the additions in the order of the plain loop
+            const float a0 = act_s[e][k], a1 = act_s[e][k + 1], a2 = act_s[e][k + 2], a3 = act_s[e][k + 3];
+            act2 += a0 * a0;
+            act2 += a1 * a1;
+            act2 += a2 * a2;
+            act2 += a3 * a3;
+        }
+        for (; k < A; ++k) act2 += act_s[e][k] * act_s[e][k];
+    }
+    float reward = goal_dist * d.dist_reward_scale + div_(1.0f, fabsf(rot_dist) + d.rot_eps) * d.rot_reward_scale +
+                   act2 * d.action_penalty_scale;
+    const bool goal_reset = at_goal || goal_flag;
+    successes = successes + (goal_reset ? 1.0f : 0.0f);
+    if (goal_reset) reward = reward + d.reach_goal_bonus;
+    if (out_of_reach) reward = reward + d.fall_penalty;
+    // resets = where(goal_dist >= fall_dist, 1, reset_buf): reset_buf already contains the fallen envs.  A wavefront's four
+    // envs are summed in its first lane, in lane order, and added to the block's sums in LDS; the wavefront that finishes
+    // last sends the block's sums on (below, behind the row's stores: an add to an address that every block adds to is
+    // slow to leave the CU, and issued here it held up every store behind it)
+    {
+        const bool counts = live && reset;
+        const float one = counts ? 1.0f : 0.0f, fin = counts ? successes : 0.0f;
+        float n_reset = 0.0f, n_fin = 0.0f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            n_reset += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, one), 16 * w));
+            n_fin += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fin), 16 * w));
+        }
+        if ((tid & 63) == 0 && n_reset != 0.0f) {
+            atomicAdd(&block_stats[0], n_reset);
+            atomicAdd(&block_stats[1], n_fin);
+        }
+    }
+    IH_STAMP(3);
+    // ---- goal resets (:168-171) then env resets (direct_rl_env.py:369-371, :200-247), simulator writes left out
+    const uint64_t uenv = static_cast<uint64_t>(env0 + ec), gen_step = d.step_index + (d.step_index_device ? steps_before : 0ull);
+    if (goal_reset) {
+        const float r0 = d.goal_samples ? sample[0] : 2.0f * inhand_uniform(d.seed, gen_step, uenv, 0) - 1.0f;
+        const float r1 = d.goal_samples ? sample[1] : 2.0f * inhand_uniform(d.seed, gen_step, uenv, 1) - 1.0f;
+        goal = randomize_rotation(r0, r1);
+    }
+    if (reset) {
+        const float r0 = d.reset_goal_samples ? sample[2] : 2.0f * inhand_uniform(d.seed, gen_step, uenv, 2) - 1.0f;
+        const float r1 = d.reset_goal_samples ? sample[3] : 2.0f * inhand_uniform(d.seed, gen_step, uenv, 3) - 1.0f;
+        goal = randomize_rotation(r0, r1);
+        successes = 0.0f;
+        ep = 0;
+    }
+    const f4 diff = quat_mul(obj_rot, quat_conjugate(goal));
+    if (live && g == 0) {
+        d.terminated[env] = out_of_reach;
+        d.time_outs[env] = time_out;
+        if (d.reset_buf) d.reset_buf[env] = reset;
+        d.reward[env] = reward;
+        if (goal_reset || reset) store4u(d.goal_rot + 4 * env, goal);
+        d.reset_goal_buf[env] = 0;  // set by compute_rewards, cleared again by _reset_target_pose for exactly those envs
+        d.successes[env] = successes;
+        d.episode_length_buf[env] = ep;
+    }
+    IH_STAMP(4);
+    // ---- compute_full_observations :298-322: joint positions and velocities; the object, hand and goal values; the
+    // fingertips' states; the actions -- each run dealt over the env's sixteen threads
+    const uint32_t row_at = __umul24(e, O);
+#pragma unroll
+    for (int t = 0; t < kJointRounds; ++t) {
+        const uint32_t c = g + 16u * t;
+        if (live && c < J) st_b<float>(b_row, 4u * (row_at + c), div_(2.0f * joint[t] - hi[t] - lo[t], hi[t] - lo[t]));   // unscale :330-332
+        else if (live && c < 2 * J) st_b<float>(b_row, 4u * (row_at + c), d.vel_obs_scale * joint[t]);
+    }
+    {
+        const float first = g < 3 ? (g == 0 ? obj.x : g == 1 ? obj.y : obj.z)
+                          : g < 10 ? misc_os : g < 13 ? d.vel_obs_scale * misc_os : misc_hand;
+        const uint32_t h = g & 3;
+        const float goal_h = h == 0 ? goal.w : h == 1 ? goal.x : h == 2 ? goal.y : goal.z;
+        const float diff_h = h == 0 ? diff.w : h == 1 ? diff.x : h == 2 ? diff.y : diff.z;
+        if (live) st_b<float>(b_row, 4u * (row_at + 2 * J + g), first);
+        if (live && g < 8) st_b<float>(b_row, 4u * (row_at + 2 * J + 16 + g), g < 4 ? goal_h : diff_h);
+    }
+#pragma unroll
+    for (int t = 0; t < kTipRounds; ++t) {
+        const uint32_t k = g + 16u * t;
+        if (live && k < 13 * F) st_b<float>(b_row, 4u * (row_at + 2 * J + 24 + k), k < 3 * F ? tip[t] - (tip_a[t] == 0 ? origin[0] : tip_a[t] == 1 ? origin[1] : origin[2]) : tip[t]);
+    }
+#pragma unroll
+    for (int t = 0; t < kActionRounds; ++t) {
+        const uint32_t k = g + 16u * t;
+        if (live && k < A) st_b<float>(b_row, 4u * (row_at + 2 * J + 24 + 13 * F + k), act[t]);
+    }
+    if ((tid & 63) == 0 && atomicAdd(&waves_done, 1u) == 3u) {   // LDS takes a wavefront's operations in order: the sums are complete
+        const float n_reset = block_stats[0], n_fin = block_stats[1];
+        if (n_reset != 0.0f) unsafeAtomicAdd(d.stats, n_reset);
+        if (n_fin != 0.0f) unsafeAtomicAdd(d.stats + 1, n_fin);
+    }
+    IH_STAMP(5);
+}
+#ifdef ILX_INHAND_STAMPS
+}  // namespace ilx
+extern "C" int ilx_debug_inhand_stamps(unsigned long long* out, int count) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(ilx::g_inhand_stamps), sizeof(unsigned long long) * count) == hipSuccess ? 0 : 1;
+}
+namespace ilx {
+#endif
+
 // :422-431 from the (possibly all-reduced) sums; one thread
 __global__ void inhand_finish_kernel(ilx_inhand d) {
     const float num_resets = d.stats[0], finished = d.stats[1];
@@ -232,7 +458,10 @@ extern "C" int ilx_inhand_step(const ilx_inhand* env, void* stream) {
                         (d.num_fingertips == 0 || d.fingertip_ids),
                     ILX_EINVAL, "ilx_inhand_step: the observation needs joint state, limits, body_state_w and fingertip_ids");
     const unsigned blocks = static_cast<unsigned>((d.num_envs + kEnvsPerBlock - 1) / kEnvsPerBlock);
-    hipLaunchKernelGGL(inhand_step_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), d);
+    if (d.obs && inhand_unrolled_shape(d.num_joints, d.num_fingertips, d.num_actuated) && d.num_fingertips > 0)
+        hipLaunchKernelGGL(inhand_step_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), d);
+    else
+        hipLaunchKernelGGL(inhand_step_general_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), d);
     ILX_LAUNCH_CHECK("ilx_inhand_step");
     return ILX_OK;
 }

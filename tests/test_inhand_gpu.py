@@ -10,7 +10,7 @@ from test_oracle_inhand import VARIANTS, load_case
 pytestmark = pytest.mark.gpu
 
 
-def make_env(dev, s, ema, max_succ):
+def make_env(dev, s, ema, max_succ, obs_dim=157):
     from isaaclab_amd.envs.inhand_step import InHandManipulationCfg, InHandManipulationStep
 
     n = s["joint_pos"].shape[0]
@@ -18,7 +18,7 @@ def make_env(dev, s, ema, max_succ):
     env = InHandManipulationStep(cfg, n, dev, num_joints=24, num_bodies=26, actuated_dof_indices=[int(i) for i in s["actuated"]],
                                  finger_bodies=[int(i) for i in s["fingers"]], lower_limits=s["lower"], upper_limits=s["upper"],
                                  in_hand_pos=s["in_hand_pos"], env_origins=s["env_origins"])
-    assert env.max_episode_length == 600 and env.obs_dim == 157
+    assert env.max_episode_length == 600 and env.obs_dim == obs_dim
     for k in ("cur_targets", "prev_targets", "goal_rot", "successes", "consecutive_successes", "episode_length_buf"):
         getattr(env, k).copy_(s[k])
     env.set_sim_state(s["joint_pos"].to(dev), s["joint_vel"].to(dev), s["body_state"].to(dev), s["object_state"].to(dev))
@@ -104,6 +104,38 @@ def test_inhand_step_at_benchmark_size(dev):
         assert_close(obs, r["obs"], rtol=1e-5, atol=2e-6, what=f"obs step {step}")
         assert_close(env.consecutive_successes, o.s["consecutive_successes"], rtol=1e-5, what=f"consecutive successes step {step}")
         assert r["terminated"].sum() > 50 and (step > 0 or r["goal_resets"].sum() > 20)
+
+
+@pytest.mark.parametrize("n, fingers", [(1000, None), (16 * 7 + 3, None), (1000, [3, 7, 11, 15, 19, 22, 25])],
+                         ids=["ragged-last-block", "small", "seven-fingertips"])
+def test_inhand_step_other_shapes(dev, n, fingers):
+    """Env counts that leave the last 16-env workgroup partly empty (its spare threads read a clamped env and store
+    nothing), and a hand with more fingertips than the unrolled kernel takes (the general kernel runs): two steps against
+    the oracle."""
+    from isaaclab_amd import synth
+
+    s = synth.inhand_state(n, seed=12)
+    if fingers is not None:
+        s["fingers"] = fingers
+    s["actuated"], s["fingers"] = torch.tensor(s["actuated"]), torch.tensor(s["fingers"])
+    obs_dim = 2 * 24 + 24 + 13 * len(s["fingers"]) + len(s["actuated"])
+    env = make_env(dev, s, 0.8, 50, obs_dim)
+    o = IH.InHandOracle(IH.InHandCfg(act_moving_average=0.8, max_consecutive_success=50), s, s["actuated"].tolist(), s["fingers"].tolist())
+    gen = torch.Generator().manual_seed(5)
+    for step in range(2):
+        actions = s["actions"] if step == 0 else torch.rand(n, s["actions"].shape[1], generator=gen) * 2 - 1
+        gs, rs = torch.rand(n, 2, generator=gen) * 2 - 1, torch.rand(n, 2, generator=gen) * 2 - 1
+        r = o.step(actions, gs, rs)
+        obs, reward, terminated, time_outs = env.step(actions.to(dev), gs.to(dev), rs.to(dev))
+        assert obs.shape == (n, obs_dim)
+        assert_exact(terminated, r["terminated"], f"terminated step {step}")
+        assert_exact(time_outs, r["time_outs"], f"time_outs step {step}")
+        assert_exact(env.successes, o.s["successes"], f"successes step {step}")
+        assert_exact(env.episode_length_buf, o.s["episode_length_buf"], f"episode_length_buf step {step}")
+        assert_close(reward, r["reward"], rtol=1e-5, atol=1e-5, what=f"reward step {step}")
+        assert_close(obs, r["obs"], rtol=1e-5, atol=2e-6, what=f"obs step {step}")
+        assert_close(env.goal_rot, o.s["goal_rot"], rtol=1e-5, atol=1e-6, what=f"goal_rot step {step}")
+        assert_close(env.consecutive_successes, o.s["consecutive_successes"], rtol=1e-5, what=f"consecutive successes step {step}")
 
 
 def test_inhand_step_replayed_from_a_graph_equals_eager(dev):
