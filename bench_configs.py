@@ -229,6 +229,15 @@ def build_locomotion(device, envs, seed, robot="anymal_c", actuator="mlp", stati
         launches["actuator_dc_motor_joint_action"] = (actuate_first_dc, 1)
         del launches["joint_action_process"]
         nbytes["actuator_dc_motor_joint_action"] = nbytes[act_kernel] + nbytes.pop("joint_action_process")
+        if fused and env.paired_substeps:   # as for the network actuators: a substep's scene update and the next actuator launch as one
+            def update_and_actuate_dc():
+                ca = ArticulationActions(joint_positions=d.joint_pos_target, joint_velocities=d.joint_vel_target,
+                                         joint_efforts=d.joint_effort_target)
+                env.actuator.compute(ca, d.joint_pos, d.joint_vel, scene_update=env.scene.describe_update(LV.PHYSICS_DT))
+
+            launches["actuator_dc_motor+scene_update"] = (update_and_actuate_dc, LV.DECIMATION - 1)
+            nbytes["actuator_dc_motor+scene_update"] = nbytes[act_kernel] + nbytes["scene_update"]
+            launches[act_kernel], launches["scene_update"] = (actuate, 0), (launches["scene_update"][0], 0)
     if fused:   # the refresh's bytes dealt to the two launches: pose in / out and clocks with the update, the results with the cast
         nbytes["scene_update_prepare"] = nbytes["scene_update"] + 28 + 28 + 5
         nbytes["raycaster_cast"] = nbytes.pop("raycaster_refresh") - (28 + 28 + 5)
