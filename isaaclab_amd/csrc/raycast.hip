@@ -764,16 +764,18 @@ __global__ void __launch_bounds__(256) scene_update_prepare_kernel(SceneArgs s, 
     prepare_env(a, env, r.refresh, pos, q, dr, bx0, bx1, by0, by1, recs, &r.ts_new);
 }
 
-// The staged lattice cell that the index estimate names for coordinate x (line l[k] is line lo_abs + k of the patch):
-// true when x lies strictly inside that cell c = [lo, hi] by the margin.  On an evenly spaced lattice the estimate
+// The staged lattice cell that the index estimate names for coordinate x (staged line k is line lo_abs + k of the patch),
+// and whether x lies strictly inside a cell [lo, hi] by the margin.  On an evenly spaced lattice the estimate
 // is the cell for every such x; where it is not (uneven lines, the window's edge, NaN) the ray is not served here.
 // (The estimate only picks the cell that the test below then accepts or refuses: floor and conversion as one instruction,
 // saturating like the conversion it replaces; the clamp to [0, n - 2], n >= 2, as a median.)
-ILX_DEV bool lattice_cell(const float* l, int n, float x, float x0, float inv, int lo_abs, int& c, float& lo, float& hi) {
-    int guess;
+ILX_DEV int lattice_index(int n, float x, float x0, float inv, int lo_abs) {
+    int guess, c;
     asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(guess) : "v"((x - x0) * inv));
     asm("v_med3_i32 %0, %1, 0, %2" : "=v"(c) : "v"(guess - lo_abs), "s"(n - 2));
-    lo = l[c], hi = l[c + 1];
+    return c;
+}
+ILX_DEV bool lattice_inside(float x, float lo, float hi) {
     const float m = (hi - lo) * kLatMargin;
     return (x - lo) > m && (hi - x) > m;
 }
@@ -866,18 +868,20 @@ raycaster_update_lattice_kernel(ScanArgs a, const LatEnvRec* __restrict__ recs, 
     // with the operations of ray_triangle_z_inside / ray_triangle_z_distance that feed it.  Near the diagonal both
     // faces go through the full test.
     auto serve = [&](f3 o, float dz, int ray) -> bool {
-        int ci, cj;
-        float xlo, xhi, ylo, yhi;
-        const bool in_x = lattice_cell(st.lines, wi, o.x, E.x0, E.inv_dx, i_lo, ci, xlo, xhi);
-        const bool in_y = lattice_cell(st.lines + kLatWin, wj, o.y, E.y0, E.inv_dy, j_lo, cj, ylo, yhi);
+        const int ci = lattice_index(wi, o.x, E.x0, E.inv_dx, i_lo), cj = lattice_index(wj, o.y, E.y0, E.inv_dy, j_lo);
         const int jabs = j_lo + cj;
-        // the cell's bit and its four heights are asked for with the lines (their addresses need the cell's indices, not
-        // the lines' values): one LDS latency for the ray instead of three
+        // the cell's lines, its bit and its four heights are all asked for at once (their addresses need the cell's indices,
+        // not each other's values): one LDS latency for the ray instead of four
         int mask_row = ci;
         asm("" : "+v"(mask_row));   // no instruction: keeps the word's address a shift and an add of its own (derived from the heights' address it was a 64-bit multiply-add)
-        const uint32_t word = st.mask[mask_row];
+        float xlo = st.lines[ci], xhi = st.lines[ci + 1], ylo = st.lines[kLatWin + cj], yhi = st.lines[kLatWin + cj + 1];
+        uint32_t word = st.mask[mask_row];
         const float* zc = st.z + ci * kLatWin + cj;
-        const float z00 = zc[0], z01 = zc[1], z10 = zc[kLatWin], z11 = zc[kLatWin + 1];
+        float z00 = zc[0], z01 = zc[1], z10 = zc[kLatWin], z11 = zc[kLatWin + 1];
+        // no instruction: the nine values are in registers here.  Without it the compiler moves each read behind the test
+        // that decides whether its value is used -- lines, lines, bit, heights: four LDS latencies one after the other
+        asm volatile("" : "+v"(xlo), "+v"(xhi), "+v"(ylo), "+v"(yhi), "+v"(word), "+v"(z00), "+v"(z01), "+v"(z10), "+v"(z11));
+        const bool in_x = lattice_inside(o.x, xlo, xhi), in_y = lattice_inside(o.y, ylo, yhi);
         if (!(in_x && in_y && ((word >> cj) & 1u) && dz != 0.0f)) return false;
         const float wx = xhi - xlo, wy = yhi - ylo;
         const float sx = o.x - xlo, sy = o.y - ylo, sz = o.z - z00;  // ray start relative to v0 = v00

@@ -159,12 +159,6 @@ ILX_DEV SceneThread scene_update_thread(const SceneArgs& s, unsigned block, bool
     const Base b_acc = block_base(s.joint_acc, env0 * s.j);
     const Base b_ray_ts = block_base(s.ray_ts, env0), b_ray_last = block_base(s.ray_ts_last, env0);
     const Base b_ray_outdated = block_base(s.ray_outdated, env0);
-    auto clock_at = [&](Base ts, Base ts_last, Base outdated, float period) {   // read_clock with tick = 1
-        Clock c{ld_b<float>(ts, 4u * le), ld_b<float>(ts_last, 4u * le), ld_b<uint8_t>(outdated, le) != 0};
-        c.ts_new = c.ts_new + a.dt;                                            // sensor_base.py:199
-        c.refresh = c.refresh || ((c.ts_new - c.last + 1e-6f) >= period);      // sensor_base.py:200
-        return c;
-    };
     auto clock_to = [&](Base ts, Base ts_last, Base outdated, const Clock& c, bool lazy) {   // write_clock
         st_b<float>(ts, 4u * le, c.ts_new);
         if (lazy) {
@@ -181,25 +175,51 @@ ILX_DEV SceneThread scene_update_thread(const SceneArgs& s, unsigned block, bool
         return in;
     };
 
-    // Everything the thread may read goes out before the barrier, in one trip to memory: the clock, and the inputs of
-    // the first body / joint the thread owns (read whether or not the env turns out to refresh).
-    Clock c{0.0f, 0.0f, false};
-    int slot = 0;
-    const bool body_ahead = active && has_contact && !s.contact_lazy && k0 < nb;
-    const bool joint_ahead = active && s.joint_vel && k0 < nj;
-    BodyIn first_body{};
-    float first_v = 0.0f, first_prev = 0.0f;
-    if (active && has_contact) c = clock_at(b_ts, b_ts_last, b_outdated, a.period);
-    if (active && has_contact && a.head) slot = next_slot(ld_b<int32_t>(b_head, 4u * le), a.h);
-    if (body_ahead) first_body = body_at(k0);
-    if (joint_ahead) {
-        const uint32_t at = 4u * (__umul24(le, nj) + k0);
-        first_v = ld_b<float>(b_vel, at), first_prev = ld_b<float>(b_prev, at);
+    // Everything the thread may read goes out before the barrier, in ONE trip to memory: the clocks, the ring's head, and
+    // the inputs of the first body / joint the thread owns (read whether or not the env turns out to refresh).  The loads
+    // are unconditional -- a thread without an env reads the block's first one, a thread past the bodies or joints the
+    // last of them, an array the scene does not have is replaced by one it has, at offset 0 -- and nothing is computed
+    // from them until all are out: a load inside a branch is waited for where the branch ends, and with the clock's
+    // arithmetic next to its loads each group of loads was a trip of its own (three before the barrier).
+    if (!has_contact && !s.joint_vel && !s.ray_ts) {
+        __syncthreads();
+        return SceneThread{env, false, Clock{0.0f, 0.0f, false}};
     }
-    // the ray caster's clock belongs to the env's first thread alone: read in the same trip
+    const Base b_any = has_contact ? b_ts : (s.joint_vel ? b_vel : b_ray_ts);
+    auto base_or_any = [&](Base b, const void* p) { return p ? b : b_any; };
+    auto at_or_0 = [&](uint32_t off, const void* p) { return p ? off : 0u; };
+    const uint32_t le_c = active ? le : 0u;
+    const uint32_t eb_c = __umul24(le_c, nb) + min(k0, nb - 1u);
+    const uint32_t jt_c = __umul24(le_c, nj) + min(k0, nj - 1u);
+    const Base l_ts = base_or_any(b_ts, a.ts), l_ts_last = base_or_any(b_ts_last, a.ts), l_outdated = base_or_any(b_outdated, a.ts);
+    const float c_ts = ld_b<float>(l_ts, at_or_0(4u * le_c, a.ts)), c_last = ld_b<float>(l_ts_last, at_or_0(4u * le_c, a.ts));
+    const uint32_t c_flag = ld_b<uint8_t>(l_outdated, at_or_0(le_c, a.ts));
+    const int32_t head_in = ld_b<int32_t>(base_or_any(b_head, a.head), at_or_0(4u * le_c, a.head));
+    const Base l_in = base_or_any(b_in, a.in);
+    const uint32_t in_at = at_or_0(__umul24(eb_c, 12u), a.in);
+    BodyIn first_body{f3{ld_b<float>(l_in, in_at), ld_b<float>(l_in, in_at + (a.in ? 4u : 0u)), ld_b<float>(l_in, in_at + (a.in ? 8u : 0u))},
+                      ld_b<float>(base_or_any(b_cur_air, a.cur_air), at_or_0(4u * eb_c, a.cur_air)),
+                      ld_b<float>(base_or_any(b_cur_contact, a.cur_air), at_or_0(4u * eb_c, a.cur_air))};
+    float first_v = ld_b<float>(base_or_any(b_vel, s.joint_vel), at_or_0(4u * jt_c, s.joint_vel));
+    float first_prev = ld_b<float>(base_or_any(b_prev, s.joint_vel), at_or_0(4u * jt_c, s.joint_vel));
+    const float r_ts = ld_b<float>(base_or_any(b_ray_ts, s.ray_ts), at_or_0(4u * le_c, s.ray_ts));
+    const float r_last = ld_b<float>(base_or_any(b_ray_last, s.ray_ts), at_or_0(4u * le_c, s.ray_ts));
+    const uint32_t r_flag = ld_b<uint8_t>(base_or_any(b_ray_outdated, s.ray_ts), at_or_0(le_c, s.ray_ts));
+    // no instruction: all of them are in registers here -- one wait, with no store pending yet.  Left to the compiler each
+    // value is waited for at its first use, behind the stores of the values used before it, and since loads and stores
+    // share one in-order counter each such wait is then a wait for those stores to be acknowledged as well
+    asm volatile("" ::"v"(c_ts), "v"(c_last), "v"(c_flag), "v"(head_in), "v"(first_body.f.x), "v"(first_body.f.y), "v"(first_body.f.z),
+                 "v"(first_body.cur_air), "v"(first_body.cur_contact), "v"(first_v), "v"(first_prev), "v"(r_ts), "v"(r_last), "v"(r_flag));
+    auto ticked = [&](float ts, float last, uint32_t flag, float period, bool mine) {   // read_clock with tick = 1
+        Clock k{ts + a.dt, last, flag != 0};                                    // sensor_base.py:199
+        k.refresh = k.refresh || ((k.ts_new - k.last + 1e-6f) >= period);        // sensor_base.py:200
+        return mine ? k : Clock{0.0f, 0.0f, false};
+    };
+    const Clock c = ticked(c_ts, c_last, c_flag, a.period, active && has_contact);
+    const int slot = (active && has_contact && a.head) ? next_slot(head_in, a.h) : 0;
+    // the ray caster's clock belongs to the env's first thread alone
     const bool ray_clock = active && k0 == 0 && s.ray_ts && ray_clock_too;
-    Clock r{0.0f, 0.0f, false};
-    if (ray_clock) r = clock_at(b_ray_ts, b_ray_last, b_ray_outdated, s.ray_period);
+    const Clock r = ticked(r_ts, r_last, r_flag, s.ray_period, ray_clock);
     __syncthreads();
     SceneThread out{env, active && k0 == 0, r};
     if (!active) return out;
@@ -208,52 +228,62 @@ ILX_DEV SceneThread scene_update_thread(const SceneArgs& s, unsigned block, bool
         if (has_contact && a.head && c.refresh && !s.contact_lazy) st_b<int32_t>(b_head, 4u * le, slot);
         if (ray_clock) clock_to(b_ray_ts, b_ray_last, b_ray_outdated, r, true);
     }
+    // (the thread's first joint and body, whose inputs are in registers, ahead of the loops over further ones: a loop
+    // with loads in it makes the compiler wait at its top for everything in flight, the stores issued so far included)
+    auto joint_store = [&](uint32_t j, float v, float prev) {
+        const uint32_t at = 4u * (__umul24(le, nj) + j);
+        st_b<float>(b_acc, at, div_(v - prev, s.joint_elapsed));
+        st_b<float>(b_prev, at, v);
+    };
+    if (s.joint_vel && k0 < nj) joint_store(k0, first_v, first_prev);
+    const bool refresh = has_contact && c.refresh && !s.contact_lazy;
+    const float elapsed = c.ts_new - c.last;
+    auto body_store = [&](uint32_t body, const BodyIn& in) {   // contact_body with the block's addressing
+        const uint32_t eb = __umul24(le, nb) + body, eb12 = __umul24(eb, 12u);
+        const f3 f = in.f;
+        if (a.net) st_b<float>(b_net, eb12, f.x), st_b<float>(b_net, eb12 + 4u, f.y), st_b<float>(b_net, eb12 + 8u, f.z);
+        if (a.hist && a.head) {   // the ring: one row written
+            const uint32_t at = __umul24(__umul24(__umul24(le, nh) + static_cast<uint32_t>(slot), nb) + body, 12u);
+            st_b<float>(b_hist, at, f.x), st_b<float>(b_hist, at + 4u, f.y), st_b<float>(b_hist, at + 8u, f.z);
+        } else if (a.hist) {      // contact_sensor.py:326-328: every row moves one slot up
+            const uint32_t hb = __umul24(__umul24(__umul24(le, nh), nb) + body, 12u), row = __umul24(nb, 12u);
+            f3 old[kMaxContactHistory - 1];
+#pragma unroll
+            for (uint32_t k = 0; k < kMaxContactHistory - 1; ++k) {   // (a row past the last but one: that one again, not stored)
+                const uint32_t at = hb + __umul24(min(k, max(nh, 2u) - 2u), row);
+                old[k] = f3{ld_b<float>(b_hist, at), ld_b<float>(b_hist, at + 4u), ld_b<float>(b_hist, at + 8u)};
+            }
+#pragma unroll
+            for (uint32_t k = 0; k < kMaxContactHistory - 1; ++k)   // no instruction: all rows are here before the first store
+                asm volatile("" ::"v"(old[k].x), "v"(old[k].y), "v"(old[k].z));
+            st_b<float>(b_hist, hb, f.x), st_b<float>(b_hist, hb + 4u, f.y), st_b<float>(b_hist, hb + 8u, f.z);
+#pragma unroll
+            for (uint32_t k = 0; k < kMaxContactHistory - 1; ++k)
+                if (k + 1 < nh) {
+                    const uint32_t at = hb + __umul24(k + 1, row);
+                    st_b<float>(b_hist, at, old[k].x), st_b<float>(b_hist, at + 4u, old[k].y), st_b<float>(b_hist, at + 8u, old[k].z);
+                }
+        }
+        if (a.cur_air) {  // contact_sensor.py:346-373
+            const bool contact = norm3(f) > a.thr;
+            const float ca = in.cur_air, cc = in.cur_contact;
+            const bool first_contact = (ca > 0.0f) && contact;
+            const bool first_detached = (cc > 0.0f) && !contact;
+            if (first_contact) st_b<float>(b_last_air, 4u * eb, ca + elapsed);
+            st_b<float>(b_cur_air, 4u * eb, contact ? 0.0f : ca + elapsed);
+            if (first_detached) st_b<float>(b_last_contact, 4u * eb, cc + elapsed);
+            st_b<float>(b_cur_contact, 4u * eb, contact ? cc + elapsed : 0.0f);
+        }
+    };
+    if (refresh && k0 < nb) body_store(k0, first_body);
     if (s.joint_vel) {
-        for (uint32_t j = k0; j < nj; j += static_cast<uint32_t>(s.width)) {
+        for (uint32_t j = k0 + static_cast<uint32_t>(s.width); j < nj; j += static_cast<uint32_t>(s.width)) {
             const uint32_t at = 4u * (__umul24(le, nj) + j);
-            const float v = j == k0 ? first_v : ld_b<float>(b_vel, at);
-            const float prev = j == k0 ? first_prev : ld_b<float>(b_prev, at);
-            st_b<float>(b_acc, at, div_(v - prev, s.joint_elapsed));
-            st_b<float>(b_prev, at, v);
+            joint_store(j, ld_b<float>(b_vel, at), ld_b<float>(b_prev, at));
         }
     }
-    if (has_contact && c.refresh && !s.contact_lazy) {
-        const float elapsed = c.ts_new - c.last;
-        for (uint32_t body = k0; body < nb; body += static_cast<uint32_t>(s.width)) {
-            const BodyIn in = body == k0 ? first_body : body_at(body);
-            // contact_body with the block's addressing
-            const uint32_t eb = __umul24(le, nb) + body, eb12 = __umul24(eb, 12u);
-            const f3 f = in.f;
-            if (a.net) st_b<float>(b_net, eb12, f.x), st_b<float>(b_net, eb12 + 4u, f.y), st_b<float>(b_net, eb12 + 8u, f.z);
-            if (a.hist && a.head) {   // the ring: one row written
-                const uint32_t at = __umul24(__umul24(__umul24(le, nh) + static_cast<uint32_t>(slot), nb) + body, 12u);
-                st_b<float>(b_hist, at, f.x), st_b<float>(b_hist, at + 4u, f.y), st_b<float>(b_hist, at + 8u, f.z);
-            } else if (a.hist) {      // contact_sensor.py:326-328: every row moves one slot up
-                const uint32_t hb = __umul24(__umul24(__umul24(le, nh), nb) + body, 12u), row = __umul24(nb, 12u);
-                f3 old[kMaxContactHistory - 1];
-#pragma unroll
-                for (uint32_t k = 0; k < kMaxContactHistory - 1; ++k)
-                    if (k + 1 < nh) old[k] = f3{ld_b<float>(b_hist, hb + __umul24(k, row)), ld_b<float>(b_hist, hb + __umul24(k, row) + 4u), ld_b<float>(b_hist, hb + __umul24(k, row) + 8u)};
-                st_b<float>(b_hist, hb, f.x), st_b<float>(b_hist, hb + 4u, f.y), st_b<float>(b_hist, hb + 8u, f.z);
-#pragma unroll
-                for (uint32_t k = 0; k < kMaxContactHistory - 1; ++k)
-                    if (k + 1 < nh) {
-                        const uint32_t at = hb + __umul24(k + 1, row);
-                        st_b<float>(b_hist, at, old[k].x), st_b<float>(b_hist, at + 4u, old[k].y), st_b<float>(b_hist, at + 8u, old[k].z);
-                    }
-            }
-            if (a.cur_air) {  // contact_sensor.py:346-373
-                const bool contact = norm3(f) > a.thr;
-                const float ca = in.cur_air, cc = in.cur_contact;
-                const bool first_contact = (ca > 0.0f) && contact;
-                const bool first_detached = (cc > 0.0f) && !contact;
-                if (first_contact) st_b<float>(b_last_air, 4u * eb, ca + elapsed);
-                st_b<float>(b_cur_air, 4u * eb, contact ? 0.0f : ca + elapsed);
-                if (first_detached) st_b<float>(b_last_contact, 4u * eb, cc + elapsed);
-                st_b<float>(b_cur_contact, 4u * eb, contact ? cc + elapsed : 0.0f);
-            }
-        }
-    }
+    if (refresh)
+        for (uint32_t body = k0 + static_cast<uint32_t>(s.width); body < nb; body += static_cast<uint32_t>(s.width)) body_store(body, body_at(body));
     return out;
 }
 
