@@ -611,9 +611,10 @@ constexpr int kPatchBins = 64;
 
 // The per-env part of the preparation: the record of env `env` from its pose (already loaded: `pos`, `q`, drift `dr`)
 // and the pattern's box; for a due env also RayCasterData.pos_w / quat_w and the refresh time.  `now` (or null): the
-// env's clock value when the caller has it in a register (else it is read from clock_now).
+// env's clock value when the caller has it in a register (else it is read from clock_now).  `sel_before`: the `sel` that the
+// env's record held (any value: it is only a guess at the patch).
 ILX_DEV void prepare_env(const ScanArgs& a, int64_t env, bool due, f3 pos, f4 q, f3 dr, float bx0, float bx1, float by0, float by1,
-                         LatEnvRec* __restrict__ recs, const float* now = nullptr) {
+                         LatEnvRec* __restrict__ recs, int32_t sel_before, const float* now = nullptr) {
     const float inf = __builtin_inff();
     LatEnvRec le{};
     le.sel = kLatNotDue;
@@ -655,8 +656,23 @@ ILX_DEV void prepare_env(const ScanArgs& a, int64_t env, bool due, f3 pos, f4 q,
             // descriptors are fetched together (one trip to memory for the test and for the fields of the chosen one)
             const int bx = max(0, min(kPatchBins - 1, static_cast<int>((0.5f * (mnx + mxx) - a.mesh.pb_x0) * a.mesh.pb_inv_x)));
             const int by = max(0, min(kPatchBins - 1, static_cast<int>((0.5f * (mny + mxy) - a.mesh.pb_y0) * a.mesh.pb_inv_y)));
-            const short4 cand = a.mesh.patch_bins[by * kPatchBins + bx];
-            if (cand.x == -2) {
+            // The patch of the env's last refresh is asked for together with the bin: an env rarely leaves its patch from one
+            // refresh to the next, and when the old patch still holds the rectangle the candidates' descriptors -- a third trip
+            // to memory behind the pose and the bin -- are not needed.  (Which of several holding patches is taken makes no
+            // difference to the hits, see above.)
+            const int before = max(0, min(sel_before, a.mesh.num_patches - 1));
+            LatticePatch old_patch = a.mesh.patches[before];
+            int2 cand_words = *reinterpret_cast<const int2*>(a.mesh.patch_bins + (by * kPatchBins + bx));
+            // no instruction: both are in registers here, whole.  (Otherwise the compiler reads the old patch one field at a
+            // time, each behind the comparison that decides whether the next is needed, and the bin behind all of them.)
+            asm volatile("" : "+v"(old_patch.x0), "+v"(old_patch.y0), "+v"(old_patch.x1), "+v"(old_patch.y1), "+v"(old_patch.inv_dx),
+                         "+v"(old_patch.inv_dy), "+v"(old_patch.nx), "+v"(old_patch.ny), "+v"(old_patch.z_off), "+v"(old_patch.line_off),
+                         "+v"(old_patch.mask_off), "+v"(old_patch.mask_stride), "+v"(old_patch.face_base), "+v"(cand_words.x), "+v"(cand_words.y));
+            const short4 cand = {static_cast<short>(cand_words.x), static_cast<short>(cand_words.x >> 16), static_cast<short>(cand_words.y),
+                                 static_cast<short>(cand_words.y >> 16)};
+            if (holds(old_patch)) {
+                sel = before, P = old_patch;
+            } else if (cand.x == -2) {
                 for (int p = 0; p < a.mesh.num_patches && sel < 0; ++p) {
                     P = a.mesh.patches[p];
                     if (holds(P)) sel = p;
@@ -699,7 +715,9 @@ __global__ void __launch_bounds__(256) raycaster_prepare_kernel(ScanArgs a, LatE
     const bool due = env < a.n && (!a.env_mask || a.env_mask[env]);
     f3 pos{0.0f, 0.0f, 0.0f}, dr{0.0f, 0.0f, 0.0f};
     f4 q{1.0f, 0.0f, 0.0f, 0.0f};
+    int32_t sel_before = -1;
     if (due) {
+        sel_before = recs[env].sel;
         pos = load3(a.pos_w + a.pos_stride * env);
         q = load4u(a.quat_w + a.quat_stride * env);
         if (a.drift) dr = load3(a.drift + 3 * env);
@@ -734,7 +752,7 @@ __global__ void __launch_bounds__(256) raycaster_prepare_kernel(ScanArgs a, LatE
     }
     ILX_PREP_STAMP(1)
     if (env >= a.n) return;
-    prepare_env(a, env, due, pos, q, dr, bx0, bx1, by0, by1, recs);
+    prepare_env(a, env, due, pos, q, dr, bx0, bx1, by0, by1, recs, sel_before);
     ILX_PREP_STAMP(4)
 }
 
@@ -760,8 +778,9 @@ __global__ void __launch_bounds__(256) scene_update_prepare_kernel(SceneArgs s, 
     const f4 q = load4u(a.quat_w + a.quat_stride * env);
     const f3 dr = a.drift ? load3(a.drift + 3 * env) : f3{0.0f, 0.0f, 0.0f};
     const float bx0 = box_cache[0], bx1 = box_cache[1], by0 = box_cache[2], by1 = box_cache[3];
+    const int32_t sel_before = recs[env].sel;
     write_clock(s.ray_ts, s.ray_ts_last, s.ray_outdated, env, r, true);
-    prepare_env(a, env, r.refresh, pos, q, dr, bx0, bx1, by0, by1, recs, &r.ts_new);
+    prepare_env(a, env, r.refresh, pos, q, dr, bx0, bx1, by0, by1, recs, sel_before, &r.ts_new);
 }
 
 // The staged lattice cell that the index estimate names for coordinate x (staged line k is line lo_abs + k of the patch),
