@@ -122,6 +122,32 @@ def capture_step(cfg, reducer):
     return graphs
 
 
+def capture_commands(cfg, reducer):
+    """The env step recorded once into a command list per statistics vector (isaaclab_amd.utils.command_list): a replay
+    issues the same launches with the same arguments from a C loop, one hipLaunchKernel each -- 2.9 us of host time per
+    launch where a graph replay costs 14 us however few nodes it has.  Call after capture_step (the generator's step
+    count is in device memory by then).  None: the step has work that a list does not hold (a statistics vector that
+    only a torch launch could clear)."""
+    from isaaclab_amd.utils.command_list import CommandList
+
+    own_clear = reducer is not None and hasattr(cfg.env, "clear_log_sums")
+    if reducer is not None and not own_clear:
+        return None
+    if own_clear:
+        cfg.env.clear_log_sums = True
+    lists = []
+    for i in range(2 if reducer is not None else 1):
+        if reducer is not None:
+            cfg.bind_log_sums(reducer.buffer(i))
+        commands = CommandList()
+        with commands.record():
+            cfg.step()
+        lists.append(commands)
+    if own_clear:
+        cfg.env.clear_log_sums = False
+    return lists
+
+
 def cpu_baseline(seed, envs=NUM_ENVS, warmup=2, steps=10, root_scatter="origins"):
     """The oracle step (unfused PyTorch CPU ops + C ray cast) at the workload's full env count on the host's cores:
     `warmup` untimed steps, then `steps` timed ones between perf_counter reads -- the step-loop timing of
@@ -231,6 +257,17 @@ def main():
         if reducer is not None:
             reducer.end_step()
 
+    lists = None
+
+    def commands_step():
+        i = 0
+        if reducer is not None:
+            i = reducer.index
+            reducer.begin_step(zero=False)   # the step's first launch zeroes the vector itself
+        lists[i].replay()
+        if reducer is not None:
+            reducer.end_step()
+
     restart_clocks = getattr(cfg, "restart_sensor_clocks", None)
     warm_steps = {}   # untimed steps actually run ahead of each timed region
 
@@ -238,7 +275,7 @@ def main():
         if restart_clocks is not None:   # the sensors' clocks start every timed region where an env reset leaves them
             restart_clocks()
         # a recorded graph settles over its first replays: each gets its share of warm-up whatever --warmup says
-        warm = max(args.warmup, GRAPH_WARMUP_REPLAYS * len(graphs)) if replayed else args.warmup
+        warm = max(args.warmup, GRAPH_WARMUP_REPLAYS * (2 if reducer is not None else 1)) if replayed else args.warmup
         for _ in range(warm):
             one_step()
         warm_steps[one_step.__name__] = warm
@@ -281,12 +318,27 @@ def main():
             cfg.overlap_in_graph = False
             graphs = capture_step(cfg, reducer)
             other_s = timed(graph_step, replayed=True)
+    # The step re-issued from a command list: the same launches, the same single chain in the reference's order, issued by a
+    # C loop on the stream instead of replayed as graph nodes.  Where that is faster -- the host pays 2.9 us per launch
+    # instead of 14 us per replay, which decides the configurations of two to four short launches, and the launches follow
+    # each other more closely on a plain stream than as nodes of a graph -- it is the line's value and the graph replay is
+    # reported beside it.  (The in-hand step on several GPUs has a collective inside and is not recorded.)
+    commands_s, headline_mode, replaced_s = None, ("hip_graph" if use_graph else "eager"), None
+    if graphs is not None and (world == 1 or args.config != "shadow"):
+        lists = capture_commands(cfg, reducer)
+        if lists is not None:
+            commands_s = timed(commands_step, replayed=True)
+            mine = torch.tensor([commands_s, elapsed], device=device, dtype=torch.float64)
+            if dist is not None:   # every rank takes the same decision: on the slowest rank's times
+                dist.all_reduce(mine, op=dist.ReduceOp.MAX)
+            if float(mine[0]) < float(mine[1]):
+                replaced_s, elapsed, headline_mode = elapsed, commands_s, "command_list"
     # The same run of steps once more, untimed, with a look at the sensor clocks after every step: on how many steps did
     # every env's contact sensor and height scanner refresh (a step on which the clocks skip the refresh does less work).
     refresh_check = None
     if restart_clocks is not None:
         restart_clocks()
-        one_step = graph_step if use_graph else eager_step
+        one_step = commands_step if headline_mode == "command_list" else (graph_step if use_graph else eager_step)
         total = args.warmup + args.steps
         full = 0
         for _ in range(total):
@@ -413,12 +465,24 @@ def main():
                 line["mlp_exact_f32_us"] = round(exact_us, 2)
         if use_graph:
             line["graph_warmup_replays"] = warm_steps.get("graph_step", 0) // len(graphs)
-        line["launch_mode"] = ("hip-graph replay of the step recorded as one chain in the reference's order (no launch ahead of a physics "
-                               "step it would depend on), once per statistics vector" if use_graph else "eager: one host call per launch")
+        notes = {"hip_graph": "hip-graph replay of the step recorded as one chain in the reference's order (no launch ahead of a physics "
+                              "step it would depend on), once per statistics vector",
+                 "eager": "eager: one host call per launch",
+                 "command_list": "command list: the step's launches, recorded once as one chain in the reference's order, issued by a C "
+                                 "loop (ilx_commands_replay), once per statistics vector"}
+        line["launch_mode"] = notes[headline_mode]
+
+        def side(seconds, note):
+            return {"ms_per_step": seconds / args.steps * 1e3, "value": args.envs * world * args.steps / seconds, "note": note}
+
         if other_s is not None:
-            line["eager" if use_graph else "hip_graph"] = {
-                "ms_per_step": other_s / args.steps * 1e3, "value": args.envs * world * args.steps / other_s,
-                "note": "the same step " + ("issued launch by launch from the host" if use_graph else "replayed from a captured graph")}
+            line["eager" if use_graph else "hip_graph"] = side(
+                other_s, "the same step " + ("issued launch by launch from the host" if use_graph else "replayed from a captured graph"))
+        if replaced_s is not None:   # the mode that the command list took the line's value from
+            line["hip_graph" if use_graph else "eager"] = side(
+                replaced_s, "the same step " + ("replayed from a captured graph" if use_graph else "issued launch by launch from the host"))
+        elif commands_s is not None:
+            line["command_list"] = side(commands_s, "the same step, one chain, issued from a command list (ilx_commands_replay)")
         if two_branch_s is not None:
             line["hip_graph_two_branches"] = {
                 "ms_per_step": two_branch_s / args.steps * 1e3, "value": args.envs * world * args.steps / two_branch_s,

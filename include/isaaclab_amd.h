@@ -36,6 +36,27 @@ int ilx_version(void);
 const char* ilx_last_error(void);
 
 /* ------------------------------------------------------------------------------------------------
+ * Command lists.  No counterpart in the reference (its launches are torch's).  A step of a few short
+ * launches is bound by what the host pays to issue it: a captured HIP graph costs 14 us per replay
+ * however few nodes it has, a launch issued from C 2.9 us.  Between ilx_commands_begin and
+ * ilx_commands_end every call of this library made by the calling thread keeps its kernel launches
+ * -- kernel, grid and a copy of the arguments, device pointers included -- in the list instead of
+ * issuing them (nothing runs; argument checks and host-side set-up happen as usual).
+ * ilx_commands_replay issues the kept launches in order on `stream`, one hipLaunchKernel each, with
+ * no allocation and no other host work.  Like a captured graph the list holds the pointers it was
+ * recorded with: the buffers must stay where they are, and whatever changes from step to step must
+ * live in device memory (e.g. ilx_mdp::step_index_device).  The recorded calls must all name one
+ * stream (a list is one chain; ilx_commands_end fails otherwise).  A list may be replayed from any
+ * thread, by one thread at a time.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct ilx_commands_s* ilx_commands_t;
+int ilx_commands_begin(ilx_commands_t* out);                 /* start recording on the calling thread */
+int ilx_commands_end(void);                                  /* stop recording */
+int ilx_commands_count(ilx_commands_t commands, int* count); /* number of launches kept */
+int ilx_commands_replay(ilx_commands_t commands, void* stream);
+int ilx_commands_destroy(ilx_commands_t commands);
+
+/* ------------------------------------------------------------------------------------------------
  * isaaclab.utils.math — source/isaaclab/isaaclab/utils/math.py
  * One launch evaluates one function over n rows.  Operand meaning per op:
  *   a, b, c, d : inputs (row widths in the table), out0/out1 : outputs.

@@ -190,6 +190,11 @@ class RayCasterCameraDesc(ctypes.Structure):
 DEPTH_CLIP = {"none": 0, "max": 1, "zero": 2}
 raycaster_camera_refresh = _sig("ilx_raycaster_camera_refresh", ctypes.POINTER(RayCasterCameraDesc), P)
 scene_update = _sig("ilx_scene_update", ctypes.POINTER(Scene), P)
+commands_begin = _sig("ilx_commands_begin", ctypes.POINTER(c_void_p))
+commands_end = _sig("ilx_commands_end")
+commands_count = _sig("ilx_commands_count", P, ctypes.POINTER(c_int))
+commands_replay = _sig("ilx_commands_replay", P, P)
+commands_destroy = _sig("ilx_commands_destroy", P)
 raycaster_refresh = _sig("ilx_raycaster_refresh", ctypes.POINTER(RayCasterDesc), P)
 raycaster_refresh_static = _sig("ilx_raycaster_refresh_static", ctypes.POINTER(RayCasterDesc), P)
 raycaster_reserve = _sig("ilx_raycaster_reserve", P, c_int64, ctypes.c_int32, ctypes.c_int32)

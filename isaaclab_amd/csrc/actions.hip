@@ -98,7 +98,7 @@ extern "C" int ilx_joint_action_to_limits(const float* raw_action, const float* 
                 "ilx_joint_action_to_limits: Moving average weight must be in the range [0, 1]. Got %g.", alpha_scalar);
     ToLimitsArgs p{raw_action, scale, scale_scalar, clip, rescale_to_limits, soft_joint_pos_limits, joint_ids, num_joints,
                    alpha, alpha_scalar, prev_applied_actions, processed, n, a};
-    hipLaunchKernelGGL(joint_action_to_limits_kernel, dim3(blocks_for(n * a)), dim3(256), 0, as_stream(stream), p);
+    ILX_LAUNCH(joint_action_to_limits_kernel, dim3(blocks_for(n * a)), dim3(256), 0, as_stream(stream), p);
     ILX_LAUNCH_CHECK("ilx_joint_action_to_limits");
     return ILX_OK;
 }
@@ -111,7 +111,7 @@ extern "C" int ilx_binary_joint_action(const float* raw_action, const uint8_t* r
     ILX_REQUIRE((raw_action != nullptr) != (raw_action_bool != nullptr), ILX_EINVAL,
                 "ilx_binary_joint_action: exactly one of the float and the boolean action is given");
     ILX_REQUIRE(open_command && close_command && processed, ILX_EINVAL, "ilx_binary_joint_action: NULL operand");
-    hipLaunchKernelGGL(binary_joint_action_kernel, dim3(blocks_for(n * j)), dim3(256), 0, as_stream(stream), raw_action,
+    ILX_LAUNCH(binary_joint_action_kernel, dim3(blocks_for(n * j)), dim3(256), 0, as_stream(stream), raw_action,
                        raw_action_bool, open_command, close_command, clip, processed, n, j);
     ILX_LAUNCH_CHECK("ilx_binary_joint_action");
     return ILX_OK;
@@ -123,7 +123,7 @@ extern "C" int ilx_non_holonomic_action_apply(const float* body_quat_w, int64_t 
     if (n == 0) return ILX_OK;
     ILX_REQUIRE(body_quat_w && processed && joint_vel_command, ILX_EINVAL, "ilx_non_holonomic_action_apply: NULL operand");
     ILX_REQUIRE(body_quat_stride >= 4, ILX_EINVAL, "ilx_non_holonomic_action_apply: bad quaternion stride");
-    hipLaunchKernelGGL(non_holonomic_kernel, dim3(blocks_for(n)), dim3(256), 0, as_stream(stream), body_quat_w, body_quat_stride,
+    ILX_LAUNCH(non_holonomic_kernel, dim3(blocks_for(n)), dim3(256), 0, as_stream(stream), body_quat_w, body_quat_stride,
                        processed, joint_vel_command, n);
     ILX_LAUNCH_CHECK("ilx_non_holonomic_action_apply");
     return ILX_OK;

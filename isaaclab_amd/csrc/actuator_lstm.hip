@@ -296,11 +296,11 @@ template <int HP>
 static void launch_lstm(const LstmArgs& a, size_t lds, hipStream_t s) {
     const dim3 g(blocks_for(a.rows, kLstmBlock)), b(kLstmBlock);
     switch (a.head_act) {
-        case ILX_ACT_SOFTSIGN: hipLaunchKernelGGL((actuator_lstm_kernel<HP, ILX_ACT_SOFTSIGN>), g, b, lds, s, a); break;
-        case ILX_ACT_ELU: hipLaunchKernelGGL((actuator_lstm_kernel<HP, ILX_ACT_ELU>), g, b, lds, s, a); break;
-        case ILX_ACT_TANH: hipLaunchKernelGGL((actuator_lstm_kernel<HP, ILX_ACT_TANH>), g, b, lds, s, a); break;
-        case ILX_ACT_RELU: hipLaunchKernelGGL((actuator_lstm_kernel<HP, ILX_ACT_RELU>), g, b, lds, s, a); break;
-        default: hipLaunchKernelGGL((actuator_lstm_kernel<HP, ILX_ACT_IDENTITY>), g, b, lds, s, a); break;
+        case ILX_ACT_SOFTSIGN: ILX_LAUNCH((actuator_lstm_kernel<HP, ILX_ACT_SOFTSIGN>), g, b, lds, s, a); break;
+        case ILX_ACT_ELU: ILX_LAUNCH((actuator_lstm_kernel<HP, ILX_ACT_ELU>), g, b, lds, s, a); break;
+        case ILX_ACT_TANH: ILX_LAUNCH((actuator_lstm_kernel<HP, ILX_ACT_TANH>), g, b, lds, s, a); break;
+        case ILX_ACT_RELU: ILX_LAUNCH((actuator_lstm_kernel<HP, ILX_ACT_RELU>), g, b, lds, s, a); break;
+        default: ILX_LAUNCH((actuator_lstm_kernel<HP, ILX_ACT_IDENTITY>), g, b, lds, s, a); break;
     }
 }
 

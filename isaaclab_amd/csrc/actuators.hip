@@ -1180,16 +1180,16 @@ static int actuator_pd(int model, const float* q_des, const float* qd_des, const
         if (rc != ILX_OK) return rc;
         dim3 both(g.x + su_blocks);
         if (model == ILX_ACTUATOR_DC_MOTOR)
-            hipLaunchKernelGGL(pd_scene_kernel<1>, both, b, 0, s, q_des, qd_des, tau_ff, q, qd, stiffness, damping, effort_limit,
+            ILX_LAUNCH(pd_scene_kernel<1>, both, b, 0, s, q_des, qd_des, tau_ff, q, qd, stiffness, damping, effort_limit,
                                velocity_limit, params_per_env, saturation_effort, computed, applied, total, j, sa, su_blocks);
         else
-            hipLaunchKernelGGL(pd_scene_kernel<0>, both, b, 0, s, q_des, qd_des, tau_ff, q, qd, stiffness, damping, effort_limit,
+            ILX_LAUNCH(pd_scene_kernel<0>, both, b, 0, s, q_des, qd_des, tau_ff, q, qd, stiffness, damping, effort_limit,
                                velocity_limit, params_per_env, saturation_effort, computed, applied, total, j, sa, su_blocks);
     } else if (model == ILX_ACTUATOR_DC_MOTOR)
-        hipLaunchKernelGGL(actuator_pd_kernel<1>, g, b, 0, s, q_des, qd_des, tau_ff, q, qd, stiffness, damping,
+        ILX_LAUNCH(actuator_pd_kernel<1>, g, b, 0, s, q_des, qd_des, tau_ff, q, qd, stiffness, damping,
                            effort_limit, velocity_limit, params_per_env, saturation_effort, computed, applied, total, j);
     else
-        hipLaunchKernelGGL(actuator_pd_kernel<0>, g, b, 0, s, q_des, qd_des, tau_ff, q, qd, stiffness, damping,
+        ILX_LAUNCH(actuator_pd_kernel<0>, g, b, 0, s, q_des, qd_des, tau_ff, q, qd, stiffness, damping,
                            effort_limit, velocity_limit, params_per_env, saturation_effort, computed, applied, total, j);
     ILX_LAUNCH_CHECK("ilx_actuator_pd");
     return ILX_OK;
@@ -1239,10 +1239,10 @@ extern "C" int ilx_actuator_pd_joint_action(int model, const float* raw_action, 
     const int64_t total = n * j;
     dim3 g(blocks_for(total)), b(256);
     if (model == ILX_ACTUATOR_DC_MOTOR)
-        hipLaunchKernelGGL(pd_joint_action_kernel<1>, g, b, 0, as_stream(stream), ja, q_des, qd_des, tau_ff, q, qd, stiffness, damping,
+        ILX_LAUNCH(pd_joint_action_kernel<1>, g, b, 0, as_stream(stream), ja, q_des, qd_des, tau_ff, q, qd, stiffness, damping,
                            effort_limit, velocity_limit, params_per_env, saturation_effort, computed, applied, total, j);
     else
-        hipLaunchKernelGGL(pd_joint_action_kernel<0>, g, b, 0, as_stream(stream), ja, q_des, qd_des, tau_ff, q, qd, stiffness, damping,
+        ILX_LAUNCH(pd_joint_action_kernel<0>, g, b, 0, as_stream(stream), ja, q_des, qd_des, tau_ff, q, qd, stiffness, damping,
                            effort_limit, velocity_limit, params_per_env, saturation_effort, computed, applied, total, j);
     ILX_LAUNCH_CHECK("ilx_actuator_pd_joint_action");
     return ILX_OK;
@@ -1283,7 +1283,7 @@ static int launch_mlp(const NetArgs& a, bool force_generic, bool exact_f32, hipS
             pos_vel = a.feat_slot[f] == f % a.hist_len && (((a.feat_is_pos >> f) & 1u) != 0) == (f < a.hist_len);
         const bool three = nhid == 3 && small && split && pos_vel && a.hist_len == 3;
         if (a.ja_raw && three) {   // the step's first actuator launch: the joint action's processing rides on it
-            hipLaunchKernelGGL((mlp_split_joint_action_kernel<ACT>), dim3(stay_blocks), dim3(256), 0, s, a);
+            ILX_LAUNCH((mlp_split_joint_action_kernel<ACT>), dim3(stay_blocks), dim3(256), 0, s, a);
             return ILX_OK;
         }
         scene_inside = scene && scene->num_envs > 0 && three;
@@ -1292,27 +1292,27 @@ static int launch_mlp(const NetArgs& a, bool force_generic, bool exact_f32, hipS
             if (rc != ILX_OK) return rc;
         }
         if (scene_inside)   // the network's workgroups first in the grid, the update's behind them
-            hipLaunchKernelGGL((mlp_split_scene_kernel<ACT>), dim3(stay_blocks + su_blocks), dim3(256), 0, s, a, sa, 0u, stay_blocks,
+            ILX_LAUNCH((mlp_split_scene_kernel<ACT>), dim3(stay_blocks + su_blocks), dim3(256), 0, s, a, sa, 0u, stay_blocks,
                                stay_blocks);
         else if (nhid == 3 && small && split && pos_vel && a.hist_len == 3) {  // the ANYdrive network's shape: three samples
-            hipLaunchKernelGGL((mlp_split_persistent_kernel<ACT>), dim3(stay_blocks), dim3(256), 0, s, a);
+            ILX_LAUNCH((mlp_split_persistent_kernel<ACT>), dim3(stay_blocks), dim3(256), 0, s, a);
         }
         else if (nhid == 3 && small && split)
-            hipLaunchKernelGGL((mlp_mfma_split_kernel<ACT, 3, 0>), dim3(tile_blocks), dim3(256), 0, s, a);
+            ILX_LAUNCH((mlp_mfma_split_kernel<ACT, 3, 0>), dim3(tile_blocks), dim3(256), 0, s, a);
         else if (nhid == 2 && small && split)
-            hipLaunchKernelGGL((mlp_mfma_split_kernel<ACT, 2, 0>), dim3(tile_blocks), dim3(256), 0, s, a);
+            ILX_LAUNCH((mlp_mfma_split_kernel<ACT, 2, 0>), dim3(tile_blocks), dim3(256), 0, s, a);
         else if (nhid == 3 && small)
-            hipLaunchKernelGGL((mlp_mfma_tile_kernel<ACT, 3>), dim3(tile_blocks), dim3(256), 0, s, a);
+            ILX_LAUNCH((mlp_mfma_tile_kernel<ACT, 3>), dim3(tile_blocks), dim3(256), 0, s, a);
         else if (nhid == 2 && small)
-            hipLaunchKernelGGL((mlp_mfma_tile_kernel<ACT, 2>), dim3(tile_blocks), dim3(256), 0, s, a);
+            ILX_LAUNCH((mlp_mfma_tile_kernel<ACT, 2>), dim3(tile_blocks), dim3(256), 0, s, a);
         else
-            hipLaunchKernelGGL(mlp_mfma_kernel<ACT>, dim3(static_cast<unsigned>((tiles + 3) / 4)), dim3(256), 0, s, a);
+            ILX_LAUNCH(mlp_mfma_kernel<ACT>, dim3(static_cast<unsigned>((tiles + 3) / 4)), dim3(256), 0, s, a);
     } else {
         if (scene) {
             const int rc = ilx_scene_update(scene, s);
             if (rc != ILX_OK) return rc;
         }
-        hipLaunchKernelGGL(mlp_generic_kernel<ACT>, dim3(blocks_for(a.rows, 128)), dim3(128), 0, s, a);
+        ILX_LAUNCH(mlp_generic_kernel<ACT>, dim3(blocks_for(a.rows, 128)), dim3(128), 0, s, a);
     }
     return ILX_OK;
 }
@@ -1476,7 +1476,7 @@ extern "C" int ilx_actuator_delayed_pd(const float* q_des, const float* qd_des, 
     a.lookup_x = lookup_angles, a.lookup_y = lookup_max_torque, a.lookup_n = lookup_size;
     a.computed = computed, a.applied = applied, a.n = n, a.j = j, a.envs_per_block = 256 / j;
     const unsigned blocks = static_cast<unsigned>((n + a.envs_per_block - 1) / a.envs_per_block);
-    hipLaunchKernelGGL(actuator_delayed_pd_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), a);
+    ILX_LAUNCH(actuator_delayed_pd_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), a);
     ILX_LAUNCH_CHECK("ilx_actuator_delayed_pd");
     return ILX_OK;
 }
@@ -1487,7 +1487,7 @@ extern "C" int ilx_linear_interpolation(const float* x, const float* y, int32_t 
     ILX_REQUIRE(count >= 0, ILX_EINVAL, "ilx_linear_interpolation: negative count");
     if (count == 0) return ILX_OK;
     ILX_REQUIRE(x && y && q && out, ILX_EINVAL, "ilx_linear_interpolation: NULL operand");
-    hipLaunchKernelGGL(linear_interpolation_kernel, dim3(blocks_for(count)), dim3(256), 0, as_stream(stream), x, y, num_samples, q, out, count);
+    ILX_LAUNCH(linear_interpolation_kernel, dim3(blocks_for(count)), dim3(256), 0, as_stream(stream), x, y, num_samples, q, out, count);
     ILX_LAUNCH_CHECK("ilx_linear_interpolation");
     return ILX_OK;
 }

@@ -81,7 +81,7 @@ extern "C" int ilx_joint_action_process(const float* raw_action, float* action, 
     ILX_REQUIRE(raw_action && processed, ILX_EINVAL, "ilx_joint_action_process: NULL operand");
     ILX_REQUIRE(!prev_action || action, ILX_EINVAL, "ilx_joint_action_process: prev_action needs action");
     const int64_t total = n * a;
-    hipLaunchKernelGGL(joint_action_kernel, dim3(blocks_for(total)), dim3(256), 0, as_stream(stream), raw_action, action,
+    ILX_LAUNCH(joint_action_kernel, dim3(blocks_for(total)), dim3(256), 0, as_stream(stream), raw_action, action,
                        prev_action, scale, scale_scalar, offset, offset_scalar, clip, processed, total, nullptr, 0, nullptr);
     ILX_LAUNCH_CHECK("ilx_joint_action_process");
     return ILX_OK;
@@ -97,7 +97,7 @@ extern "C" int ilx_joint_action_process_begin(const float* raw_action, float* ac
     ILX_REQUIRE(log_count >= 0 && (log_count == 0 || log_sums), ILX_EINVAL,
                 "ilx_joint_action_process_begin: %d floats at a NULL pointer", log_count);
     const int64_t total = n * a;
-    hipLaunchKernelGGL(joint_action_kernel, dim3(blocks_for(total)), dim3(256), 0, as_stream(stream), raw_action, action,
+    ILX_LAUNCH(joint_action_kernel, dim3(blocks_for(total)), dim3(256), 0, as_stream(stream), raw_action, action,
                        prev_action, scale, scale_scalar, offset, offset_scalar, clip, processed, total, log_sums,
                        log_sums ? log_count : 0, step_index_device);
     ILX_LAUNCH_CHECK("ilx_joint_action_process_begin");
@@ -110,7 +110,7 @@ extern "C" int ilx_root_frame_derive(const float* root_state, float gx, float gy
     ILX_REQUIRE(n >= 0, ILX_EINVAL, "ilx_root_frame_derive: negative env count");
     ILX_REQUIRE(root_state, ILX_EINVAL, "ilx_root_frame_derive: root_state is NULL");
     if (n == 0) return ILX_OK;
-    hipLaunchKernelGGL(root_frame_derive_kernel, dim3(blocks_for(n)), dim3(256), 0, as_stream(stream), root_state, gx, gy,
+    ILX_LAUNCH(root_frame_derive_kernel, dim3(blocks_for(n)), dim3(256), 0, as_stream(stream), root_state, gx, gy,
                        gz, lin_vel_b, ang_vel_b, projected_gravity_b, heading_w, n);
     ILX_LAUNCH_CHECK("ilx_root_frame_derive");
     return ILX_OK;
@@ -121,7 +121,7 @@ extern "C" int ilx_root_state_pack(const float* root_transforms_xyzw, const floa
     ILX_REQUIRE(n >= 0, ILX_EINVAL, "ilx_root_state_pack: negative env count");
     ILX_REQUIRE(root_transforms_xyzw && root_velocities && root_state, ILX_EINVAL, "ilx_root_state_pack: NULL operand");
     if (n == 0) return ILX_OK;
-    hipLaunchKernelGGL(root_state_pack_kernel, dim3(blocks_for(n)), dim3(256), 0, as_stream(stream), root_transforms_xyzw,
+    ILX_LAUNCH(root_state_pack_kernel, dim3(blocks_for(n)), dim3(256), 0, as_stream(stream), root_transforms_xyzw,
                        root_velocities, root_state, n);
     ILX_LAUNCH_CHECK("ilx_root_state_pack");
     return ILX_OK;
@@ -132,7 +132,7 @@ extern "C" int ilx_joint_acc(const float* joint_vel, float* previous_joint_vel, 
     ILX_REQUIRE(count >= 0, ILX_EINVAL, "ilx_joint_acc: negative element count");
     ILX_REQUIRE(joint_vel && previous_joint_vel && joint_acc, ILX_EINVAL, "ilx_joint_acc: NULL operand");
     if (count == 0) return ILX_OK;
-    hipLaunchKernelGGL(joint_acc_kernel, dim3(blocks_for(count)), dim3(256), 0, as_stream(stream), joint_vel,
+    ILX_LAUNCH(joint_acc_kernel, dim3(blocks_for(count)), dim3(256), 0, as_stream(stream), joint_vel,
                        previous_joint_vel, joint_acc, time_elapsed, count);
     ILX_LAUNCH_CHECK("ilx_joint_acc");
     return ILX_OK;

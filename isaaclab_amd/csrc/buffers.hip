@@ -99,8 +99,8 @@ extern "C" int ilx_circular_buffer_append(const ilx_circular_buffer* ring, const
                 "ilx_circular_buffer_append: ordered row stride below max_len * width");
     ILX_REQUIRE(!delayed_out || delayed_stride >= cb.d, ILX_ESHAPE, "ilx_circular_buffer_append: delayed row stride below the width %d", cb.d);
     RingArgs a{cb, data, data_stride, ordered_out, ordered_stride, time_lags, delayed_out, delayed_stride};
-    hipLaunchKernelGGL(ring_append_kernel, dim3(blocks_for(cb.n * cb.d)), dim3(256), 0, as_stream(stream), a);
-    if (data) hipLaunchKernelGGL(ring_count_kernel, dim3(blocks_for(cb.n)), dim3(256), 0, as_stream(stream), cb.num_pushes, cb.n);
+    ILX_LAUNCH(ring_append_kernel, dim3(blocks_for(cb.n * cb.d)), dim3(256), 0, as_stream(stream), a);
+    if (data) ILX_LAUNCH(ring_count_kernel, dim3(blocks_for(cb.n)), dim3(256), 0, as_stream(stream), cb.num_pushes, cb.n);
     ILX_LAUNCH_CHECK("ilx_circular_buffer_append");
     return ILX_OK;
 }
@@ -113,7 +113,7 @@ extern "C" int ilx_circular_buffer_reset(const ilx_circular_buffer* ring, const 
     if (cb.n == 0 || count == 0) return ILX_OK;
     ilx_circular_buffer c = cb;
     if (c.d == 0) c.d = 1, c.buffer = nullptr;   // nothing appended yet: only the counts
-    hipLaunchKernelGGL(ring_reset_kernel, dim3(blocks_for(count * c.d)), dim3(256), 0, as_stream(stream), c, env_ids, count);
+    ILX_LAUNCH(ring_reset_kernel, dim3(blocks_for(count * c.d)), dim3(256), 0, as_stream(stream), c, env_ids, count);
     ILX_LAUNCH_CHECK("ilx_circular_buffer_reset");
     return ILX_OK;
 }

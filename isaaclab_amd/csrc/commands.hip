@@ -206,7 +206,7 @@ extern "C" int ilx_pose2d_command_compute(const ilx_pose2d_command* cmd, float d
     if (const int s = check_pose2d(*cmd, "ilx_pose2d_command_compute")) return s;
     if (cmd->num_envs == 0) return ILX_OK;
     Pose2dArgs a{*cmd, 0, dt, nullptr, nullptr};
-    hipLaunchKernelGGL(pose2d_command_kernel, dim3(blocks_for(cmd->num_envs)), dim3(256), 0, as_stream(stream), a);
+    ILX_LAUNCH(pose2d_command_kernel, dim3(blocks_for(cmd->num_envs)), dim3(256), 0, as_stream(stream), a);
     ILX_LAUNCH_CHECK("ilx_pose2d_command_compute");
     return ILX_OK;
 }
@@ -217,7 +217,7 @@ extern "C" int ilx_pose2d_command_reset(const ilx_pose2d_command* cmd, const uin
     if (cmd->num_envs == 0) return ILX_OK;
     ILX_REQUIRE(reset_mask, ILX_EINVAL, "ilx_pose2d_command_reset: reset_mask is NULL");
     Pose2dArgs a{*cmd, 1, 0.0f, reset_mask, log_sums};
-    hipLaunchKernelGGL(pose2d_command_kernel, dim3(blocks_for(cmd->num_envs)), dim3(256), 0, as_stream(stream), a);
+    ILX_LAUNCH(pose2d_command_kernel, dim3(blocks_for(cmd->num_envs)), dim3(256), 0, as_stream(stream), a);
     ILX_LAUNCH_CHECK("ilx_pose2d_command_reset");
     return ILX_OK;
 }
@@ -227,7 +227,7 @@ extern "C" int ilx_normal_velocity_command_compute(const ilx_normal_velocity_com
     if (const int s = check_normal_vel(*cmd, "ilx_normal_velocity_command_compute")) return s;
     if (cmd->num_envs == 0) return ILX_OK;
     NormalVelArgs a{*cmd, 0, dt, nullptr, nullptr};
-    hipLaunchKernelGGL(normal_velocity_command_kernel, dim3(blocks_for(cmd->num_envs)), dim3(256), 0, as_stream(stream), a);
+    ILX_LAUNCH(normal_velocity_command_kernel, dim3(blocks_for(cmd->num_envs)), dim3(256), 0, as_stream(stream), a);
     ILX_LAUNCH_CHECK("ilx_normal_velocity_command_compute");
     return ILX_OK;
 }
@@ -239,7 +239,7 @@ extern "C" int ilx_normal_velocity_command_reset(const ilx_normal_velocity_comma
     if (cmd->num_envs == 0) return ILX_OK;
     ILX_REQUIRE(reset_mask, ILX_EINVAL, "ilx_normal_velocity_command_reset: reset_mask is NULL");
     NormalVelArgs a{*cmd, 1, 0.0f, reset_mask, log_sums};
-    hipLaunchKernelGGL(normal_velocity_command_kernel, dim3(blocks_for(cmd->num_envs)), dim3(256), 0, as_stream(stream), a);
+    ILX_LAUNCH(normal_velocity_command_kernel, dim3(blocks_for(cmd->num_envs)), dim3(256), 0, as_stream(stream), a);
     ILX_LAUNCH_CHECK("ilx_normal_velocity_command_reset");
     return ILX_OK;
 }

@@ -6,6 +6,10 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstring>
+#include <tuple>
+#include <utility>
+#include <vector>
 
 #include "../../include/isaaclab_amd.h"
 
@@ -41,7 +45,53 @@ inline int device_cu_count() {
     return cached[dev];
 }
 
+// ---- launches and command lists (ilx_commands_*) -----------------------------------------------------------------
+// Every kernel of the library is launched through ILX_LAUNCH.  While the calling thread records a command list the launch
+// is kept -- kernel, geometry and a copy of its arguments -- instead of issued; ilx_commands_replay issues the kept
+// launches in order with one hipLaunchKernel each.
+struct Command {
+    const void* kernel;
+    dim3 grid, block;
+    unsigned shmem;
+    std::vector<char> blob;      // the arguments, each at its own alignment
+    std::vector<void*> args;     // pointers into the blob, in parameter order
+};
+struct CommandList {
+    std::vector<Command> commands;
+    hipStream_t stream = nullptr;   // the stream the recorded calls named
+    bool any = false, mixed = false, open = true;
+};
+CommandList*& recording_list();     // thread-local; null: launches are issued
+
+template <typename... P, typename... A>
+inline void launch(void (*kernel)(P...), dim3 grid, dim3 block, unsigned shmem, hipStream_t stream, A&&... a) {
+    static_assert(sizeof...(P) == sizeof...(A), "one argument per kernel parameter");
+    std::tuple<P...> params{static_cast<P>(std::forward<A>(a))...};   // converted to the parameter types, as a call would
+    CommandList* list = recording_list();
+    std::apply(
+        [&](auto&... p) {
+            if (!list) {
+                void* ptrs[sizeof...(P) + 1] = {static_cast<void*>(&p)...};
+                (void)hipLaunchKernel(reinterpret_cast<const void*>(kernel), grid, block, ptrs, shmem, stream);
+                return;
+            }
+            if (list->any && stream != list->stream) list->mixed = true;
+            list->any = true, list->stream = stream;
+            Command c{reinterpret_cast<const void*>(kernel), grid, block, shmem, {}, {}};
+            size_t at = 0, offsets[sizeof...(P) + 1] = {};
+            int k = 0;
+            ((at = (at + alignof(P) - 1) / alignof(P) * alignof(P), offsets[k++] = at, at += sizeof(P)), ...);
+            c.blob.resize(at + 1);
+            k = 0;
+            ((std::memcpy(c.blob.data() + offsets[k], &p, sizeof(P)), c.args.push_back(c.blob.data() + offsets[k]), ++k), ...);
+            list->commands.push_back(std::move(c));   // (a moved vector keeps its storage: the pointers stay good)
+        },
+        params);
+}
+
 }  // namespace ilx
+
+#define ILX_LAUNCH(kernel, grid, block, shmem, stream, ...) ilx::launch(kernel, grid, block, shmem, stream, ##__VA_ARGS__)
 
 #define ILX_REQUIRE(cond, code, ...)                 \
     do {                                             \

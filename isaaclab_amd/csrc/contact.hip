@@ -63,7 +63,7 @@ extern "C" int ilx_contact_update(const float* net_forces_in, float* net_forces_
                   last_contact_time, timestamp, timestamp_last_update, is_outdated, dt, update_period, force_threshold,
                   advance_clock, n, b, h, b > 256 ? 1 : 256 / b};
     const unsigned blocks = static_cast<unsigned>((n + a.envs_per_block - 1) / a.envs_per_block);
-    hipLaunchKernelGGL(contact_update_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), a);
+    ILX_LAUNCH(contact_update_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), a);
     ILX_LAUNCH_CHECK("ilx_contact_update");
     return ILX_OK;
 }
@@ -77,7 +77,7 @@ extern "C" int ilx_scene_update(const ilx_scene* scene, void* stream) {
     unsigned blocks = 0;
     const int rc = scene_args_from(d, s, blocks);
     if (rc != ILX_OK) return rc;
-    hipLaunchKernelGGL(scene_update_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), s);
+    ILX_LAUNCH(scene_update_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), s);
     ILX_LAUNCH_CHECK("ilx_scene_update");
     return ILX_OK;
 }

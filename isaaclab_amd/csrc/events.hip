@@ -256,7 +256,7 @@ extern "C" int ilx_event_reset_root_state_uniform(const int64_t* env_ids, int64_
     if (count == 0) return ILX_OK;
     ILX_REQUIRE(env_ids && default_root_state && pose_range_host && velocity_range_host && root_state_w, ILX_EINVAL,
                 "ilx_event_reset_root_state_uniform: NULL operand");
-    hipLaunchKernelGGL(reset_root_kernel, dim3(blocks_for(count)), dim3(256), 0, as_stream(stream), env_ids, count,
+    ILX_LAUNCH(reset_root_kernel, dim3(blocks_for(count)), dim3(256), 0, as_stream(stream), env_ids, count,
                        default_root_state, env_origins, range6(pose_range_host), range6(velocity_range_host),
                        EventRng{u, 12, seed, draw}, root_state_w);
     ILX_LAUNCH_CHECK("ilx_event_reset_root_state_uniform");
@@ -275,7 +275,7 @@ extern "C" int ilx_event_reset_root_state_from_terrain(const int64_t* env_ids, i
                 "ilx_event_reset_root_state_from_terrain: NULL operand");
     ILX_REQUIRE(valid_positions && terrain_levels && terrain_types && num_terrain_cols > 0 && num_patches > 0, ILX_EINVAL,
                 "ilx_event_reset_root_state_from_terrain: the flat patches need their table, the envs' levels and types, and the table's shape");
-    hipLaunchKernelGGL(reset_root_from_terrain_kernel, dim3(blocks_for(count)), dim3(256), 0, as_stream(stream), env_ids, count,
+    ILX_LAUNCH(reset_root_from_terrain_kernel, dim3(blocks_for(count)), dim3(256), 0, as_stream(stream), env_ids, count,
                        default_root_state, TerrainPatches{valid_positions, terrain_levels, terrain_types, patch_ids, num_terrain_cols, num_patches},
                        range6(pose_range_host), range6(velocity_range_host), EventRng{u, 9, seed, draw}, root_state_w);
     ILX_LAUNCH_CHECK("ilx_event_reset_root_state_from_terrain");
@@ -292,7 +292,7 @@ extern "C" int ilx_event_reset_joints(int by_scale, const int64_t* env_ids, int6
     ILX_REQUIRE(env_ids && default_joint_pos && default_joint_vel && soft_joint_pos_limits && soft_joint_vel_limits && joint_pos &&
                     joint_vel,
                 ILX_EINVAL, "ilx_event_reset_joints: NULL operand");
-    hipLaunchKernelGGL(reset_joints_kernel, dim3(blocks_for(count * j)), dim3(256), 0, as_stream(stream), by_scale, env_ids, count, j,
+    ILX_LAUNCH(reset_joints_kernel, dim3(blocks_for(count * j)), dim3(256), 0, as_stream(stream), by_scale, env_ids, count, j,
                        default_joint_pos, default_joint_vel, soft_joint_pos_limits, soft_joint_vel_limits, position_lo, position_hi,
                        velocity_lo, velocity_hi, EventRng{u, 2 * j, seed, draw}, joint_pos, joint_vel);
     ILX_LAUNCH_CHECK("ilx_event_reset_joints");
@@ -305,7 +305,7 @@ extern "C" int ilx_event_push_by_setting_velocity(const int64_t* env_ids, int64_
     ILX_REQUIRE(count >= 0, ILX_EINVAL, "ilx_event_push_by_setting_velocity: negative env count");
     if (count == 0) return ILX_OK;
     ILX_REQUIRE(env_ids && velocity_range_host && root_state_w, ILX_EINVAL, "ilx_event_push_by_setting_velocity: NULL operand");
-    hipLaunchKernelGGL(push_velocity_kernel, dim3(blocks_for(count * 6)), dim3(256), 0, as_stream(stream), env_ids, count,
+    ILX_LAUNCH(push_velocity_kernel, dim3(blocks_for(count * 6)), dim3(256), 0, as_stream(stream), env_ids, count,
                        range6(velocity_range_host), EventRng{u, 6, seed, draw}, root_state_w);
     ILX_LAUNCH_CHECK("ilx_event_push_by_setting_velocity");
     return ILX_OK;
@@ -329,7 +329,7 @@ extern "C" int ilx_curriculum_terrain_levels(const int64_t* env_ids, int64_t cou
                 "ilx_curriculum_terrain_levels: without move flags the root state and a command of width >= 2 are needed");
     CurriculumArgs a{env_ids, count, root_state_w, command, command_dim, half_terrain_size, max_episode_length_s, move_up, move_down,
                      terrain_levels, terrain_types, terrain_origins, num_rows, num_cols, random_levels, seed, draw, env_origins};
-    hipLaunchKernelGGL(terrain_levels_kernel, dim3(blocks_for(count)), dim3(256), 0, as_stream(stream), a);
+    ILX_LAUNCH(terrain_levels_kernel, dim3(blocks_for(count)), dim3(256), 0, as_stream(stream), a);
     ILX_LAUNCH_CHECK("ilx_curriculum_terrain_levels");
     return ILX_OK;
 }
@@ -345,7 +345,7 @@ extern "C" int ilx_event_reset_root_state_random_orientation(const int64_t* env_
                 "ilx_event_reset_root_state_random_orientation: NULL operand");
     ILX_REQUIRE((u != nullptr) == (normal_draws != nullptr), ILX_EINVAL,
                 "ilx_event_reset_root_state_random_orientation: uniform and normal draws are injected together");
-    hipLaunchKernelGGL(reset_root_random_orientation_kernel, dim3(blocks_for(count)), dim3(256), 0, as_stream(stream), env_ids, count,
+    ILX_LAUNCH(reset_root_random_orientation_kernel, dim3(blocks_for(count)), dim3(256), 0, as_stream(stream), env_ids, count,
                        default_root_state, env_origins, range6(pose_range_host), range6(velocity_range_host),
                        EventRng{u, 9, seed, draw}, NormalRng{normal_draws, seed, draw}, root_state_w);
     ILX_LAUNCH_CHECK("ilx_event_reset_root_state_random_orientation");
@@ -362,7 +362,7 @@ extern "C" int ilx_event_apply_external_force_torque(const int64_t* env_ids, int
                 num_selected_bodies, num_bodies);
     if (count == 0) return ILX_OK;
     ILX_REQUIRE(env_ids && external_force_b && external_torque_b, ILX_EINVAL, "ilx_event_apply_external_force_torque: NULL operand");
-    hipLaunchKernelGGL(external_wrench_kernel, dim3(blocks_for(count * num_selected_bodies * 3)), dim3(256), 0, as_stream(stream),
+    ILX_LAUNCH(external_wrench_kernel, dim3(blocks_for(count * num_selected_bodies * 3)), dim3(256), 0, as_stream(stream),
                        env_ids, count, body_ids, num_selected_bodies, num_bodies, force_lo, force_hi, torque_lo, torque_hi, u, seed, draw,
                        external_force_b, external_torque_b);
     ILX_LAUNCH_CHECK("ilx_event_apply_external_force_torque");
@@ -380,7 +380,7 @@ extern "C" int ilx_event_reset_scene_to_default(const int64_t* env_ids, int64_t 
     ILX_REQUIRE(!joint_pos || (j > 0 && default_joint_pos && default_joint_vel && joint_vel), ILX_EINVAL,
                 "ilx_event_reset_scene_to_default: the joint state comes with its defaults");
     if (!joint_pos) j = 0;
-    hipLaunchKernelGGL(scene_to_default_kernel, dim3(blocks_for(count * (13 + j))), dim3(256), 0, as_stream(stream), env_ids, count, j,
+    ILX_LAUNCH(scene_to_default_kernel, dim3(blocks_for(count * (13 + j))), dim3(256), 0, as_stream(stream), env_ids, count, j,
                        default_root_state, env_origins, root_state_w, default_joint_pos, default_joint_vel, joint_pos, joint_vel);
     ILX_LAUNCH_CHECK("ilx_event_reset_scene_to_default");
     return ILX_OK;

@@ -62,7 +62,7 @@ extern "C" int ilx_frame_transformer_update(const ilx_frame_transformer* sensor,
                 ILX_EINVAL, "ilx_frame_transformer_update: an offset needs both its position and its orientation");
     ILX_REQUIRE(s.source_pos_w && s.source_quat_w && s.target_pos_w && s.target_quat_w && s.target_pos_source && s.target_quat_source,
                 ILX_EINVAL, "ilx_frame_transformer_update: NULL data buffer");
-    hipLaunchKernelGGL(frame_transformer_kernel, dim3(blocks_for(s.num_envs * s.num_frames)), dim3(256), 0, as_stream(stream), s);
+    ILX_LAUNCH(frame_transformer_kernel, dim3(blocks_for(s.num_envs * s.num_frames)), dim3(256), 0, as_stream(stream), s);
     ILX_LAUNCH_CHECK("ilx_frame_transformer_update");
     return ILX_OK;
 }

@@ -346,7 +346,7 @@ extern "C" int ilx_diff_ik_set_command(const ilx_ik_frame* frame, int command_ty
     for (int k = 0; k < 7; ++k) c.scale[k] = (raw_actions && k < c.dim) ? scale_host[k] : 1.0f;
     c.relative = use_relative_mode;
     c.pos_des = ee_pos_des, c.quat_des = ee_quat_des;
-    hipLaunchKernelGGL(ik_command_kernel, dim3(blocks_for(n)), dim3(256), 0, as_stream(stream), c);
+    ILX_LAUNCH(ik_command_kernel, dim3(blocks_for(n)), dim3(256), 0, as_stream(stream), c);
     ILX_LAUNCH_CHECK("ilx_diff_ik_set_command");
     return ILX_OK;
 }
@@ -380,10 +380,10 @@ extern "C" int ilx_diff_ik_compute(const ilx_ik_frame* frame, int command_type, 
     a.out = joint_pos_des, a.out_stride = joint_pos_des_stride;
     const dim3 grid(blocks_for(n, 64)), block(64);
     switch (ik_method) {
-        case ILX_IK_PINV: hipLaunchKernelGGL(diff_ik_kernel<ILX_IK_PINV>, grid, block, 0, as_stream(stream), a); break;
-        case ILX_IK_SVD: hipLaunchKernelGGL(diff_ik_kernel<ILX_IK_SVD>, grid, block, 0, as_stream(stream), a); break;
-        case ILX_IK_TRANS: hipLaunchKernelGGL(diff_ik_kernel<ILX_IK_TRANS>, grid, block, 0, as_stream(stream), a); break;
-        default: hipLaunchKernelGGL(diff_ik_kernel<ILX_IK_DLS>, grid, block, 0, as_stream(stream), a); break;
+        case ILX_IK_PINV: ILX_LAUNCH(diff_ik_kernel<ILX_IK_PINV>, grid, block, 0, as_stream(stream), a); break;
+        case ILX_IK_SVD: ILX_LAUNCH(diff_ik_kernel<ILX_IK_SVD>, grid, block, 0, as_stream(stream), a); break;
+        case ILX_IK_TRANS: ILX_LAUNCH(diff_ik_kernel<ILX_IK_TRANS>, grid, block, 0, as_stream(stream), a); break;
+        default: ILX_LAUNCH(diff_ik_kernel<ILX_IK_DLS>, grid, block, 0, as_stream(stream), a); break;
     }
     ILX_LAUNCH_CHECK("ilx_diff_ik_compute");
     return ILX_OK;

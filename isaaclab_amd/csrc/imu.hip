@@ -66,7 +66,7 @@ extern "C" int ilx_imu_update(const ilx_imu* imu, int32_t advance_clock, float d
                 ILX_EINVAL, "ilx_imu_update: NULL data buffer");
     ILX_REQUIRE(s.timestamp && s.timestamp_last_update && s.is_outdated, ILX_EINVAL, "ilx_imu_update: NULL clock buffer");
     ILX_REQUIRE(dt > 0.0f, ILX_EINVAL, "ilx_imu_update: the derivative's time step must be positive (update() comes before the first read)");
-    hipLaunchKernelGGL(imu_update_kernel, dim3(blocks_for(s.num_sensors)), dim3(256), 0, as_stream(stream), s, advance_clock, dt_clock, dt);
+    ILX_LAUNCH(imu_update_kernel, dim3(blocks_for(s.num_sensors)), dim3(256), 0, as_stream(stream), s, advance_clock, dt_clock, dt);
     ILX_LAUNCH_CHECK("ilx_imu_update");
     return ILX_OK;
 }

@@ -437,7 +437,7 @@ extern "C" int ilx_inhand_apply_action(const ilx_inhand* env, void* stream) {
     if (d.num_envs == 0) return ILX_OK;
     ILX_REQUIRE(d.actuated_ids && d.lower_limits && d.upper_limits && d.actions && d.cur_targets && d.prev_targets, ILX_EINVAL,
                 "ilx_inhand_apply_action: NULL operand");
-    hipLaunchKernelGGL(inhand_apply_action_kernel, dim3(blocks_for(d.num_envs * d.num_actuated)), dim3(256), 0, as_stream(stream), d);
+    ILX_LAUNCH(inhand_apply_action_kernel, dim3(blocks_for(d.num_envs * d.num_actuated)), dim3(256), 0, as_stream(stream), d);
     ILX_LAUNCH_CHECK("ilx_inhand_apply_action");
     return ILX_OK;
 }
@@ -459,9 +459,9 @@ extern "C" int ilx_inhand_step(const ilx_inhand* env, void* stream) {
                     ILX_EINVAL, "ilx_inhand_step: the observation needs joint state, limits, body_state_w and fingertip_ids");
     const unsigned blocks = static_cast<unsigned>((d.num_envs + kEnvsPerBlock - 1) / kEnvsPerBlock);
     if (d.obs && inhand_unrolled_shape(d.num_joints, d.num_fingertips, d.num_actuated) && d.num_fingertips > 0)
-        hipLaunchKernelGGL(inhand_step_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), d);
+        ILX_LAUNCH(inhand_step_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), d);
     else
-        hipLaunchKernelGGL(inhand_step_general_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), d);
+        ILX_LAUNCH(inhand_step_general_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), d);
     ILX_LAUNCH_CHECK("ilx_inhand_step");
     return ILX_OK;
 }
@@ -469,7 +469,7 @@ extern "C" int ilx_inhand_step(const ilx_inhand* env, void* stream) {
 extern "C" int ilx_inhand_finish(const ilx_inhand* env, void* stream) {
     ILX_REQUIRE(env, ILX_EINVAL, "ilx_inhand_finish: descriptor is NULL");
     ILX_REQUIRE(env->stats && env->consecutive_successes, ILX_EINVAL, "ilx_inhand_finish: NULL operand");
-    hipLaunchKernelGGL(inhand_finish_kernel, dim3(1), dim3(1), 0, as_stream(stream), *env);
+    ILX_LAUNCH(inhand_finish_kernel, dim3(1), dim3(1), 0, as_stream(stream), *env);
     ILX_LAUNCH_CHECK("ilx_inhand_finish");
     return ILX_OK;
 }

@@ -123,7 +123,7 @@ static const OpShape kShapes[ILX_MATH_OP_COUNT] = {
 template <int OP>
 static void launch(const float* a, const float* b, const float* c, const float* d, float* o0, float* o1, int64_t n,
                    hipStream_t s) {
-    hipLaunchKernelGGL(math_op_kernel<OP>, dim3(blocks_for(n)), dim3(256), 0, s, a, b, c, d, o0, o1, n);
+    ILX_LAUNCH(math_op_kernel<OP>, dim3(blocks_for(n)), dim3(256), 0, s, a, b, c, d, o0, o1, n);
 }
 
 }  // namespace ilx
@@ -189,9 +189,9 @@ extern "C" int ilx_math_range_op(int mode, const float* x, const float* lower, c
     if (total == 0) return ILX_OK;
     hipStream_t s = as_stream(stream);
     dim3 g(blocks_for(total)), b(256);
-    if (mode == 0) hipLaunchKernelGGL(range_op_kernel<0>, g, b, 0, s, x, lower, upper, bounds_per_row, out, total, w);
-    if (mode == 1) hipLaunchKernelGGL(range_op_kernel<1>, g, b, 0, s, x, lower, upper, bounds_per_row, out, total, w);
-    if (mode == 2) hipLaunchKernelGGL(range_op_kernel<2>, g, b, 0, s, x, lower, upper, bounds_per_row, out, total, w);
+    if (mode == 0) ILX_LAUNCH(range_op_kernel<0>, g, b, 0, s, x, lower, upper, bounds_per_row, out, total, w);
+    if (mode == 1) ILX_LAUNCH(range_op_kernel<1>, g, b, 0, s, x, lower, upper, bounds_per_row, out, total, w);
+    if (mode == 2) ILX_LAUNCH(range_op_kernel<2>, g, b, 0, s, x, lower, upper, bounds_per_row, out, total, w);
     ILX_LAUNCH_CHECK("ilx_math_range_op");
     return ILX_OK;
 }

@@ -1081,7 +1081,7 @@ __global__ void mdp_begin_step_kernel(float* log_sums, int count, uint64_t* step
 extern "C" int ilx_mdp_begin_step(float* log_sums, int32_t count, uint64_t* step_index_device, void* stream) {
     ILX_REQUIRE(count >= 0 && (count == 0 || log_sums), ILX_EINVAL, "ilx_mdp_begin_step: %d floats at a NULL pointer", count);
     if (count == 0 && !step_index_device) return ILX_OK;
-    hipLaunchKernelGGL(mdp_begin_step_kernel, dim3(1), dim3(64), 0, as_stream(stream), log_sums, log_sums ? count : 0, step_index_device);
+    ILX_LAUNCH(mdp_begin_step_kernel, dim3(1), dim3(64), 0, as_stream(stream), log_sums, log_sums ? count : 0, step_index_device);
     ILX_LAUNCH_CHECK("ilx_mdp_begin_step");
     return ILX_OK;
 }
@@ -1276,7 +1276,7 @@ static int mdp_step(ilx_mdp_plan_t plan, const ilx_mdp* desc, void* stream, cons
     for (int k = 0; k < 3; ++k) hot.gravity[k] = d.gravity_dir[k];
     hot.num_envs = d.num_envs, hot.seed = d.seed, hot.step_index = d.step_index;
     hot.terms = plan->d_terms, hot.step_index_device = d.step_index_device, hot.reward_owner = plan->reward_owner;
-    hipLaunchKernelGGL(mdp_step_kernel, dim3(blocks), dim3(kBlock), lds_bytes, as_stream(stream), m, hot);
+    ILX_LAUNCH(mdp_step_kernel, dim3(blocks), dim3(kBlock), lds_bytes, as_stream(stream), m, hot);
     ILX_LAUNCH_CHECK("ilx_mdp_step");
     return ILX_OK;
 }

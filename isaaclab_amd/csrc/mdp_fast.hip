@@ -1080,7 +1080,7 @@ static int launch(const ilx_mdp_plan_s& p, const ilx_mdp& d, void* stream, const
             if (rc != ILX_OK) return rc;
         }
     }
-    hipLaunchKernelGGL(mdp_fast_kernel<S>, dim3(a.decide_blocks + a.scan_blocks + a.scene_blocks), dim3(kFastBlock), 0, as_stream(stream), a);
+    ILX_LAUNCH(mdp_fast_kernel<S>, dim3(a.decide_blocks + a.scan_blocks + a.scene_blocks), dim3(kFastBlock), 0, as_stream(stream), a);
     ILX_LAUNCH_CHECK("ilx_mdp_step");
     return ILX_OK;
 }

@@ -94,7 +94,7 @@ extern "C" int ilx_modifier_apply(int32_t kind, const ilx_modifier* mod, void* s
     if (kind == ILX_MOD_INTEGRATOR)
         ILX_REQUIRE(m.x_n && m.y_n, ILX_EINVAL, "ilx_modifier_apply: the integrator needs its integral and previous-value buffers");
     ModifierArgs a{m, kind};
-    hipLaunchKernelGGL(modifier_kernel, dim3(blocks_for(m.n * m.d)), dim3(256), 0, as_stream(stream), a);
+    ILX_LAUNCH(modifier_kernel, dim3(blocks_for(m.n * m.d)), dim3(256), 0, as_stream(stream), a);
     ILX_LAUNCH_CHECK("ilx_modifier_apply");
     return ILX_OK;
 }
@@ -104,7 +104,7 @@ extern "C" int ilx_modifier_reset(float* state_a, int64_t len_a, float* state_b,
     ILX_REQUIRE(count >= 0 && len_a >= 0 && len_b >= 0, ILX_EINVAL, "ilx_modifier_reset: negative size");
     if (count == 0 || len_a + len_b == 0) return ILX_OK;
     ILX_REQUIRE((state_a || len_a == 0) && (state_b || len_b == 0), ILX_EINVAL, "ilx_modifier_reset: NULL state buffer");
-    hipLaunchKernelGGL(modifier_reset_kernel, dim3(blocks_for(count * (len_a + len_b))), dim3(256), 0, as_stream(stream), state_a, len_a,
+    ILX_LAUNCH(modifier_reset_kernel, dim3(blocks_for(count * (len_a + len_b))), dim3(256), 0, as_stream(stream), state_a, len_a,
                        state_b, len_b, env_ids, count);
     ILX_LAUNCH_CHECK("ilx_modifier_reset");
     return ILX_OK;

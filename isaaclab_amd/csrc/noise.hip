@@ -54,7 +54,7 @@ extern "C" int ilx_noise_apply(int32_t kind, int32_t operation, const ilx_noise*
     ILX_REQUIRE(s.data && s.out, ILX_EINVAL, "ilx_noise_apply: data or out is NULL");
     ILX_REQUIRE(s.data_stride >= s.d && s.out_stride >= s.d, ILX_ESHAPE, "ilx_noise_apply: row strides (%lld, %lld) below the width %d",
                 static_cast<long long>(s.data_stride), static_cast<long long>(s.out_stride), s.d);
-    hipLaunchKernelGGL(noise_kernel, dim3(blocks_for(s.n * s.d)), dim3(256), 0, as_stream(stream), s, kind, operation);
+    ILX_LAUNCH(noise_kernel, dim3(blocks_for(s.n * s.d)), dim3(256), 0, as_stream(stream), s, kind, operation);
     ILX_LAUNCH_CHECK("ilx_noise_apply");
     return ILX_OK;
 }

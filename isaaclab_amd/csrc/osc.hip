@@ -402,7 +402,7 @@ extern "C" int ilx_osc_set_command(const ilx_osc* osc, const float* command, int
     ILX_REQUIRE(!wrench || (o.desired_ee_wrench_task && o.desired_ee_wrench_b), ILX_EINVAL,
                 "ilx_osc_set_command: wrench target buffers are NULL");
     OscCmdArgs a{o, command, action_dim, target_dim, current_ee_pose_b, current_task_frame_pose_b};
-    hipLaunchKernelGGL(osc_set_command_kernel, dim3(blocks_for(o.num_envs, 128)), dim3(128), 0, as_stream(stream), a);
+    ILX_LAUNCH(osc_set_command_kernel, dim3(blocks_for(o.num_envs, 128)), dim3(128), 0, as_stream(stream), a);
     ILX_LAUNCH_CHECK("ilx_osc_set_command");
     return ILX_OK;
 }
@@ -447,7 +447,7 @@ extern "C" int ilx_osc_compute(const ilx_osc* osc, int has_pose_target, int has_
     }
     OscArgs a{o, has_pose_target, has_wrench_target, num_dof, jacobian_b, current_ee_pose_b, current_ee_vel_b, current_ee_force_b,
               mass_matrix, gravity, current_joint_pos, current_joint_vel, nullspace_joint_pos_target, joint_efforts};
-    hipLaunchKernelGGL(osc_compute_kernel, dim3(blocks_for(o.num_envs, 64)), dim3(64), 0, as_stream(stream), a);
+    ILX_LAUNCH(osc_compute_kernel, dim3(blocks_for(o.num_envs, 64)), dim3(64), 0, as_stream(stream), a);
     ILX_LAUNCH_CHECK("ilx_osc_compute");
     return ILX_OK;
 }

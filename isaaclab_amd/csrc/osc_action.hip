@@ -116,7 +116,7 @@ extern "C" int ilx_osc_action_state_update(const ilx_osc_action_state* state, vo
         ILX_REQUIRE(s.jac_bodies > 0 && s.jac_body_idx >= 0 && s.jac_body_idx < s.jac_bodies && s.jac_cols > 0 && s.num_joints > 0, ILX_EINVAL,
                     "ilx_osc_action_state_update: bad Jacobian shape or body index");
     }
-    hipLaunchKernelGGL(osc_action_state_kernel, dim3((s.num_envs + 127) / 128), dim3(128), 0, as_stream(stream), s);
+    ILX_LAUNCH(osc_action_state_kernel, dim3((s.num_envs + 127) / 128), dim3(128), 0, as_stream(stream), s);
     ILX_LAUNCH_CHECK("ilx_osc_action_state_update");
     return ILX_OK;
 }

@@ -156,7 +156,7 @@ extern "C" int ilx_pose_op(int32_t op, const float* a, int64_t a_batch, const fl
                 "ilx_pose_op: operand batches (%lld, %lld) are neither 1 nor %lld", static_cast<long long>(a_batch),
                 static_cast<long long>(b_batch), static_cast<long long>(n));
     PoseArgs s{op, a, b, a_batch, b_batch, scalar, out, flag, n};
-    hipLaunchKernelGGL(pose_op_kernel, dim3(blocks_for(n)), dim3(256), 0, as_stream(stream), s);
+    ILX_LAUNCH(pose_op_kernel, dim3(blocks_for(n)), dim3(256), 0, as_stream(stream), s);
     ILX_LAUNCH_CHECK("ilx_pose_op");
     return ILX_OK;
 }
@@ -171,7 +171,7 @@ extern "C" int ilx_camera_op(int32_t op, const float* data, const float* intrins
     ILX_REQUIRE(intrinsics_batch == 1 || intrinsics_batch == n, ILX_ESHAPE, "ilx_camera_op: %lld calibration matrices for %lld images",
                 static_cast<long long>(intrinsics_batch), static_cast<long long>(n));
     CameraArgs s{op, data, intrinsics, intrinsics_batch, out, n, h, w};
-    hipLaunchKernelGGL(camera_op_kernel, dim3(blocks_for(n * per)), dim3(256), 0, as_stream(stream), s);
+    ILX_LAUNCH(camera_op_kernel, dim3(blocks_for(n * per)), dim3(256), 0, as_stream(stream), s);
     ILX_LAUNCH_CHECK("ilx_camera_op");
     return ILX_OK;
 }
@@ -181,7 +181,7 @@ extern "C" int ilx_sample_cylinder(float radius, float h_min, float h_max, const
     ILX_REQUIRE(n >= 0, ILX_EINVAL, "ilx_sample_cylinder: negative count");
     if (n == 0) return ILX_OK;
     ILX_REQUIRE(out, ILX_EINVAL, "ilx_sample_cylinder: out is NULL");
-    hipLaunchKernelGGL(sample_cylinder_kernel, dim3(blocks_for(n)), dim3(256), 0, as_stream(stream), radius, h_min, h_max, u, seed, draw,
+    ILX_LAUNCH(sample_cylinder_kernel, dim3(blocks_for(n)), dim3(256), 0, as_stream(stream), radius, h_min, h_max, u, seed, draw,
                        out, n);
     ILX_LAUNCH_CHECK("ilx_sample_cylinder");
     return ILX_OK;

@@ -1782,16 +1782,16 @@ static void launch_lattice(ilx_mesh_t mesh, ScanArgs a, int hints, void* ws, flo
     float4* pattern = static_cast<float4*>(ws);
     LatEnvRec* recs = reinterpret_cast<LatEnvRec*>(static_cast<char*>(ws) + lattice_workspace_bytes(0, a.r));
     if (!(hints & ILX_RAYS_PREPARED))
-        hipLaunchKernelGGL(raycaster_prepare_kernel, dim3(blocks_for(a.n)), dim3(256), 0, as_stream(stream), a, recs, pattern, box,
+        ILX_LAUNCH(raycaster_prepare_kernel, dim3(blocks_for(a.n)), dim3(256), 0, as_stream(stream), a, recs, pattern, box,
                            (box && reuse) ? 1 : 0);
     const bool last_launch = (hints & ILX_RAYS_Z_PARALLEL_CHECKED) && mesh->h.d_cells;
     ScanArgs cast = a;
     if ((hints & ILX_RAYS_HEIGHT_ONLY) && last_launch && a.height) cast.ray_hits_w = nullptr;   // nothing reads the hit records as a work list
-    hipLaunchKernelGGL(raycaster_update_lattice_kernel, dim3(static_cast<unsigned>((a.n + kLatWaves - 1) / kLatWaves)),
+    ILX_LAUNCH(raycaster_update_lattice_kernel, dim3(static_cast<unsigned>((a.n + kLatWaves - 1) / kLatWaves)),
                        dim3(64 * kLatWaves), 0, as_stream(stream), cast, recs, pattern);
     if (last_launch) return;
     a.outdated = nullptr;
-    hipLaunchKernelGGL(raycaster_update_kernel, dim3(std::min(ray_grid(a.n * a.r), 256u)), dim3(kRayBlock), 0, as_stream(stream), a);
+    ILX_LAUNCH(raycaster_update_kernel, dim3(std::min(ray_grid(a.n * a.r), 256u)), dim3(kRayBlock), 0, as_stream(stream), a);
 }
 
 // The workspace of `stream` with room for `bytes`, and the four floats behind it that keep the scan pattern's bounding
@@ -1880,9 +1880,9 @@ extern "C" int ilx_raycast_mesh(ilx_mesh_t mesh, const float* ray_starts, const 
         // column kernel, then the tree kernel for whatever rays were not z-parallel after all (it leaves at once
         // when the column kernel did not raise this call's flag)
         take_ticket(mesh, a.ticket, a.off_grid);
-        hipLaunchKernelGGL(raycast_column_kernel, dim3(column_grid(num_rays)), dim3(kRayBlock), 0, as_stream(stream), a);
+        ILX_LAUNCH(raycast_column_kernel, dim3(column_grid(num_rays)), dim3(kRayBlock), 0, as_stream(stream), a);
     }
-    hipLaunchKernelGGL(raycast_kernel, dim3(ray_grid(num_rays)), dim3(kRayBlock), 0, as_stream(stream), a);
+    ILX_LAUNCH(raycast_kernel, dim3(ray_grid(num_rays)), dim3(kRayBlock), 0, as_stream(stream), a);
     ILX_LAUNCH_CHECK("ilx_raycast_mesh");
     return ILX_OK;
 }
@@ -1894,7 +1894,7 @@ extern "C" int ilx_raycast_mesh_stats(ilx_mesh_t mesh, const float* ray_starts, 
     ILX_REQUIRE(ray_starts && ray_directions && ray_hits && counters, ILX_EINVAL, "ilx_raycast_mesh_stats: NULL operand");
     CastArgs a{mesh->h.dev, ray_starts, ray_directions, max_dist, ray_hits, nullptr, nullptr, nullptr, num_rays, counters,
                0, nullptr};
-    hipLaunchKernelGGL(raycast_kernel, dim3(ray_grid(num_rays)), dim3(kRayBlock), 0, as_stream(stream), a);
+    ILX_LAUNCH(raycast_kernel, dim3(ray_grid(num_rays)), dim3(kRayBlock), 0, as_stream(stream), a);
     ILX_LAUNCH_CHECK("ilx_raycast_mesh_stats");
     return ILX_OK;
 }
@@ -1984,7 +1984,7 @@ extern "C" int ilx_scene_update_prepare_raycaster(const ilx_scene* scene, const 
             status = scene_args_from(*scene, s, blocks);
             if (status != ILX_OK) return status;
             const unsigned prep_blocks = blocks_for(a.n);
-            hipLaunchKernelGGL(scene_update_prepare_kernel, dim3(prep_blocks + blocks), dim3(256), 0, as_stream(stream), s, a, recs,
+            ILX_LAUNCH(scene_update_prepare_kernel, dim3(prep_blocks + blocks), dim3(256), 0, as_stream(stream), s, a, recs,
                                box, prep_blocks);
             ILX_LAUNCH_CHECK("ilx_scene_update_prepare_raycaster");
             return ILX_OK;
@@ -1992,7 +1992,7 @@ extern "C" int ilx_scene_update_prepare_raycaster(const ilx_scene* scene, const 
         // first use of this pattern on this stream: the update, then the preparation launch proper (it packs the pattern)
         status = ilx_scene_update(scene, stream);
         if (status != ILX_OK) return status;
-        hipLaunchKernelGGL(raycaster_prepare_kernel, dim3(blocks_for(a.n)), dim3(256), 0, as_stream(stream), a, recs,
+        ILX_LAUNCH(raycaster_prepare_kernel, dim3(blocks_for(a.n)), dim3(256), 0, as_stream(stream), a, recs,
                            static_cast<float4*>(ws), box, 0);
         ILX_LAUNCH_CHECK("ilx_scene_update_prepare_raycaster");
         return ILX_OK;
@@ -2083,13 +2083,13 @@ static int launch_scan(ilx_mesh_t mesh, ScanArgs a, int hints, void* stream, voi
     }
     if ((hints & ILX_RAYS_Z_PARALLEL) && mesh->h.d_cells) {
         take_ticket(mesh, a.ticket, a.off_grid);
-        hipLaunchKernelGGL(raycaster_update_column_kernel, dim3(column_grid(rays)), dim3(kRayBlock), 0, as_stream(stream), a);
-        hipLaunchKernelGGL(raycaster_update_kernel, dim3(ray_grid(rays)), dim3(kRayBlock), 0, as_stream(stream), a);
+        ILX_LAUNCH(raycaster_update_column_kernel, dim3(column_grid(rays)), dim3(kRayBlock), 0, as_stream(stream), a);
+        ILX_LAUNCH(raycaster_update_kernel, dim3(ray_grid(rays)), dim3(kRayBlock), 0, as_stream(stream), a);
         return ILX_OK;
     }
-    hipLaunchKernelGGL(raycaster_update_kernel, dim3(ray_grid(rays)), dim3(kRayBlock), 0, as_stream(stream), a);
+    ILX_LAUNCH(raycaster_update_kernel, dim3(ray_grid(rays)), dim3(kRayBlock), 0, as_stream(stream), a);
     if (a.outdated)
-        hipLaunchKernelGGL(sensor_refreshed_kernel, dim3(blocks_for(a.n)), dim3(256), 0, as_stream(stream), a.clock_now, a.clock_last,
+        ILX_LAUNCH(sensor_refreshed_kernel, dim3(blocks_for(a.n)), dim3(256), 0, as_stream(stream), a.clock_now, a.clock_last,
                            a.outdated, a.n);
     return ILX_OK;
 }
@@ -2112,9 +2112,9 @@ extern "C" int ilx_raycaster_camera_refresh(const ilx_raycaster_camera* rc, void
     CameraArgs a{d.mesh->h.dev, d.view_pos, d.view_quat, d.view_pos_stride, d.view_quat_stride, d.offset_pos, d.offset_quat,
                  d.ray_starts, d.ray_directions, d.is_outdated, d.pos_w, d.quat_w_world, d.frame, d.ray_hits_w,
                  d.distance_to_image_plane, d.distance_to_camera, d.normals, d.max_distance, d.depth_clipping, d.num_envs, d.num_rays};
-    hipLaunchKernelGGL(raycaster_camera_kernel, dim3(ray_grid(d.num_envs * d.num_rays)), dim3(kRayBlock), 0, as_stream(stream), a);
+    ILX_LAUNCH(raycaster_camera_kernel, dim3(ray_grid(d.num_envs * d.num_rays)), dim3(kRayBlock), 0, as_stream(stream), a);
     if (d.is_outdated)
-        hipLaunchKernelGGL(sensor_refreshed_kernel, dim3(blocks_for(d.num_envs)), dim3(256), 0, as_stream(stream), d.timestamp,
+        ILX_LAUNCH(sensor_refreshed_kernel, dim3(blocks_for(d.num_envs)), dim3(256), 0, as_stream(stream), d.timestamp,
                            d.timestamp_last_update, d.is_outdated, d.num_envs);
     ILX_LAUNCH_CHECK("ilx_raycaster_camera_refresh");
     return ILX_OK;

@@ -86,7 +86,7 @@ extern "C" int ilx_sample(int kind, const float* a, int64_t a_row_stride, int64_
     ILX_REQUIRE(out, ILX_EINVAL, "ilx_sample: out is NULL");
     SampleArgs s{kind, a, b, a_row_stride, a_col_stride, b_row_stride, b_col_stride, a_scalar, b_scalar, u, z, seed, draw, out, rows, width};
     const int64_t threads = quat ? rows : rows * width;
-    hipLaunchKernelGGL(sample_kernel, dim3(blocks_for(threads)), dim3(256), 0, as_stream(stream), s);
+    ILX_LAUNCH(sample_kernel, dim3(blocks_for(threads)), dim3(256), 0, as_stream(stream), s);
     ILX_LAUNCH_CHECK("ilx_sample");
     return ILX_OK;
 }

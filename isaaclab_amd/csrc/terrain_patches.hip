@@ -49,7 +49,7 @@ extern "C" int ilx_flat_patch_rays(const float* centre_x, const float* centre_y,
     if (count == 0) return ILX_OK;
     ILX_REQUIRE(centre_x && centre_y && ring && patch_ids && flat_patches && ray_starts && ray_directions, ILX_EINVAL,
                 "ilx_flat_patch_rays: NULL operand");
-    hipLaunchKernelGGL(flat_patch_rays_kernel, dim3(blocks_for(count * ring_points)), dim3(256), 0, as_stream(stream), centre_x, centre_y,
+    ILX_LAUNCH(flat_patch_rays_kernel, dim3(blocks_for(count * ring_points)), dim3(256), 0, as_stream(stream), centre_x, centre_y,
                        ring, patch_ids, count, ring_points, flat_patches, ray_starts, ray_directions);
     ILX_LAUNCH_CHECK("ilx_flat_patch_rays");
     return ILX_OK;
@@ -60,7 +60,7 @@ extern "C" int ilx_flat_patch_check(const float* ray_hits, const int64_t* patch_
     ILX_REQUIRE(count >= 0 && ring_points > 0, ILX_EINVAL, "ilx_flat_patch_check: bad shape (%lld, %d)", static_cast<long long>(count), ring_points);
     if (count == 0) return ILX_OK;
     ILX_REQUIRE(ray_hits && patch_ids && flat_patches && not_valid, ILX_EINVAL, "ilx_flat_patch_check: NULL operand");
-    hipLaunchKernelGGL(flat_patch_check_kernel, dim3(blocks_for(count)), dim3(256), 0, as_stream(stream), ray_hits, patch_ids, count,
+    ILX_LAUNCH(flat_patch_check_kernel, dim3(blocks_for(count)), dim3(256), 0, as_stream(stream), ray_hits, patch_ids, count,
                        ring_points, z_lo, z_hi, max_height_diff, flat_patches, not_valid);
     ILX_LAUNCH_CHECK("ilx_flat_patch_check");
     return ILX_OK;

@@ -49,3 +49,29 @@ def test_cpu_tensors_are_refused():
 
     with pytest.raises(Exception, match="GPU"):
         m.quat_mul(torch.zeros(2, 4), torch.zeros(2, 4))
+
+
+def test_command_list_bookkeeping_needs_no_gpu():
+    """Recording state, the error cases and an empty list's replay: no HIP call is made."""
+    from isaaclab_amd import _abi
+    from isaaclab_amd.utils.command_list import CommandList
+
+    assert _abi.commands_end() == -1 and b"not recording" in _abi.lib.ilx_last_error()
+    assert _abi.commands_begin(None) == -1
+    assert _abi.commands_replay(None, None) == -1
+    commands = CommandList()
+    with pytest.raises(Exception, match="nothing recorded"):
+        commands.replay(stream=0)
+    with commands.record():
+        handle = ctypes.c_void_p()
+        assert _abi.commands_begin(ctypes.byref(handle)) == -1 and b"recording already" in _abi.lib.ilx_last_error()
+        assert _abi.commands_replay(commands._handle, None) == -1 and b"still being recorded" in _abi.lib.ilx_last_error()
+        # argument checks run as usual while recording
+        assert _abi.math_op(999, None, None, None, None, None, None, 4, None) == -1
+    assert len(commands) == 0
+    commands.replay(stream=0)          # nothing to issue
+    with pytest.raises(RuntimeError, match="boom"):
+        with commands.record():
+            raise RuntimeError("boom")
+    assert commands._handle is None and _abi.commands_end() == -1   # the failed block left no recording behind
+    commands.destroy()

@@ -282,3 +282,52 @@ def test_fused_first_and_last_launches_equal_the_separate_ones(dev, config, robo
     for name, other in (("separate launches", run(False, False, True)), ("plan-interpreting kernel", run(True, True, False))):
         for key, value in fused.items():
             assert_exact(value, other[key].cpu(), f"{config} {robot or ''}: {key} against the {name}")
+
+
+@pytest.mark.parametrize("config", ["cartpole", "reach", "anymal", "h1", "shadow"])
+def test_step_replayed_from_a_command_list_equals_the_step_issued_directly(dev, config):
+    """The step's launches kept in a command list (ilx_commands_begin / _end) and re-issued by ilx_commands_replay against
+    the same step issued call by call: nothing runs while recording, a replay runs exactly the step -- every buffer bit for
+    bit over three steps, the generator's step count advancing in device memory in both."""
+    import bench_configs as BC
+    from isaaclab_amd.utils.command_list import CommandList
+
+    def buffers(cfg):
+        env = cfg.env
+        if config == "shadow":
+            return dict(obs=env.obs, reward=env.reward, goal_rot=env.goal_rot, successes=env.successes, episode_length=env.episode_length_buf,
+                        terminated=env.reset_terminated, time_outs=env.reset_time_outs, consecutive=env.consecutive_successes,
+                        cur_targets=env.cur_targets, prev_targets=env.prev_targets)
+        m, d = env.mdp, env.data
+        out = dict(obs=m.obs, reward=m.reward_buf, terminated=m.terminated, time_outs=m.time_outs, episode_sums=m.episode_sums,
+                   episode_length=m.episode_length_buf, action=env.action, prev_action=env.prev_action, joint_acc=d._joint_acc,
+                   applied=d.applied_torque)
+        if config in ("anymal", "h1"):
+            out.update(height_scan=env.height_scan, air_time=env.contact.data.current_air_time, scanner_clock=env.scanner._timestamp_last_update)
+        return out
+
+    def run(listed):
+        cfg = BC.build(config, dev, 1000, seed=31)
+        cfg.env.count_steps_on_device()
+        cfg.step()                       # whatever is created at the first step is created here
+        before = {k: v.clone() for k, v in buffers(cfg).items()}
+        if listed:
+            commands = CommandList()
+            with commands.record():
+                cfg.step()
+            torch.cuda.synchronize()
+            for k, v in buffers(cfg).items():
+                assert_exact(v, before[k].cpu(), f"{config}: {k} while recording")
+            assert len(commands) == sum(n for _, n in cfg.launches.values()), "one kept launch per launch of the step"
+            for _ in range(3):
+                commands.replay()
+        else:
+            for _ in range(3):
+                cfg.step()
+        torch.cuda.synchronize()
+        return {k: v.cpu().clone() for k, v in buffers(cfg).items()}
+
+    direct, listed = run(False), run(True)
+    assert direct["obs"].abs().sum() > 0
+    for k, v in direct.items():
+        assert_exact(listed[k], v, f"{config}: {k} after three replays")
