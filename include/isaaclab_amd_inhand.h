@@ -62,6 +62,12 @@ typedef struct ilx_inhand {
     /* NULL, or one word in device memory that is added to step_index and that ilx_inhand_finish advances by one: a step
      * recorded in a HIP graph then draws fresh numbers at every replay (no counterpart in the reference). */
     uint64_t* step_index_device;
+    /* NULL, or scratch of 2 * ceil(num_envs / 16) floats in device memory (no counterpart in the reference): ilx_inhand_step
+     * then leaves its two sums there as one pair per workgroup, stored the usual way, and ilx_inhand_finish adds them up
+     * (in a fixed order) before it uses `stats`.  With NULL every workgroup adds its pair to `stats` itself: a thousand
+     * float adds to one cache line, which the launch waits 4 us for at 8 192 envs.  A caller that all-reduces `stats`
+     * between the two calls (several GPUs) passes NULL. */
+    float* block_sums;
 } ilx_inhand;
 
 int ilx_inhand_apply_action(const ilx_inhand* env, void* stream);

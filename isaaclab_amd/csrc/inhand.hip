@@ -140,7 +140,10 @@ __global__ void __launch_bounds__(256) inhand_step_general_kernel(ilx_inhand d) 
         s.obj_pos[0] = obj.x, s.obj_pos[1] = obj.y, s.obj_pos[2] = obj.z;
     }
     __syncthreads();
-    if (tid < 2 && block_stats[tid] != 0.0f) unsafeAtomicAdd(d.stats + tid, block_stats[tid]);
+    if (tid < 2) {
+        if (d.block_sums) d.block_sums[2 * blockIdx.x + tid] = block_stats[tid];
+        else if (block_stats[tid] != 0.0f) unsafeAtomicAdd(d.stats + tid, block_stats[tid]);
+    }
     if (!live || !d.obs) return;
     // ---- compute_full_observations :298-322
     const int O = 2 * J + 24 + 13 * F + A;
@@ -396,8 +399,12 @@ __global__ void __launch_bounds__(256) inhand_step_kernel(ilx_inhand d) {
     }
     if ((tid & 63) == 0 && atomicAdd(&waves_done, 1u) == 3u) {   // LDS takes a wavefront's operations in order: the sums are complete
         const float n_reset = block_stats[0], n_fin = block_stats[1];
-        if (n_reset != 0.0f) unsafeAtomicAdd(d.stats, n_reset);
-        if (n_fin != 0.0f) unsafeAtomicAdd(d.stats + 1, n_fin);
+        if (d.block_sums) {   // a plain store per block: ilx_inhand_finish adds them up
+            d.block_sums[2 * blockIdx.x] = n_reset, d.block_sums[2 * blockIdx.x + 1] = n_fin;
+        } else {
+            if (n_reset != 0.0f) unsafeAtomicAdd(d.stats, n_reset);
+            if (n_fin != 0.0f) unsafeAtomicAdd(d.stats + 1, n_fin);
+        }
     }
     IH_STAMP(5);
 }
@@ -409,9 +416,25 @@ extern "C" int ilx_debug_inhand_stamps(unsigned long long* out, int count) {
 namespace ilx {
 #endif
 
-// :422-431 from the (possibly all-reduced) sums; one thread
-__global__ void inhand_finish_kernel(ilx_inhand d) {
-    const float num_resets = d.stats[0], finished = d.stats[1];
+// :422-431 from the (possibly all-reduced) sums.  One thread -- or, with per-workgroup sums to add up first, one block:
+// thread t adds the pairs t, t + 256, ..., the block adds the threads' sums as a tree; the order is fixed, so the result
+// does not change from run to run.
+__global__ void __launch_bounds__(256) inhand_finish_kernel(ilx_inhand d, int pairs) {
+    __shared__ float part[2][256];
+    const int tid = threadIdx.x;
+    float n_reset = 0.0f, n_fin = 0.0f;
+    if (d.block_sums) {
+        for (int i = tid; i < pairs; i += 256) n_reset += d.block_sums[2 * i], n_fin += d.block_sums[2 * i + 1];
+        part[0][tid] = n_reset, part[1][tid] = n_fin;
+        __syncthreads();
+        for (int w = 128; w > 0; w >>= 1) {
+            if (tid < w) part[0][tid] += part[0][tid + w], part[1][tid] += part[1][tid + w];
+            __syncthreads();
+        }
+        n_reset = part[0][0], n_fin = part[1][0];
+    }
+    if (tid != 0) return;
+    const float num_resets = d.stats[0] + n_reset, finished = d.stats[1] + n_fin;
     const float prev = d.consecutive_successes[0];
     if (num_resets > 0.0f) d.consecutive_successes[0] = div_(d.av_factor * finished, num_resets) + d.one_minus_av_factor * prev;
     d.stats[0] = 0.0f;
@@ -469,7 +492,8 @@ extern "C" int ilx_inhand_step(const ilx_inhand* env, void* stream) {
 extern "C" int ilx_inhand_finish(const ilx_inhand* env, void* stream) {
     ILX_REQUIRE(env, ILX_EINVAL, "ilx_inhand_finish: descriptor is NULL");
     ILX_REQUIRE(env->stats && env->consecutive_successes, ILX_EINVAL, "ilx_inhand_finish: NULL operand");
-    ILX_LAUNCH(inhand_finish_kernel, dim3(1), dim3(1), 0, as_stream(stream), *env);
+    const int pairs = static_cast<int>((env->num_envs + kEnvsPerBlock - 1) / kEnvsPerBlock);
+    ILX_LAUNCH(inhand_finish_kernel, dim3(1), dim3(env->block_sums ? 256 : 1), 0, as_stream(stream), *env, pairs);
     ILX_LAUNCH_CHECK("ilx_inhand_finish");
     return ILX_OK;
 }

@@ -17,6 +17,12 @@ import torch
 from .. import _abi
 from ..distributed import all_reduce_log_sums
 
+
+def _world_size() -> int:
+    import torch.distributed as dist
+
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
 c_f, c_i32, c_i64, c_u64, P = ctypes.c_float, ctypes.c_int32, ctypes.c_int64, ctypes.c_uint64, ctypes.c_void_p
 
 
@@ -36,6 +42,7 @@ class InHandDesc(ctypes.Structure):
         ("av_factor", c_f), ("one_minus_av_factor", c_f), ("act_moving_average", c_f), ("one_minus_act_moving_average", c_f),
         ("max_consecutive_success", c_i32), ("max_episode_length", c_i64),
         ("goal_samples", P), ("reset_goal_samples", P), ("seed", c_u64), ("step_index", c_u64), ("step_index_device", P),
+        ("block_sums", P),
     ]
 
 
@@ -96,6 +103,8 @@ class InHandManipulationStep:
         self.obs, self.reward = z(n, self.obs_dim), z(n)
         self.reset_terminated, self.reset_time_outs, self.reset_buf = (z(n, dtype=torch.bool) for _ in range(3))
         self.stats = z(2)
+        self._block_sums = z(2 * ((n + 15) // 16))   # per-workgroup sums of the step launch (one GPU: see _fill)
+        self.sums_per_workgroup = True
         self.joint_pos = self.joint_vel = self.body_state_w = self.object_state_w = None
         self._step_counter = None   # see count_steps_on_device
         d = self.desc = InHandDesc(num_envs=n, num_joints=num_joints, num_bodies=num_bodies, num_actuated=a,
@@ -125,6 +134,8 @@ class InHandManipulationStep:
         d.obs, d.reward = p(self.obs), p(self.reward)
         d.terminated, d.time_outs, d.reset_buf = (t.data_ptr() for t in (self.reset_terminated, self.reset_time_outs, self.reset_buf))
         d.goal_samples, d.reset_goal_samples = p(goal_samples), p(reset_goal_samples)
+        # on several GPUs `stats` is all-reduced between the step and the finish launch: the workgroups add to it themselves
+        d.block_sums = p(self._block_sums) if self.sums_per_workgroup and _world_size() == 1 else None
 
     def step(self, actions: torch.Tensor, goal_samples=None, reset_goal_samples=None):
         """direct_rl_env.py:330-386 without the simulator: returns (obs, reward, terminated, time_outs)."""

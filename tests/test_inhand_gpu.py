@@ -178,3 +178,29 @@ def test_inhand_step_replayed_from_a_graph_equals_eager(dev):
         for k, (x, y) in enumerate(zip(one, two)):
             assert_exact(y, x, f"buffer {k}, step {step}")
     assert not torch.equal(outs[1][0][2], outs[1][1][2]), "new goals are drawn from step to step"
+
+
+def test_inhand_sums_per_workgroup_equal_the_adds_to_one_address(dev):
+    """The step's two global sums left as one pair per workgroup and added up by the finish launch (ilx_inhand::block_sums)
+    against every workgroup adding its pair to `stats` itself: all buffers bit for bit over three steps (the sums are sums of
+    small whole numbers: exact in any order)."""
+    from isaaclab_amd import synth
+
+    outs = []
+    for per_workgroup in (True, False):
+        s = synth.inhand_state(3000, seed=21)
+        s["actuated"], s["fingers"] = torch.tensor(s["actuated"]), torch.tensor(s["fingers"])
+        env = make_env(dev, s, 0.8, 50)
+        env.sums_per_workgroup = per_workgroup
+        env.episode_length_buf[::3] = 598
+        trace = []
+        for step in range(3):
+            env.step(s["actions"].to(dev))
+            torch.cuda.synchronize()
+            assert (env.desc.block_sums is not None) == per_workgroup
+            trace.append([t.cpu().clone() for t in (env.obs, env.reward, env.goal_rot, env.successes, env.consecutive_successes, env.stats)])
+        outs.append(trace)
+    assert outs[0][2][4].item() != 0.0, "resets happened: the statistic moved"
+    for step, (a, b) in enumerate(zip(*outs)):
+        for k, (x, y) in enumerate(zip(a, b)):
+            assert_exact(x, y, f"buffer {k}, step {step}")
