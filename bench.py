@@ -292,10 +292,10 @@ def main():
             dist.barrier()
         return time.perf_counter() - t0
 
-    # The step is eight to eleven short launches (2-40 us each): issued one by one from the host they are launch-bound, so
-    # the measured mode records the step in a HIP graph and replays it.  The in-hand env (four launches, a collective between
-    # them on several GPUs) is measured eagerly (replayed from a graph it takes 30 us against 24; reported beside it on one
-    # GPU).  The other mode is timed as well and reported beside the headline.
+    # The step is three to seven short launches (2-17 us each): issued one by one from Python they are bound by the host, so
+    # the step is recorded -- in a HIP graph, and in a command list (below) -- and replayed.  The in-hand env (four launches,
+    # a collective between them on several GPUs) is timed eagerly first (a graph replay of it is slower than that; on one
+    # GPU both and the command list are reported).  Every mode is timed and reported in the line.
     use_graph = not args.eager and args.config != "shadow"   # four launches: a replay's fixed cost is above their host time
     other_s = None
     # The headline is the step recorded as ONE chain in the reference's own order (manager_based_rl_env.py:172-195; scene
