@@ -108,6 +108,7 @@ class LocomotionVelocityStep:
         self.concurrent_chains = False
         # the managers add the done envs' statistics to mdp.log_sums; set, every step starts the vector at zero itself
         self.clear_log_sums = False
+        self.on_physics = None      # callable(substep) or None: called where the simulator's step belongs (one-chain step)
         self._advance_count_first = False   # see count_steps_on_device
         self._side_streams: dict[int, torch.cuda.Stream] = {}   # by priority, see _fork_stream
         # the last scene update of a step also issues the preparation of the scanner's refresh (see step_sensors)
@@ -236,6 +237,8 @@ class LocomotionVelocityStep:
                 self.actuator.compute(ca, d.joint_pos, d.joint_vel, joint_action=ride)
             else:
                 self.actuator.compute(ca, d.joint_pos, d.joint_vel, scene_update=update)
+            if self.on_physics is not None:
+                self.on_physics(k)     # <physics k>: a simulator steps here (see SegmentedCommandList)
         self.scanner._update_outdated_buffers(height_out=self.height_scan, height_offset=self.height_scan_offset, prepared=prepared)
         return self.step_managers(noise_u, command_samples, reset_command_samples)
 

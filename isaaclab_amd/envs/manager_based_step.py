@@ -81,6 +81,7 @@ class ManagerBasedStep:
         self.physics = None
         # the managers add the done envs' statistics to mdp.log_sums; set, every step starts the vector at zero itself
         self.clear_log_sums = False
+        self.on_physics = None      # callable(substep) or None: called where the simulator's step belongs
         self._advance_count_first = False   # see count_steps_on_device
 
     def count_steps_on_device(self):
@@ -151,7 +152,9 @@ class ManagerBasedStep:
             # action terms' apply_actions + write_data_to_sim (actuators); from the second substep on the launch of the
             # actuator model also carries the scene update of the substep before (no physics step lies between them)
             self.apply_action(update, first=k == 0)
-            d.joint_pos, d.joint_vel = ph["joint_pos"][k], ph["joint_vel"][k]   # <sim.step>
+            if self.on_physics is not None:
+                self.on_physics(k)     # <sim.step>: a simulator steps here (see SegmentedCommandList)
+            d.joint_pos, d.joint_vel = ph["joint_pos"][k], ph["joint_vel"][k]   # its results, here synthetic
             # (the last substep's update travels with the managers' launch)
             update = self.scene.describe_update(self.physics_dt) if self.paired_substeps else None
             if update is None:

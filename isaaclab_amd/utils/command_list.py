@@ -61,3 +61,54 @@ class CommandList:
             self.destroy()
         except Exception:
             pass
+
+
+class SegmentedCommandList:
+    """A step with a simulator in it: one command list per stretch of launches between two physics steps.
+
+    The step drivers call ``env.on_physics(substep)`` where the simulator's step belongs.  ``record`` cuts the recording
+    there, ``replay(physics)`` issues the stretches in order and calls ``physics(substep)`` between them -- the
+    simulator's own stepping call, which is not this library's and is therefore not recorded.  The simulator must
+    write its results where the recorded launches read them (the lists hold those addresses).
+
+        step = SegmentedCommandList()
+        step.record(env, lambda: env.step(actions))
+        step.replay(lambda k: sim.step())
+    """
+
+    def __init__(self):
+        self.segments: list[CommandList] = []
+
+    def record(self, env, one_step):
+        for seg in self.segments:
+            seg.destroy()
+        self.segments = []
+        stack = contextlib.ExitStack()
+
+        def open_segment():
+            commands = CommandList()
+            stack.enter_context(commands.record())
+            self.segments.append(commands)
+
+        def cut(substep):
+            stack.close()          # ends the stretch before the physics step ...
+            open_segment()         # ... and starts the one behind it
+
+        before = env.on_physics
+        env.on_physics = cut
+        try:
+            open_segment()
+            one_step()
+        finally:
+            env.on_physics = before
+            stack.close()
+        return self
+
+    def __len__(self) -> int:
+        return sum(len(seg) for seg in self.segments)
+
+    def replay(self, physics=None, stream: int | None = None):
+        for k, seg in enumerate(self.segments):
+            if k > 0 and physics is not None:
+                physics(k - 1)
+            seg.replay(stream)

@@ -331,3 +331,38 @@ def test_step_replayed_from_a_command_list_equals_the_step_issued_directly(dev, 
     assert direct["obs"].abs().sum() > 0
     for k, v in direct.items():
         assert_exact(listed[k], v, f"{config}: {k} after three replays")
+
+
+@pytest.mark.parametrize("config", ["cartpole", "anymal"])
+def test_step_recorded_in_stretches_around_the_physics_steps(dev, config):
+    """The one-chain step cut where the simulator's steps belong (SegmentedCommandList): decimation + 1 stretches whose
+    replay, with a callback between them standing in for the simulator, equals the step issued directly -- bit for bit over
+    three steps -- and the callback sees every substep in order."""
+    import bench_configs as BC
+    from isaaclab_amd.utils.command_list import SegmentedCommandList
+
+    def final(cfg):
+        m = cfg.env.mdp
+        return [t.cpu().clone() for t in (m.obs, m.reward_buf, m.terminated, m.time_outs, m.episode_sums, cfg.env.action)]
+
+    direct = BC.build(config, dev, 1000, seed=5)
+    direct.env.count_steps_on_device()
+    for _ in range(4):
+        direct.step()
+    torch.cuda.synchronize()
+
+    cfg = BC.build(config, dev, 1000, seed=5)
+    cfg.env.count_steps_on_device()
+    cfg.step()
+    step = SegmentedCommandList().record(cfg.env, cfg.step)
+    decimation = cfg.info["decimation"]
+    assert len(step.segments) == decimation + 1 and all(len(seg) >= 1 for seg in step.segments)
+    assert len(step) == sum(n for _, n in cfg.launches.values())
+    assert cfg.env.on_physics is None
+    seen = []
+    for _ in range(3):
+        step.replay(lambda k: (torch.cuda.current_stream().synchronize(), seen.append(k)))   # "the simulator": waits for the launches so far
+    torch.cuda.synchronize()
+    assert seen == list(range(decimation)) * 3
+    for k, (a, b) in enumerate(zip(final(cfg), final(direct))):
+        assert_exact(a, b, f"{config}: buffer {k}")
