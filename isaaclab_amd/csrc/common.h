@@ -55,6 +55,10 @@ struct Command {
     unsigned shmem;
     std::vector<char> blob;      // the arguments, each at its own alignment
     std::vector<void*> args;     // pointers into the blob, in parameter order
+    Command(const Command&) = delete;             // (a copy's pointers would name the original's blob;
+    Command(Command&&) noexcept = default;        //  a moved vector keeps its storage)
+    Command& operator=(Command&&) noexcept = default;
+    Command(const void* k, dim3 g, dim3 b, unsigned s) : kernel(k), grid(g), block(b), shmem(s) {}
 };
 struct CommandList {
     std::vector<Command> commands;
@@ -77,7 +81,7 @@ inline void launch(void (*kernel)(P...), dim3 grid, dim3 block, unsigned shmem, 
             }
             if (list->any && stream != list->stream) list->mixed = true;
             list->any = true, list->stream = stream;
-            Command c{reinterpret_cast<const void*>(kernel), grid, block, shmem, {}, {}};
+            Command c(reinterpret_cast<const void*>(kernel), grid, block, shmem);
             size_t at = 0, offsets[sizeof...(P) + 1] = {};
             int k = 0;
             ((at = (at + alignof(P) - 1) / alignof(P) * alignof(P), offsets[k++] = at, at += sizeof(P)), ...);
