@@ -893,13 +893,13 @@ raycaster_update_lattice_kernel(ScanArgs a, const LatEnvRec* __restrict__ recs, 
         // not each other's values): one LDS latency for the ray instead of four
         int mask_row = ci;
         asm("" : "+v"(mask_row));   // no instruction: keeps the word's address a shift and an add of its own (derived from the heights' address it was a 64-bit multiply-add)
-        float xlo = st.lines[ci], xhi = st.lines[ci + 1], ylo = st.lines[kLatWin + cj], yhi = st.lines[kLatWin + cj + 1];
-        uint32_t word = st.mask[mask_row];
+        const float xlo = st.lines[ci], xhi = st.lines[ci + 1], ylo = st.lines[kLatWin + cj], yhi = st.lines[kLatWin + cj + 1];
+        const uint32_t word = st.mask[mask_row];
         const float* zc = st.z + ci * kLatWin + cj;
-        float z00 = zc[0], z01 = zc[1], z10 = zc[kLatWin], z11 = zc[kLatWin + 1];
+        const float z00 = zc[0], z01 = zc[1], z10 = zc[kLatWin], z11 = zc[kLatWin + 1];
         // no instruction: the nine values are in registers here.  Without it the compiler moves each read behind the test
         // that decides whether its value is used -- lines, lines, bit, heights: four LDS latencies one after the other
-        asm volatile("" : "+v"(xlo), "+v"(xhi), "+v"(ylo), "+v"(yhi), "+v"(word), "+v"(z00), "+v"(z01), "+v"(z10), "+v"(z11));
+        asm volatile("" ::"v"(xlo), "v"(xhi), "v"(ylo), "v"(yhi), "v"(word), "v"(z00), "v"(z01), "v"(z10), "v"(z11));
         const bool in_x = lattice_inside(o.x, xlo, xhi), in_y = lattice_inside(o.y, ylo, yhi);
         if (!(in_x && in_y && ((word >> cj) & 1u) && dz != 0.0f)) return false;
         const float wx = xhi - xlo, wy = yhi - ylo;
