@@ -421,6 +421,24 @@ def main():
                         "frac": w["hbm_frac"]}
         roofline.update(launch_us=kern[worst], launches_per_step=launches[worst], share_of_step=share[worst],
                         algorithmic_bytes_per_launch=nbytes[worst] * args.envs, traffic=None)
+        # the same kernel's average in the committed rocprofv3 kernel trace of this command: there every launch runs inside
+        # the step, behind another kernel and on data that kernel or the step before left, not back to back with itself
+        trace_symbol = {"raycaster_cast": "raycaster_update_lattice_kernel", "mdp_step": "mdp_fast_kernel",
+                        "actuator_net_mlp+scene_update": "mlp_split_scene_kernel", "actuator_net_mlp": "mlp_split_persistent_kernel",
+                        "actuator_net_mlp_joint_action": "mlp_split_joint_action_kernel",
+                        "scene_update_prepare": "scene_update_prepare_kernel", "scene_update": "scene_update_kernel"}.get(worst)
+        if trace_symbol and args.config == "anymal" and args.envs == NUM_ENVS:
+            try:
+                import csv
+                with open(os.path.join(ROOT, "profiles", "r3_bench_kernel_stats.csv")) as f:
+                    for row in csv.DictReader(f):
+                        if trace_symbol in row["Name"]:
+                            in_step_us = float(row["AverageNs"]) / 1e3
+                            roofline["launch_us_in_step_rocprof"] = round(in_step_us, 2)
+                            roofline["frac_in_step_rocprof"] = round(roofline["frac"] * kern[worst] / in_step_us, 4)
+                            break
+            except (OSError, KeyError, ValueError):
+                pass
         if "traffic" in profiles and worst in profiles["traffic"]:   # HBM-side bytes per launch from the committed counter passes
             roofline["traffic"] = profiles["traffic"][worst]["hbm_bytes_per_launch"]
         if "sq" in profiles and worst in profiles["sq"] and "SQ_INSTS_VALU" in profiles["sq"][worst]:
