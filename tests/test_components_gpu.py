@@ -474,3 +474,30 @@ def test_contact_sensor_many_bodies(dev):
         assert_exact(s.data.net_forces_w_history, st["hist"], f"hist step {k}")
         assert_exact(s.data.current_air_time, st["ca"], f"cur_air step {k}")
         assert_exact(s.data.last_contact_time, st["lc"], f"last_contact step {k}")
+
+
+def test_command_list_of_one_call_and_the_refusal_of_two_streams(dev):
+    """A list records any entry point: one math call kept, then issued by the replay (its output buffer is written only
+    then); calls on two streams inside one recording are refused when the recording ends."""
+    from isaaclab_amd.utils import math as m
+    from isaaclab_amd.utils.command_list import CommandList
+
+    q = torch.rand(64, 4, device=dev) - 0.5
+    direct = m.quat_mul(q, q).clone()
+    commands = CommandList()
+    with commands.record():
+        out = m.quat_mul(q, q)
+    assert len(commands) == 1
+    out.zero_()
+    torch.cuda.synchronize()
+    commands.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, direct)
+    side = torch.cuda.Stream()
+    with pytest.raises(Exception, match="more than one stream"):
+        with commands.record():
+            m.quat_mul(q, q)
+            with torch.cuda.stream(side):
+                m.quat_mul(q, q)
+    with pytest.raises(Exception, match="more than one stream"):
+        commands.replay()
