@@ -798,7 +798,7 @@ __global__ void __launch_bounds__(256, 8) mlp_mfma_split_kernel(NetArgs a) {
 // w, w + nblocks * 4, ... and has the next tile's rows in flight while it computes the current one.  With a wavefront
 // per tile (mlp_split_block) all six tiles of a SIMD run their address preamble at once, sharing its issue slots, so the
 // first row load leaves after a microsecond, and every workgroup waits for its own copy of the weight image; here a
-// SIMD's two wavefronts pay both once and the other four tiles' loads travel under compute.  The free wavefront slots
+// SIMD's few wavefronts (kStayPerCu) pay both once and the other tiles' loads travel under compute.  The free wavefront slots
 // are what mlp_split_scene_kernel's scene-update workgroups run in.
 struct TileAt {
     RowAt<uint32_t> at;
@@ -990,10 +990,10 @@ __global__ void __launch_bounds__(256, 4) mlp_split_joint_action_kernel(NetArgs 
 // The actuator network of one physics substep and the scene update of the substep before it, which have no physics step
 // between them and share no buffer (articulation.py:1399-1436 writes torques and the network's histories;
 // interactive_scene.py:496-513 reads joint velocities and contact forces and writes joint_acc, the contact buffers and
-// the sensor clocks), as workgroups of one grid: the network's first -- two per CU, which stay for the whole launch and
+// the sensor clocks), as workgroups of one grid: the network's first -- kStayPerCu per CU, which stay for the whole launch and
 // are bound by the vector and matrix pipes --, the update's, bound by memory, run in the wavefront slots beside them.  One
 // launch and its fixed cost fewer per substep, and the overlap of the two does not depend on how two queues happen to run.
-// Registers: six wavefronts per SIMD (80 vector registers, what the network's body needs): two of the network, four of
+// Registers: six wavefronts per SIMD (80 vector registers, what the network's body needs): kStayPerCu of the network, the rest of
 // the update.
 // `mlp_first`, `su_first`: where each kind's workgroups start in the grid.
 template <int ACT>
@@ -1248,13 +1248,13 @@ extern "C" int ilx_actuator_pd_joint_action(int model, const float* raw_action, 
     return ILX_OK;
 }
 
-// Workgroups per CU of the network kernels whose wavefronts stay (mlp_split_persistent).  Three wavefronts per SIMD: the
+// Workgroups per CU of the network kernels whose wavefronts stay (mlp_split_persistent).  Four wavefronts per SIMD: the
 // vector pipe takes an instruction every other cycle and a wavefront alone offers one every four, while the matrix
-// products and LDS reads of one wavefront want the arithmetic of another to hide behind; more than three only delays the
-// first row loads (every wavefront runs its address preamble first) and, in the launch shared with the scene update,
-// takes the wavefront slots the update's workgroups run in.  Measured at 196 608 rows: 2 / 3 / 4 / 6 per CU = 9.5 / 9.2 /
-// 9.1 / 9.0 us alone, 12.0 / 11.9 / 12.6 / 12.9 us with the scene update in the grid.
-constexpr unsigned kStayPerCu = 3;
+// products and LDS reads of one wavefront want the arithmetic of another to hide behind; more only delays the first row
+// loads (every wavefront runs its address preamble first) and, in the launch shared with the scene update, takes the
+// wavefront slots the update's workgroups run in.  Measured at 196 608 rows, the whole step of seven launches (four of
+// them the network's) on one box: 2 / 3 / 4 per CU = 84.9 / 84.1 / 82.7 us, on another 4 / 5 / 6 = 80.5 / 82.3 / 82.9.
+constexpr unsigned kStayPerCu = 4;
 
 // `scene` (or null): the scene update that goes with this launch -- as workgroups of the same grid where the launch is
 // the three-sample split kernel's, else as a launch of its own ahead of it.
